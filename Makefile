@@ -1,0 +1,24 @@
+# Builds the gfx950 engine (libvehicle_pm_gpu.so) and the CPU oracle (test infrastructure).
+# The same commands are issued by __graft_entry__.build().
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+PKG     := ocean-perception_amd
+# -ffp-contract=off: every float op is a single IEEE rounding, on device and host, so results are
+# bit-identical to the CPU path (hipcc's default is fp-contract=fast).
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wextra -Wno-unused-parameter
+LIB     := $(PKG)/lib/libvehicle_pm_gpu.so
+SRCS    := $(PKG)/csrc/pm_engine.hip $(PKG)/host/patchmatch_gpu.cpp
+HDRS    := include/pm/patchmatch.h $(wildcard $(PKG)/csrc/*.hpp) $(wildcard $(PKG)/host/*.hpp)
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -Iinclude -I$(PKG)/csrc -I$(PKG)/host -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB); $(MAKE) -C oracle clean
+.PHONY: all oracle clean

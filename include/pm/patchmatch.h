@@ -1,0 +1,185 @@
+/*
+ * pm/patchmatch.h -- C ABI of the MI355X (gfx950) PatchMatch stereo engine.
+ *
+ * This is the drop-in boundary for the reference module src/vehicle/patchmatch_gpu
+ * (library target `vehicle_pm_gpu`, src/vehicle/patchmatch_gpu/CMakeLists.txt:1,10).
+ * Host code (C++ wrapper bm::pm::PatchmatchGpu in ocean-perception_amd/host/, or any FFI)
+ * sees only plain pointers and sizes; no HIP, torch or OpenCV type crosses this header.
+ * All `file:line` citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - every entry point returns PM_OK (0) or a negative pm_status; nothing throws or aborts
+ *     (the reference aborts through glog CHECK / cv::Exception and never checks CUDA errors,
+ *     patchmatch_gpu.cu:331-411);
+ *   - images are single channel, row major; `*_step` arguments are row strides in BYTES
+ *     (cv::Mat::step), 0 meaning "tightly packed";
+ *   - disparity maps are float32, 0 = background / unknown (patchmatch_gpu.cu:422-423);
+ *   - one handle = one device + one HIP stream + preallocated scratch; a handle is not
+ *     re-entrant (one in-flight call), different handles are independent.  Every entry point
+ *     binds the handle's device first, so it may be called from any host thread (the reference's
+ *     `Sequence` caller invokes Match from a playback worker thread,
+ *     test/stereo_matching/patchmatch_gpu_test.cpp:122-136).
+ */
+#ifndef PM_PATCHMATCH_H_
+#define PM_PATCHMATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+#define PM_MAX_ITERS 16
+#define PM_MAX_PATCH 15 /* largest supported window side (odd) */
+
+typedef struct pm_handle pm_handle;
+
+typedef enum pm_status {
+  PM_OK = 0,
+  PM_ERR_INVALID_ARG = -1, /* null pointer, even / oversized patch, bad enum ...            */
+  PM_ERR_SIZE = -2,        /* image larger than the handle was planned for, batch too large */
+  PM_ERR_HIP = -3,         /* a HIP runtime call failed; pm_last_error() has the text       */
+  PM_ERR_NO_DEVICE = -4,   /* no usable gfx950 device (the engine has NO CPU fallback)      */
+  PM_ERR_NOMEM = -5
+} pm_status;
+
+/* Which reference code the sweeps/cost reproduce bit for bit. */
+typedef enum pm_semantics {
+  /* src/vehicle/stereo_matching/patchmatch.cpp (AddNoise :143-155, PropagateNeighbors :158-196,
+   * Propagate :248-311, RemoveBackground :314-360) with the cost functor of
+   * test/stereo_matching/patchmatch_test.cpp:30-45 on patch_w x patch_h windows.
+   * This is the parity target named by BASELINE.json. */
+  PM_SEM_CPU = 0,
+  /* src/vehicle/patchmatch_gpu/patchmatch_gpu.cu kernels (L1GradientCost3x3 :72-114,
+   * PropagateRow :116-172, PropagateCol :175-230, MaskBackground :233-270) run race-free as one
+   * stripe per row / column. */
+  PM_SEM_GPU = 1
+} pm_semantics;
+
+/* How the directional sweeps are executed on the device (results are identical). */
+typedef enum pm_engine {
+  PM_ENGINE_AUTO = 0,
+  PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor */
+  PM_ENGINE_WAVE = 2    /* one wavefront per chain, window taps spread over the 64 lanes           */
+} pm_engine;
+
+/*
+ * Mirrors bm::pm::PatchmatchGpu::Params (patchmatch_gpu.h:79-92): the four scalar fields keep
+ * their names and defaults.  The nested detector_params / matcher_params of the reference
+ * configure the CPU seeder (SparseInit, patchmatch_gpu.cu:414-442); seeds are an explicit input
+ * at this boundary, so they live in the C++ wrapper, not here.
+ * The remaining fields expose what the reference hard-codes per call site.
+ */
+typedef struct pm_params {
+  uint32_t struct_size; /* = sizeof(pm_params), checked by pm_create */
+  uint32_t abi_version; /* = PM_ABI_VERSION */
+
+  /* --- reference fields ------------------------------------------------------------------ */
+  float cost_alpha;          /* 0.9  PM_SEM_GPU cost weight (patchmatch_gpu.h:85)              */
+  int patchmatch_iters;      /* 3    iterations of {noise, 4 sweeps} (patchmatch_gpu.h:86)      */
+  int init_dilate_factor;    /* 4    seed dilation 2*(2^f+1)+1 (patchmatch_gpu.h:87, .cu:436)   */
+  float cost_improve_factor; /* 0.8  PM_SEM_GPU MaskBackground (patchmatch_gpu.h:88, .cu:267)   */
+
+  /* --- what the reference hard-codes ------------------------------------------------------ */
+  int semantics;                  /* pm_semantics */
+  int engine;                     /* pm_engine */
+  float noise_amp[PM_MAX_ITERS];  /* amplitude of iteration i; default 32/2^i (patchmatch_gpu.cu:395);
+                                     the CPU test uses 32, 8, 2, 0.5 (patchmatch_test.cpp:173-179) */
+  int patch_w[PM_MAX_ITERS];      /* PM_SEM_CPU window of iteration i (odd, <= PM_MAX_PATCH)      */
+  int patch_h[PM_MAX_ITERS];
+  int bg_patch_w, bg_patch_h;     /* PM_SEM_CPU RemoveBackground window (patchmatch_test.cpp:183) */
+  float win_by_factor;            /* PM_SEM_CPU RemoveBackground factor, 1.5 (patchmatch_test.cpp:183) */
+  float functor_alpha;            /* 0.7  L1GradientCostFunction (patchmatch_test.cpp:35)          */
+  float functor_tau_color;        /* 50   (patchmatch_test.cpp:36)                                 */
+  float functor_tau_grad;         /* 20   (patchmatch_test.cpp:37)                                 */
+  uint64_t noise_seed;            /* 123  cv::RNG seed (patchmatch.cpp:146, patchmatch_gpu.cu:341) */
+  int left_right_check;           /* 1    right view + MaskOcclusions (patchmatch_gpu.cu:357-372)  */
+} pm_params;
+
+/* Fills *p with the reference defaults for the given semantics. */
+void pm_params_default(pm_params* p, int semantics);
+
+/* Replaces the constructor PatchmatchGpu::PatchmatchGpu(const Params&) (patchmatch_gpu.cu:322-328)
+ * and the lazy GpuMat scratch of patchmatch_gpu.h:120-123: all device memory for up to `max_batch`
+ * pairs of `max_rows` x `max_cols` is allocated here, and the unit-noise image the reference
+ * creates on first use (patchmatch_gpu.cu:339-344, Q3/Q20) is generated on the device per size. */
+int pm_create(const pm_params* params, int device, int max_rows, int max_cols, int max_batch,
+              pm_handle** out);
+void pm_destroy(pm_handle* h);
+const char* pm_last_error(const pm_handle* h);
+/* Text for a status code (valid without a handle). */
+const char* pm_status_string(int status);
+
+/* Replaces void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp,
+ * Image1f& dispr) (patchmatch_gpu.h:99-102, patchmatch_gpu.cu:331-376) with host buffers.
+ * seed_l / seed_r: sparse-init disparity maps (what SparseInit returns, .cu:414-442) in left /
+ * right image coordinates, or NULL for "all background".  disp_r may be NULL when
+ * left_right_check == 0. */
+int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                size_t image_step, const float* seed_l, const float* seed_r, size_t seed_step,
+                float* disp_l, float* disp_r, size_t disp_step);
+
+/* n independent pairs per call (pair i -> batch slot i); arrays of n pointers, tightly packed. */
+int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right,
+                      int rows, int cols, const float* const* seed_l, const float* const* seed_r,
+                      float* const* disp_l, float* const* disp_r);
+
+/* Replaces void PatchmatchGpu::Match(const cu::GpuMat& ...) (patchmatch_gpu.h:104-108,
+ * patchmatch_gpu.cu:379-411) widened to whole pairs: all pointers are DEVICE memory holding n
+ * tightly packed planes ([n][rows][cols]); nothing is copied through the host and the call only
+ * enqueues work on the handle's stream (pm_synchronize to wait).  Gradients are computed inside. */
+int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows,
+                    int cols, const float* d_seed_l, const float* d_seed_r, float* d_disp_l,
+                    float* d_disp_r);
+int pm_synchronize(pm_handle* h);
+/* The hipStream_t the handle enqueues on (as void*), for event timing by the caller. */
+void* pm_stream(pm_handle* h);
+
+/* ---- single stages, host buffers: one entry point per reference function ------------------ */
+
+/* GradientMagnitude (patchmatch_gpu.cu:307-319) / ComputeGradient (patchmatch_test.cpp:48-64). */
+int pm_gradient_magnitude(pm_handle* h, const uint8_t* image, int rows, int cols, float* grad);
+/* The cv::RNG(seed) uniform [-1,1) image of patchmatch_gpu.cu:339-344, as generated on the device. */
+int pm_unit_noise(pm_handle* h, int rows, int cols, float* noise);
+/* AddForegroundNoise (patchmatch_gpu.cu:298-304) == Patchmatch::AddNoise(disp, amount, disp > 0)
+ * (patchmatch.cpp:143-155 as called at patchmatch_test.cpp:173-179). */
+int pm_add_noise(pm_handle* h, float* disp, int rows, int cols, float amount);
+/* Patchmatch::Propagate (patchmatch.cpp:248-311) for PM_SEM_CPU, or the PropagateRow(+1),
+ * PropagateCol(+1), PropagateRow(-1), PropagateCol(-1) sequence (patchmatch_gpu.cu:397-403) for
+ * PM_SEM_GPU.  pass_mask bit k enables the k-th of those four sweeps.  disp is updated in place. */
+int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                 float* disp, int patch_h, int patch_w, int pass_mask);
+/* Patchmatch::RemoveBackground (patchmatch.cpp:314-360) / MaskBackground (patchmatch_gpu.cu:233-270). */
+int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                         float* disp, int patch_h, int patch_w, float factor);
+/* MaskOcclusions (patchmatch_gpu.cu:273-295). */
+int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols);
+
+/* ---- per-kernel timing (hipEvents on the handle's stream) ---------------------------------- */
+
+enum {
+  PM_K_PREP = 0,     /* u8 -> mirrored copies + Sobel magnitude        */
+  PM_K_SEED = 1,     /* seed upload / mirror                           */
+  PM_K_NOISE = 2,    /* foreground noise + clamp + cost of current d   */
+  PM_K_SWEEP_ROW = 3,
+  PM_K_SWEEP_COL = 4,
+  PM_K_BACKGROUND = 5,
+  PM_K_FINALIZE = 6, /* un-mirror + MaskOcclusions                     */
+  PM_K_COUNT = 7
+};
+typedef struct pm_profile {
+  uint64_t launches[PM_K_COUNT];
+  double total_ms[PM_K_COUNT]; /* sum of hipEventElapsedTime over those launches */
+} pm_profile;
+/* on != 0: bracket every kernel with events (adds host overhead; use for roofline legs only). */
+int pm_profile_enable(pm_handle* h, int on);
+/* Waits for the stream, then accumulates pending events into *out and resets the counters. */
+int pm_profile_read(pm_handle* h, pm_profile* out);
+const char* pm_kernel_name(int kernel_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PM_PATCHMATCH_H_ */

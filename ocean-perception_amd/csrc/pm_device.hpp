@@ -1,0 +1,231 @@
+// pm_device.hpp -- device-side arithmetic of the PatchMatch stereo engine (gfx950).
+//
+// Everything here is compiled with -ffp-contract=off: each float operation is one IEEE-754
+// binary32 rounding, in the same order as the reference code it reproduces, so disparities
+// are bit-identical to the CPU path.  `file:line` citations are relative to the reference tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pm {
+
+// Device memory of one call: B pairs, each with four u8 images (L, R, mirrored L, mirrored R),
+// their Sobel magnitudes as f32 and as saturated u8, and per view a disparity plane and the
+// cost of that disparity.  All planes share one pitch (elements per row, multiple of 64) so that
+// row y of every plane starts on a 256-byte boundary for f32 and a 64-byte one for u8.
+struct PlaneSet {
+  uint8_t* img8;       // [B][4][rows][pitch]   0=L 1=R 2=Lm 3=Rm
+  float* g32;          // [B][4][rows][pitch]
+  uint8_t* g8;         // [B][4][rows][pitch]   saturate_cast<uchar>(g32)
+  float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
+  float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
+  const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
+  int rows, cols, pitch;
+  int n_views;         // 1 or 2
+  size_t plane;        // rows * pitch
+};
+
+// The planes one view works on.  View 1 is "the same algorithm on the horizontally mirrored
+// (R, L) pair" (src/vehicle/patchmatch_gpu/patchmatch_gpu.cu:357-368): the mirrored copies are
+// written once by the prep kernel, so no flip pass exists.
+struct View {
+  const uint8_t* ref8;   // reference image ("iml")
+  const uint8_t* tgt8;   // target image ("imr")
+  const float* refg;     // gradient magnitude of ref ("Gl")
+  const float* tgtg;     // gradient magnitude of tgt ("Gr")
+  const uint8_t* refg8;  // saturated u8 of refg
+  float* disp;
+  float* cost;
+};
+
+__device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
+  const int b = slot / ps.n_views, v = slot - b * ps.n_views;
+  const int iref = v == 0 ? 0 : 3, itgt = v == 0 ? 1 : 2;
+  const size_t base4 = (size_t)b * 4;
+  View w;
+  w.ref8 = ps.img8 + (base4 + iref) * ps.plane;
+  w.tgt8 = ps.img8 + (base4 + itgt) * ps.plane;
+  w.refg = ps.g32 + (base4 + iref) * ps.plane;
+  w.tgtg = ps.g32 + (base4 + itgt) * ps.plane;
+  w.refg8 = ps.g8 + (base4 + iref) * ps.plane;
+  w.disp = ps.disp + ((size_t)b * 2 + v) * ps.plane;
+  w.cost = ps.cost + ((size_t)b * 2 + v) * ps.plane;
+  return w;
+}
+
+// Constants of one cost evaluation.
+struct CostParams {
+  int semantics;  // PM_SEM_CPU / PM_SEM_GPU
+  int pw, ph;     // window (PM_SEM_CPU); PM_SEM_GPU uses the 5-tap 3x3 and radius 1
+  // PM_SEM_CPU: L1GradientCostFunction (test/stereo_matching/patchmatch_test.cpp:30-45)
+  float alpha, one_minus_alpha, tau_color, tau_grad;
+  double inv_n;  // 1./(pw*ph): cv::mean multiplies the sum by the reciprocal in double
+  // PM_SEM_GPU: L1GradientCost3x3 (patchmatch_gpu.cu:72-114)
+  float g_alpha, g_one_minus_alpha;
+};
+
+// saturate_cast<uchar>(float) = clamp(cvRound(v), 0, 255); cvRound rounds half to even.
+__device__ __forceinline__ int sat_u8(float v) {
+  const int iv = __float2int_rn(v);
+  return min(max(iv, 0), 255);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PM_SEM_CPU tap arithmetic.  One window sample of cv::getRectSubPix on the path (integer y, so
+// the vertical weight is 0 and the sample is the horizontal two-tap lerp):
+//   8u:  (r0*a11 + r1*a12 + 2^15) >> 16,  a11 = cvRound((1-a)*2^16), a12 = cvRound(a*2^16)
+//   32f: r0*(1-a) + r1*a
+// (OpenCV 3.4 modules/imgproc/src/samplers.cpp getRectSubPix_Cn_; called from GetPatchSubpix,
+// src/vehicle/stereo_matching/patchmatch.cpp:98-111.)
+// ---------------------------------------------------------------------------------------------
+struct CpuLerp {
+  int ipx;  // column of the first tap of the window row
+  int a11, a12;
+  float a, ia;
+};
+
+__device__ __forceinline__ CpuLerp cpu_lerp(int x, float d, int pw) {
+  float cx = (float)x - d;
+  cx = cx - (float)(pw - 1) * 0.5f;
+  CpuLerp l;
+  const float fl = floorf(cx);
+  l.ipx = (int)fl;
+  l.a = cx - fl;
+  l.ia = 1.f - l.a;
+  l.a11 = __float2int_rn(l.ia * 65536.f);
+  l.a12 = __float2int_rn(l.a * 65536.f);
+  return l;
+}
+
+__device__ __forceinline__ int cpu_tap_color(int left, int r0, int r1, const CpuLerp& l) {
+  const int v = (r0 * l.a11 + r1 * l.a12 + (1 << 15)) >> 16;
+  return abs(left - v);
+}
+__device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, const CpuLerp& l) {
+  float s = g0 * l.ia;
+  s = s + g1 * l.a;
+  return abs(left_g8 - sat_u8(s));
+}
+
+// mean = (float)(sum * (1./N)); cost = alpha*min(mean_c, tau_c) + (1-alpha)*min(mean_g, tau_g).
+__device__ __forceinline__ float cpu_cost_from_sums(int sc, int sg, const CostParams& cp) {
+  const float mc = (float)((double)sc * cp.inv_n);
+  const float mg = (float)((double)sg * cp.inv_n);
+  const float ec = fminf(mc, cp.tau_color);
+  const float eg = fminf(mg, cp.tau_grad);
+  const float t0 = cp.alpha * ec;
+  const float t1 = cp.one_minus_alpha * eg;
+  return t0 + t1;
+}
+
+// Whole-window cost by one lane.  Valid for pw/2 <= x <= cols-pw/2-1, ph/2 <= y <= rows-ph/2-1 and
+// 0 <= d <= x - pw/2 (then 0 <= ipx and ipx + pw <= cols, the second tap of the last column has
+// weight 0 when it would fall outside and is clamped).
+__device__ __forceinline__ float cpu_cost_lane(const View& v, int pitch, int cols, int x, int y, float d,
+                                const CostParams& cp) {
+  const CpuLerp l = cpu_lerp(x, d, cp.pw);
+  const int x0 = x - cp.pw / 2, y0 = y - cp.ph / 2;
+  int sc = 0, sg = 0;
+  for (int i = 0; i < cp.ph; ++i) {
+    const size_t row = (size_t)(y0 + i) * pitch;
+    const uint8_t* lp = v.ref8 + row + x0;
+    const uint8_t* lg = v.refg8 + row + x0;
+    const uint8_t* rp = v.tgt8 + row;
+    const float* rg = v.tgtg + row;
+    int c0 = l.ipx;
+    int r0 = rp[c0];
+    float g0 = rg[c0];
+    for (int j = 0; j < cp.pw; ++j) {
+      const int c1 = min(c0 + 1, cols - 1);
+      const int r1 = rp[c1];
+      const float g1 = rg[c1];
+      sc += cpu_tap_color(lp[j], r0, r1, l);
+      sg += cpu_tap_grad(lg[j], g0, g1, l);
+      r0 = r1;
+      g0 = g1;
+      c0 = c1;
+    }
+  }
+  return cpu_cost_from_sums(sc, sg, cp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PM_SEM_GPU: GetSubpixel (patchmatch_gpu.cu:18-42) at an integer row, and L1GradientCost3x3
+// (:72-114): taps (-1,-1) (-1,+1) (0,0) (+1,-1) (+1,+1), accumulated in that order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gpu_tap(float il, float gl, float r0, float r1, float g0, float g1, float tcol,
+                         const CostParams& cp) {
+  const float ic = 1.0f - tcol;
+  float rs = ic * r0;
+  rs = rs + tcol * r1;
+  float gs = ic * g0;
+  gs = gs + tcol * g1;
+  const float e0 = fabsf(il - rs);
+  const float e1 = fabsf(gl - gs);
+  const float t0 = cp.g_alpha * e0;
+  const float t1 = cp.g_one_minus_alpha * e1;
+  return t0 + t1;
+}
+
+__device__ __forceinline__ float gpu_cost_lane(const View& v, int pitch, int x, int y, float xr, const CostParams& cp) {
+  const int dy[5] = {-1, -1, 0, 1, 1};
+  const int dx[5] = {-1, 1, 0, -1, 1};
+  float cost = 0.f;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const float xs = xr + (float)dx[t];
+    const float f0 = floorf(xs);
+    const int col0 = (int)f0, col1 = (int)ceilf(xs);
+    const float tcol = xs - f0;
+    const size_t lrow = (size_t)(y + dy[t]) * pitch;
+    const float il = (float)v.ref8[lrow + x + dx[t]];
+    const float gl = v.refg[lrow + x + dx[t]];
+    const float r0 = (float)v.tgt8[lrow + col0], r1 = (float)v.tgt8[lrow + col1];
+    const float g0 = v.tgtg[lrow + col0], g1 = v.tgtg[lrow + col1];
+    const float s = gpu_tap(il, gl, r0, r1, g0, g1, tcol, cp);
+    cost = cost + s;
+  }
+  return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate rule of one sweep step: what a pixel holding (d0, c0) does when its predecessor in
+// the sweep holds `cand`.  Returns true and fills (nd, nc) when the pixel changes.
+//   PM_SEM_CPU  PropagateNeighbors (patchmatch.cpp:158-196): candidate considered only if
+//               x - cand >= pw/2, adopted on a strictly smaller cost; d0 is already clamped to
+//               [0, x - pw/2] (the noise kernel applies the clamp of :175 to every interior pixel,
+//               which every pass-A visit would otherwise do before any neighbour reads it).
+//   PM_SEM_GPU  PropagateRow/Col (patchmatch_gpu.cu:156-171): xr = max(x - cand, r), adopted on a
+//               strictly smaller cost, stored as min(cand, x - r).
+// A candidate equal to d0 (or mapping to the same xr) has an equal cost and is never adopted, so
+// its evaluation is skipped; this is exact, not an approximation.
+// ---------------------------------------------------------------------------------------------
+template <typename CostFn>
+__device__ __forceinline__ bool sweep_step(int semantics, int x, int half_w, float d0, float c0, float cand,
+                                           float& nd, float& nc, CostFn&& cost_at) {
+  if (semantics == 0) {
+    if (cand == d0) return false;
+    if (!(((float)x - cand) >= (float)half_w)) return false;
+    const float c1 = cost_at(cand);
+    if (c1 < c0) {
+      nd = cand;
+      nc = c1;
+      return true;
+    }
+    return false;
+  } else {
+    const float r = (float)half_w;
+    const float xr0 = fmaxf((float)x - d0, r), xr1 = fmaxf((float)x - cand, r);
+    if (xr0 == xr1) return false;
+    const float c1 = cost_at(xr1);
+    if (c1 < c0) {
+      nd = fminf(cand, (float)x - r);
+      nc = c1;
+      return true;
+    }
+    return false;
+  }
+}
+
+}  // namespace pm

@@ -1,0 +1,801 @@
+// pm_engine.hip -- C-ABI implementation (include/pm/patchmatch.h) of the gfx950 PatchMatch
+// stereo engine: handle, device memory plan, kernel launches, per-kernel timing.
+//
+// There is deliberately NO CPU fallback in this file: without a usable HIP device pm_create
+// fails with PM_ERR_NO_DEVICE.  `file:line` citations are relative to the reference tree.
+#include "pm/patchmatch.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pm_kernels.hpp"
+#include "pm_wave.hpp"
+
+using namespace pm;
+
+namespace {
+
+constexpr int kMaxEvents = 512;  // event pairs kept before a forced drain
+
+struct EventRec {
+  hipEvent_t start, stop;
+  int klass;
+};
+
+}  // namespace
+
+struct pm_handle {
+  pm_params params;
+  int device = 0;
+  int max_rows = 0, max_cols = 0, max_batch = 0;
+  int max_pitch = 0;
+  hipStream_t stream = nullptr;
+
+  // engine planes (see pm::PlaneSet)
+  uint8_t* img8 = nullptr;
+  float* g32 = nullptr;
+  uint8_t* g8 = nullptr;
+  float* disp = nullptr;
+  float* cost = nullptr;
+  float* noise = nullptr;
+  int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
+
+  // staging for the host-buffer entry points: tightly packed [B][rows][cols]
+  uint8_t* st_left = nullptr;
+  uint8_t* st_right = nullptr;
+  float* st_seed_l = nullptr;
+  float* st_seed_r = nullptr;
+  float* st_disp_l = nullptr;
+  float* st_disp_r = nullptr;
+  void* pinned = nullptr;  // host staging, pinned
+  size_t pinned_bytes = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventRec> ev_pool;
+  int ev_used = 0;
+  pm_profile prof{};
+
+  char err[512] = {0};
+};
+
+namespace {
+
+void set_err(pm_handle* h, const char* fmt, ...) {
+  if (!h) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(h->err, sizeof(h->err), fmt, ap);
+  va_end(ap);
+}
+
+#define PM_HIP(h, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err((h), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return PM_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+int check_patch(pm_handle* h, int pw, int ph) {
+  if (pw < 3 || ph < 3 || pw > PM_MAX_PATCH || ph > PM_MAX_PATCH || (pw % 2) == 0 || (ph % 2) == 0) {
+    // patchmatch.cpp:257-258 CHECKs oddness; 1x1 is excluded because its passes A/B and C/D visit
+    // different pixel sets, which the engine's shared cost plane does not model.
+    set_err(h, "patch %dx%d unsupported: sides must be odd and within [3, %d]", pw, ph, PM_MAX_PATCH);
+    return PM_ERR_INVALID_ARG;
+  }
+  return PM_OK;
+}
+
+// cv::RNG(seed) + RNG::fill(CV_32F, UNIFORM, -1, 1) (OpenCV 3.4 modules/core/src/rand.cpp
+// randf_32f): multiply-with-carry generator, out = (float)(int)next * 2^-31 + 0.  The generator
+// is inherently sequential and the image depends only on (seed, rows, cols): it is built once per
+// size on the host and uploaded, exactly as the reference does (patchmatch_gpu.cu:339-344).
+void fill_unit_noise(float* dst, int rows, int cols, int pitch, uint64_t seed) {
+  uint64_t state = seed ? seed : 0xffffffffu;
+  const float scale = (float)(2.0 * 2.3283064365386962890625e-10);
+  for (int y = 0; y < rows; ++y) {
+    float* row = dst + (size_t)y * pitch;
+    for (int x = 0; x < cols; ++x) {
+      state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+      const float t = (float)(int32_t)(uint32_t)state;
+      const float m = t * scale;
+      row[x] = m + 0.0f;
+    }
+    for (int x = cols; x < pitch; ++x) row[x] = 0.f;
+  }
+}
+
+PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
+  PlaneSet ps;
+  ps.img8 = h->img8;
+  ps.g32 = h->g32;
+  ps.g8 = h->g8;
+  ps.disp = h->disp;
+  ps.cost = h->cost;
+  ps.noise = h->noise;
+  ps.rows = rows;
+  ps.cols = cols;
+  ps.pitch = align_up(cols, 64);
+  ps.n_views = n_views;
+  ps.plane = (size_t)rows * ps.pitch;
+  return ps;
+}
+
+CostParams cost_params(const pm_params& p, int pw, int ph) {
+  CostParams cp;
+  cp.semantics = p.semantics;
+  cp.pw = p.semantics == PM_SEM_CPU ? pw : 3;
+  cp.ph = p.semantics == PM_SEM_CPU ? ph : 3;
+  cp.alpha = p.functor_alpha;
+  cp.one_minus_alpha = 1.f - p.functor_alpha;
+  cp.tau_color = p.functor_tau_color;
+  cp.tau_grad = p.functor_tau_grad;
+  cp.inv_n = 1. / (double)(cp.pw * cp.ph);
+  cp.g_alpha = p.cost_alpha;
+  cp.g_one_minus_alpha = 1.f - p.cost_alpha;
+  return cp;
+}
+
+// Pixels the sweeps visit.
+//  PM_SEM_CPU (patchmatch.cpp:264-310): every pass skips y < ph/2, x < pw/2, y > h-ph/2-1,
+//  x > w-pw/2-1; with sides >= 3 the loop bounds 1 / h-2 / w-2 lie outside that set, so all four
+//  passes visit exactly [pw/2, w-pw/2-1] x [ph/2, h-ph/2-1].
+//  PM_SEM_GPU (patchmatch_gpu.cu:134,143-144,192,201-202 with radius 1): union of the four sweeps
+//  = [1, W-2] x [1, H-2]; each sweep's exclusive loop end trims one position (see sweep_geom).
+Interior interior(const pm_params& p, int rows, int cols, int pw, int ph) {
+  Interior in;
+  if (p.semantics == PM_SEM_CPU) {
+    in.x_lo = pw / 2;
+    in.x_hi = cols - pw / 2 - 1;
+    in.y_lo = ph / 2;
+    in.y_hi = rows - ph / 2 - 1;
+  } else {
+    in.x_lo = 1;
+    in.x_hi = cols - 2;
+    in.y_lo = 1;
+    in.y_hi = rows - 2;
+  }
+  return in;
+}
+
+// k-th sweep of an iteration: 0 = row +1 (pass A), 1 = col +1 (B), 2 = row -1 (C), 3 = col -1 (D).
+SweepGeom sweep_geom(const pm_params& p, const Interior& in, int k) {
+  SweepGeom g;
+  g.axis = k & 1;
+  g.dir = k < 2 ? 1 : -1;
+  const int lo = g.axis == 0 ? in.x_lo : in.y_lo, hi = g.axis == 0 ? in.x_hi : in.y_hi;
+  g.c_lo = g.axis == 0 ? in.y_lo : in.x_lo;
+  g.c_hi = g.axis == 0 ? in.y_hi : in.x_hi;
+  if (p.semantics == PM_SEM_CPU) {
+    g.s_first = g.dir > 0 ? lo : hi;
+    g.s_last = g.dir > 0 ? hi : lo;
+  } else {
+    // `for (col = start; dir > 0 ? col < end : col > end; col += dir)` (patchmatch_gpu.cu:156)
+    g.s_first = g.dir > 0 ? lo : hi;
+    g.s_last = g.dir > 0 ? hi - 1 : lo + 1;
+  }
+  return g;
+}
+
+struct Launch {
+  pm_handle* h;
+  int klass;
+  bool timed;
+  EventRec* rec = nullptr;
+  Launch(pm_handle* h_, int k) : h(h_), klass(k), timed(h_->profiling) {
+    if (!timed) return;
+    if (h->ev_used == (int)h->ev_pool.size()) {
+      if ((int)h->ev_pool.size() >= kMaxEvents) {
+        timed = false;  // drained by pm_profile_read; never block inside a launch path
+        return;
+      }
+      EventRec r;
+      r.klass = k;
+      if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+        timed = false;
+        return;
+      }
+      h->ev_pool.push_back(r);
+    }
+    rec = &h->ev_pool[h->ev_used++];
+    rec->klass = k;
+    (void)hipEventRecord(rec->start, h->stream);
+  }
+  ~Launch() {
+    if (timed && rec) (void)hipEventRecord(rec->stop, h->stream);
+  }
+};
+
+int launch_check(pm_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_err(h, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PM_ERR_HIP;
+  }
+  return PM_OK;
+}
+
+dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
+
+int ensure_noise(pm_handle* h, int rows, int cols) {
+  const int pitch = align_up(cols, 64);
+  if (h->noise_rows == rows && h->noise_cols == cols && h->noise_pitch == pitch) return PM_OK;
+  const size_t bytes = sizeof(float) * (size_t)rows * pitch;
+  if (bytes > h->pinned_bytes) {
+    set_err(h, "internal: pinned staging too small for noise");
+    return PM_ERR_SIZE;
+  }
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  fill_unit_noise((float*)h->pinned, rows, cols, pitch, h->params.noise_seed);
+  PM_HIP(h, hipMemcpyAsync(h->noise, h->pinned, bytes, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  h->noise_rows = rows;
+  h->noise_cols = cols;
+  h->noise_pitch = pitch;
+  return PM_OK;
+}
+
+int check_size(pm_handle* h, int rows, int cols, int n) {
+  if (rows < 8 || cols < 8) {
+    set_err(h, "image %dx%d too small (min 8x8)", cols, rows);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (rows > h->max_rows || cols > h->max_cols || n > h->max_batch || n < 1) {
+    set_err(h, "request %d x (%dx%d) exceeds plan %d x (%dx%d)", n, cols, rows, h->max_batch, h->max_cols,
+            h->max_rows);
+    return PM_ERR_SIZE;
+  }
+  return PM_OK;
+}
+
+int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
+  const int chains = g.c_hi - g.c_lo + 1;
+  if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
+  Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
+  int engine = h->params.engine;
+  if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_WAVE;
+  if (engine == PM_ENGINE_SERIAL) {
+    hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0,
+                       h->stream, ps, cp, g);
+  } else {
+    launch_sweep_wave(ps, cp, g, slots, h->stream);
+  }
+  return launch_check(h, "sweep");
+}
+
+// iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
+// (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
+int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
+  const pm_params& p = h->params;
+  CostParams cp{};
+  int last_pw = 0, last_ph = 0;
+  for (int it = 0; it < p.patchmatch_iters; ++it) {
+    const int pw = p.patch_w[it], ph = p.patch_h[it];
+    cp = cost_params(p, pw, ph);
+    const Interior in = interior(p, ps.rows, ps.cols, cp.pw, cp.ph);
+    {
+      Launch l(h, PM_K_NOISE);
+      hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in,
+                         p.noise_amp[it]);
+    }
+    if (int rc = launch_check(h, "noise_cost")) return rc;
+    for (int k = 0; k < 4; ++k)
+      if (int rc = run_sweep(h, ps, cp, sweep_geom(p, in, k), slots)) return rc;
+    last_pw = cp.pw;
+    last_ph = cp.ph;
+  }
+  {
+    const CostParams bcp = cost_params(p, p.bg_patch_w, p.bg_patch_h);
+    const Interior in = interior(p, ps.rows, ps.cols, bcp.pw, bcp.ph);
+    const int cached = (p.patchmatch_iters > 0 && bcp.pw == last_pw && bcp.ph == last_ph) ? 1 : 0;
+    const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
+    Launch l(h, PM_K_BACKGROUND);
+    hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, bcp, in,
+                       factor, cached);
+  }
+  return launch_check(h, "background");
+}
+
+int validate_params(pm_handle* h, const pm_params& p) {
+  if (p.struct_size != sizeof(pm_params) || p.abi_version != PM_ABI_VERSION) {
+    set_err(h, "pm_params size/version mismatch (got %u/%u, want %zu/%d)", p.struct_size, p.abi_version,
+            sizeof(pm_params), PM_ABI_VERSION);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.semantics != PM_SEM_CPU && p.semantics != PM_SEM_GPU) {
+    set_err(h, "unknown semantics %d", p.semantics);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_WAVE) {
+    set_err(h, "unknown engine %d", p.engine);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.patchmatch_iters < 0 || p.patchmatch_iters > PM_MAX_ITERS) {
+    set_err(h, "patchmatch_iters %d outside [0, %d]", p.patchmatch_iters, PM_MAX_ITERS);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.semantics == PM_SEM_CPU) {
+    for (int i = 0; i < p.patchmatch_iters; ++i)
+      if (int rc = check_patch(h, p.patch_w[i], p.patch_h[i])) return rc;
+    if (int rc = check_patch(h, p.bg_patch_w, p.bg_patch_h)) return rc;
+    if (!(p.win_by_factor > 0.f)) {
+      set_err(h, "win_by_factor must be > 0");
+      return PM_ERR_INVALID_ARG;
+    }
+  }
+  for (int i = 0; i < p.patchmatch_iters; ++i)
+    if (!(p.noise_amp[i] >= 0.f)) {
+      set_err(h, "noise_amp[%d] must be >= 0", i);
+      return PM_ERR_INVALID_ARG;
+    }
+  return PM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+
+extern "C" {
+
+void pm_params_default(pm_params* p, int semantics) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->struct_size = (uint32_t)sizeof(pm_params);
+  p->abi_version = PM_ABI_VERSION;
+  p->cost_alpha = 0.9f;           // patchmatch_gpu.h:85
+  p->patchmatch_iters = 3;        // patchmatch_gpu.h:86
+  p->init_dilate_factor = 4;      // patchmatch_gpu.h:87
+  p->cost_improve_factor = 0.8f;  // patchmatch_gpu.h:88
+  p->semantics = semantics;
+  p->engine = PM_ENGINE_AUTO;
+  for (int i = 0; i < PM_MAX_ITERS; ++i) {
+    p->noise_amp[i] = (float)(32.0 / std::pow(2.0, (double)(float)i));  // patchmatch_gpu.cu:395
+    p->patch_w[i] = 3;
+    p->patch_h[i] = 3;
+  }
+  p->bg_patch_w = 3;  // patchmatch_test.cpp:183
+  p->bg_patch_h = 3;
+  p->win_by_factor = 1.5f;        // patchmatch_test.cpp:183
+  p->functor_alpha = 0.7f;        // patchmatch_test.cpp:35
+  p->functor_tau_color = 50.0f;   // patchmatch_test.cpp:36
+  p->functor_tau_grad = 20.0f;    // patchmatch_test.cpp:37
+  p->noise_seed = 123;            // patchmatch.cpp:146, patchmatch_gpu.cu:341
+  p->left_right_check = 1;
+}
+
+const char* pm_status_string(int status) {
+  switch (status) {
+    case PM_OK: return "ok";
+    case PM_ERR_INVALID_ARG: return "invalid argument";
+    case PM_ERR_SIZE: return "size exceeds the handle's plan";
+    case PM_ERR_HIP: return "HIP runtime error";
+    case PM_ERR_NO_DEVICE: return "no usable HIP device";
+    case PM_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char* pm_kernel_name(int k) {
+  static const char* names[PM_K_COUNT] = {"prep", "seed", "noise_cost", "sweep_row", "sweep_col", "background",
+                                          "finalize"};
+  return (k >= 0 && k < PM_K_COUNT) ? names[k] : "?";
+}
+
+const char* pm_last_error(const pm_handle* h) { return h ? h->err : "null handle"; }
+
+void pm_destroy(pm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& r : h->ev_pool) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  void* dev[] = {h->img8, h->g32, h->g8, h->disp, h->cost, h->noise, h->st_left, h->st_right,
+                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int pm_create(const pm_params* params, int device, int max_rows, int max_cols, int max_batch, pm_handle** out) {
+  if (!out) return PM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!params || max_rows < 8 || max_cols < 8 || max_batch < 1) return PM_ERR_INVALID_ARG;
+  pm_handle* h = new (std::nothrow) pm_handle();
+  if (!h) return PM_ERR_NOMEM;
+  // On failure the handle is still handed back so the caller can read pm_last_error(); such a
+  // handle is good for pm_last_error / pm_destroy only.
+  *out = h;
+  h->params = *params;
+  h->device = device;
+  if (int rc = validate_params(h, *params)) return rc;
+
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_err(h, "no HIP device available (%s); this engine has no CPU fallback",
+            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return PM_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    set_err(h, "device %d out of range (0..%d)", device, count - 1);
+    return PM_ERR_NO_DEVICE;
+  }
+  PM_HIP(h, hipSetDevice(device));
+  PM_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+  h->max_rows = max_rows;
+  h->max_cols = max_cols;
+  h->max_batch = max_batch;
+  h->max_pitch = align_up(max_cols, 64);
+  const size_t plane = (size_t)max_rows * h->max_pitch;
+  const size_t B = (size_t)max_batch;
+  // +256 B of slack after the last plane: window loops may prefetch one element past a row end.
+  PM_HIP(h, hipMalloc((void**)&h->img8, B * 4 * plane + 256));
+  PM_HIP(h, hipMalloc((void**)&h->g32, sizeof(float) * (B * 4 * plane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->g8, B * 4 * plane + 256));
+  PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
+  const size_t tight = (size_t)max_rows * max_cols;
+  PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
+  PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
+  PM_HIP(h, hipMalloc((void**)&h->st_seed_l, sizeof(float) * B * tight));
+  PM_HIP(h, hipMalloc((void**)&h->st_seed_r, sizeof(float) * B * tight));
+  PM_HIP(h, hipMalloc((void**)&h->st_disp_l, sizeof(float) * B * tight));
+  PM_HIP(h, hipMalloc((void**)&h->st_disp_r, sizeof(float) * B * tight));
+  // pinned host staging: per pair 2 u8 images + 2 seeds + 2 outputs (also used for the noise table)
+  h->pinned_bytes = B * tight * (2 + 4 * sizeof(float));
+  const size_t noise_bytes = sizeof(float) * plane;
+  if (h->pinned_bytes < noise_bytes) h->pinned_bytes = noise_bytes;
+  PM_HIP(h, hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
+  // the cost planes are read only where the noise kernel wrote them; clear once so that tools that
+  // scan whole planes never see uninitialised memory
+  PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->disp, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
+}
+
+int pm_synchronize(pm_handle* h) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
+}
+
+void* pm_stream(pm_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                    const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!d_left || !d_right || !d_disp_l) {
+    set_err(h, "pm_match_device: null image or output pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, n)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  const int n_views = h->params.left_right_check ? 2 : 1;
+  if (n_views == 2 && !d_disp_r) {
+    set_err(h, "pm_match_device: disp_r required when left_right_check is set");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  const PlaneSet ps = plane_set(h, rows, cols, n_views);
+  {
+    Launch l(h, PM_K_PREP);
+    hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_left, d_right,
+                       (size_t)cols);
+  }
+  if (int rc = launch_check(h, "prep")) return rc;
+  {
+    Launch l(h, PM_K_SEED);
+    hipLaunchKernelGGL(k_seed, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
+                       (size_t)cols);
+  }
+  if (int rc = launch_check(h, "seed")) return rc;
+  if (int rc = run_views(h, ps, n * n_views)) return rc;
+  {
+    Launch l(h, PM_K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_disp_l, d_disp_r,
+                       (size_t)cols);
+  }
+  return launch_check(h, "finalize");
+}
+
+int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int rows,
+                      int cols, const float* const* seed_l, const float* const* seed_r, float* const* disp_l,
+                      float* const* disp_r) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right || !disp_l) {
+    set_err(h, "pm_match_batch_u8: null pointer array");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, n)) return rc;
+  const bool lr = h->params.left_right_check != 0;
+  if (lr && !disp_r) {
+    set_err(h, "pm_match_batch_u8: disp_r required when left_right_check is set");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;  // uses the pinned buffer: before staging inputs
+  const size_t px = (size_t)rows * cols;
+  float* psl = (float*)h->pinned;  // floats first so every sub-buffer stays 4-byte aligned
+  float* psr = psl + n * px;
+  float* pdl = psr + n * px;
+  float* pdr = pdl + n * px;
+  uint8_t* pl = (uint8_t*)(pdr + n * px);
+  uint8_t* pr = pl + n * px;
+  bool any_sl = false, any_sr = false;
+  for (int i = 0; i < n; ++i) {
+    if (!left[i] || !right[i] || !disp_l[i] || (lr && !disp_r[i])) {
+      set_err(h, "pm_match_batch_u8: null pointer for pair %d", i);
+      return PM_ERR_INVALID_ARG;
+    }
+    std::memcpy(pl + i * px, left[i], px);
+    std::memcpy(pr + i * px, right[i], px);
+    if (seed_l && seed_l[i]) {
+      std::memcpy(psl + i * px, seed_l[i], sizeof(float) * px);
+      any_sl = true;
+    } else {
+      std::memset(psl + i * px, 0, sizeof(float) * px);
+    }
+    if (seed_r && seed_r[i]) {
+      std::memcpy(psr + i * px, seed_r[i], sizeof(float) * px);
+      any_sr = true;
+    } else {
+      std::memset(psr + i * px, 0, sizeof(float) * px);
+    }
+  }
+  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, n * px, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, n * px, hipMemcpyHostToDevice, h->stream));
+  if (any_sl) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
+  if (any_sr) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
+  if (int rc = pm_match_device(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
+                               any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
+    return rc;
+  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
+  if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(disp_l[i], pdl + i * px, sizeof(float) * px);
+    if (lr) std::memcpy(disp_r[i], pdr + i * px, sizeof(float) * px);
+  }
+  return PM_OK;
+}
+
+int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
+                const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
+                size_t disp_step) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right || !disp_l) {
+    set_err(h, "pm_match_u8: null image or output pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  const bool lr = h->params.left_right_check != 0;
+  if (lr && !disp_r) {
+    set_err(h, "pm_match_u8: disp_r required when left_right_check is set");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (image_step == 0) image_step = (size_t)cols;
+  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
+  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
+  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols ||
+      disp_step < sizeof(float) * (size_t)cols) {
+    set_err(h, "pm_match_u8: a row step is smaller than a row");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  const size_t px = (size_t)rows * cols;
+  float* psl = (float*)h->pinned;
+  float* psr = psl + px;
+  float* pdl = psr + px;
+  float* pdr = pdl + px;
+  uint8_t* pl = (uint8_t*)(pdr + px);
+  uint8_t* pr = pl + px;
+  for (int y = 0; y < rows; ++y) {
+    std::memcpy(pl + (size_t)y * cols, left + (size_t)y * image_step, (size_t)cols);
+    std::memcpy(pr + (size_t)y * cols, right + (size_t)y * image_step, (size_t)cols);
+    if (seed_l) std::memcpy(psl + (size_t)y * cols, (const char*)seed_l + (size_t)y * seed_step, sizeof(float) * cols);
+    if (seed_r) std::memcpy(psr + (size_t)y * cols, (const char*)seed_r + (size_t)y * seed_step, sizeof(float) * cols);
+  }
+  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, px, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, px, hipMemcpyHostToDevice, h->stream));
+  if (seed_l) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  if (seed_r) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  if (int rc = pm_match_device(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
+                               seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
+    return rc;
+  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  for (int y = 0; y < rows; ++y) {
+    std::memcpy((char*)disp_l + (size_t)y * disp_step, pdl + (size_t)y * cols, sizeof(float) * cols);
+    if (lr) std::memcpy((char*)disp_r + (size_t)y * disp_step, pdr + (size_t)y * cols, sizeof(float) * cols);
+  }
+  return PM_OK;
+}
+
+// ---- single stages ----------------------------------------------------------------------------
+
+namespace {
+
+// uploads a tightly packed pair into staging and runs prep for one pair / one view
+int stage_prep(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, PlaneSet* ps_out) {
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  const size_t px = (size_t)rows * cols;
+  PM_HIP(h, hipMemcpyAsync(h->st_left, left, px, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipMemcpyAsync(h->st_right, right ? right : left, px, hipMemcpyHostToDevice, h->stream));
+  const PlaneSet ps = plane_set(h, rows, cols, 1);
+  hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, h->st_left, h->st_right,
+                     (size_t)cols);
+  if (int rc = launch_check(h, "prep")) return rc;
+  *ps_out = ps;
+  return PM_OK;
+}
+
+int stage_disp_in(pm_handle* h, const PlaneSet& ps, const float* disp) {
+  const size_t px = (size_t)ps.rows * ps.cols;
+  PM_HIP(h, hipMemcpyAsync(h->st_disp_l, disp, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_copy_in, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, h->st_disp_l);
+  return launch_check(h, "copy_in");
+}
+
+int stage_out(pm_handle* h, const PlaneSet& ps, float* dst, int which) {
+  const size_t px = (size_t)ps.rows * ps.cols;
+  hipLaunchKernelGGL(k_copy_out, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, h->st_disp_l, which);
+  if (int rc = launch_check(h, "copy_out")) return rc;
+  PM_HIP(h, hipMemcpyAsync(dst, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
+}
+
+}  // namespace
+
+int pm_gradient_magnitude(pm_handle* h, const uint8_t* image, int rows, int cols, float* grad) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!image || !grad) {
+    set_err(h, "pm_gradient_magnitude: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  PlaneSet ps;
+  if (int rc = stage_prep(h, image, nullptr, rows, cols, &ps)) return rc;
+  return stage_out(h, ps, grad, 1);
+}
+
+int pm_unit_noise(pm_handle* h, int rows, int cols, float* noise) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!noise) {
+    set_err(h, "pm_unit_noise: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  return stage_out(h, plane_set(h, rows, cols, 1), noise, 2);
+}
+
+int pm_add_noise(pm_handle* h, float* disp, int rows, int cols, float amount) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!disp || !(amount >= 0.f)) {
+    set_err(h, "pm_add_noise: null pointer or negative amount");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  const PlaneSet ps = plane_set(h, rows, cols, 1);
+  if (int rc = stage_disp_in(h, ps, disp)) return rc;
+  CostParams cp = cost_params(h->params, 3, 3);
+  const Interior none{1, 0, 1, 0};  // empty: noise only, no clamp / cost
+  hipLaunchKernelGGL(k_noise_cost, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, none, amount);
+  if (int rc = launch_check(h, "noise")) return rc;
+  return stage_out(h, ps, disp, 0);
+}
+
+int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
+                 int patch_h, int patch_w, int pass_mask) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right || !disp) {
+    set_err(h, "pm_propagate: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (h->params.semantics == PM_SEM_CPU)
+    if (int rc = check_patch(h, patch_w, patch_h)) return rc;
+  PlaneSet ps;
+  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
+  if (int rc = stage_disp_in(h, ps, disp)) return rc;
+  const CostParams cp = cost_params(h->params, patch_w, patch_h);
+  const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
+  hipLaunchKernelGGL(k_noise_cost, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, in, -1.f);
+  if (int rc = launch_check(h, "cost")) return rc;
+  for (int k = 0; k < 4; ++k)
+    if (pass_mask & (1 << k))
+      if (int rc = run_sweep(h, ps, cp, sweep_geom(h->params, in, k), 1)) return rc;
+  return stage_out(h, ps, disp, 0);
+}
+
+int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
+                         int patch_h, int patch_w, float factor) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right || !disp || !(factor > 0.f)) {
+    set_err(h, "pm_remove_background: null pointer or non-positive factor");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (h->params.semantics == PM_SEM_CPU)
+    if (int rc = check_patch(h, patch_w, patch_h)) return rc;
+  PlaneSet ps;
+  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
+  if (int rc = stage_disp_in(h, ps, disp)) return rc;
+  const CostParams cp = cost_params(h->params, patch_w, patch_h);
+  const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
+  hipLaunchKernelGGL(k_background, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, in, factor, 0);
+  if (int rc = launch_check(h, "background")) return rc;
+  return stage_out(h, ps, disp, 0);
+}
+
+int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!disp_l || !disp_r) {
+    set_err(h, "pm_mask_occlusions: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  const size_t px = (size_t)rows * cols;
+  PM_HIP(h, hipMemcpyAsync(h->st_disp_l, disp_l, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipMemcpyAsync(h->st_disp_r, disp_r, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_mask_occlusions, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, h->st_disp_l,
+                     h->st_disp_r, rows, cols);
+  if (int rc = launch_check(h, "mask_occlusions")) return rc;
+  PM_HIP(h, hipMemcpyAsync(disp_l, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+
+int pm_profile_enable(pm_handle* h, int on) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  h->profiling = on != 0;
+  return PM_OK;
+}
+
+int pm_profile_read(pm_handle* h, pm_profile* out) {
+  if (!h || !out) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    const EventRec& r = h->ev_pool[i];
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      h->prof.launches[r.klass] += 1;
+      h->prof.total_ms[r.klass] += (double)ms;
+    }
+  }
+  h->ev_used = 0;
+  *out = h->prof;
+  std::memset(&h->prof, 0, sizeof(h->prof));
+  return PM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// pm_kernels.hpp -- gfx950 kernels of the PatchMatch stereo engine.
+// `file:line` citations are relative to the reference tree (/root/reference).
+#pragma once
+
+#include "pm_device.hpp"
+
+namespace pm {
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+// ---------------------------------------------------------------------------------------------
+// prep: u8 pair -> {L, R, mirrored L, mirrored R} as u8, Sobel magnitude as f32 and saturated u8.
+// Replaces upload+convertTo (patchmatch_gpu.cu:346-349), GradientMagnitude x2 (:351-352,
+// :307-319: Sobel x, Sobel y, magnitude = 3 passes per image) and the four cu::flip (:357-360)
+// with one pass: 2 B/px read, 4*(1+4+1) B/px written.
+// Sobel: kernels [-1 0 1]x[1 2 1]^T, unnormalised, BORDER_REFLECT_101 (OpenCV default); every
+// intermediate is an integer < 2^24, the only rounding is the correctly rounded sqrt.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return p;
+}
+
+__device__ __forceinline__ float sobel_mag(const uint8_t* im, size_t stride, int rows, int cols, int x, int y) {
+  const uint8_t* r0 = im + (size_t)reflect101(y - 1, rows) * stride;
+  const uint8_t* r1 = im + (size_t)y * stride;
+  const uint8_t* r2 = im + (size_t)reflect101(y + 1, rows) * stride;
+  const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+  const int dx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+  const int dy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
+  const float fx = (float)dx, fy = (float)dy;
+  const float sx = fx * fx, sy = fy * fy;
+  return __fsqrt_rn(sx + sy);
+}
+
+// in_left / in_right: [B][rows][in_stride] u8.  grid = (ceil(cols/256), rows, B).
+__global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __restrict__ in_left,
+                                              const uint8_t* __restrict__ in_right, size_t in_stride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= ps.cols) return;
+  const size_t in_plane = (size_t)ps.rows * in_stride;
+  const uint8_t* srcs[2] = {in_left + (size_t)b * in_plane, in_right + (size_t)b * in_plane};
+  const int xm = ps.cols - 1 - x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint8_t p = srcs[i][(size_t)y * in_stride + x];
+    const float g = sobel_mag(srcs[i], in_stride, ps.rows, ps.cols, x, y);
+    const uint8_t g8 = (uint8_t)sat_u8(g);
+    const size_t direct = ((size_t)b * 4 + i) * ps.plane + (size_t)y * ps.pitch + x;
+    const size_t mirror = ((size_t)b * 4 + 2 + i) * ps.plane + (size_t)y * ps.pitch + xm;
+    ps.img8[direct] = p;
+    ps.img8[mirror] = p;
+    ps.g32[direct] = g;
+    ps.g32[mirror] = g;
+    ps.g8[direct] = g8;
+    ps.g8[mirror] = g8;
+  }
+}
+
+// seed maps -> disparity planes; the right-view seed is mirrored like the images
+// (patchmatch_gpu.cu:362-366).  A null seed pointer means "all background".
+__global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restrict__ seed_l,
+                                              const float* __restrict__ seed_r, size_t seed_stride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= ps.cols) return;
+  const size_t sp = (size_t)ps.rows * seed_stride;
+  const size_t o = (size_t)y * ps.pitch + x;
+  ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
+  if (ps.n_views > 1)
+    ps.disp[((size_t)b * 2 + 1) * ps.plane + o] =
+        seed_r ? seed_r[(size_t)b * sp + (size_t)y * seed_stride + (ps.cols - 1 - x)] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise + clamp + cost of the current disparity, one lane per pixel.
+//   AddForegroundNoise (patchmatch_gpu.cu:298-304): d = max((d + s*U) * [d > 0], 0) -- four
+//   elementwise OpenCV-CUDA passes in the reference, fused here;
+//   == Patchmatch::AddNoise(disp, amount, disp > 0) (patchmatch.cpp:143-155, called at
+//   patchmatch_test.cpp:173-179): both add (int32)rng * amount * 2^-31 where d > 0 (amount is a
+//   power of two on every reference call site, so scaling the unit noise is exact).
+// Then, for the pixels the sweeps visit, PM_SEM_CPU applies the clamp of patchmatch.cpp:175 and
+// both semantics store cost(d) so that no sweep ever re-evaluates the cost of the current value.
+// amount < 0 skips the noise (used by the single-stage entry points).
+// grid = (ceil(cols/256), rows, slots).
+// ---------------------------------------------------------------------------------------------
+struct Interior {
+  int x_lo, x_hi, y_lo, y_hi;  // inclusive bounds of the pixels visited by the sweeps
+};
+
+__global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, Interior in, float amount) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, slot = blockIdx.z;
+  if (x >= ps.cols) return;
+  const View v = make_view(ps, slot);
+  const size_t o = (size_t)y * ps.pitch + x;
+  float d = v.disp[o];
+  if (amount >= 0.f) {
+    if (d > 0.f) {
+      const float m = ps.noise[o] * amount;
+      const float s = m + d;
+      d = s > 0.f ? s : 0.f;
+    } else {
+      d = 0.f;
+    }
+  }
+  if (x >= in.x_lo && x <= in.x_hi && y >= in.y_lo && y <= in.y_hi) {
+    float c;
+    if (cp.semantics == 0) {
+      const float hi = (float)x - (float)(cp.pw / 2);
+      d = d > 0.f ? d : 0.f;
+      d = d < hi ? d : hi;
+      c = cpu_cost_lane(v, ps.pitch, ps.cols, x, y, d, cp);
+    } else {
+      c = gpu_cost_lane(v, ps.pitch, x, y, fmaxf((float)x - d, 1.f), cp);
+    }
+    v.cost[o] = c;
+  }
+  v.disp[o] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Directional sweep, PM_ENGINE_SERIAL: one lane per chain (a row for axis 0, a column for axis 1),
+// strictly sequential along the chain -- the form whose equivalence with the reference loops
+// (patchmatch.cpp:264-310; patchmatch_gpu.cu:156-171, :214-229) is evident.  Used as the
+// on-device anchor for the faster engines, never for the benchmark.
+//   axis 0: chain index = row y in [c_lo, c_hi], steps x from s_first to s_last (step dir)
+//   axis 1: chain index = column x,              steps y
+// The predecessor value is read once before the first step (a border or not-yet-visited pixel,
+// which this sweep never writes) and then carried in a register.
+// grid = (ceil(chains/64), 1, slots), block = 64.
+// ---------------------------------------------------------------------------------------------
+struct SweepGeom {
+  int axis;           // 0 = along a row, 1 = along a column
+  int dir;            // +1 / -1
+  int c_lo, c_hi;     // chains (inclusive)
+  int s_first, s_last;  // first and last visited position along the chain (inclusive)
+};
+
+__global__ void __launch_bounds__(64) k_sweep_serial(PlaneSet ps, CostParams cp, SweepGeom g) {
+  const int chain = g.c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = blockIdx.z;
+  if (chain > g.c_hi) return;
+  const View v = make_view(ps, slot);
+  const int half_w = cp.semantics == 0 ? cp.pw / 2 : 1;
+  const int n = (g.s_last - g.s_first) * g.dir + 1;
+  if (n <= 0) return;
+  int x = g.axis == 0 ? g.s_first - g.dir : chain;
+  int y = g.axis == 0 ? chain : g.s_first - g.dir;
+  float prev = v.disp[(size_t)y * ps.pitch + x];
+  for (int s = 0; s < n; ++s) {
+    if (g.axis == 0) x += g.dir; else y += g.dir;
+    const size_t o = (size_t)y * ps.pitch + x;
+    const float d0 = v.disp[o];
+    const float c0 = v.cost[o];
+    float nd = d0, nc = c0;
+    const bool changed = sweep_step(cp.semantics, x, half_w, d0, c0, prev, nd, nc, [&](float arg) {
+      return cp.semantics == 0 ? cpu_cost_lane(v, ps.pitch, ps.cols, x, y, arg, cp)
+                               : gpu_cost_lane(v, ps.pitch, x, y, arg, cp);
+    });
+    if (changed) {
+      v.disp[o] = nd;
+      v.cost[o] = nc;
+    }
+    prev = nd;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Background mask, one lane per pixel.
+//   PM_SEM_CPU  RemoveBackground (patchmatch.cpp:314-360): d0 = clamp(d); zero d if
+//               cost(d0) > cost(0) / win_by_factor.  cost(d0) comes from the cost plane when the
+//               window is the one the last sweeps used and d is already inside the clamp.
+//   PM_SEM_GPU  MaskBackground (patchmatch_gpu.cu:233-270): zero d unless cost(d) < f * cost(0).
+// `cached` != 0: ps.cost holds cost(d) for this window.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_background(PlaneSet ps, CostParams cp, Interior in, float factor, int cached) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, slot = blockIdx.z;
+  if (x < in.x_lo || x > in.x_hi || y < in.y_lo || y > in.y_hi) return;
+  const View v = make_view(ps, slot);
+  const size_t o = (size_t)y * ps.pitch + x;
+  const float d = v.disp[o];
+  if (cp.semantics == 0) {
+    const float hi = (float)x - (float)(cp.pw / 2);
+    float d0 = d > 0.f ? d : 0.f;
+    d0 = d0 < hi ? d0 : hi;
+    const float c = (cached && d0 == d) ? v.cost[o] : cpu_cost_lane(v, ps.pitch, ps.cols, x, y, d0, cp);
+    const float c_bg = cpu_cost_lane(v, ps.pitch, ps.cols, x, y, 0.f, cp);
+    const float thr = c_bg / factor;
+    if (c > thr) v.disp[o] = 0.f;
+  } else {
+    const float cost0 = gpu_cost_lane(v, ps.pitch, x, y, (float)x, cp);
+    const float cost1 = cached ? v.cost[o] : gpu_cost_lane(v, ps.pitch, x, y, fmaxf((float)x - d, 1.f), cp);
+    const float thr = factor * cost0;
+    if (!(cost1 < thr)) v.disp[o] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: un-mirror the right view (cu::flip, patchmatch_gpu.cu:368) and MaskOcclusions
+// (:273-295) fused with the copy into the caller's tightly packed outputs.
+//   dr = dispr(y, (int)max(x - dl, 0));  zero dl if dr > 1.4*dl || dr < 0.7*dl  (double compare)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_finalize(PlaneSet ps, float* __restrict__ out_l, float* __restrict__ out_r,
+                                                  size_t out_stride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= ps.cols) return;
+  const size_t op = (size_t)ps.rows * out_stride;
+  const float* dl_plane = ps.disp + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
+  float dl = dl_plane[x];
+  if (ps.n_views > 1) {
+    const float* dr_plane = ps.disp + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
+    const int xr = (int)fmaxf((float)x - dl, 0.f);
+    const float dr = dr_plane[ps.cols - 1 - xr];
+    if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) dl = 0.f;
+    if (out_r) out_r[(size_t)b * op + (size_t)y * out_stride + x] = dr_plane[ps.cols - 1 - x];
+  }
+  out_l[(size_t)b * op + (size_t)y * out_stride + x] = dl;
+}
+
+// Stand-alone MaskOcclusions on caller planes (single-stage entry point).
+__global__ void __launch_bounds__(256) k_mask_occlusions(float* __restrict__ displ, const float* __restrict__ dispr,
+                                                         int rows, int cols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols || y >= rows) return;
+  const float dl = displ[(size_t)y * cols + x];
+  const int xr = (int)fmaxf((float)x - dl, 0.f);
+  const float dr = dispr[(size_t)y * cols + xr];
+  if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) displ[(size_t)y * cols + x] = 0.f;
+}
+
+// Plain copies between tightly packed caller planes and the pitched disparity plane of view 0.
+__global__ void __launch_bounds__(256) k_copy_in(PlaneSet ps, const float* __restrict__ src) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ps.cols) return;
+  ps.disp[(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
+}
+__global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict__ dst, int which) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ps.cols) return;
+  const float* src = which == 0 ? ps.disp : (which == 1 ? ps.g32 : ps.noise);
+  dst[(size_t)y * ps.cols + x] = src[(size_t)y * ps.pitch + x];
+}
+
+}  // namespace pm

@@ -1,0 +1,99 @@
+// patchmatch_gpu.cpp -- bm::pm::PatchmatchGpu over the C ABI (see patchmatch_gpu.hpp).
+#include "patchmatch_gpu.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace bm {
+namespace pm {
+
+pm_params PatchmatchGpu::Params::ToC() const {
+  pm_params p;
+  pm_params_default(&p, semantics);
+  p.cost_alpha = cost_alpha;
+  p.patchmatch_iters = patchmatch_iters;
+  p.init_dilate_factor = init_dilate_factor;
+  p.cost_improve_factor = cost_improve_factor;
+  p.engine = engine;
+  for (int i = 0; i < PM_MAX_ITERS; ++i) {
+    p.patch_w[i] = patch_size;
+    p.patch_h[i] = patch_size;
+  }
+  p.bg_patch_w = patch_size;
+  p.bg_patch_h = patch_size;
+  p.left_right_check = left_right_check ? 1 : 0;
+  return p;
+}
+
+PatchmatchGpu::PatchmatchGpu(const Params& params) : params_(params) {
+  if (params_.max_rows > 0 && params_.max_cols > 0) EnsurePlan(params_.max_rows, params_.max_cols);
+}
+
+PatchmatchGpu::~PatchmatchGpu() { pm_destroy(handle_); }
+
+void PatchmatchGpu::Check(int status, const char* what) const {
+  if (status == PM_OK) return;
+  std::string msg = std::string(what) + ": " + pm_status_string(status);
+  if (handle_) msg += std::string(" -- ") + pm_last_error(handle_);
+  throw std::runtime_error(msg);
+}
+
+// The reference allocates its GpuMats lazily on the first Match and never resizes the noise image
+// (patchmatch_gpu.cu:339-344); here a size that exceeds the plan re-plans explicitly.
+void PatchmatchGpu::EnsurePlan(int rows, int cols) {
+  if (handle_ && rows <= plan_rows_ && cols <= plan_cols_) return;
+  if (handle_) {
+    pm_destroy(handle_);
+    handle_ = nullptr;
+  }
+  const pm_params p = params_.ToC();
+  const int rc = pm_create(&p, params_.device, rows, cols, params_.max_batch < 1 ? 1 : params_.max_batch, &handle_);
+  if (rc != PM_OK) {
+    std::string msg = std::string("pm_create: ") + pm_status_string(rc);
+    if (handle_) msg += std::string(" -- ") + pm_last_error(handle_);
+    pm_destroy(handle_);
+    handle_ = nullptr;
+    throw std::runtime_error(msg);
+  }
+  plan_rows_ = rows;
+  plan_cols_ = cols;
+}
+
+void PatchmatchGpu::SetSeeds(const Image1f& seed_l, const Image1f& seed_r) {
+  seed_l_ = seed_l;
+  seed_r_ = seed_r;
+}
+
+void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
+    throw std::invalid_argument("PatchmatchGpu::Match: images empty or of different size");
+  if (!seed_l_.empty() && (seed_l_.rows != iml.rows || seed_l_.cols != iml.cols))
+    throw std::invalid_argument("PatchmatchGpu::Match: left seed map does not match the image size");
+  if (!seed_r_.empty() && (seed_r_.rows != iml.rows || seed_r_.cols != iml.cols))
+    throw std::invalid_argument("PatchmatchGpu::Match: right seed map does not match the image size");
+  EnsurePlan(iml.rows, iml.cols);
+  // like GpuMat::download (patchmatch_gpu.cu:374-375) the outputs are (re)allocated to the image size
+  if (disp.rows != iml.rows || disp.cols != iml.cols) disp.create(iml.rows, iml.cols);
+  if (dispr.rows != iml.rows || dispr.cols != iml.cols) dispr.create(iml.rows, iml.cols);
+  Check(pm_match_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
+                    seed_l_.empty() ? nullptr : seed_l_.data(), seed_r_.empty() ? nullptr : seed_r_.data(), 0,
+                    disp.data(), dispr.data(), disp.step),
+        "pm_match_u8");
+}
+
+void PatchmatchGpu::Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, int cols, const float* d_seed_l,
+                          const float* d_seed_r, float* d_disp, float* d_dispr) {
+  EnsurePlan(rows, cols);
+  Check(pm_match_device(handle_, 1, d_iml, d_imr, rows, cols, d_seed_l, d_seed_r, d_disp, d_dispr),
+        "pm_match_device");
+  Check(pm_synchronize(handle_), "pm_synchronize");
+}
+
+Image1f PatchmatchGpu::SparseInit(const Image1b&, const Image1b&, int) {
+  throw std::logic_error(
+      "PatchmatchGpu::SparseInit: the GFTT + template-match seeder is not part of this build; "
+      "provide seed maps through SetSeeds()");
+}
+
+}  // namespace pm
+}  // namespace bm

@@ -1,0 +1,165 @@
+// patchmatch_gpu.hpp -- host-side C++ mirror of the reference's bm::pm::PatchmatchGpu
+// (src/vehicle/patchmatch_gpu/patchmatch_gpu.h:77-124) on top of the C ABI in pm/patchmatch.h.
+//
+// Same namespace, class name, Params field names / defaults and Match() signatures, so a caller
+// written against the reference (test/stereo_matching/patchmatch_gpu_test.cpp:68-88) compiles
+// against this header after swapping the include.  No HIP header is included here: host code is
+// plain C++17 and reaches the device only through the C ABI.
+//
+// Image types: the reference's Image1b / Image1f are cv::Mat_<uchar> / cv::Mat_<float>
+// (src/vehicle/vision_core/cv_types.hpp:8-12).  OpenCV is not a dependency of this library; the
+// minimal bm::core::Image<T> below carries the members the path uses (rows, cols, step, ptr(),
+// at(), empty(), create()).  When <opencv2/core.hpp> is available, the template overloads of
+// Match() accept cv::Mat_ directly (anything with rows/cols/step/data).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pm/patchmatch.h"
+
+namespace bm {
+namespace core {
+
+template <typename T>
+class Image {
+ public:
+  int rows = 0, cols = 0;
+  size_t step = 0;  // bytes per row, as cv::Mat::step
+
+  Image() = default;
+  Image(int rows_, int cols_, T value = T()) { create(rows_, cols_, value); }
+
+  void create(int rows_, int cols_, T value = T()) {
+    rows = rows_;
+    cols = cols_;
+    step = sizeof(T) * (size_t)cols_;
+    storage_.assign((size_t)rows_ * cols_, value);
+  }
+  bool empty() const { return storage_.empty(); }
+  T* ptr(int r = 0) { return storage_.data() + (size_t)r * cols; }
+  const T* ptr(int r = 0) const { return storage_.data() + (size_t)r * cols; }
+  T& at(int r, int c) { return storage_[(size_t)r * cols + c]; }
+  const T& at(int r, int c) const { return storage_[(size_t)r * cols + c]; }
+  T* data() { return storage_.data(); }
+  const T* data() const { return storage_.data(); }
+
+ private:
+  std::vector<T> storage_;
+};
+
+typedef Image<uint8_t> Image1b;
+typedef Image<float> Image1f;
+
+}  // namespace core
+
+namespace ft {
+
+// Field names and defaults of ft::FeatureDetector::Params
+// (src/vehicle/feature_tracking/feature_detector.hpp:22-47) and ft::StereoMatcher::Params
+// (src/vehicle/feature_tracking/stereo_matcher.hpp:17-29): the configuration of the sparse seeder.
+struct FeatureDetectorParams {
+  int max_features_per_frame = 200;
+  int min_distance_btw_tracked_and_detected_features = 20;
+  double gftt_quality_level = 0.01;
+  int gftt_block_size = 5;
+  bool gftt_use_harris_corner_detector = false;
+  double gftt_k = 0.04;
+  bool subpixel_corners = false;
+  int subpix_winsize = 10;
+  int subpix_zerozone = -1;
+  int subpix_maxiters = 10;
+  float subpix_epsilon = 0.01f;
+};
+
+struct StereoMatcherParams {
+  int templ_cols = 31;
+  int templ_rows = 11;
+  int max_disp = 128;
+  double max_matching_cost = 0.15;
+  bool bidirectional = false;
+  bool subpixel_refinement = false;
+};
+
+}  // namespace ft
+
+namespace pm {
+
+using core::Image1b;
+using core::Image1f;
+
+class PatchmatchGpu final {
+ public:
+  struct Params final {
+    // --- reference fields (patchmatch_gpu.h:82-88) ---
+    ft::FeatureDetectorParams detector_params;
+    ft::StereoMatcherParams matcher_params;
+    float cost_alpha = 0.9f;
+    int patchmatch_iters = 3;
+    int init_dilate_factor = 4;
+    float cost_improve_factor = 0.8f;
+
+    // --- engine fields (pm_params) ---
+    int semantics = PM_SEM_GPU;  // which reference code is reproduced; PM_SEM_CPU = stereo_matching/patchmatch.cpp
+    int engine = PM_ENGINE_AUTO;
+    int patch_size = 3;          // PM_SEM_CPU window side for every iteration and the background mask
+    bool left_right_check = true;
+    int device = 0;
+    int max_rows = 0, max_cols = 0;  // 0: plan on the first Match()
+    int max_batch = 1;
+
+    // Fills a pm_params from these fields.
+    pm_params ToC() const;
+  };
+
+  PatchmatchGpu(const PatchmatchGpu&) = delete;
+  PatchmatchGpu& operator=(const PatchmatchGpu&) = delete;
+
+  explicit PatchmatchGpu(const Params& params);
+  ~PatchmatchGpu();
+
+  // patchmatch_gpu.h:99-102.  Seeds come from SetSeeds() (explicit input at this boundary);
+  // without seeds every pixel starts as background, as when the reference's seeder finds no match.
+  void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr);
+
+  // patchmatch_gpu.h:104-108 widened to a device-resident pair: raw device pointers to tightly
+  // packed planes.  Gl/Gr of the reference are computed inside the engine.
+  void Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, int cols, const float* d_seed_l,
+             const float* d_seed_r, float* d_disp, float* d_dispr);
+
+  // The sparse-init maps Match() starts from (what SparseInit returns, patchmatch_gpu.cu:414-442):
+  // left-image and right-image coordinates.  Kept until replaced; pass empty images to clear.
+  void SetSeeds(const Image1f& seed_l, const Image1f& seed_r);
+
+  // patchmatch_gpu.h:110-112 -- the GFTT + template-matching seeder needs OpenCV's detector; it is
+  // the next row of the scope table and not part of this build yet.
+  Image1f SparseInit(const Image1b& iml, const Image1b& imr, int dilate_factor);
+
+  // Anything that looks like a cv::Mat_ (rows, cols, step, data).
+  template <typename MatB, typename MatF>
+  void MatchMat(const MatB& iml, const MatB& imr, MatF& disp, MatF& dispr) {
+    EnsurePlan(iml.rows, iml.cols);
+    Check(pm_match_u8(handle_, (const uint8_t*)iml.data, (const uint8_t*)imr.data, iml.rows, iml.cols,
+                      (size_t)iml.step, seed_l_.empty() ? nullptr : seed_l_.data(),
+                      seed_r_.empty() ? nullptr : seed_r_.data(), 0, (float*)disp.data, (float*)dispr.data,
+                      (size_t)disp.step),
+          "pm_match_u8");
+  }
+
+  pm_handle* handle() { return handle_; }
+
+ private:
+  void EnsurePlan(int rows, int cols);
+  void Check(int status, const char* what) const;
+
+  Params params_;
+  pm_handle* handle_ = nullptr;
+  int plan_rows_ = 0, plan_cols_ = 0;
+  Image1f seed_l_, seed_r_;
+};
+
+}  // namespace pm
+}  // namespace bm

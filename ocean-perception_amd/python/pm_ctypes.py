@@ -1,0 +1,300 @@
+"""ctypes binding of the C ABI in include/pm/patchmatch.h (libvehicle_pm_gpu.so).
+
+This is the Python-side stub a maintainer would add to call the engine; tests/ and bench.py go
+through it, so every GPU test exercises the C ABI itself.  There is no fallback of any kind: if the
+library is missing the import fails, and without a HIP device pm_create raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PM_ABI_VERSION = 1
+PM_MAX_ITERS = 16
+PM_MAX_PATCH = 15
+PM_SEM_CPU, PM_SEM_GPU = 0, 1
+PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE = 0, 1, 2
+PM_OK = 0
+PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM = -1, -2, -3, -4, -5
+PM_K_COUNT = 7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libvehicle_pm_gpu.so"))
+
+# every symbol include/pm/patchmatch.h declares
+EXPORTS = [
+    "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
+    "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
+    "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
+    "pm_remove_background", "pm_mask_occlusions", "pm_profile_enable", "pm_profile_read",
+    "pm_kernel_name",
+]
+
+
+class PmParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("abi_version", C.c_uint32),
+        ("cost_alpha", C.c_float),
+        ("patchmatch_iters", C.c_int),
+        ("init_dilate_factor", C.c_int),
+        ("cost_improve_factor", C.c_float),
+        ("semantics", C.c_int),
+        ("engine", C.c_int),
+        ("noise_amp", C.c_float * PM_MAX_ITERS),
+        ("patch_w", C.c_int * PM_MAX_ITERS),
+        ("patch_h", C.c_int * PM_MAX_ITERS),
+        ("bg_patch_w", C.c_int),
+        ("bg_patch_h", C.c_int),
+        ("win_by_factor", C.c_float),
+        ("functor_alpha", C.c_float),
+        ("functor_tau_color", C.c_float),
+        ("functor_tau_grad", C.c_float),
+        ("noise_seed", C.c_uint64),
+        ("left_right_check", C.c_int),
+    ]
+
+
+class PmProfile(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * PM_K_COUNT), ("total_ms", C.c_double * PM_K_COUNT)]
+
+
+class PmError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({detail})")
+
+
+_lib = None
+
+
+def load():
+    """dlopen the engine (cached).  Raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    lib = C.CDLL(LIB_PATH)
+    u8p, f32p, vp = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.pm_params_default.argtypes = [C.POINTER(PmParams), C.c_int]
+    lib.pm_params_default.restype = None
+    lib.pm_create.argtypes = [C.POINTER(PmParams), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pm_create.restype = C.c_int
+    lib.pm_destroy.argtypes = [vp]
+    lib.pm_destroy.restype = None
+    lib.pm_last_error.argtypes = [vp]
+    lib.pm_last_error.restype = C.c_char_p
+    lib.pm_status_string.argtypes = [C.c_int]
+    lib.pm_status_string.restype = C.c_char_p
+    lib.pm_match_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t, f32p, f32p, C.c_size_t, f32p, f32p,
+                                C.c_size_t]
+    lib.pm_match_u8.restype = C.c_int
+    lib.pm_match_batch_u8.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp),
+                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.pm_match_batch_u8.restype = C.c_int
+    lib.pm_match_device.argtypes = [vp, C.c_int, u8p, u8p, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+    lib.pm_match_device.restype = C.c_int
+    lib.pm_synchronize.argtypes = [vp]
+    lib.pm_synchronize.restype = C.c_int
+    lib.pm_stream.argtypes = [vp]
+    lib.pm_stream.restype = C.c_void_p
+    lib.pm_gradient_magnitude.argtypes = [vp, u8p, C.c_int, C.c_int, f32p]
+    lib.pm_gradient_magnitude.restype = C.c_int
+    lib.pm_unit_noise.argtypes = [vp, C.c_int, C.c_int, f32p]
+    lib.pm_unit_noise.restype = C.c_int
+    lib.pm_add_noise.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_float]
+    lib.pm_add_noise.restype = C.c_int
+    lib.pm_propagate.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
+    lib.pm_propagate.restype = C.c_int
+    lib.pm_remove_background.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_float]
+    lib.pm_remove_background.restype = C.c_int
+    lib.pm_mask_occlusions.argtypes = [vp, f32p, f32p, C.c_int, C.c_int]
+    lib.pm_mask_occlusions.restype = C.c_int
+    lib.pm_profile_enable.argtypes = [vp, C.c_int]
+    lib.pm_profile_enable.restype = C.c_int
+    lib.pm_profile_read.argtypes = [vp, C.POINTER(PmProfile)]
+    lib.pm_profile_read.restype = C.c_int
+    lib.pm_kernel_name.argtypes = [C.c_int]
+    lib.pm_kernel_name.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def default_params(semantics=PM_SEM_CPU, **kw):
+    """pm_params_default + keyword overrides.  `patch` sets every per-iteration and background
+    window; `noise_amp` / `patch_w` / `patch_h` accept sequences."""
+    p = PmParams()
+    load().pm_params_default(C.byref(p), semantics)
+    patch = kw.pop("patch", None)
+    if patch is not None:
+        for i in range(PM_MAX_ITERS):
+            p.patch_w[i] = patch
+            p.patch_h[i] = patch
+        p.bg_patch_w = patch
+        p.bg_patch_h = patch
+    for k, v in kw.items():
+        if k in ("noise_amp", "patch_w", "patch_h"):
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+    return p
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One pm_handle.  Methods mirror the C entry points; numpy arrays in, numpy arrays out."""
+
+    def __init__(self, params=None, device=0, max_rows=720, max_cols=1280, max_batch=1):
+        self.lib = load()
+        self.params = params if params is not None else default_params()
+        self.h = C.c_void_p()
+        rc = self.lib.pm_create(C.byref(self.params), device, max_rows, max_cols, max_batch, C.byref(self.h))
+        if rc != PM_OK:
+            detail = self.lib.pm_last_error(self.h).decode() if self.h else ""
+            status = self.lib.pm_status_string(rc).decode()
+            if self.h:
+                self.lib.pm_destroy(self.h)
+                self.h = C.c_void_p()
+            raise PmError(rc, "pm_create", f"{status}: {detail}")
+
+    def close(self):
+        if self.h:
+            self.lib.pm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != PM_OK:
+            raise PmError(rc, what, self.lib.pm_last_error(self.h).decode())
+
+    # --- whole path -----------------------------------------------------------------------------
+    def match(self, left, right, seed_l=None, seed_r=None):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        rows, cols = left.shape
+        sl = sr = None
+        psl = psr = None
+        if seed_l is not None:
+            sl, psl = _f32(seed_l)
+        if seed_r is not None:
+            sr, psr = _f32(seed_r)
+        dl = np.empty((rows, cols), np.float32)
+        dr = np.empty((rows, cols), np.float32)
+        lr = bool(self.params.left_right_check)
+        self._check(self.lib.pm_match_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, dl.ctypes.data_as(C.c_void_p),
+                                         dr.ctypes.data_as(C.c_void_p) if lr else None, 0), "pm_match_u8")
+        return (dl, dr) if lr else (dl, None)
+
+    def match_batch(self, lefts, rights, seeds_l=None, seeds_r=None):
+        n = len(lefts)
+        keep = []
+
+        def arr(items, conv):
+            out = (C.c_void_p * n)()
+            for i, it in enumerate(items):
+                if it is None:
+                    out[i] = None
+                else:
+                    a, p = conv(it)
+                    keep.append(a)
+                    out[i] = p
+            return out
+
+        rows, cols = np.asarray(lefts[0]).shape
+        pl, pr = arr(lefts, _u8), arr(rights, _u8)
+        psl = arr(seeds_l, _f32) if seeds_l is not None else None
+        psr = arr(seeds_r, _f32) if seeds_r is not None else None
+        dls = [np.empty((rows, cols), np.float32) for _ in range(n)]
+        drs = [np.empty((rows, cols), np.float32) for _ in range(n)]
+        pdl, pdr = arr(dls, _f32), arr(drs, _f32)
+        lr = bool(self.params.left_right_check)
+        self._check(self.lib.pm_match_batch_u8(self.h, n, pl, pr, rows, cols, psl, psr, pdl, pdr if lr else None),
+                    "pm_match_batch_u8")
+        return dls, (drs if lr else None)
+
+    def match_device(self, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
+        """All arguments are raw device addresses (ints)."""
+        self._check(self.lib.pm_match_device(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
+                                             d_disp_r), "pm_match_device")
+
+    def synchronize(self):
+        self._check(self.lib.pm_synchronize(self.h), "pm_synchronize")
+
+    def stream(self):
+        return self.lib.pm_stream(self.h)
+
+    # --- single stages --------------------------------------------------------------------------
+    def gradient_magnitude(self, image):
+        image, p = _u8(image)
+        g = np.empty(image.shape, np.float32)
+        self._check(self.lib.pm_gradient_magnitude(self.h, p, image.shape[0], image.shape[1],
+                                                   g.ctypes.data_as(C.c_void_p)), "pm_gradient_magnitude")
+        return g
+
+    def unit_noise(self, rows, cols):
+        n = np.empty((rows, cols), np.float32)
+        self._check(self.lib.pm_unit_noise(self.h, rows, cols, n.ctypes.data_as(C.c_void_p)), "pm_unit_noise")
+        return n
+
+    def add_noise(self, disp, amount):
+        d = np.array(disp, dtype=np.float32, order="C", copy=True)
+        self._check(self.lib.pm_add_noise(self.h, d.ctypes.data_as(C.c_void_p), d.shape[0], d.shape[1], amount),
+                    "pm_add_noise")
+        return d
+
+    def propagate(self, left, right, disp, patch_h, patch_w, pass_mask=15):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        d = np.array(disp, dtype=np.float32, order="C", copy=True)
+        self._check(self.lib.pm_propagate(self.h, pl, pr, d.shape[0], d.shape[1], d.ctypes.data_as(C.c_void_p),
+                                          patch_h, patch_w, pass_mask), "pm_propagate")
+        return d
+
+    def remove_background(self, left, right, disp, patch_h, patch_w, factor):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        d = np.array(disp, dtype=np.float32, order="C", copy=True)
+        self._check(self.lib.pm_remove_background(self.h, pl, pr, d.shape[0], d.shape[1],
+                                                  d.ctypes.data_as(C.c_void_p), patch_h, patch_w, factor),
+                    "pm_remove_background")
+        return d
+
+    def mask_occlusions(self, disp_l, disp_r):
+        dl = np.array(disp_l, dtype=np.float32, order="C", copy=True)
+        dr, pdr = _f32(disp_r)
+        self._check(self.lib.pm_mask_occlusions(self.h, dl.ctypes.data_as(C.c_void_p), pdr, dl.shape[0],
+                                                dl.shape[1]), "pm_mask_occlusions")
+        return dl
+
+    # --- profiling ------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.pm_profile_enable(self.h, 1 if on else 0), "pm_profile_enable")
+
+    def profile_read(self):
+        prof = PmProfile()
+        self._check(self.lib.pm_profile_read(self.h, C.byref(prof)), "pm_profile_read")
+        return {self.lib.pm_kernel_name(k).decode(): (int(prof.launches[k]), float(prof.total_ms[k]))
+                for k in range(PM_K_COUNT)}

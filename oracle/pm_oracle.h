@@ -1,0 +1,151 @@
+/*
+ * pm_oracle.h -- CPU restatement of the reference PatchMatch stereo path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: it may be
+ * imported / linked / executed only by tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py, and there only as the checker or the reported
+ * CPU baseline.  The product path (ocean-perception_amd/, include/) never calls it.
+ *
+ * PARITY UNPINNED.  The reference's tests for this path hold no assertions and no
+ * golden vectors (test/stereo_matching/patchmatch_test.cpp, patchmatch_gpu_test.cpp:
+ * imshow demos only), the reference cannot be compiled here (needs OpenCV 3.4.0 EXACT,
+ * glog, Eigen, Boost, CUDA -- none present), and every arithmetic primitive of the path
+ * lives in OpenCV 3.4.0 (CMakeLists.txt:28), which is not vendored.  This file restates
+ * the reference's own code line by line and OpenCV 3.4's published algorithms
+ * (getRectSubPix, Sobel, dilate, RNG, mean, saturate_cast) as documented per function;
+ * it is pinned only by hand-computed known-answer tests and by an independent numpy
+ * restatement (tests/pyref.py).  Floating point is evaluated without FMA contraction
+ * (-ffp-contract=off), one IEEE-754 binary32 rounding per operation.
+ *
+ * Two semantics are restated:
+ *   PMO_SEM_CPU  src/vehicle/stereo_matching/patchmatch.cpp + the cost functor and
+ *                recipe of test/stereo_matching/patchmatch_test.cpp  (the parity target)
+ *   PMO_SEM_GPU  src/vehicle/patchmatch_gpu/patchmatch_gpu.cu kernels, executed
+ *                race-free as ONE stripe per row/column (the reference's 16 overlapping
+ *                stripes race).
+ */
+#ifndef PM_ORACLE_H_
+#define PM_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMO_MAX_ITERS 16
+
+enum { PMO_SEM_CPU = 0, PMO_SEM_GPU = 1 };
+
+/* One rectified view pair, all planes contiguous rows*cols. */
+typedef struct pmo_images {
+  int rows, cols;
+  const uint8_t* il;  /* reference ("left") image  */
+  const uint8_t* ir;  /* target ("right") image    */
+  const float* gl;    /* gradient magnitude of il  */
+  const float* gr;    /* gradient magnitude of ir  */
+} pmo_images;
+
+/* Constants of L1GradientCostFunction, test/stereo_matching/patchmatch_test.cpp:30-45. */
+typedef struct pmo_functor {
+  float alpha;      /* 0.7 */
+  float tau_color;  /* 50  */
+  float tau_grad;   /* 20  */
+} pmo_functor;
+
+typedef struct pmo_params {
+  int semantics;                   /* PMO_SEM_CPU / PMO_SEM_GPU */
+  int n_iters;                     /* PatchmatchGpu::Params::patchmatch_iters */
+  float noise_amp[PMO_MAX_ITERS];  /* per-iteration noise amplitude */
+  int patch_w[PMO_MAX_ITERS];      /* per-iteration window (SEM_CPU); SEM_GPU: always the 5-tap 3x3 */
+  int patch_h[PMO_MAX_ITERS];
+  int bg_patch_w, bg_patch_h;      /* RemoveBackground window (SEM_CPU) */
+  float bg_factor;                 /* SEM_CPU: win_by_factor; SEM_GPU: cost_improve_factor */
+  float cost_alpha;                /* SEM_GPU: PatchmatchGpu::Params::cost_alpha */
+  pmo_functor functor;             /* SEM_CPU */
+  uint64_t noise_seed;             /* 123 */
+  int left_right_check;            /* run the right view + MaskOcclusions */
+  int literal;                     /* SEM_CPU: 1 = via getRectSubPix patches + functor (the reference's
+                                      call structure), 0 = fused direct formula (same results) */
+  int nthreads;                    /* rows/columns of a sweep are independent -> exact with any count */
+} pmo_params;
+
+void pmo_params_default(pmo_params* p, int semantics);
+
+/* ---- OpenCV 3.4 primitives (restated) ------------------------------------------------ */
+
+/* cv::RNG(seed) then RNG::fill(mat, UNIFORM, lo, hi) on a continuous CV_32F matrix. */
+void pmo_rng_fill_uniform(float* dst, size_t n, double lo, double hi, uint64_t seed);
+/* first n raw 32-bit outputs of cv::RNG(seed) (KATs). */
+void pmo_rng_raw(uint32_t* dst, size_t n, uint64_t seed);
+
+/* ComputeGradient (patchmatch_test.cpp:48-64) == GradientMagnitude (patchmatch_gpu.cu:307-319). */
+void pmo_gradient_magnitude(const uint8_t* im, int rows, int cols, float* g);
+
+/* cv::dilate with a (2k+1)x(2k+1) MORPH_RECT, anchor (k,k). */
+void pmo_dilate_rect(const float* src, float* dst, int rows, int cols, int k);
+
+/* cv::getRectSubPix, 8u->8u and 32f->32f, single channel. */
+void pmo_get_rect_subpix_u8(const uint8_t* src, int rows, int cols, int pw, int ph,
+                            float cx, float cy, uint8_t* dst);
+void pmo_get_rect_subpix_f32(const float* src, int rows, int cols, int pw, int ph,
+                             float cx, float cy, float* dst);
+
+void pmo_flip_h_u8(const uint8_t* src, uint8_t* dst, int rows, int cols);
+void pmo_flip_h_f32(const float* src, float* dst, int rows, int cols);
+
+/* ---- SEM_CPU: stereo_matching/patchmatch.cpp ------------------------------------------ */
+
+/* L1GradientCostFunction on extracted patches (n = pw*ph); gl/gr are the f32 patches,
+ * saturate-cast to u8 inside as the reference's implicit Image1f->Image1b conversion does. */
+float pmo_cpu_functor(const uint8_t* pl, const uint8_t* pr, const float* gl, const float* gr,
+                      int n, const pmo_functor* f);
+/* cost of disparity d at integer pixel (x,y): literal (patches) and direct (fused). */
+float pmo_cpu_cost_literal(const pmo_images* im, int pw, int ph, float x, float y, float d,
+                           const pmo_functor* f);
+float pmo_cpu_cost_direct(const pmo_images* im, int pw, int ph, int x, int y, float d,
+                          const pmo_functor* f);
+
+/* Patchmatch::AddNoise (patchmatch.cpp:143-155); mask may be NULL. */
+void pmo_cpu_add_noise(float* disp, int rows, int cols, float amount, const uint8_t* mask,
+                       uint64_t seed);
+/* Patchmatch::Propagate (patchmatch.cpp:248-311); pass_mask bit0..3 = passes A..D. */
+void pmo_cpu_propagate(const pmo_images* im, float* disp, int ph, int pw, const pmo_functor* f,
+                       int pass_mask, int literal, int nthreads);
+/* Patchmatch::RemoveBackground (patchmatch.cpp:314-360). */
+void pmo_cpu_remove_background(const pmo_images* im, float* disp, int ph, int pw,
+                               const pmo_functor* f, float win_by_factor, int literal,
+                               int nthreads);
+
+/* ---- SEM_GPU: patchmatch_gpu/patchmatch_gpu.cu ----------------------------------------- */
+
+float pmo_gpu_get_subpixel(const float* im, int rows, int cols, float row, float col);
+float pmo_gpu_cost5(const pmo_images* im, int yl, int xl, float yr, float xr, float alpha);
+void pmo_gpu_add_foreground_noise(float* disp, const float* unit_noise, size_t n, float scale);
+void pmo_gpu_propagate_row(const pmo_images* im, float* disp, int direction, int patch_size,
+                           float alpha, int nthreads);
+void pmo_gpu_propagate_col(const pmo_images* im, float* disp, int direction, int patch_size,
+                           float alpha, int nthreads);
+void pmo_gpu_mask_background(const pmo_images* im, float* disp, int patch_size, float alpha,
+                             float improve_factor, int nthreads);
+void pmo_gpu_mask_occlusions(float* displ, const float* dispr, int rows, int cols);
+
+/* ---- pipelines -------------------------------------------------------------------------- */
+
+/* One view: iterations {noise, 4 sweeps} + background mask, on `disp` (seed in, result out).
+ * SEM_GPU == PatchmatchGpu::Match(GpuMat...) (patchmatch_gpu.cu:379-411);
+ * SEM_CPU == the recipe of patchmatch_test.cpp:173-183 with p's schedule. */
+void pmo_match_view(const pmo_params* p, const pmo_images* im, float* disp);
+
+/* Both views + cross-check, structure of PatchmatchGpu::Match (patchmatch_gpu.cu:331-376).
+ * seed_l / seed_r are given in left / right image coordinates (seed_r is mirrored
+ * internally as the reference computes it on the mirrored pair); disp_r comes back in
+ * right-image coordinates.  With left_right_check == 0 only disp_l is produced. */
+void pmo_match(const pmo_params* p, const uint8_t* left, const uint8_t* right, int rows, int cols,
+               const float* seed_l, const float* seed_r, float* disp_l, float* disp_r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* PM_ORACLE_H_ */

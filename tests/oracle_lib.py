@@ -1,0 +1,271 @@
+"""ctypes binding of oracle/libpm_oracle.so (the CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libpm_oracle.so")
+PMO_MAX_ITERS = 16
+SEM_CPU, SEM_GPU = 0, 1
+
+
+class Images(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("il", C.c_void_p), ("ir", C.c_void_p),
+                ("gl", C.c_void_p), ("gr", C.c_void_p)]
+
+
+class Functor(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("tau_color", C.c_float), ("tau_grad", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("semantics", C.c_int), ("n_iters", C.c_int),
+        ("noise_amp", C.c_float * PMO_MAX_ITERS),
+        ("patch_w", C.c_int * PMO_MAX_ITERS), ("patch_h", C.c_int * PMO_MAX_ITERS),
+        ("bg_patch_w", C.c_int), ("bg_patch_h", C.c_int), ("bg_factor", C.c_float),
+        ("cost_alpha", C.c_float), ("functor", Functor), ("noise_seed", C.c_uint64),
+        ("left_right_check", C.c_int), ("literal", C.c_int), ("nthreads", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.pmo_params_default.argtypes = [C.POINTER(Params), C.c_int]
+    lib.pmo_rng_fill_uniform.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64]
+    lib.pmo_rng_raw.argtypes = [vp, C.c_size_t, C.c_uint64]
+    lib.pmo_gradient_magnitude.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.pmo_dilate_rect.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    lib.pmo_get_rect_subpix_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]
+    lib.pmo_get_rect_subpix_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]
+    lib.pmo_cpu_functor.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(Functor)]
+    lib.pmo_cpu_functor.restype = C.c_float
+    lib.pmo_cpu_cost_literal.argtypes = [C.POINTER(Images), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.POINTER(Functor)]
+    lib.pmo_cpu_cost_literal.restype = C.c_float
+    lib.pmo_cpu_cost_direct.argtypes = [C.POINTER(Images), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.POINTER(Functor)]
+    lib.pmo_cpu_cost_direct.restype = C.c_float
+    lib.pmo_cpu_add_noise.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, C.c_uint64]
+    lib.pmo_cpu_propagate.argtypes = [C.POINTER(Images), vp, C.c_int, C.c_int, C.POINTER(Functor), C.c_int, C.c_int,
+                                      C.c_int]
+    lib.pmo_cpu_remove_background.argtypes = [C.POINTER(Images), vp, C.c_int, C.c_int, C.POINTER(Functor), C.c_float,
+                                              C.c_int, C.c_int]
+    lib.pmo_gpu_get_subpixel.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float]
+    lib.pmo_gpu_get_subpixel.restype = C.c_float
+    lib.pmo_gpu_cost5.argtypes = [C.POINTER(Images), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+    lib.pmo_gpu_cost5.restype = C.c_float
+    lib.pmo_gpu_add_foreground_noise.argtypes = [vp, vp, C.c_size_t, C.c_float]
+    lib.pmo_gpu_propagate_row.argtypes = [C.POINTER(Images), vp, C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.pmo_gpu_propagate_col.argtypes = [C.POINTER(Images), vp, C.c_int, C.c_int, C.c_float, C.c_int]
+    lib.pmo_gpu_mask_background.argtypes = [C.POINTER(Images), vp, C.c_int, C.c_float, C.c_float, C.c_int]
+    lib.pmo_gpu_mask_occlusions.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.pmo_match_view.argtypes = [C.POINTER(Params), C.POINTER(Images), vp]
+    lib.pmo_match.argtypes = [C.POINTER(Params), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pmo_flip_h_u8.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.pmo_flip_h_f32.argtypes = [vp, vp, C.c_int, C.c_int]
+    for name in ("pmo_params_default", "pmo_rng_fill_uniform", "pmo_rng_raw", "pmo_gradient_magnitude",
+                 "pmo_dilate_rect", "pmo_get_rect_subpix_u8", "pmo_get_rect_subpix_f32", "pmo_cpu_add_noise",
+                 "pmo_cpu_propagate", "pmo_cpu_remove_background", "pmo_gpu_add_foreground_noise",
+                 "pmo_gpu_propagate_row", "pmo_gpu_propagate_col", "pmo_gpu_mask_background",
+                 "pmo_gpu_mask_occlusions", "pmo_match_view", "pmo_match", "pmo_flip_h_u8", "pmo_flip_h_f32"):
+        getattr(lib, name).restype = None
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def c_u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def c_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def functor(alpha=0.7, tau_color=50.0, tau_grad=20.0):
+    return Functor(alpha, tau_color, tau_grad)
+
+
+def default_params(semantics=SEM_CPU, patch=None, **kw):
+    p = Params()
+    load().pmo_params_default(C.byref(p), semantics)
+    if patch is not None:
+        for i in range(PMO_MAX_ITERS):
+            p.patch_w[i] = patch
+            p.patch_h[i] = patch
+        p.bg_patch_w = patch
+        p.bg_patch_h = patch
+    for k, v in kw.items():
+        if k in ("noise_amp", "patch_w", "patch_h"):
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+    return p
+
+
+def rng_fill_uniform(n, lo, hi, seed=123):
+    out = np.empty(n, np.float32)
+    load().pmo_rng_fill_uniform(_p(out), n, lo, hi, seed)
+    return out
+
+
+def rng_raw(n, seed=123):
+    out = np.empty(n, np.uint32)
+    load().pmo_rng_raw(_p(out), n, seed)
+    return out
+
+
+def gradient_magnitude(im):
+    im = c_u8(im)
+    g = np.empty(im.shape, np.float32)
+    load().pmo_gradient_magnitude(_p(im), im.shape[0], im.shape[1], _p(g))
+    return g
+
+
+def dilate_rect(src, k):
+    src = c_f32(src)
+    dst = np.empty_like(src)
+    load().pmo_dilate_rect(_p(src), _p(dst), src.shape[0], src.shape[1], k)
+    return dst
+
+
+def get_rect_subpix(src, pw, ph, cx, cy):
+    if src.dtype == np.uint8:
+        src = c_u8(src)
+        dst = np.empty((ph, pw), np.uint8)
+        load().pmo_get_rect_subpix_u8(_p(src), src.shape[0], src.shape[1], pw, ph, cx, cy, _p(dst))
+    else:
+        src = c_f32(src)
+        dst = np.empty((ph, pw), np.float32)
+        load().pmo_get_rect_subpix_f32(_p(src), src.shape[0], src.shape[1], pw, ph, cx, cy, _p(dst))
+    return dst
+
+
+class ImageSet:
+    """Keeps the numpy planes alive next to the C struct."""
+
+    def __init__(self, il, ir, gl=None, gr=None):
+        self.il, self.ir = c_u8(il), c_u8(ir)
+        self.gl = c_f32(gl) if gl is not None else gradient_magnitude(self.il)
+        self.gr = c_f32(gr) if gr is not None else gradient_magnitude(self.ir)
+        self.c = Images(self.il.shape[0], self.il.shape[1], _p(self.il), _p(self.ir), _p(self.gl), _p(self.gr))
+
+
+def cpu_functor(pl, pr, gl, gr, f=None):
+    f = f or functor()
+    pl, pr, gl, gr = c_u8(pl), c_u8(pr), c_f32(gl), c_f32(gr)
+    return float(load().pmo_cpu_functor(_p(pl), _p(pr), _p(gl), _p(gr), pl.size, C.byref(f)))
+
+
+def cpu_cost(ims, pw, ph, x, y, d, literal=True, f=None):
+    f = f or functor()
+    if literal:
+        return float(load().pmo_cpu_cost_literal(C.byref(ims.c), pw, ph, float(x), float(y), d, C.byref(f)))
+    return float(load().pmo_cpu_cost_direct(C.byref(ims.c), pw, ph, int(x), int(y), d, C.byref(f)))
+
+
+def cpu_add_noise(disp, amount, mask=None, seed=123):
+    d = np.array(disp, np.float32, order="C", copy=True)
+    m = c_u8(mask) if mask is not None else None
+    load().pmo_cpu_add_noise(_p(d), d.shape[0], d.shape[1], amount, _p(m) if m is not None else None, seed)
+    return d
+
+
+def cpu_propagate(ims, disp, ph, pw, pass_mask=15, literal=False, nthreads=1, f=None):
+    f = f or functor()
+    d = np.array(disp, np.float32, order="C", copy=True)
+    load().pmo_cpu_propagate(C.byref(ims.c), _p(d), ph, pw, C.byref(f), pass_mask, int(literal), nthreads)
+    return d
+
+
+def cpu_remove_background(ims, disp, ph, pw, factor=1.5, literal=False, nthreads=1, f=None):
+    f = f or functor()
+    d = np.array(disp, np.float32, order="C", copy=True)
+    load().pmo_cpu_remove_background(C.byref(ims.c), _p(d), ph, pw, C.byref(f), factor, int(literal), nthreads)
+    return d
+
+
+def gpu_get_subpixel(im, row, col):
+    im = c_f32(im)
+    return float(load().pmo_gpu_get_subpixel(_p(im), im.shape[0], im.shape[1], row, col))
+
+
+def gpu_cost5(ims, yl, xl, yr, xr, alpha=0.9):
+    return float(load().pmo_gpu_cost5(C.byref(ims.c), yl, xl, yr, xr, alpha))
+
+
+def gpu_add_foreground_noise(disp, unit, scale):
+    d = np.array(disp, np.float32, order="C", copy=True)
+    u = c_f32(unit)
+    load().pmo_gpu_add_foreground_noise(_p(d), _p(u), d.size, scale)
+    return d
+
+
+def gpu_propagate(ims, disp, pass_mask=15, alpha=0.9, nthreads=1):
+    """The Row(+1), Col(+1), Row(-1), Col(-1) sequence of patchmatch_gpu.cu:397-403."""
+    d = np.array(disp, np.float32, order="C", copy=True)
+    lib = load()
+    if pass_mask & 1:
+        lib.pmo_gpu_propagate_row(C.byref(ims.c), _p(d), 1, 3, alpha, nthreads)
+    if pass_mask & 2:
+        lib.pmo_gpu_propagate_col(C.byref(ims.c), _p(d), 1, 3, alpha, nthreads)
+    if pass_mask & 4:
+        lib.pmo_gpu_propagate_row(C.byref(ims.c), _p(d), -1, 3, alpha, nthreads)
+    if pass_mask & 8:
+        lib.pmo_gpu_propagate_col(C.byref(ims.c), _p(d), -1, 3, alpha, nthreads)
+    return d
+
+
+def gpu_mask_background(ims, disp, alpha=0.9, improve=0.8, nthreads=1):
+    d = np.array(disp, np.float32, order="C", copy=True)
+    load().pmo_gpu_mask_background(C.byref(ims.c), _p(d), 3, alpha, improve, nthreads)
+    return d
+
+
+def gpu_mask_occlusions(displ, dispr):
+    dl = np.array(displ, np.float32, order="C", copy=True)
+    dr = c_f32(dispr)
+    load().pmo_gpu_mask_occlusions(_p(dl), _p(dr), dl.shape[0], dl.shape[1])
+    return dl
+
+
+def match_view(params, ims, seed):
+    d = np.array(seed, np.float32, order="C", copy=True)
+    load().pmo_match_view(C.byref(params), C.byref(ims.c), _p(d))
+    return d
+
+
+def match(params, left, right, seed_l=None, seed_r=None):
+    left, right = c_u8(left), c_u8(right)
+    rows, cols = left.shape
+    sl = c_f32(seed_l) if seed_l is not None else None
+    sr = c_f32(seed_r) if seed_r is not None else None
+    dl = np.zeros((rows, cols), np.float32)
+    dr = np.zeros((rows, cols), np.float32)
+    load().pmo_match(C.byref(params), _p(left), _p(right), rows, cols, _p(sl) if sl is not None else None,
+                     _p(sr) if sr is not None else None, _p(dl), _p(dr))
+    return dl, (dr if params.left_right_check else None)

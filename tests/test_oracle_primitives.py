@@ -1,0 +1,114 @@
+"""Known-answer tests of the oracle's OpenCV-primitive restatements (hand-computed) and agreement
+with the independent numpy restatement (tests/pyref.py)."""
+import numpy as np
+import pytest
+
+import pyref
+
+
+def test_rng_first_outputs_by_hand(oracle):
+    # state0 = 123: next = 123 * 4164903690 + 0
+    s1 = 123 * 4164903690
+    s2 = (s1 & 0xFFFFFFFF) * 4164903690 + (s1 >> 32)
+    raw = oracle.rng_raw(2, 123)
+    assert int(raw[0]) == s1 & 0xFFFFFFFF
+    assert int(raw[1]) == s2 & 0xFFFFFFFF
+    # seed 0 is replaced by 0xffffffff (cv::RNG::RNG(uint64))
+    assert int(oracle.rng_raw(1, 0)[0]) == (0xFFFFFFFF * 4164903690) & 0xFFFFFFFF
+
+
+def test_rng_matches_independent_restatement(oracle):
+    assert np.array_equal(oracle.rng_raw(4096, 123), pyref.rng_raw(4096, 123))
+    for lo, hi in ((-1.0, 1.0), (-32.0, 32.0), (-0.5, 0.5), (0.0, 7.0)):
+        a = oracle.rng_fill_uniform(5000, lo, hi, 123)
+        assert np.array_equal(a, pyref.rng_fill_uniform(5000, lo, hi, 123))
+        assert a.min() >= lo and a.max() < hi
+
+
+def test_rng_power_of_two_amplitude_is_scaled_unit_noise(oracle):
+    # AddNoise(amount) (patchmatch.cpp:146-147) == unit noise * amount (patchmatch_gpu.cu:301) exactly
+    unit = oracle.rng_fill_uniform(10000, -1.0, 1.0, 123)
+    for amount in (32.0, 16.0, 8.0, 2.0, 0.5, 0.25):
+        assert np.array_equal(oracle.rng_fill_uniform(10000, -amount, amount, 123), unit * np.float32(amount))
+
+
+def test_sobel_known_answers(oracle):
+    # horizontal ramp I = 3x: dx = 8*3 = 24 in the interior, dy = 0; reflect-101 makes border dx = 0
+    im = np.tile((3 * np.arange(10)).astype(np.uint8), (6, 1))
+    g = oracle.gradient_magnitude(im)
+    assert np.all(g[:, 1:-1] == 24.0)
+    assert np.all(g[:, 0] == 0.0) and np.all(g[:, -1] == 0.0)
+    # single bright pixel of 100 at (3,3): neighbours see |dx|,|dy| in {100, 200}
+    im = np.zeros((7, 7), np.uint8)
+    im[3, 3] = 100
+    g = oracle.gradient_magnitude(im)
+    assert g[3, 3] == 0.0
+    assert g[3, 2] == 200.0 and g[3, 4] == 200.0 and g[2, 3] == 200.0 and g[4, 3] == 200.0
+    assert g[2, 2] == np.float32(np.sqrt(np.float32(20000.0)))
+    assert np.all(g[0] == 0) and np.all(g[:, 0] == 0)
+
+
+@pytest.mark.parametrize("shape", [(5, 7), (16, 16), (33, 20), (2, 9)])
+def test_sobel_matches_independent_restatement(oracle, shape):
+    rng = np.random.default_rng(7)
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(oracle.gradient_magnitude(im), pyref.gradient_magnitude(im))
+
+
+def test_dilate(oracle):
+    src = np.zeros((9, 11), np.float32)
+    src[4, 5] = 3.0
+    src[0, 0] = 7.0
+    out = oracle.dilate_rect(src, 2)
+    exp = np.zeros_like(src)
+    exp[2:7, 3:8] = 3.0
+    exp[0:3, 0:3] = 7.0
+    assert np.array_equal(out, exp)
+    rng = np.random.default_rng(3)
+    src = rng.random((13, 17)).astype(np.float32)
+    for k in (1, 3, 17):
+        assert np.array_equal(oracle.dilate_rect(src, k), pyref.dilate_rect(src, k))
+
+
+def test_rect_subpix_known_answers(oracle):
+    src = np.arange(8 * 10, dtype=np.uint8).reshape(8, 10) * 2
+    # integer centre + odd window = exact copy
+    assert np.array_equal(oracle.get_rect_subpix(src, 3, 3, 4.0, 3.0), src[2:5, 3:6])
+    # half-pixel shift: (s0 + s1) / 2 with round-half-up of the fixed-point sum: values 2n, 2n+2 -> 2n+1
+    p = oracle.get_rect_subpix(src, 3, 1, 4.5, 3.0)
+    assert np.array_equal(p[0], src[3, 3:6] + 1)
+    # a = 0.25: (3*s0 + s1)/4 = s0 + 0.5 -> rounds up
+    p = oracle.get_rect_subpix(src, 1, 1, 4.25, 3.0)
+    assert p[0, 0] == src[3, 4] + 1
+    # replicate border on the left / top
+    p = oracle.get_rect_subpix(src, 3, 3, 0.0, 0.0)
+    assert np.array_equal(p, src[np.ix_([0, 0, 1], [0, 0, 1])])
+    # float path: exact lerp
+    srcf = src.astype(np.float32)
+    p = oracle.get_rect_subpix(srcf, 3, 1, 4.25, 3.0)
+    assert np.array_equal(p[0], srcf[3, 3:6] * np.float32(0.75) + srcf[3, 4:7] * np.float32(0.25))
+
+
+def test_rect_subpix_matches_independent_restatement(oracle):
+    rng = np.random.default_rng(11)
+    src8 = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    srcf = (rng.random((20, 30)) * 600).astype(np.float32)
+    for _ in range(300):
+        pw, ph = int(rng.choice([3, 5, 7, 11])), int(rng.choice([3, 5, 7, 11]))
+        y = int(rng.integers(ph // 2, 20 - ph // 2))          # integer centre row, as on the path
+        x = float(np.float32(rng.uniform(pw // 2, 30 - pw // 2 - 1)))
+        for src in (src8, srcf):
+            assert np.array_equal(oracle.get_rect_subpix(src, pw, ph, x, float(y)), pyref.rect_subpix(src, pw, ph, x, y))
+    # last interior column / row with zero fraction goes through OpenCV's border branch
+    for src in (src8, srcf):
+        assert np.array_equal(oracle.get_rect_subpix(src, 5, 5, 27.0, 17.0), src[15:20, 25:30])
+
+
+def test_gpu_get_subpixel(oracle):
+    rng = np.random.default_rng(5)
+    im = (rng.random((6, 9)) * 255).astype(np.float32)
+    assert oracle.gpu_get_subpixel(im, 2.0, 3.0) == im[2, 3]
+    assert oracle.gpu_get_subpixel(im, 2.0, 3.5) == np.float32(np.float32(0.5) * im[2, 3] + np.float32(0.5) * im[2, 4])
+    for _ in range(200):
+        r, c = float(np.float32(rng.uniform(0, 5))), float(np.float32(rng.uniform(0, 8)))
+        assert oracle.gpu_get_subpixel(im, r, c) == pyref.gpu_get_subpixel(im, r, c)
