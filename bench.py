@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: PatchMatch stereo Match() on MI355X.
+
+Workload (BASELINE.json configs[1]): one 1280x720 synthetic stereo pair per GPU, 8 iterations,
+11x11 window, fp32 cost, reference-CPU semantics (PM_SEM_CPU), left + right view + cross-check.
+A "step" is one Match() through the C ABI entry point pm_match_device with the u8 pair and the seed
+maps already resident in HBM and the disparity maps written to HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank r matches pair r (stereo pairs are independent: no data-path collective, weak scaling).  The K
+timed steps are bracketed by barrier + synchronize on both sides; rank 0 prints ONE JSON line with
+the whole-job pairs/s (max elapsed over ranks), the roofline of the dominant kernel (per-launch
+duration from HIP events recorded by the engine on its own stream during the timed steps) and the
+CPU baseline (the oracle -- a port of the reference CPU path -- timed on this host, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
+
+ROWS, COLS, ITERS, PATCH = 720, 1280, 8, 11
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured streaming
+# Algorithmic bytes of one directional sweep: per pixel and view the sweep reads the four
+# f32-equivalent image planes once (16 B), reads the disparity (4 B) and writes it (4 B).
+SWEEP_BYTES_PER_PX = 24
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo with --dry-run for CPU tests")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise sharding/barrier/reduction without a GPU (no compute, no engine)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--iters", type=int, default=ITERS)
+    ap.add_argument("--patch", type=int, default=PATCH)
+    ap.add_argument("--engine", type=int, default=0)
+    return ap.parse_args()
+
+
+class Dist:
+    """One process per GPU; torch.distributed only for the barrier and the max over ranks."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if args.backend == "nccl":
+                import torch
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=args.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+        self.device = f"cuda:{self.local_rank}" if args.backend == "nccl" and not args.dry_run else "cpu"
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        if not self.dist:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=self.device if self.device != "cpu" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def shard(rank, world, steps):
+    """Pair index matched by `rank` at each step: independent pairs, contiguous by rank."""
+    return [rank for _ in range(steps)]
+
+
+def cpu_baseline(args):
+    """The oracle (port of src/vehicle/stereo_matching/patchmatch.cpp + the test recipe, literal call
+    structure, single thread like the reference) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import synth
+    p = synth.make_pair(0, args.rows, args.cols)
+    band_rows = min(64, args.rows)
+    y0 = (args.rows - band_rows) // 2
+    band = slice(y0, y0 + band_rows)
+    prm = O.default_params(O.SEM_CPU, patch=args.patch, n_iters=args.iters, nthreads=1, literal=1, left_right_check=1)
+    t0 = time.perf_counter()
+    O.match(prm, p["left"][band], p["right"][band], p["seed_l"][band], p["seed_r"][band])
+    t = time.perf_counter() - t0
+    h = args.patch // 2
+    scale = (args.rows - 2 * h) / float(band_rows - 2 * h)  # swept rows of the full image / of the band
+    return {
+        "value": 1.0 / (t * scale), "unit": "pairs/s", "cores": 1, "kind": "port",
+        "sample": f"oracle (literal getRectSubPix+functor port, 1 thread) on a {band_rows}-row full-width band of "
+                  f"pair 0, both views, {args.iters} iterations, {args.patch}x{args.patch}: {t:.2f} s; scaled by "
+                  f"swept rows {args.rows - 2 * h}/{band_rows - 2 * h}",
+        "host_cores": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    d = Dist(args)
+    steps, warmup = args.steps, args.warmup
+    result = {
+        "metric": "stereo_pairs_per_sec_1280x720_patchmatch", "unit": "pairs/s", "n_gpus": d.world, "steps": steps,
+        "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"1 synthetic {args.cols}x{args.rows} stereo pair per GPU, {args.iters} iterations, "
+                               f"{args.patch}x{args.patch} window, fp32 cost, PM_SEM_CPU, left+right view + cross-check "
+                               "(BASELINE.json configs[1])",
+                   "pairs_per_gpu_per_step": 1, "sharding": "pair index = rank, no collective"},
+    }
+    if args.dry_run:
+        # plumbing only: same barrier / reduction path, no engine, no numbers worth reading
+        d.barrier()
+        t0 = time.perf_counter()
+        for _ in shard(d.rank, d.world, steps):
+            time.sleep(0.001 * (1 + d.rank))
+        elapsed = d.max_over_ranks(time.perf_counter() - t0)
+        d.barrier()
+        if d.rank == 0:
+            result.update(value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, dry_run=True)
+            print(json.dumps(result), flush=True)
+        d.close()
+        return
+
+    import numpy as np
+    import torch
+    import pm_ctypes as pm
+    import synth
+
+    torch.cuda.set_device(d.local_rank)
+    dev = torch.device(f"cuda:{d.local_rank}")
+    pair = synth.make_pair(d.rank, args.rows, args.cols)
+    L = torch.from_numpy(pair["left"]).to(dev).contiguous()
+    R = torch.from_numpy(pair["right"]).to(dev).contiguous()
+    SL = torch.from_numpy(pair["seed_l"]).to(dev).contiguous()
+    SR = torch.from_numpy(pair["seed_r"]).to(dev).contiguous()
+    DL = torch.empty((args.rows, args.cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine)
+    eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=1)
+
+    def step():
+        eng.match_device(1, L.data_ptr(), R.data_ptr(), args.rows, args.cols, SL.data_ptr(), SR.data_ptr(),
+                         DL.data_ptr(), DR.data_ptr())
+
+    for _ in range(warmup):
+        step()
+    eng.synchronize()
+    ref = DL.clone()
+    eng.profile_read()
+    eng.profile_enable(True)
+
+    torch.cuda.synchronize()
+    d.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in shard(d.rank, d.world, steps):
+        step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    d.barrier()
+    torch.cuda.synchronize()
+    elapsed = d.max_over_ranks(elapsed_local)
+
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    deterministic = bool(torch.equal(ref, DL))
+    fg = float((DL > 0).float().mean().item())
+    err = (DL - torch.from_numpy(pair["gt"]).to(dev)).abs()
+    within1 = float((err[DL > 0] < 1.0).float().mean().item()) if fg > 0 else 0.0
+
+    if d.rank == 0:
+        px_views = args.rows * args.cols * 2
+        dom = max(("sweep_row", "sweep_col"), key=lambda k: prof[k][1])
+        n_launch, total_ms = prof[dom]
+        avg_ms = total_ms / max(n_launch, 1)
+        achieved = SWEEP_BYTES_PER_PX * px_views / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
+        gpu_ms = sum(v[1] for v in prof.values())
+        result.update(
+            value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, ms_per_frame=1e3 * elapsed / steps,
+            roofline={"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                      "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_PX * px_views, "avg_launch_ms": avg_ms,
+                      "launches": n_launch},
+            kernels_ms_per_step={k: v[1] / steps for k, v in prof.items()},
+            gpu_busy_ms_per_step=gpu_ms / steps,
+            check={"deterministic_across_steps": deterministic, "foreground_fraction": fg,
+                   "foreground_within_1px_of_truth": within1},
+        )
+        if d.world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(result), flush=True)
+    eng.close()
+    d.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,7 @@ using namespace pm;
 
 namespace {
 
-constexpr int kMaxEvents = 512;  // event pairs kept before a forced drain
+constexpr int kMaxEvents = 16384;  // event pairs kept before a forced drain
 
 struct EventRec {
   hipEvent_t start, stop;

@@ -32,7 +32,7 @@ __device__ __forceinline__ float sobel_mag(const uint8_t* im, size_t stride, int
   const int dy = ((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]);
   const float fx = (float)dx, fy = (float)dy;
   const float sx = fx * fx, sy = fy * fy;
-  return __fsqrt_rn(sx + sy);
+  return sqrtf(sx + sy);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the 1-ulp native form
 }
 
 // in_left / in_right: [B][rows][in_stride] u8.  grid = (ceil(cols/256), rows, B).

@@ -1,0 +1,77 @@
+"""The C-ABI shared library loads and exports every symbol include/pm/patchmatch.h declares, and
+fails loudly without a GPU (no compute is attempted here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pm", "patchmatch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_lists(pm):
+    assert declared_functions() == sorted(pm.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(pm):
+    lib = pm.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/pm/patchmatch.h but not exported"
+
+
+def test_params_default_matches_reference_defaults(pm):
+    p = pm.default_params(pm.PM_SEM_GPU)
+    assert p.struct_size == C.sizeof(pm.PmParams) and p.abi_version == pm.PM_ABI_VERSION
+    # patchmatch_gpu.h:85-88
+    assert abs(p.cost_alpha - 0.9) < 1e-7 and p.patchmatch_iters == 3
+    assert p.init_dilate_factor == 4 and abs(p.cost_improve_factor - 0.8) < 1e-7
+    # noise schedule 32 / 2^i (patchmatch_gpu.cu:395), seed 123 (patchmatch_gpu.cu:341)
+    assert [p.noise_amp[i] for i in range(4)] == [32.0, 16.0, 8.0, 4.0] and p.noise_seed == 123
+    assert p.left_right_check == 1
+    q = pm.default_params(pm.PM_SEM_CPU)
+    assert abs(q.functor_alpha - 0.7) < 1e-7 and q.functor_tau_color == 50.0 and q.functor_tau_grad == 20.0
+    assert abs(q.win_by_factor - 1.5) < 1e-7
+
+
+def test_status_strings(pm):
+    lib = pm.load()
+    assert lib.pm_status_string(0) == b"ok"
+    assert b"device" in lib.pm_status_string(pm.PM_ERR_NO_DEVICE)
+    assert lib.pm_kernel_name(3) == b"sweep_row"
+
+
+def test_create_rejects_bad_arguments_without_touching_a_device(pm):
+    lib = pm.load()
+    h = C.c_void_p()
+    assert lib.pm_create(None, 0, 64, 64, 1, C.byref(h)) == pm.PM_ERR_INVALID_ARG
+    p = pm.default_params(pm.PM_SEM_CPU, patch=4)  # even window: patchmatch.cpp:257-258 CHECKs oddness
+    rc = lib.pm_create(C.byref(p), 0, 64, 64, 1, C.byref(h))
+    assert rc == pm.PM_ERR_INVALID_ARG and b"odd" in lib.pm_last_error(h)
+    lib.pm_destroy(h)
+    p = pm.default_params(pm.PM_SEM_CPU)
+    p.struct_size = 8
+    rc = lib.pm_create(C.byref(p), 0, 64, 64, 1, C.byref(h))
+    assert rc == pm.PM_ERR_INVALID_ARG
+    lib.pm_destroy(h)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback(pm):
+    with pytest.raises(pm.PmError) as e:
+        pm.Engine(pm.default_params(pm.PM_SEM_CPU), max_rows=64, max_cols=64)
+    assert e.value.status == pm.PM_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)

@@ -1,0 +1,40 @@
+"""The N>1 path of bench.py on CPU: two processes, gloo backend, --dry-run (no engine, no compute).
+Checks the launcher contract (env rendezvous on 127.0.0.1), the barrier / max-over-ranks reduction and
+that exactly one JSON line comes from rank 0 with the whole-job aggregate."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_two_ranks_gloo_dry_run():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+           "5", "--warmup", "1", "--backend", "gloo", "--dry-run"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and out["unit"] == "pairs/s"
+    # rank 1 sleeps 2 ms per step: the max over ranks (>= 10 ms for 5 steps) must be what is reported
+    assert out["ms_per_step"] >= 2.0
+    assert abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5 / 1e3)) < 1e-6 * out["value"]
+
+
+def test_shard_is_rank_local():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.shard(3, 8, 4) == [3, 3, 3, 3]

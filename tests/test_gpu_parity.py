@@ -1,0 +1,295 @@
+"""Parity of the HIP engine (through the C ABI, via ctypes) against the CPU oracle.
+
+Bar: bit-exact float32 disparity maps (tolerance 0) -- every arithmetic step of the engine is a
+single IEEE rounding in the oracle's order, and the cost functor's sums are integers, so there is
+no tolerance to state.  Cases follow the reference's own call patterns
+(test/stereo_matching/patchmatch_test.cpp:149-183, patchmatch_gpu_test.cpp:68-88) on seeded
+synthetic pairs at sizes the oracle finishes in seconds; full-size (1280x720, 8 iterations, 11x11)
+coverage goes through size-independent properties and engine-vs-engine equality.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_same, small_pair
+
+pytestmark = pytest.mark.gpu
+
+SEMS = [0, 1]
+ENGINES = [1, 2]  # PM_ENGINE_SERIAL, PM_ENGINE_WAVE
+
+
+def mk(pm, sem, engine=0, patch=3, iters=3, lr=1, rows=64, cols=96, batch=1, **kw):
+    p = pm.default_params(sem, patch=patch, patchmatch_iters=iters, engine=engine, left_right_check=lr, **kw)
+    return pm.Engine(p, max_rows=rows, max_cols=cols, max_batch=batch)
+
+
+def oparams(oracle, sem, patch=3, iters=3, lr=1, **kw):
+    return oracle.default_params(sem, patch=patch, n_iters=iters, left_right_check=lr, nthreads=8, **kw)
+
+
+# ---- single stages: one per reference function ------------------------------------------------------
+@pytest.mark.parametrize("shape", [(8, 8), (37, 53), (64, 64), (48, 129)])
+def test_gradient_magnitude(pm, oracle, shape):
+    rng = np.random.default_rng(shape[0])
+    im = rng.integers(0, 256, shape, dtype=np.uint8)
+    with mk(pm, 0, rows=shape[0], cols=shape[1]) as e:
+        assert_same(e.gradient_magnitude(im), oracle.gradient_magnitude(im), "gradient")
+
+
+def test_unit_noise_and_add_noise(pm, oracle):
+    rows, cols = 45, 70
+    with mk(pm, 1, rows=rows, cols=cols) as e:
+        unit = e.unit_noise(rows, cols)
+        assert_same(unit, oracle.rng_fill_uniform(rows * cols, -1.0, 1.0, 123).reshape(rows, cols), "unit noise")
+        d = np.zeros((rows, cols), np.float32)
+        d[10:30, 20:50] = 12.5
+        d[0, 0] = 0.001
+        for amp in (32.0, 8.0, 0.5, 0.0):
+            got = e.add_noise(d, amp)
+            assert_same(got, oracle.gpu_add_foreground_noise(d, unit, amp), f"AddForegroundNoise {amp}")
+            assert_same(got, oracle.cpu_add_noise(d, amp, (d > 0).astype(np.uint8)), f"AddNoise {amp}")
+        # the noise table follows the image size (the reference never resizes it)
+        assert_same(e.unit_noise(20, 33), oracle.rng_fill_uniform(20 * 33, -1.0, 1.0, 123).reshape(20, 33), "resized")
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("pw,ph", [(3, 3), (5, 5), (7, 3), (3, 9), (11, 11), (15, 15)])
+def test_cpu_propagate_each_pass(pm, oracle, synth, engine, pw, ph):
+    rows, cols = 40, 72
+    l, r, sl, _, _ = small_pair(synth, 11, rows, cols, n_points=20, dilate_factor=2)
+    ims = oracle.ImageSet(l, r)
+    d = oracle.cpu_add_noise(sl, 8.0, (sl > 0).astype(np.uint8))
+    with mk(pm, 0, engine, rows=rows, cols=cols) as e:
+        for mask in (1, 2, 4, 8, 15):
+            got = e.propagate(l, r, d, ph, pw, mask)
+            assert_same(got, oracle.cpu_propagate(ims, d, ph, pw, pass_mask=mask, nthreads=8), f"pass mask {mask}")
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_gpu_propagate_each_sweep(pm, oracle, synth, engine):
+    rows, cols = 40, 72
+    l, r, sl, _, _ = small_pair(synth, 12, rows, cols, n_points=20, dilate_factor=2)
+    ims = oracle.ImageSet(l, r)
+    unit = oracle.rng_fill_uniform(rows * cols, -1.0, 1.0).reshape(rows, cols)
+    d = oracle.gpu_add_foreground_noise(sl, unit, 16.0)
+    with mk(pm, 1, engine, rows=rows, cols=cols) as e:
+        for mask in (1, 2, 4, 8, 15):
+            assert_same(e.propagate(l, r, d, 3, 3, mask), oracle.gpu_propagate(ims, d, pass_mask=mask, nthreads=8),
+                        f"sweep mask {mask}")
+
+
+def test_remove_background_and_mask_occlusions(pm, oracle, synth):
+    rows, cols = 50, 90
+    l, r, sl, sr, _ = small_pair(synth, 13, rows, cols, n_points=30, dilate_factor=2)
+    ims = oracle.ImageSet(l, r)
+    d = oracle.cpu_add_noise(sl, 2.0, (sl > 0).astype(np.uint8))
+    with mk(pm, 0, rows=rows, cols=cols) as e:
+        for (pw, ph, f) in ((3, 3, 1.5), (5, 5, 2.0), (11, 7, 1.5)):
+            assert_same(e.remove_background(l, r, d, ph, pw, f), oracle.cpu_remove_background(ims, d, ph, pw, f),
+                        f"RemoveBackground {pw}x{ph}")
+        assert_same(e.mask_occlusions(sl, sr), oracle.gpu_mask_occlusions(sl, sr), "MaskOcclusions")
+    with mk(pm, 1, rows=rows, cols=cols) as e:
+        for f in (0.8, 0.5):
+            assert_same(e.remove_background(l, r, d, 3, 3, f), oracle.gpu_mask_background(ims, d, 0.9, f),
+                        f"MaskBackground {f}")
+
+
+# ---- the whole path ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sem", SEMS)
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("rows,cols", [(48, 80), (67, 131), (120, 188)])
+def test_match_both_views(pm, oracle, synth, sem, engine, rows, cols):
+    l, r, sl, sr, _ = small_pair(synth, rows, rows, cols, n_points=40, dilate_factor=2)
+    with mk(pm, sem, engine, patch=5, iters=3, rows=rows, cols=cols) as e:
+        dl, dr = e.match(l, r, sl, sr)
+    el, er = oracle.match(oparams(oracle, sem, 5, 3), l, r, sl, sr)
+    assert_same(dl, el, "left disparity")
+    assert_same(dr, er, "right disparity")
+    assert (dl > 0).mean() > 0.2  # the case is not degenerate
+
+
+@pytest.mark.parametrize("patch", [3, 7, 11])
+def test_match_cpu_semantics_window_sizes(pm, oracle, synth, patch):
+    rows, cols = 60, 100
+    l, r, sl, sr, _ = small_pair(synth, 20 + patch, rows, cols, n_points=40, dilate_factor=2)
+    with mk(pm, 0, 2, patch=patch, iters=4, rows=rows, cols=cols) as e:
+        dl, dr = e.match(l, r, sl, sr)
+    el, er = oracle.match(oparams(oracle, 0, patch, 4), l, r, sl, sr)
+    assert_same(dl, el, "left")
+    assert_same(dr, er, "right")
+
+
+def test_match_reference_cpu_test_recipe(pm, oracle, synth):
+    # patchmatch_test.cpp:173-183: noise 32, 8, 2, 0.5; windows 5x5, 5x5, 3x3, 3x3; background 3x3 / 1.5
+    rows, cols = 120, 188  # 376x240 halved, the reference test size / 2
+    l, r, sl, sr, _ = small_pair(synth, 31, rows, cols, n_points=60, dilate_factor=3)
+    sched = dict(noise_amp=[32.0, 8.0, 2.0, 0.5], patch_w=[5, 5, 3, 3], patch_h=[5, 5, 3, 3])
+    p = pm.default_params(0, patchmatch_iters=4, bg_patch_w=3, bg_patch_h=3, win_by_factor=1.5, left_right_check=0,
+                          **sched)
+    with pm.Engine(p, max_rows=rows, max_cols=cols) as e:
+        dl, _ = e.match(l, r, sl, None)
+    op = oracle.default_params(0, n_iters=4, bg_patch_w=3, bg_patch_h=3, bg_factor=1.5, left_right_check=0,
+                               nthreads=8, literal=1, **sched)
+    el, _ = oracle.match(op, l, r, sl, None)
+    assert_same(dl, el, "patchmatch_test.cpp recipe (literal oracle)")
+
+
+def test_match_reference_gpu_test_settings(pm, oracle, synth):
+    # patchmatch_gpu_test.cpp:68-88: 376x240, alpha 0.9, 3 iterations, Match called 5 times in a row
+    rows, cols = 240, 376
+    l, r, sl, sr, _ = small_pair(synth, 32, rows, cols)
+    el, er = oracle.match(oparams(oracle, 1, 3, 3), l, r, sl, sr)
+    with mk(pm, 1, rows=rows, cols=cols) as e:
+        for _ in range(5):
+            dl, dr = e.match(l, r, sl, sr)
+            assert_same(dl, el, "left")
+            assert_same(dr, er, "right")
+
+
+@pytest.mark.parametrize("sem", SEMS)
+def test_batch_equals_singles(pm, oracle, synth, sem):
+    rows, cols = 40, 70
+    pairs = [small_pair(synth, 40 + i, rows, cols, n_points=20, dilate_factor=2) for i in range(3)]
+    with mk(pm, sem, patch=5, iters=2, rows=rows, cols=cols, batch=3) as e:
+        dls, drs = e.match_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs],
+                                 [p[3] for p in pairs])
+    for i, p in enumerate(pairs):
+        el, er = oracle.match(oparams(oracle, sem, 5, 2), p[0], p[1], p[2], p[3])
+        assert_same(dls[i], el, f"pair {i} left")
+        assert_same(drs[i], er, f"pair {i} right")
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------
+def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
+    rows, cols = 33, 47
+    l, r, sl, sr, _ = small_pair(synth, 50, rows, cols, n_points=12, dilate_factor=2)
+    with mk(pm, 0, patch=3, iters=2, rows=64, cols=64) as e:   # plan larger than the image
+        dl, dr = e.match(l, r, None, None)
+        assert not dl.any() and not dr.any()
+        dl, dr = e.match(l, r, sl, None)
+        el, er = oracle.match(oparams(oracle, 0, 3, 2), l, r, sl, None)
+        assert_same(dl, el)
+        assert_same(dr, er)
+        # row strides: images embedded in wider buffers (cv::Mat::step)
+        lw = np.zeros((rows, cols + 13), np.uint8); lw[:, :cols] = l
+        rw = np.zeros((rows, cols + 13), np.uint8); rw[:, :cols] = r
+        out_l = np.full((rows, cols + 5), -1, np.float32)
+        out_r = np.full((rows, cols + 5), -1, np.float32)
+        slc = np.ascontiguousarray(sl)
+        rc = e.lib.pm_match_u8(e.h, lw.ctypes.data, rw.ctypes.data, rows, cols, cols + 13, slc.ctypes.data, None, 0,
+                               out_l.ctypes.data, out_r.ctypes.data, 4 * (cols + 5))
+        assert rc == 0
+        assert_same(out_l[:, :cols], el, "strided left")
+        assert np.all(out_l[:, cols:] == -1)
+        # errors: too large for the plan, null pointers, tiny image
+        big = np.zeros((65, 64), np.uint8)
+        with pytest.raises(pm.PmError) as ex:
+            e.match(big, big)
+        assert ex.value.status == pm.PM_ERR_SIZE
+        assert e.lib.pm_match_u8(e.h, None, rw.ctypes.data, rows, cols, 0, None, None, 0, out_l.ctypes.data,
+                                 out_r.ctypes.data, 0) == pm.PM_ERR_INVALID_ARG
+        with pytest.raises(pm.PmError):
+            e.match(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.uint8))
+        with pytest.raises(pm.PmError):
+            e.propagate(l, r, sl, 4, 3)
+        # smallest supported image, and the engine still works after the errors
+        t = np.arange(64, dtype=np.uint8).reshape(8, 8) * 3
+        s8 = np.full((8, 8), 2.0, np.float32)
+        dl, dr = e.match(t, t, s8, s8)
+        el, er = oracle.match(oparams(oracle, 0, 3, 2), t, t, s8, s8)
+        assert_same(dl, el)
+        assert_same(dr, er)
+
+
+def test_left_right_check_off(pm, oracle, synth):
+    rows, cols = 40, 64
+    l, r, sl, sr, _ = small_pair(synth, 51, rows, cols, n_points=20, dilate_factor=2)
+    for sem in SEMS:
+        with mk(pm, sem, patch=5, iters=2, lr=0, rows=rows, cols=cols) as e:
+            dl, dr = e.match(l, r, sl, sr)
+        assert dr is None
+        el, _ = oracle.match(oparams(oracle, sem, 5, 2, lr=0), l, r, sl, sr)
+        assert_same(dl, el)
+
+
+def test_device_entry_point_with_torch_buffers(pm, oracle, synth):
+    torch = pytest.importorskip("torch")
+    rows, cols = 48, 80
+    pairs = [small_pair(synth, 60 + i, rows, cols, n_points=20, dilate_factor=2) for i in range(2)]
+    dev = torch.device("cuda:0")
+    t = lambda k, dt: torch.from_numpy(np.stack([p[k] for p in pairs])).to(dev, dt).contiguous()
+    L, R, SL, SR = t(0, torch.uint8), t(1, torch.uint8), t(2, torch.float32), t(3, torch.float32)
+    DL = torch.empty((2, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    torch.cuda.synchronize()
+    with mk(pm, 0, patch=5, iters=2, rows=rows, cols=cols, batch=2) as e:
+        e.match_device(2, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
+                       DR.data_ptr())
+        e.synchronize()
+        prof_off = e.profile_read()
+        assert sum(v[0] for v in prof_off.values()) == 0
+        e.profile_enable(True)
+        e.match_device(2, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
+                       DR.data_ptr())
+        prof = e.profile_read()
+    assert prof["sweep_row"][0] == 4 and prof["sweep_col"][0] == 4 and prof["noise_cost"][0] == 2
+    assert prof["sweep_row"][1] > 0
+    for i, p in enumerate(pairs):
+        el, er = oracle.match(oparams(oracle, 0, 5, 2), p[0], p[1], p[2], p[3])
+        assert_same(DL[i].cpu().numpy(), el, f"pair {i} left")
+        assert_same(DR[i].cpu().numpy(), er, f"pair {i} right")
+
+
+# ---- full size: properties and engine-vs-engine ------------------------------------------------------------
+def test_full_size_baseline_config_properties(pm, oracle, synth):
+    """BASELINE.json configs[1]: one 1280x720 pair, 8 iterations, 11x11 window."""
+    rows, cols, patch, iters = 720, 1280, 11, 8
+    p = synth.make_pair(0, rows, cols)
+    l, r, sl, sr = p["left"], p["right"], p["seed_l"], p["seed_r"]
+    with mk(pm, 0, 2, patch=patch, iters=iters, rows=rows, cols=cols) as e:
+        dl, dr = e.match(l, r, sl, sr)
+        dl2, dr2 = e.match(l, r, sl, sr)
+    with mk(pm, 0, 1, patch=patch, iters=iters, rows=rows, cols=cols) as e:
+        sl_, sr_ = e.match(l, r, sl, sr)
+    assert_same(dl, dl2, "run-to-run determinism (left)")
+    assert_same(dr, dr2, "run-to-run determinism (right)")
+    assert_same(dl, sl_, "wave engine == serial anchor (left)")
+    assert_same(dr, sr_, "wave engine == serial anchor (right)")
+    assert np.isfinite(dl).all() and np.isfinite(dr).all() and dl.min() >= 0 and dr.min() >= 0
+    h = patch // 2
+    xs = np.arange(cols, dtype=np.float32)[None, :]
+    assert np.all(dl[h:rows - h, h:cols - h] <= (xs - h)[:, h:cols - h])          # patchmatch.cpp:175
+    assert np.all(dr[h:rows - h, h:cols - h] <= (cols - 1 - xs - h)[:, h:cols - h])
+    # border pixels are never swept (patchmatch.cpp:267-270): they only see the noise passes
+    unit = oracle.rng_fill_uniform(rows * cols, -1.0, 1.0).reshape(rows, cols)
+    border = sl.copy()
+    for i in range(iters):
+        border = oracle.gpu_add_foreground_noise(border, unit, 32.0 / 2 ** i)
+    bl = oracle.gpu_mask_occlusions(border, dr)  # the cross-check also applies to border pixels
+    for sl_b in (np.s_[:h, :], np.s_[rows - h:, :], np.s_[:, :h], np.s_[:, cols - h:]):
+        # left border pixels: noise-only value, then MaskOcclusions against the final right map
+        assert_same(dl[sl_b], bl[sl_b], "untouched border")
+    # MaskOcclusions is idempotent on its own output
+    assert_same(oracle.gpu_mask_occlusions(dl, dr), dl, "cross-check idempotence")
+    # and the result is a disparity map: most foreground pixels within 1 px of the synthetic truth
+    fg = dl > 0
+    assert fg.mean() > 0.15 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.95
+    # a 64-row band of the same pair is an independent problem the oracle can afford at 11x11 / 8 it.
+    band = np.s_[300:364, :]
+    with mk(pm, 0, 2, patch=patch, iters=iters, rows=64, cols=cols) as e:
+        bdl, bdr = e.match(l[band], r[band], sl[band], sr[band])
+    el, er = oracle.match(oparams(oracle, 0, patch, iters), l[band], r[band], sl[band], sr[band])
+    assert_same(bdl, el, "64-row band at full width, left")
+    assert_same(bdr, er, "64-row band at full width, right")
+
+
+def test_full_size_gpu_semantics_engines_agree(pm, oracle, synth):
+    rows, cols = 720, 1280
+    p = synth.make_pair(1, rows, cols)
+    with mk(pm, 1, 2, iters=3, rows=rows, cols=cols) as e:
+        dl, dr = e.match(p["left"], p["right"], p["seed_l"], p["seed_r"])
+    el, er = oracle.match(oparams(oracle, 1, 3, 3), p["left"], p["right"], p["seed_l"], p["seed_r"])
+    assert_same(dl, el, "1280x720 PM_SEM_GPU left vs oracle")
+    assert_same(dr, er, "1280x720 PM_SEM_GPU right vs oracle")
