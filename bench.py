@@ -184,6 +184,12 @@ def main():
 
     prof = eng.profile_read()
     eng.profile_enable(False)
+    # work counters: one extra untimed step (the counting atomics would distort the timed ones)
+    eng.debug_counters_enable(True)
+    eng.debug_counters()
+    step()
+    counters = eng.debug_counters()
+    eng.debug_counters_enable(False)
     deterministic = bool(torch.equal(ref, DL))
     fg = float((DL > 0).float().mean().item())
     err = (DL - torch.from_numpy(pair["gt"]).to(dev)).abs()
@@ -204,6 +210,7 @@ def main():
                       "launches": n_launch},
             kernels_ms_per_step={k: v[1] / steps for k, v in prof.items()},
             gpu_busy_ms_per_step=gpu_ms / steps,
+            run_engine_counters_per_step=counters,
             check={"deterministic_across_steps": deterministic, "foreground_fraction": fg,
                    "foreground_within_1px_of_truth": within1},
         )

@@ -62,7 +62,11 @@ typedef enum pm_semantics {
 typedef enum pm_engine {
   PM_ENGINE_AUTO = 0,
   PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor */
-  PM_ENGINE_WAVE = 2    /* one wavefront per chain, window taps spread over the 64 lanes           */
+  PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes           */
+  PM_ENGINE_SEGMENTED = 3, /* chains cut into speculative segments (one wavefront each) + exact fix-up */
+  PM_ENGINE_RUN = 4,    /* one wavefront per chain, a whole adoption run (<= 64-pw+1 positions) per step */
+  PM_ENGINE_RUNSEG = 5, /* run steps on speculative chain segments + exact sequential fix-up             */
+  PM_ENGINE_RUNBLK = 6  /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint (default) */
 } pm_engine;
 
 /*
@@ -178,6 +182,11 @@ int pm_profile_enable(pm_handle* h, int on);
 /* Waits for the stream, then accumulates pending events into *out and resets the counters. */
 int pm_profile_read(pm_handle* h, pm_profile* out);
 const char* pm_kernel_name(int kernel_class);
+/* Work counters of the run engine since the last call (then reset): for row sweeps [0..3] and column
+ * sweeps [4..7]: wave steps, steps that evaluated a candidate, pixels that adopted, positions swept. */
+int pm_debug_counters(pm_handle* h, uint64_t out[8]);
+/* Counting costs one same-address atomic set per wavefront (it serialises large grids): off by default. */
+int pm_debug_counters_enable(pm_handle* h, int on);
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,21 @@ struct PlaneSet {
   uint8_t* img8;       // [B][4][rows][pitch]   0=L 1=R 2=Lm 3=Rm
   float* g32;          // [B][4][rows][pitch]
   uint8_t* g8;         // [B][4][rows][pitch]   saturate_cast<uchar>(g32)
-  float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
-  float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
+  // Transposed copies ([cols][pitch_t], element (x, y) at x * pitch_t + y): a column sweep gives one
+  // lane to each image ROW, so with these the 64 lanes of a load read 64 consecutive bytes/words.
+  uint8_t* timg8;      // [B][4][cols][pitch_t]
+  float* tg32;         // [B][4][cols][pitch_t]
+  uint8_t* tg8;        // [B][4][cols][pitch_t]
+  int pitch_t;         // align_up(rows, 64)
+  size_t plane_t;      // cols * pitch_t
+  // Disparity and cost-of-disparity planes are double buffered: the segmented sweeps read buffer
+  // `cur` and write buffer `cur ^ 1` (the old values must survive for the fix-up pass); in-place
+  // kernels work on buffer `cur`.
+  float* disp[2];      // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
+  float* cost[2];      // [B][2][rows][pitch]   cost of disp under the current window
+  int cur;
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
+  unsigned long long* counters;  // [8] work counters (see pm_debug_counters), one atomic per wavefront
   int rows, cols, pitch;
   int n_views;         // 1 or 2
   size_t plane;        // rows * pitch
@@ -35,8 +47,14 @@ struct View {
   const float* refg;     // gradient magnitude of ref ("Gl")
   const float* tgtg;     // gradient magnitude of tgt ("Gr")
   const uint8_t* refg8;  // saturated u8 of refg
-  float* disp;
+  const uint8_t* tref8;  // transposed copies of ref8 / tgt8 / tgtg / refg8
+  const uint8_t* ttgt8;
+  const float* ttgtg;
+  const uint8_t* trefg8;
+  float* disp;      // buffer `cur`
   float* cost;
+  float* disp_out;  // buffer `cur ^ 1`
+  float* cost_out;
 };
 
 __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
@@ -49,8 +67,15 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.refg = ps.g32 + (base4 + iref) * ps.plane;
   w.tgtg = ps.g32 + (base4 + itgt) * ps.plane;
   w.refg8 = ps.g8 + (base4 + iref) * ps.plane;
-  w.disp = ps.disp + ((size_t)b * 2 + v) * ps.plane;
-  w.cost = ps.cost + ((size_t)b * 2 + v) * ps.plane;
+  w.tref8 = ps.timg8 + (base4 + iref) * ps.plane_t;
+  w.ttgt8 = ps.timg8 + (base4 + itgt) * ps.plane_t;
+  w.ttgtg = ps.tg32 + (base4 + itgt) * ps.plane_t;
+  w.trefg8 = ps.tg8 + (base4 + iref) * ps.plane_t;
+  const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
+  w.disp = ps.disp[ps.cur] + dofs;
+  w.cost = ps.cost[ps.cur] + dofs;
+  w.disp_out = ps.disp[ps.cur ^ 1] + dofs;
+  w.cost_out = ps.cost[ps.cur ^ 1] + dofs;
   return w;
 }
 
@@ -98,14 +123,48 @@ __device__ __forceinline__ CpuLerp cpu_lerp(int x, float d, int pw) {
   return l;
 }
 
+// r0, r1 <= 255 and a11, a12 <= 65536 fit 24 bits: v_mad_u32_u24 (full rate) instead of v_mul_lo_u32.
 __device__ __forceinline__ int cpu_tap_color(int left, int r0, int r1, const CpuLerp& l) {
-  const int v = (r0 * l.a11 + r1 * l.a12 + (1 << 15)) >> 16;
+  unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
+  t = __umul24((unsigned)r0, (unsigned)l.a11) + t;
+  const int v = (int)(t >> 16);
   return abs(left - v);
 }
 __device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, const CpuLerp& l) {
   float s = g0 * l.ia;
   s = s + g1 * l.a;
   return abs(left_g8 - sat_u8(s));
+}
+// accumulate forms: acc + |left - sample| as one v_sad_u32
+__device__ __forceinline__ unsigned cpu_acc_color(unsigned acc, int left, int r0, int r1, const CpuLerp& l) {
+  unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
+  t = __umul24((unsigned)r0, (unsigned)l.a11) + t;
+  return __usad((unsigned)left, t >> 16, acc);
+}
+__device__ __forceinline__ unsigned cpu_acc_grad(unsigned acc, int left_g8, float g0, float g1, const CpuLerp& l) {
+  float s = g0 * l.ia;
+  s = s + g1 * l.a;
+  return __usad((unsigned)left_g8, (unsigned)sat_u8(s), acc);
+}
+// Loads addressed as (wave-uniform plane base) + (32-bit unsigned byte offset): the form that maps
+// to global_load ... v_off, s[base:base+1] -- no 64-bit per-lane address arithmetic, no VGPR pairs.
+// Offsets are relative to one view's plane, i.e. < 4 GiB for any image this engine accepts.
+__device__ __forceinline__ int ld_u8(const uint8_t* base, unsigned off) { return base[(size_t)off]; }
+__device__ __forceinline__ float ld_f32(const float* base, unsigned byte_off) {
+  return *(const float*)((const char*)base + (size_t)byte_off);
+}
+// Two adjacent elements with one load (the pair may start at any byte / dword).
+__device__ __forceinline__ void load_pair_u8(const uint8_t* base, unsigned off, int& a, int& b) {
+  unsigned short v;
+  __builtin_memcpy(&v, base + (size_t)off, 2);
+  a = v & 0xff;
+  b = v >> 8;
+}
+__device__ __forceinline__ void load_pair_f32(const float* base, unsigned byte_off, float& a, float& b) {
+  struct P { float x, y; } v;
+  __builtin_memcpy(&v, (const char*)base + (size_t)byte_off, 8);
+  a = v.x;
+  b = v.y;
 }
 
 // mean = (float)(sum * (1./N)); cost = alpha*min(mean_c, tau_c) + (1-alpha)*min(mean_g, tau_g).

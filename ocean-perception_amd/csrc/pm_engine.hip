@@ -10,12 +10,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "pm_kernels.hpp"
 #include "pm_wave.hpp"
+#include "pm_run.hpp"
 
 using namespace pm;
 
@@ -41,9 +43,15 @@ struct pm_handle {
   uint8_t* img8 = nullptr;
   float* g32 = nullptr;
   uint8_t* g8 = nullptr;
-  float* disp = nullptr;
-  float* cost = nullptr;
+  uint8_t* timg8 = nullptr;  // transposed copies for the column sweeps
+  float* tg32 = nullptr;
+  uint8_t* tg8 = nullptr;
+  float* disp[2] = {nullptr, nullptr};
+  float* cost[2] = {nullptr, nullptr};
+  int cur = 0;  // which disparity/cost buffer holds the current state
   float* noise = nullptr;
+  unsigned long long* counters = nullptr;  // device, 8 words
+  bool counters_on = false;                // same-address atomics serialise: opt-in only
   int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
 
   // staging for the host-buffer entry points: tightly packed [B][rows][cols]
@@ -120,9 +128,18 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.img8 = h->img8;
   ps.g32 = h->g32;
   ps.g8 = h->g8;
-  ps.disp = h->disp;
-  ps.cost = h->cost;
+  ps.timg8 = h->timg8;
+  ps.tg32 = h->tg32;
+  ps.tg8 = h->tg8;
+  ps.pitch_t = align_up(rows, 64);
+  ps.plane_t = (size_t)cols * ps.pitch_t;
+  ps.disp[0] = h->disp[0];
+  ps.disp[1] = h->disp[1];
+  ps.cost[0] = h->cost[0];
+  ps.cost[1] = h->cost[1];
+  ps.cur = h->cur;
   ps.noise = h->noise;
+  ps.counters = h->counters_on ? h->counters : nullptr;
   ps.rows = rows;
   ps.cols = cols;
   ps.pitch = align_up(cols, 64);
@@ -227,6 +244,18 @@ int launch_check(pm_handle* h, const char* what) {
 
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
 
+// transposed copies of the 12 image-type planes of n pairs (run by every path that ran k_prep)
+int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
+  const dim3 grid((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 63) / 64), (unsigned)(n * 4)), block(256);
+  hipLaunchKernelGGL(k_transpose<uint8_t>, grid, block, 0, h->stream, (const uint8_t*)ps.img8, ps.timg8, ps.rows,
+                     ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
+  hipLaunchKernelGGL(k_transpose<float>, grid, block, 0, h->stream, (const float*)ps.g32, ps.tg32, ps.rows, ps.cols,
+                     ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
+  hipLaunchKernelGGL(k_transpose<uint8_t>, grid, block, 0, h->stream, (const uint8_t*)ps.g8, ps.tg8, ps.rows, ps.cols,
+                     ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
+  return launch_check(h, "transpose");
+}
+
 int ensure_noise(pm_handle* h, int rows, int cols) {
   const int pitch = align_up(cols, 64);
   if (h->noise_rows == rows && h->noise_cols == cols && h->noise_pitch == pitch) return PM_OK;
@@ -258,24 +287,71 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
   return PM_OK;
 }
 
-int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
+int seg_len_from_env() {
+  // experiment knob (positions per speculative segment, rounded to a multiple of 64)
+  static int v = [] {
+    const char* e = getenv("PM_SEG_LEN");
+    int x = e ? atoi(e) : 128;
+    if (x < 64) x = 64;
+    return (x + 63) / 64 * 64;
+  }();
+  return v;
+}
+
+int runblk_waves_from_env() {
+  static int v = [] {
+    const char* e = getenv("PM_RUNBLK_WAVES");
+    int x = e ? atoi(e) : 16;
+    return x < 1 ? 1 : (x > 16 ? 16 : x);
+  }();
+  return v;
+}
+
+int runseg_len_from_env() {
+  static int v = [] {
+    const char* e = getenv("PM_RUNSEG_LEN");
+    int x = e ? atoi(e) : 160;
+    return x < 32 ? 32 : x;
+  }();
+  return v;
+}
+
+// One directional sweep.  The segmented engine ping-pongs: it reads buffer ps.cur and leaves the
+// result in the other one, so ps.cur / h->cur are flipped afterwards.
+int run_sweep(pm_handle* h, PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
   const int chains = g.c_hi - g.c_lo + 1;
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
   int engine = h->params.engine;
-  if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_WAVE;
+  if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK;
+  if (cp.semantics != PM_SEM_CPU && engine >= PM_ENGINE_SEGMENTED)
+    engine = PM_ENGINE_WAVE;  // PM_SEM_GPU: one lane per chain (its 5-tap cost is too small to spread)
   if (engine == PM_ENGINE_SERIAL) {
     hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0,
                        h->stream, ps, cp, g);
-  } else {
+  } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
+  } else if (engine == PM_ENGINE_RUN) {
+    launch_sweep_run(ps, cp, g, slots, 0, 0, h->stream);
+  } else if (engine == PM_ENGINE_RUNSEG) {
+    launch_sweep_run(ps, cp, g, slots, runseg_len_from_env(), 0, h->stream);
+    ps.cur ^= 1;
+    h->cur = ps.cur;
+  } else if (engine == PM_ENGINE_RUNBLK) {
+    launch_sweep_run(ps, cp, g, slots, 0, runblk_waves_from_env(), h->stream);
+    ps.cur ^= 1;
+    h->cur = ps.cur;
+  } else {
+    launch_sweep_segmented(ps, cp, g, slots, seg_len_from_env(), h->stream);
+    ps.cur ^= 1;
+    h->cur = ps.cur;
   }
   return launch_check(h, "sweep");
 }
 
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
-int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
+int run_views(pm_handle* h, PlaneSet& ps, int slots) {
   const pm_params& p = h->params;
   CostParams cp{};
   int last_pw = 0, last_ph = 0;
@@ -316,7 +392,7 @@ int validate_params(pm_handle* h, const pm_params& p) {
     set_err(h, "unknown semantics %d", p.semantics);
     return PM_ERR_INVALID_ARG;
   }
-  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_WAVE) {
+  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_RUNBLK) {
     set_err(h, "unknown engine %d", p.engine);
     return PM_ERR_INVALID_ARG;
   }
@@ -403,7 +479,7 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  void* dev[] = {h->img8, h->g32, h->g8, h->disp, h->cost, h->noise, h->st_left, h->st_right,
+  void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->disp[0], h->disp[1], h->cost[0], h->cost[1], h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -449,9 +525,25 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->img8, B * 4 * plane + 256));
   PM_HIP(h, hipMalloc((void**)&h->g32, sizeof(float) * (B * 4 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->g8, B * 4 * plane + 256));
-  PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
-  PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
+  const size_t plane_t = (size_t)max_cols * align_up(max_rows, 64);
+  PM_HIP(h, hipMalloc((void**)&h->timg8, B * 4 * plane_t + 256));
+  PM_HIP(h, hipMalloc((void**)&h->tg32, sizeof(float) * (B * 4 * plane_t + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->tg8, B * 4 * plane_t + 256));
+  // Row padding ([cols, pitch)) and the slack behind the last plane are read (with weight 0) by the
+  // paired bilinear loads and never written afterwards: they must hold finite values.
+  PM_HIP(h, hipMemsetAsync(h->img8, 0, B * 4 * plane + 256, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->g32, 0, sizeof(float) * (B * 4 * plane + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->g8, 0, B * 4 * plane + 256, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->timg8, 0, B * 4 * plane_t + 256, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->tg32, 0, sizeof(float) * (B * 4 * plane_t + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->tg8, 0, B * 4 * plane_t + 256, h->stream));
+  for (int i = 0; i < 2; ++i) {
+    PM_HIP(h, hipMalloc((void**)&h->disp[i], sizeof(float) * (B * 2 * plane + 64)));
+    PM_HIP(h, hipMalloc((void**)&h->cost[i], sizeof(float) * (B * 2 * plane + 64)));
+  }
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
+  PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 8, h->stream));
   const size_t tight = (size_t)max_rows * max_cols;
   PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
@@ -466,8 +558,10 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
   // the cost planes are read only where the noise kernel wrote them; clear once so that tools that
   // scan whole planes never see uninitialised memory
-  PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
-  PM_HIP(h, hipMemsetAsync(h->disp, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  for (int i = 0; i < 2; ++i) {
+    PM_HIP(h, hipMemsetAsync(h->cost[i], 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+    PM_HIP(h, hipMemsetAsync(h->disp[i], 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  }
   PM_HIP(h, hipStreamSynchronize(h->stream));
   return PM_OK;
 }
@@ -496,13 +590,17 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
     return PM_ERR_INVALID_ARG;
   }
   if (int rc = ensure_noise(h, rows, cols)) return rc;
-  const PlaneSet ps = plane_set(h, rows, cols, n_views);
+  PlaneSet ps = plane_set(h, rows, cols, n_views);
   {
     Launch l(h, PM_K_PREP);
     hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_left, d_right,
                        (size_t)cols);
   }
   if (int rc = launch_check(h, "prep")) return rc;
+  {
+    Launch l(h, PM_K_PREP);
+    if (int rc = run_transpose(h, ps, n)) return rc;
+  }
   {
     Launch l(h, PM_K_SEED);
     hipLaunchKernelGGL(k_seed, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
@@ -649,6 +747,7 @@ int stage_prep(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows
   hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, h->st_left, h->st_right,
                      (size_t)cols);
   if (int rc = launch_check(h, "prep")) return rc;
+  if (int rc = run_transpose(h, ps, 1)) return rc;
   *ps_out = ps;
   return PM_OK;
 }
@@ -773,6 +872,21 @@ int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int row
 }
 
 // ---- profiling ----------------------------------------------------------------------------------
+
+int pm_debug_counters_enable(pm_handle* h, int on) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  h->counters_on = on != 0;
+  return PM_OK;
+}
+
+int pm_debug_counters(pm_handle* h, uint64_t out[8]) {
+  if (!h || !out) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  PM_HIP(h, hipMemcpy(out, h->counters, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
+  PM_HIP(h, hipMemset(h->counters, 0, sizeof(uint64_t) * 8));
+  return PM_OK;
+}
 
 int pm_profile_enable(pm_handle* h, int on) {
   if (!h) return PM_ERR_INVALID_ARG;

@@ -60,6 +60,28 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
   }
 }
 
+// Transposes `planes` planes of rows x cols (pitch `sp`) into cols x rows (pitch `dp`) through a
+// 64x64 LDS tile (+1 column of padding: conflict-free for 4-byte elements, 2-way for bytes) so that
+// both the reads and the writes are coalesced.  grid = (ceil(cols/64), ceil(rows/64), planes), block = 256.
+template <typename T>
+__global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
+                                                   int sp, int dp, size_t src_plane, size_t dst_plane) {
+  __shared__ T tile[64][65];
+  const T* s = src + (size_t)blockIdx.z * src_plane;
+  T* d = dst + (size_t)blockIdx.z * dst_plane;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int y = y0 + r, x = x0 + tx;
+    if (y < rows && x < cols) tile[r][tx] = s[(size_t)y * sp + x];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int x = x0 + r, y = y0 + tx;
+    if (x < cols && y < rows) d[(size_t)x * dp + y] = tile[tx][r];
+  }
+}
+
 // seed maps -> disparity planes; the right-view seed is mirrored like the images
 // (patchmatch_gpu.cu:362-366).  A null seed pointer means "all background".
 __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restrict__ seed_l,
@@ -69,9 +91,9 @@ __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restri
   if (x >= ps.cols) return;
   const size_t sp = (size_t)ps.rows * seed_stride;
   const size_t o = (size_t)y * ps.pitch + x;
-  ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
+  ps.disp[ps.cur][((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
   if (ps.n_views > 1)
-    ps.disp[((size_t)b * 2 + 1) * ps.plane + o] =
+    ps.disp[ps.cur][((size_t)b * 2 + 1) * ps.plane + o] =
         seed_r ? seed_r[(size_t)b * sp + (size_t)y * seed_stride + (ps.cols - 1 - x)] : 0.f;
 }
 
@@ -119,7 +141,9 @@ __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, 
     }
     v.cost[o] = c;
   }
+  // both buffers: the ping-pong sweeps rewrite every pixel they visit but never the border
   v.disp[o] = d;
+  v.disp_out[o] = d;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,10 +235,10 @@ __global__ void __launch_bounds__(256) k_finalize(PlaneSet ps, float* __restrict
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
   const size_t op = (size_t)ps.rows * out_stride;
-  const float* dl_plane = ps.disp + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
+  const float* dl_plane = ps.disp[ps.cur] + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
   float dl = dl_plane[x];
   if (ps.n_views > 1) {
-    const float* dr_plane = ps.disp + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
+    const float* dr_plane = ps.disp[ps.cur] + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
     const int xr = (int)fmaxf((float)x - dl, 0.f);
     const float dr = dr_plane[ps.cols - 1 - xr];
     if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) dl = 0.f;
@@ -240,13 +264,13 @@ __global__ void __launch_bounds__(256) k_copy_in(PlaneSet ps, const float* __res
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  ps.disp[(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
+  ps.disp[ps.cur][(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
 }
 __global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict__ dst, int which) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  const float* src = which == 0 ? ps.disp : (which == 1 ? ps.g32 : ps.noise);
+  const float* src = which == 0 ? ps.disp[ps.cur] : (which == 1 ? ps.g32 : ps.noise);
   dst[(size_t)y * ps.cols + x] = src[(size_t)y * ps.pitch + x];
 }
 

@@ -13,13 +13,14 @@ PM_ABI_VERSION = 1
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
-PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE = 0, 1, 2
+PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_SEGMENTED, PM_ENGINE_RUN, PM_ENGINE_RUNSEG, PM_ENGINE_RUNBLK = 0, 1, 2, 3, 4, 5, 6
 PM_OK = 0
 PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM = -1, -2, -3, -4, -5
 PM_K_COUNT = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libvehicle_pm_gpu.so"))
+# PM_LIB: experiment knob to load another build of the same library (e.g. a different unroll factor)
+LIB_PATH = os.environ.get("PM_LIB") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libvehicle_pm_gpu.so"))
 
 # every symbol include/pm/patchmatch.h declares
 EXPORTS = [
@@ -27,7 +28,7 @@ EXPORTS = [
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_profile_enable", "pm_profile_read",
-    "pm_kernel_name",
+    "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
 ]
 
 
@@ -115,6 +116,10 @@ def load():
     lib.pm_profile_read.restype = C.c_int
     lib.pm_kernel_name.argtypes = [C.c_int]
     lib.pm_kernel_name.restype = C.c_char_p
+    lib.pm_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64 * 8)]
+    lib.pm_debug_counters.restype = C.c_int
+    lib.pm_debug_counters_enable.argtypes = [vp, C.c_int]
+    lib.pm_debug_counters_enable.restype = C.c_int
     _lib = lib
     return lib
 
@@ -288,6 +293,15 @@ class Engine:
         self._check(self.lib.pm_mask_occlusions(self.h, dl.ctypes.data_as(C.c_void_p), pdr, dl.shape[0],
                                                 dl.shape[1]), "pm_mask_occlusions")
         return dl
+
+    def debug_counters_enable(self, on=True):
+        self._check(self.lib.pm_debug_counters_enable(self.h, 1 if on else 0), "pm_debug_counters_enable")
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.pm_debug_counters(self.h, C.byref(out)), "pm_debug_counters")
+        names = ("steps", "evals", "adopted", "positions")
+        return {ax: {n: int(out[k * 4 + j]) for j, n in enumerate(names)} for k, ax in enumerate(("row", "col"))}
 
     # --- profiling ------------------------------------------------------------------------------
     def profile_enable(self, on=True):

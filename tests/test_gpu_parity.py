@@ -17,7 +17,7 @@ from conftest import assert_same, small_pair
 pytestmark = pytest.mark.gpu
 
 SEMS = [0, 1]
-ENGINES = [1, 2]  # PM_ENGINE_SERIAL, PM_ENGINE_WAVE
+ENGINES = [1, 2, 3, 4, 5, 6]  # PM_ENGINE_SERIAL, _WAVE, _SEGMENTED, _RUN, _RUNSEG, _RUNBLK
 
 
 def mk(pm, sem, engine=0, patch=3, iters=3, lr=1, rows=64, cols=96, batch=1, **kw):
@@ -114,7 +114,7 @@ def test_match_both_views(pm, oracle, synth, sem, engine, rows, cols):
 def test_match_cpu_semantics_window_sizes(pm, oracle, synth, patch):
     rows, cols = 60, 100
     l, r, sl, sr, _ = small_pair(synth, 20 + patch, rows, cols, n_points=40, dilate_factor=2)
-    with mk(pm, 0, 2, patch=patch, iters=4, rows=rows, cols=cols) as e:
+    with mk(pm, 0, 0, patch=patch, iters=4, rows=rows, cols=cols) as e:
         dl, dr = e.match(l, r, sl, sr)
     el, er = oracle.match(oparams(oracle, 0, patch, 4), l, r, sl, sr)
     assert_same(dl, el, "left")
@@ -248,15 +248,19 @@ def test_full_size_baseline_config_properties(pm, oracle, synth):
     rows, cols, patch, iters = 720, 1280, 11, 8
     p = synth.make_pair(0, rows, cols)
     l, r, sl, sr = p["left"], p["right"], p["seed_l"], p["seed_r"]
-    with mk(pm, 0, 2, patch=patch, iters=iters, rows=rows, cols=cols) as e:
+    with mk(pm, 0, 0, patch=patch, iters=iters, rows=rows, cols=cols) as e:   # the engine bench.py runs
         dl, dr = e.match(l, r, sl, sr)
         dl2, dr2 = e.match(l, r, sl, sr)
     with mk(pm, 0, 1, patch=patch, iters=iters, rows=rows, cols=cols) as e:
         sl_, sr_ = e.match(l, r, sl, sr)
+    with mk(pm, 0, 2, patch=patch, iters=iters, rows=rows, cols=cols) as e:
+        wl_, wr_ = e.match(l, r, sl, sr)
     assert_same(dl, dl2, "run-to-run determinism (left)")
     assert_same(dr, dr2, "run-to-run determinism (right)")
-    assert_same(dl, sl_, "wave engine == serial anchor (left)")
-    assert_same(dr, sr_, "wave engine == serial anchor (right)")
+    assert_same(dl, sl_, "default engine == serial anchor (left)")
+    assert_same(dr, sr_, "default engine == serial anchor (right)")
+    assert_same(wl_, sl_, "wave engine == serial anchor (left)")
+    assert_same(wr_, sr_, "wave engine == serial anchor (right)")
     assert np.isfinite(dl).all() and np.isfinite(dr).all() and dl.min() >= 0 and dr.min() >= 0
     h = patch // 2
     xs = np.arange(cols, dtype=np.float32)[None, :]
@@ -278,7 +282,7 @@ def test_full_size_baseline_config_properties(pm, oracle, synth):
     assert fg.mean() > 0.15 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.95
     # a 64-row band of the same pair is an independent problem the oracle can afford at 11x11 / 8 it.
     band = np.s_[300:364, :]
-    with mk(pm, 0, 2, patch=patch, iters=iters, rows=64, cols=cols) as e:
+    with mk(pm, 0, 0, patch=patch, iters=iters, rows=64, cols=cols) as e:
         bdl, bdr = e.match(l[band], r[band], sl[band], sr[band])
     el, er = oracle.match(oparams(oracle, 0, patch, iters), l[band], r[band], sl[band], sr[band])
     assert_same(bdl, el, "64-row band at full width, left")
