@@ -60,13 +60,11 @@ typedef enum pm_semantics {
 
 /* How the directional sweeps are executed on the device (results are identical). */
 typedef enum pm_engine {
-  PM_ENGINE_AUTO = 0,
-  PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor */
-  PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes           */
-  PM_ENGINE_SEGMENTED = 3, /* chains cut into speculative segments (one wavefront each) + exact fix-up */
-  PM_ENGINE_RUN = 4,    /* one wavefront per chain, a whole adoption run (<= 64-pw+1 positions) per step */
-  PM_ENGINE_RUNSEG = 5, /* run steps on speculative chain segments + exact sequential fix-up             */
-  PM_ENGINE_RUNBLK = 6  /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint (default) */
+  PM_ENGINE_AUTO = 0,   /* = PM_ENGINE_RUNBLK for PM_SEM_CPU, PM_ENGINE_WAVE for PM_SEM_GPU                   */
+  PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor         */
+  PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes                  */
+  PM_ENGINE_RUN = 3,    /* one wavefront per chain, a whole adoption run (<= 64-pw positions) per step    */
+  PM_ENGINE_RUNBLK = 4  /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint     */
 } pm_engine;
 
 /*

@@ -25,12 +25,10 @@ struct PlaneSet {
   uint8_t* tg8;        // [B][4][cols][pitch_t]
   int pitch_t;         // align_up(rows, 64)
   size_t plane_t;      // cols * pitch_t
-  // Disparity and cost-of-disparity planes are double buffered: the segmented sweeps read buffer
-  // `cur` and write buffer `cur ^ 1` (the old values must survive for the fix-up pass); in-place
-  // kernels work on buffer `cur`.
-  float* disp[2];      // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
-  float* cost[2];      // [B][2][rows][pitch]   cost of disp under the current window
-  int cur;
+  uint16_t* pk16;      // [B][4][rows][pitch]   img8 | g8 << 8: what a window reads of its own image
+  uint16_t* tpk16;     // [B][4][cols][pitch_t] transposed copy of pk16
+  float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
+  float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
   unsigned long long* counters;  // [8] work counters (see pm_debug_counters), one atomic per wavefront
   int rows, cols, pitch;
@@ -51,10 +49,10 @@ struct View {
   const uint8_t* ttgt8;
   const float* ttgtg;
   const uint8_t* trefg8;
-  float* disp;      // buffer `cur`
+  const uint16_t* refpk;   // ref8 | refg8 << 8
+  const uint16_t* trefpk;  // transposed
+  float* disp;
   float* cost;
-  float* disp_out;  // buffer `cur ^ 1`
-  float* cost_out;
 };
 
 __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
@@ -71,11 +69,11 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.ttgt8 = ps.timg8 + (base4 + itgt) * ps.plane_t;
   w.ttgtg = ps.tg32 + (base4 + itgt) * ps.plane_t;
   w.trefg8 = ps.tg8 + (base4 + iref) * ps.plane_t;
+  w.refpk = ps.pk16 + (base4 + iref) * ps.plane;
+  w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
-  w.disp = ps.disp[ps.cur] + dofs;
-  w.cost = ps.cost[ps.cur] + dofs;
-  w.disp_out = ps.disp[ps.cur ^ 1] + dofs;
-  w.cost_out = ps.cost[ps.cur ^ 1] + dofs;
+  w.disp = ps.disp + dofs;
+  w.cost = ps.cost + dofs;
   return w;
 }
 
@@ -150,6 +148,9 @@ __device__ __forceinline__ unsigned cpu_acc_grad(unsigned acc, int left_g8, floa
 // to global_load ... v_off, s[base:base+1] -- no 64-bit per-lane address arithmetic, no VGPR pairs.
 // Offsets are relative to one view's plane, i.e. < 4 GiB for any image this engine accepts.
 __device__ __forceinline__ int ld_u8(const uint8_t* base, unsigned off) { return base[(size_t)off]; }
+__device__ __forceinline__ int ld_u16(const uint16_t* base, unsigned byte_off) {
+  return *(const uint16_t*)((const char*)base + (size_t)byte_off);
+}
 __device__ __forceinline__ float ld_f32(const float* base, unsigned byte_off) {
   return *(const float*)((const char*)base + (size_t)byte_off);
 }

@@ -46,9 +46,10 @@ struct pm_handle {
   uint8_t* timg8 = nullptr;  // transposed copies for the column sweeps
   float* tg32 = nullptr;
   uint8_t* tg8 = nullptr;
-  float* disp[2] = {nullptr, nullptr};
-  float* cost[2] = {nullptr, nullptr};
-  int cur = 0;  // which disparity/cost buffer holds the current state
+  uint16_t* pk16 = nullptr;
+  uint16_t* tpk16 = nullptr;
+  float* disp = nullptr;
+  float* cost = nullptr;
   float* noise = nullptr;
   unsigned long long* counters = nullptr;  // device, 8 words
   bool counters_on = false;                // same-address atomics serialise: opt-in only
@@ -133,11 +134,10 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.tg8 = h->tg8;
   ps.pitch_t = align_up(rows, 64);
   ps.plane_t = (size_t)cols * ps.pitch_t;
-  ps.disp[0] = h->disp[0];
-  ps.disp[1] = h->disp[1];
-  ps.cost[0] = h->cost[0];
-  ps.cost[1] = h->cost[1];
-  ps.cur = h->cur;
+  ps.pk16 = h->pk16;
+  ps.tpk16 = h->tpk16;
+  ps.disp = h->disp;
+  ps.cost = h->cost;
   ps.noise = h->noise;
   ps.counters = h->counters_on ? h->counters : nullptr;
   ps.rows = rows;
@@ -253,6 +253,8 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
                      ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
   hipLaunchKernelGGL(k_transpose<uint8_t>, grid, block, 0, h->stream, (const uint8_t*)ps.g8, ps.tg8, ps.rows, ps.cols,
                      ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
+  hipLaunchKernelGGL(k_transpose<uint16_t>, grid, block, 0, h->stream, (const uint16_t*)ps.pk16, ps.tpk16, ps.rows,
+                     ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
   return launch_check(h, "transpose");
 }
 
@@ -287,71 +289,39 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
   return PM_OK;
 }
 
-int seg_len_from_env() {
-  // experiment knob (positions per speculative segment, rounded to a multiple of 64)
-  static int v = [] {
-    const char* e = getenv("PM_SEG_LEN");
-    int x = e ? atoi(e) : 128;
-    if (x < 64) x = 64;
-    return (x + 63) / 64 * 64;
-  }();
-  return v;
-}
-
 int runblk_waves_from_env() {
+  // experiment knob: wavefronts (= segments) per chain in PM_ENGINE_RUNBLK
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_WAVES");
-    int x = e ? atoi(e) : 16;
-    return x < 1 ? 1 : (x > 16 ? 16 : x);
+    int x = e ? atoi(e) : 8;
+    return x < 1 ? 1 : (x > kMaxSegWaves ? kMaxSegWaves : x);
   }();
   return v;
 }
 
-int runseg_len_from_env() {
-  static int v = [] {
-    const char* e = getenv("PM_RUNSEG_LEN");
-    int x = e ? atoi(e) : 160;
-    return x < 32 ? 32 : x;
-  }();
-  return v;
-}
-
-// One directional sweep.  The segmented engine ping-pongs: it reads buffer ps.cur and leaves the
-// result in the other one, so ps.cur / h->cur are flipped afterwards.
-int run_sweep(pm_handle* h, PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
+// One directional sweep, in place.
+int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
   const int chains = g.c_hi - g.c_lo + 1;
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
   int engine = h->params.engine;
   if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK;
-  if (cp.semantics != PM_SEM_CPU && engine >= PM_ENGINE_SEGMENTED)
+  if (cp.semantics != PM_SEM_CPU && engine >= PM_ENGINE_RUN)
     engine = PM_ENGINE_WAVE;  // PM_SEM_GPU: one lane per chain (its 5-tap cost is too small to spread)
   if (engine == PM_ENGINE_SERIAL) {
     hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0,
                        h->stream, ps, cp, g);
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
-  } else if (engine == PM_ENGINE_RUN) {
-    launch_sweep_run(ps, cp, g, slots, 0, 0, h->stream);
-  } else if (engine == PM_ENGINE_RUNSEG) {
-    launch_sweep_run(ps, cp, g, slots, runseg_len_from_env(), 0, h->stream);
-    ps.cur ^= 1;
-    h->cur = ps.cur;
-  } else if (engine == PM_ENGINE_RUNBLK) {
-    launch_sweep_run(ps, cp, g, slots, 0, runblk_waves_from_env(), h->stream);
-    ps.cur ^= 1;
-    h->cur = ps.cur;
   } else {
-    launch_sweep_segmented(ps, cp, g, slots, seg_len_from_env(), h->stream);
-    ps.cur ^= 1;
-    h->cur = ps.cur;
+    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves_from_env() : 1, h->stream);
   }
   return launch_check(h, "sweep");
 }
 
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
-int run_views(pm_handle* h, PlaneSet& ps, int slots) {
+int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
   const pm_params& p = h->params;
   CostParams cp{};
   int last_pw = 0, last_ph = 0;
@@ -479,7 +449,7 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->disp[0], h->disp[1], h->cost[0], h->cost[1], h->noise, h->counters, h->st_left, h->st_right,
+  void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -537,10 +507,12 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMemsetAsync(h->timg8, 0, B * 4 * plane_t + 256, h->stream));
   PM_HIP(h, hipMemsetAsync(h->tg32, 0, sizeof(float) * (B * 4 * plane_t + 64), h->stream));
   PM_HIP(h, hipMemsetAsync(h->tg8, 0, B * 4 * plane_t + 256, h->stream));
-  for (int i = 0; i < 2; ++i) {
-    PM_HIP(h, hipMalloc((void**)&h->disp[i], sizeof(float) * (B * 2 * plane + 64)));
-    PM_HIP(h, hipMalloc((void**)&h->cost[i], sizeof(float) * (B * 2 * plane + 64)));
-  }
+  PM_HIP(h, hipMalloc((void**)&h->pk16, sizeof(uint16_t) * (B * 4 * plane + 128)));
+  PM_HIP(h, hipMalloc((void**)&h->tpk16, sizeof(uint16_t) * (B * 4 * plane_t + 128)));
+  PM_HIP(h, hipMemsetAsync(h->pk16, 0, sizeof(uint16_t) * (B * 4 * plane + 128), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->tpk16, 0, sizeof(uint16_t) * (B * 4 * plane_t + 128), h->stream));
+  PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
   PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 8, h->stream));
@@ -558,10 +530,8 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
   // the cost planes are read only where the noise kernel wrote them; clear once so that tools that
   // scan whole planes never see uninitialised memory
-  for (int i = 0; i < 2; ++i) {
-    PM_HIP(h, hipMemsetAsync(h->cost[i], 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
-    PM_HIP(h, hipMemsetAsync(h->disp[i], 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
-  }
+  PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->disp, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   return PM_OK;
 }

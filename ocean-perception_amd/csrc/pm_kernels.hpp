@@ -57,6 +57,9 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
     ps.g32[mirror] = g;
     ps.g8[direct] = g8;
     ps.g8[mirror] = g8;
+    const uint16_t pk = (uint16_t)(p | ((unsigned)g8 << 8));
+    ps.pk16[direct] = pk;
+    ps.pk16[mirror] = pk;
   }
 }
 
@@ -91,9 +94,9 @@ __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restri
   if (x >= ps.cols) return;
   const size_t sp = (size_t)ps.rows * seed_stride;
   const size_t o = (size_t)y * ps.pitch + x;
-  ps.disp[ps.cur][((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
+  ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
   if (ps.n_views > 1)
-    ps.disp[ps.cur][((size_t)b * 2 + 1) * ps.plane + o] =
+    ps.disp[((size_t)b * 2 + 1) * ps.plane + o] =
         seed_r ? seed_r[(size_t)b * sp + (size_t)y * seed_stride + (ps.cols - 1 - x)] : 0.f;
 }
 
@@ -141,9 +144,7 @@ __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, 
     }
     v.cost[o] = c;
   }
-  // both buffers: the ping-pong sweeps rewrite every pixel they visit but never the border
   v.disp[o] = d;
-  v.disp_out[o] = d;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,10 +236,10 @@ __global__ void __launch_bounds__(256) k_finalize(PlaneSet ps, float* __restrict
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
   const size_t op = (size_t)ps.rows * out_stride;
-  const float* dl_plane = ps.disp[ps.cur] + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
+  const float* dl_plane = ps.disp + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
   float dl = dl_plane[x];
   if (ps.n_views > 1) {
-    const float* dr_plane = ps.disp[ps.cur] + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
+    const float* dr_plane = ps.disp + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
     const int xr = (int)fmaxf((float)x - dl, 0.f);
     const float dr = dr_plane[ps.cols - 1 - xr];
     if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) dl = 0.f;
@@ -264,13 +265,13 @@ __global__ void __launch_bounds__(256) k_copy_in(PlaneSet ps, const float* __res
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  ps.disp[ps.cur][(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
+  ps.disp[(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
 }
 __global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict__ dst, int which) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  const float* src = which == 0 ? ps.disp[ps.cur] : (which == 1 ? ps.g32 : ps.noise);
+  const float* src = which == 0 ? ps.disp : (which == 1 ? ps.g32 : ps.noise);
   dst[(size_t)y * ps.cols + x] = src[(size_t)y * ps.pitch + x];
 }
 

@@ -137,162 +137,6 @@ __global__ void __launch_bounds__(64) k_sweep_wave_cpu(PlaneSet ps, CostParams c
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// PM_ENGINE_SEGMENTED: the same recurrence with S times more wavefronts in flight.
-//
-// A chain of n positions is cut into segments of `seg_len`.  Pass 1 (k_sweep_seg_cpu) sweeps every
-// segment concurrently, starting each one from the OLD value of the pixel before it -- a guess for
-// the value that pixel will end up with (exact for the first segment, whose predecessor is never
-// swept).  It reads buffer `cur` and writes buffer `cur ^ 1`, so the old state survives.
-// Pass 2 (k_sweep_fix_cpu, one wavefront per chain) walks the segment boundaries in sweep order:
-// where the predecessor's final value differs from the guess it re-runs the recurrence from the
-// segment start with the true value until its state (the value just written) coincides with what
-// pass 1 stored at that position -- from there on pass 1's trajectory is the true one.  The walk is
-// sequential, so every boundary is checked against final data and the result is exactly the
-// sequential sweep, whatever the run lengths are; the usual case costs one comparison per boundary.
-// ---------------------------------------------------------------------------------------------
-struct SegGeom {
-  int seg_len;  // positions per segment (multiple of 64)
-};
-
-template <int K>
-__global__ void __launch_bounds__(64) k_sweep_seg_cpu(PlaneSet ps, CostParams cp, SweepGeom g, SegGeom sg) {
-  const int chain = g.c_lo + blockIdx.x;
-  const int seg = blockIdx.y;
-  const int slot = blockIdx.z;
-  const int lane = threadIdx.x;
-  const View v = make_view(ps, slot);
-  const int half_w = cp.pw / 2;
-  const int n = (g.s_last - g.s_first) * g.dir + 1;
-  const int i0 = seg * sg.seg_len;
-  const int i1 = min(n, i0 + sg.seg_len);
-  if (i0 >= n) return;
-  const LaneTaps<K> taps = lane_taps<K>(lane, cp.pw, cp.ph, ps.pitch);
-  const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;
-  const ptrdiff_t first = g.axis == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
-
-  float prev = v.disp[first + (ptrdiff_t)(i0 - 1) * stride];
-  for (int base = i0; base < i1; base += kWave) {
-    const int cnt = min(kWave, i1 - base);
-    const bool mine = lane < cnt;
-    const ptrdiff_t o = first + (ptrdiff_t)(base + lane) * stride;
-    const float dreg = mine ? v.disp[o] : 0.f;
-    const float creg = mine ? v.cost[o] : 0.f;
-    float dnew = dreg, cnew = creg;
-    for (int k = 0; k < cnt; ++k) {
-      const int s = g.s_first + (base + k) * g.dir;
-      const int x = g.axis == 0 ? s : chain;
-      const int y = g.axis == 0 ? chain : s;
-      const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dreg), k));
-      const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, creg), k));
-      float nd = d0, nc = c0;
-      const bool adopt = sweep_step(0, x, half_w, d0, c0, prev, nd, nc, [&](float cand) {
-        return cpu_cost_wave<K>(v, ps.pitch, ps.cols, x, y, cand, cp, taps);
-      });
-      if (adopt && lane == k) {
-        dnew = nd;
-        cnew = nc;
-      }
-      prev = nd;
-    }
-    if (mine) {
-      v.disp_out[o] = dnew;
-      v.cost_out[o] = cnew;
-    }
-  }
-}
-
-template <int K>
-__global__ void __launch_bounds__(64) k_sweep_fix_cpu(PlaneSet ps, CostParams cp, SweepGeom g, SegGeom sg) {
-  const int chain = g.c_lo + blockIdx.x;
-  const int slot = blockIdx.z;
-  const int lane = threadIdx.x;
-  const View v = make_view(ps, slot);
-  const int half_w = cp.pw / 2;
-  const int n = (g.s_last - g.s_first) * g.dir + 1;
-  const LaneTaps<K> taps = lane_taps<K>(lane, cp.pw, cp.ph, ps.pitch);
-  const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;
-  const ptrdiff_t first = g.axis == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
-
-  int idx = sg.seg_len;
-  while (idx < n) {
-    const ptrdiff_t pb = first + (ptrdiff_t)(idx - 1) * stride;
-    const float true_in = v.disp_out[pb];  // final: everything before `idx` has been settled
-    const float guessed = v.disp[pb];
-    if (true_in == guessed) {
-      idx += sg.seg_len;
-      continue;
-    }
-    float prev = true_in;
-    int j = idx;
-    int merged_at = -1;
-    while (j < n && merged_at < 0) {
-      const int cnt = min(kWave, n - j);
-      const bool mine = lane < cnt;
-      const ptrdiff_t o = first + (ptrdiff_t)(j + lane) * stride;
-      const float dreg = mine ? v.disp[o] : 0.f;
-      const float creg = mine ? v.cost[o] : 0.f;
-      const float sreg = mine ? v.disp_out[o] : 0.f;
-      float dnew = 0.f, cnew = 0.f;
-      bool changed = false;
-      for (int k = 0; k < cnt; ++k) {
-        const int s = g.s_first + (j + k) * g.dir;
-        const int x = g.axis == 0 ? s : chain;
-        const int y = g.axis == 0 ? chain : s;
-        const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dreg), k));
-        const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, creg), k));
-        const float sp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sreg), k));
-        float nd = d0, nc = c0;
-        sweep_step(0, x, half_w, d0, c0, prev, nd, nc, [&](float cand) {
-          return cpu_cost_wave<K>(v, ps.pitch, ps.cols, x, y, cand, cp, taps);
-        });
-        if (nd == sp) {  // same state as pass 1 from here on
-          merged_at = j + k;
-          break;
-        }
-        if (lane == k) {
-          dnew = nd;
-          cnew = nc;
-          changed = true;
-        }
-        prev = nd;
-      }
-      if (changed) {
-        v.disp_out[o] = dnew;
-        v.cost_out[o] = cnew;
-      }
-      j += cnt;
-    }
-    idx = merged_at >= 0 ? (merged_at / sg.seg_len + 1) * sg.seg_len : n;
-  }
-}
-
-template <int K>
-inline void launch_seg_k(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int seg_len,
-                         hipStream_t stream) {
-  const int chains = g.c_hi - g.c_lo + 1;
-  const int n = (g.s_last - g.s_first) * g.dir + 1;
-  const int nseg = (n + seg_len - 1) / seg_len;
-  const SegGeom sg{seg_len};
-  hipLaunchKernelGGL(k_sweep_seg_cpu<K>, dim3((unsigned)chains, (unsigned)nseg, (unsigned)slots), dim3(kWave), 0,
-                     stream, ps, cp, g, sg);
-  if (nseg > 1)
-    hipLaunchKernelGGL(k_sweep_fix_cpu<K>, dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave), 0, stream, ps, cp,
-                       g, sg);
-}
-
-// PM_SEM_CPU only.  Reads buffer ps.cur, leaves the result in buffer ps.cur ^ 1.
-inline void launch_sweep_segmented(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
-                                   int seg_len, hipStream_t stream) {
-  const int k = (cp.pw * cp.ph + kWave - 1) / kWave;
-  switch (k) {
-    case 1: launch_seg_k<1>(ps, cp, g, slots, seg_len, stream); break;
-    case 2: launch_seg_k<2>(ps, cp, g, slots, seg_len, stream); break;
-    case 3: launch_seg_k<3>(ps, cp, g, slots, seg_len, stream); break;
-    default: launch_seg_k<4>(ps, cp, g, slots, seg_len, stream); break;
-  }
-}
-
 inline void launch_sweep_wave(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
                               hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
