@@ -148,6 +148,128 @@ __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same stage for PM_SEM_CPU with the windows staged in LDS.  Every pixel evaluates its OWN
+// disparity, so nothing is shared between lanes except the image data: a 32x8 tile of pixels reads
+// (32+pw-1) x (8+ph-1) reference pixels and, on the target side, the same rows over the column range
+// [min ipx, max ipx + pw] of the tile's lanes (ipx = first target column of a lane's window).  The
+// tile is filled with coalesced row reads once (about 12 target pixels per output pixel instead of
+// 2*pw*ph scattered loads) and the 3*pw*ph reads per evaluation go to LDS.  If the disparities of a
+// tile span more than kTileDispRange columns the block falls back to the global-memory path of
+// k_noise_cost -- same arithmetic, same result.
+// grid = (ceil(cols/32), ceil(rows/8), slots), block = 256.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileW = 32, kTileH = 8;
+constexpr int kTileRW = 224;  // columns of the target tile held in LDS
+
+template <int TPW, int TPH>
+__global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParams cp, Interior in, float amount) {
+  constexpr int PW = TPW, PH = TPH;
+  constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
+  __shared__ uint16_t s_left[TR * LW];
+  __shared__ uint8_t s_r8[TR * kTileRW];
+  __shared__ float s_rg[TR * kTileRW];
+  __shared__ int s_red[8];
+
+  const int tid = threadIdx.x, tx = tid & (kTileW - 1), ty = tid / kTileW;
+  const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+  const int x = x0 + tx, y = y0 + ty, slot = blockIdx.z;
+  const View v = make_view(ps, slot);
+  const int cols = ps.cols, rows = ps.rows, pitch = ps.pitch;
+  const bool inimg = x < cols && y < rows;
+  const size_t o = (size_t)y * pitch + x;
+
+  float d = 0.f;
+  if (inimg) {
+    d = v.disp[o];
+    if (amount >= 0.f) {
+      if (d > 0.f) {
+        const float m = ps.noise[o] * amount;
+        const float s = m + d;
+        d = s > 0.f ? s : 0.f;
+      } else {
+        d = 0.f;
+      }
+    }
+  }
+  const bool interior = inimg && x >= in.x_lo && x <= in.x_hi && y >= in.y_lo && y <= in.y_hi;
+  CpuLerp l;
+  l.ipx = 0;
+  if (interior) {
+    const float hi = (float)x - (float)(PW / 2);
+    d = d > 0.f ? d : 0.f;
+    d = d < hi ? d : hi;
+    l = cpu_lerp(x, d, PW);
+  }
+
+  // ---- column range of the target tile: min / max of ipx over the block's interior lanes --------------
+  int lo = interior ? l.ipx : 0x7fffffff, hi_ = interior ? l.ipx : -0x7fffffff;
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    lo = min(lo, __shfl_xor(lo, ofs, 64));
+    hi_ = max(hi_, __shfl_xor(hi_, ofs, 64));
+  }
+  if ((tid & 63) == 0) {
+    s_red[(tid >> 6) * 2] = lo;
+    s_red[(tid >> 6) * 2 + 1] = hi_;
+  }
+  __syncthreads();
+  lo = min(min(s_red[0], s_red[2]), min(s_red[4], s_red[6]));
+  hi_ = max(max(s_red[1], s_red[3]), max(s_red[5], s_red[7]));
+  if (hi_ < lo) {  // no interior pixel in this tile (uniform)
+    if (inimg) v.disp[o] = d;
+    return;
+  }
+  const int rw = hi_ + PW + 1 - lo;  // columns needed: [lo, hi_ + PW]
+  const bool tiled = rw <= kTileRW;  // uniform
+
+  float c = 0.f;
+  if (tiled) {
+    // ---- fill: rows y0-PH/2 .. y0+kTileH-1+PH/2, clamped (clamped rows/columns are only ever read by
+    // pixels that are not interior, or carry weight 0) -----------------------------------------------
+    const int ry0 = y0 - PH / 2, lx0 = x0 - PW / 2;
+    for (int e = tid; e < TR * LW; e += 256) {
+      const int rr = e / LW, cc = e - rr * LW;
+      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
+      s_left[e] = v.refpk[(size_t)gy * pitch + gx];
+    }
+    for (int e = tid; e < TR * rw; e += 256) {
+      const int rr = e / rw, cc = e - rr * rw;
+      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lo + cc, 0), cols - 1);
+      s_r8[rr * kTileRW + cc] = v.tgt8[(size_t)gy * pitch + gx];
+      s_rg[rr * kTileRW + cc] = v.tgtg[(size_t)gy * pitch + gx];
+    }
+    __syncthreads();
+    if (interior) {
+      unsigned sc = 0, sg = 0;
+      const int rc = l.ipx - lo;
+#pragma unroll 1
+      for (int i = 0; i < PH; ++i) {
+        const uint16_t* lp = s_left + (ty + i) * LW + tx;
+        const uint8_t* rp = s_r8 + (ty + i) * kTileRW + rc;
+        const float* rg = s_rg + (ty + i) * kTileRW + rc;
+        int r0 = rp[0];
+        float g0 = rg[0];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          const int r1 = rp[j + 1];
+          const float g1 = rg[j + 1];
+          const int lpk = lp[j];
+          sc = cpu_acc_color(sc, lpk & 0xff, r0, r1, l);
+          sg = cpu_acc_grad(sg, lpk >> 8, g0, g1, l);
+          r0 = r1;
+          g0 = g1;
+        }
+      }
+      c = cpu_cost_from_sums((int)sc, (int)sg, cp);
+    }
+  } else if (interior) {
+    c = cpu_cost_lane(v, pitch, cols, x, y, d, cp);
+  }
+  if (interior) v.cost[o] = c;
+  if (inimg) v.disp[o] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Directional sweep, PM_ENGINE_SERIAL: one lane per chain (a row for axis 0, a column for axis 1),
 // strictly sequential along the chain -- the form whose equivalence with the reference loops
 // (patchmatch.cpp:264-310; patchmatch_gpu.cu:156-171, :214-229) is evident.  Used as the
