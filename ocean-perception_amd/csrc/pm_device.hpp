@@ -133,17 +133,28 @@ __device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, con
   s = s + g1 * l.a;
   return abs(left_g8 - sat_u8(s));
 }
-// accumulate forms: acc + |left - sample| as one v_sad_u32
+// Accumulate forms for the VALU-bound kernels: acc + |left - sample| as ONE v_sad_u8 each.
+// v_sad_u8 adds the absolute differences of all four bytes of its operands; `left` and the colour
+// sample are < 256, so only byte 0 contributes.
 __device__ __forceinline__ unsigned cpu_acc_color(unsigned acc, int left, int r0, int r1, const CpuLerp& l) {
   unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
   t = __umul24((unsigned)r0, (unsigned)l.a11) + t;
-  return __usad((unsigned)left, t >> 16, acc);
+  return __builtin_amdgcn_sad_u8((unsigned)left, t >> 16, acc);
 }
+// saturate_cast<uchar>(s) = clamp(rint(s), 0, 255) without a float->int conversion: clamp first
+// (equivalent: rint is monotone and fixes 0 and 255), then add 2^23 -- the sum is 2^23 + rint(s)
+// exactly (ulp 1, ties to even), i.e. the bit pattern 0x4B0000nn.  v_sad_u8 against the plain byte
+// `left_g8` then yields |left_g8 - nn| + 0x4B: a constant 75 per tap, removed once per evaluation by
+// cpu_grad_bias().
+constexpr unsigned kGradTapBias = 0x4Bu;
 __device__ __forceinline__ unsigned cpu_acc_grad(unsigned acc, int left_g8, float g0, float g1, const CpuLerp& l) {
   float s = g0 * l.ia;
   s = s + g1 * l.a;
-  return __usad((unsigned)left_g8, (unsigned)sat_u8(s), acc);
+  s = __builtin_amdgcn_fmed3f(s, 0.f, 255.f);
+  s = s + 8388608.f;
+  return __builtin_amdgcn_sad_u8((unsigned)left_g8, __builtin_bit_cast(unsigned, s), acc);
 }
+__device__ __forceinline__ unsigned cpu_grad_bias(int taps) { return kGradTapBias * (unsigned)taps; }
 // Loads addressed as (wave-uniform plane base) + (32-bit unsigned byte offset): the form that maps
 // to global_load ... v_off, s[base:base+1] -- no 64-bit per-lane address arithmetic, no VGPR pairs.
 // Offsets are relative to one view's plane, i.e. < 4 GiB for any image this engine accepts.

@@ -165,7 +165,8 @@ template <int TPW, int TPH>
 __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParams cp, Interior in, float amount) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
-  __shared__ uint16_t s_left[TR * LW];
+  __shared__ uint8_t s_l8[TR * LW];
+  __shared__ uint8_t s_lg[TR * LW];
   __shared__ uint8_t s_r8[TR * kTileRW];
   __shared__ float s_rg[TR * kTileRW];
   __shared__ int s_red[8];
@@ -230,7 +231,8 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     for (int e = tid; e < TR * LW; e += 256) {
       const int rr = e / LW, cc = e - rr * LW;
       const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
-      s_left[e] = v.refpk[(size_t)gy * pitch + gx];
+      s_l8[e] = v.ref8[(size_t)gy * pitch + gx];
+      s_lg[e] = v.refg8[(size_t)gy * pitch + gx];
     }
     for (int e = tid; e < TR * rw; e += 256) {
       const int rr = e / rw, cc = e - rr * rw;
@@ -244,7 +246,8 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
       const int rc = l.ipx - lo;
 #pragma unroll 1
       for (int i = 0; i < PH; ++i) {
-        const uint16_t* lp = s_left + (ty + i) * LW + tx;
+        const uint8_t* lp = s_l8 + (ty + i) * LW + tx;
+        const uint8_t* lgp = s_lg + (ty + i) * LW + tx;
         const uint8_t* rp = s_r8 + (ty + i) * kTileRW + rc;
         const float* rg = s_rg + (ty + i) * kTileRW + rc;
         int r0 = rp[0];
@@ -253,13 +256,13 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
         for (int j = 0; j < PW; ++j) {
           const int r1 = rp[j + 1];
           const float g1 = rg[j + 1];
-          const int lpk = lp[j];
-          sc = cpu_acc_color(sc, lpk & 0xff, r0, r1, l);
-          sg = cpu_acc_grad(sg, lpk >> 8, g0, g1, l);
+          sc = cpu_acc_color(sc, lp[j], r0, r1, l);
+          sg = cpu_acc_grad(sg, lgp[j], g0, g1, l);
           r0 = r1;
           g0 = g1;
         }
       }
+      sg -= cpu_grad_bias(PW * PH);
       c = cpu_cost_from_sums((int)sc, (int)sg, cp);
     }
   } else if (interior) {

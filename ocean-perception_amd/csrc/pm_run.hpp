@@ -160,18 +160,20 @@ __device__ __forceinline__ RunStep run_step(const View& v, const PlaneSet& ps, c
     const unsigned X = (unsigned)min(max(c_base + lane, 0), cols - 1);
     const unsigned R0 = (unsigned)min(max(c_base + lane - delta_r, 0), cols - 1);
     const unsigned org = (unsigned)((chain - half_h) * pitch);
-    const unsigned ol = (org + X) * 2u, orr = org + R0;
+    const unsigned ol = org + X, orr = org + R0;
 #pragma unroll
     for (int t = 0; t < ph; ++t) {
       const unsigned ro = (unsigned)(t * pitch);  // uniform
-      const int lpk = ld_u16(v.refpk, ol + ro * 2u);
+      const int l8 = ld_u8(v.ref8, ol + ro);
+      const int lg = ld_u8(v.refg8, ol + ro);
       const int r0 = ld_u8(v.tgt8, orr + ro);
       const float g0 = ld_f32(v.tgtg, (orr + ro) * 4u);
       const int r1 = wave_shl1(r0);
       const float g1 = wave_shl1f(g0);
-      sc = cpu_acc_color(sc, lpk & 0xff, r0, r1, l);
-      sg = cpu_acc_grad(sg, lpk >> 8, g0, g1, l);
+      sc = cpu_acc_color(sc, l8, r0, r1, l);
+      sg = cpu_acc_grad(sg, lg, g0, g1, l);
     }
+    sg -= cpu_grad_bias(ph);
   } else {
     // lane l <-> image row Y = c_base + l, on the transposed planes: element (x, Y) at x * pitch_t + Y.
     const int pt = ps.pitch_t;
@@ -183,14 +185,16 @@ __device__ __forceinline__ RunStep run_step(const View& v, const PlaneSet& ps, c
     for (int t = 0; t < pw; ++t) {
       const unsigned lrow = (unsigned)((chain - half_w + t) * pt);          // uniform
       const unsigned rrow = (unsigned)(min(ipx_r + t + 1, cols - 1) * pt);  // uniform
-      const int lpk = ld_u16(v.trefpk, (lrow + Y) * 2u);
+      const int l8 = ld_u8(v.tref8, lrow + Y);
+      const int lg = ld_u8(v.trefg8, lrow + Y);
       const int r1 = ld_u8(v.ttgt8, rrow + Y);
       const float g1 = ld_f32(v.ttgtg, (rrow + Y) * 4u);
-      sc = cpu_acc_color(sc, lpk & 0xff, r0, r1, l);
-      sg = cpu_acc_grad(sg, lpk >> 8, g0, g1, l);
+      sc = cpu_acc_color(sc, l8, r0, r1, l);
+      sg = cpu_acc_grad(sg, lg, g0, g1, l);
       r0 = r1;
       g0 = g1;
     }
+    sg -= cpu_grad_bias(pw);
   }
 
   // ---- window sums: W[l] = line[l] + ... + line[l + win - 1]  (both sums < 2^16, packed) ----------
