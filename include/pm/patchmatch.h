@@ -181,7 +181,8 @@ int pm_profile_enable(pm_handle* h, int on);
 int pm_profile_read(pm_handle* h, pm_profile* out);
 const char* pm_kernel_name(int kernel_class);
 /* Work counters of the run engine since the last call (then reset): for row sweeps [0..3] and column
- * sweeps [4..7]: wave steps, steps that evaluated a candidate, pixels that adopted, positions swept. */
+ * sweeps [4..7]: wave steps of the speculative round, wave steps of the fix-up rounds, fix-up rounds
+ * summed over chains, positions swept. */
 int pm_debug_counters(pm_handle* h, uint64_t out[8]);
 /* Counting costs one same-address atomic set per wavefront (it serialises large grids): off by default. */
 int pm_debug_counters_enable(pm_handle* h, int on);

@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk(PlaneSet ps, CostP
   const bool active = i0 < n;
 
   // ---- round 1: speculative sweep from the old value of the pixel before the segment --------------
+  unsigned n_steps = 0, n_fix = 0, n_rounds = 0;  // opt-in work counters (pm_debug_counters)
   float in_used = 0.f, lastv = 0.f;
   if (active) {
     in_used = c.din[i0];
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk(PlaneSet ps, CostP
     int i = i0;
     while (i < i1) {
       const RunStep st = run_step<AXIS, TPW, TPH>(v, ps, cp, g, chain, i, i1, cand, c.din, c.cin);
+      ++n_steps;
       if (st.mpos >= 0 && st.mpos < st.advance) {
         c.dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.d0 : cand;
         c.cout[i + st.mpos + 1] = st.adopt ? st.cost : st.c0;
@@ -314,6 +316,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk(PlaneSet ps, CostP
         bool merged = false;
         while (i < i1) {
           const RunStep st = run_step<AXIS, TPW, TPH>(v, ps, cp, g, chain, i, i1, cand, c.din, c.cin);
+          ++n_fix;
           const bool mine = st.mpos >= 0 && st.mpos < st.advance;
           const float val = st.mpos == st.rej_pos ? st.d0 : cand;
           const float spec = mine ? c.dout[i + st.mpos + 1] : 0.f;
@@ -345,9 +348,17 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk(PlaneSet ps, CostP
       s_changed[round & 1] = 1;
     }
     __syncthreads();
+    ++n_rounds;
     if (!s_changed[round & 1]) break;
   }
   __syncthreads();
+  if (ps.counters && lane == 0) {
+    const int base = AXIS * 4;
+    atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);
+    atomicAdd(&ps.counters[base + 1], (unsigned long long)n_fix);
+    if (w == 0) atomicAdd(&ps.counters[base + 2], (unsigned long long)n_rounds);
+    if (w == 0) atomicAdd(&ps.counters[base + 3], (unsigned long long)n);
+  }
 
   // ---- LDS -> chain values (only what changed) --------------------------------------------------------
   for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) {

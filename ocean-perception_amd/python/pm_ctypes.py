@@ -300,7 +300,7 @@ class Engine:
     def debug_counters(self):
         out = (C.c_uint64 * 8)()
         self._check(self.lib.pm_debug_counters(self.h, C.byref(out)), "pm_debug_counters")
-        names = ("steps", "evals", "adopted", "positions")
+        names = ("steps_round1", "steps_fixup", "fixup_rounds", "positions")
         return {ax: {n: int(out[k * 4 + j]) for j, n in enumerate(names)} for k, ax in enumerate(("row", "col"))}
 
     # --- profiling ------------------------------------------------------------------------------

@@ -1,0 +1,70 @@
+// Exercises the C++ mirror of bm::pm::PatchmatchGpu the way the reference's own test does
+// (test/stereo_matching/patchmatch_gpu_test.cpp:68-88): build Params, construct, call Match() five
+// times.  Reads raw inputs written by tests/test_cpp_wrapper.py, writes raw outputs for it to check
+// against the oracle.  usage: wrapper_main <dir> <rows> <cols> <semantics> <patch> <iters>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "patchmatch_gpu.hpp"
+
+using namespace bm::pm;
+using bm::core::Image1b;
+using bm::core::Image1f;
+
+template <typename T>
+static bool read_raw(const std::string& path, bm::core::Image<T>& im) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  f.read(reinterpret_cast<char*>(im.data()), sizeof(T) * (size_t)im.rows * im.cols);
+  return (bool)f;
+}
+template <typename T>
+static void write_raw(const std::string& path, const bm::core::Image<T>& im) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(im.data()), sizeof(T) * (size_t)im.rows * im.cols);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 7) return 2;
+  const std::string dir = argv[1];
+  const int rows = atoi(argv[2]), cols = atoi(argv[3]);
+  PatchmatchGpu::Params params;
+  params.matcher_params.templ_cols = 31;  // the reference test sets these; they configure the seeder
+  params.matcher_params.templ_rows = 11;
+  params.matcher_params.max_disp = 128;
+  params.cost_alpha = 0.9f;
+  params.semantics = atoi(argv[4]);
+  params.patch_size = atoi(argv[5]);
+  params.patchmatch_iters = atoi(argv[6]);
+  params.max_rows = rows;  // plan in the constructor (the reference allocates lazily in the first Match)
+  params.max_cols = cols;
+  try {
+    PatchmatchGpu pm(params);
+    Image1b il(rows, cols), ir(rows, cols);
+    Image1f sl(rows, cols), sr(rows, cols), disp, dispr;
+    if (!read_raw(dir + "/left.u8", il) || !read_raw(dir + "/right.u8", ir) || !read_raw(dir + "/seed_l.f32", sl) ||
+        !read_raw(dir + "/seed_r.f32", sr)) {
+      std::cerr << "cannot read inputs\n";
+      return 3;
+    }
+    pm.SetSeeds(sl, sr);
+    for (int i = 0; i < 5; ++i) pm.Match(il, ir, disp, dispr);
+    write_raw(dir + "/disp_l.f32", disp);
+    write_raw(dir + "/disp_r.f32", dispr);
+    bool threw = false;
+    try {
+      pm.SparseInit(il, ir, 4);
+    } catch (const std::logic_error&) {
+      threw = true;
+    }
+    if (!threw) return 4;
+    std::cout << "ok " << disp.rows << "x" << disp.cols << "\n";
+    return 0;
+  } catch (const std::exception& e) {
+    std::cout << "exception: " << e.what() << "\n";
+    return 10;
+  }
+}

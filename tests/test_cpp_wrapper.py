@@ -1,0 +1,55 @@
+"""The C++ host mirror of bm::pm::PatchmatchGpu (ocean-perception_amd/host/) compiled with plain g++ -- no HIP
+header on the host side -- and driven like the reference's own test
+(test/stereo_matching/patchmatch_gpu_test.cpp:68-88)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_same, small_pair
+
+PKG = os.path.join(ROOT, "ocean-perception_amd")
+LIBDIR = os.path.join(PKG, "lib")
+
+
+@pytest.fixture(scope="module")
+def wrapper_exe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "wrapper_main"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(PKG, "host"), os.path.join(ROOT, "tests", "cpp", "wrapper_main.cpp"), "-L" + LIBDIR,
+           "-lvehicle_pm_gpu", "-Wl,-rpath," + LIBDIR, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(out)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_wrapper_builds_with_gxx_and_fails_loudly_without_gpu(wrapper_exe, tmp_path):
+    r = subprocess.run([wrapper_exe, str(tmp_path), "32", "48", "1", "3", "2"], capture_output=True, text=True)
+    assert r.returncode == 10 and "no HIP device" in r.stdout and "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sem,patch", [(1, 3), (0, 5)])
+def test_wrapper_match_matches_oracle(wrapper_exe, tmp_path, oracle, synth, sem, patch):
+    rows, cols = 60, 94
+    l, r, sl, sr, _ = small_pair(synth, 70 + sem, rows, cols, n_points=30, dilate_factor=2)
+    for name, arr in (("left.u8", l), ("right.u8", r), ("seed_l.f32", sl), ("seed_r.f32", sr)):
+        np.ascontiguousarray(arr).tofile(os.path.join(tmp_path, name))
+    res = subprocess.run([wrapper_exe, str(tmp_path), str(rows), str(cols), str(sem), str(patch), "3"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    dl = np.fromfile(os.path.join(tmp_path, "disp_l.f32"), np.float32).reshape(rows, cols)
+    dr = np.fromfile(os.path.join(tmp_path, "disp_r.f32"), np.float32).reshape(rows, cols)
+    el, er = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8), l, r, sl, sr)
+    assert_same(dl, el, "left")
+    assert_same(dr, er, "right")
