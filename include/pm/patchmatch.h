@@ -60,11 +60,12 @@ typedef enum pm_semantics {
 
 /* How the directional sweeps are executed on the device (results are identical). */
 typedef enum pm_engine {
-  PM_ENGINE_AUTO = 0,   /* = PM_ENGINE_RUNBLK for PM_SEM_CPU, PM_ENGINE_WAVE for PM_SEM_GPU                   */
+  PM_ENGINE_AUTO = 0,   /* = PM_ENGINE_RUNBLK2 for PM_SEM_CPU, PM_ENGINE_WAVE for PM_SEM_GPU                  */
   PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor         */
   PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes                  */
   PM_ENGINE_RUN = 3,    /* one wavefront per chain, a whole adoption run (<= 64-pw positions) per step    */
-  PM_ENGINE_RUNBLK = 4  /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint     */
+  PM_ENGINE_RUNBLK = 4, /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint     */
+  PM_ENGINE_RUNBLK2 = 5 /* as RUNBLK with two segments per wavefront (32-lane strips)                      */
 } pm_engine;
 
 /*

@@ -18,6 +18,7 @@
 #include "pm_kernels.hpp"
 #include "pm_wave.hpp"
 #include "pm_run.hpp"
+#include "pm_run2.hpp"
 
 using namespace pm;
 
@@ -305,7 +306,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
   int engine = h->params.engine;
-  if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK;
+  if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK2;
   if (cp.semantics != PM_SEM_CPU && engine >= PM_ENGINE_RUN)
     engine = PM_ENGINE_WAVE;  // PM_SEM_GPU: one lane per chain (its 5-tap cost is too small to spread)
   if (engine == PM_ENGINE_SERIAL) {
@@ -313,6 +314,8 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
                        h->stream, ps, cp, g);
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
+  } else if (engine == PM_ENGINE_RUNBLK2) {
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), h->stream);
   } else {
     launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves_from_env() : 1, h->stream);
   }
@@ -382,7 +385,7 @@ int validate_params(pm_handle* h, const pm_params& p) {
     set_err(h, "unknown semantics %d", p.semantics);
     return PM_ERR_INVALID_ARG;
   }
-  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_RUNBLK) {
+  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_RUNBLK2) {
     set_err(h, "unknown engine %d", p.engine);
     return PM_ERR_INVALID_ARG;
   }

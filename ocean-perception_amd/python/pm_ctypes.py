@@ -13,7 +13,7 @@ PM_ABI_VERSION = 1
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
-PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUN, PM_ENGINE_RUNBLK = 0, 1, 2, 3, 4
+PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUN, PM_ENGINE_RUNBLK, PM_ENGINE_RUNBLK2 = 0, 1, 2, 3, 4, 5
 PM_OK = 0
 PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM = -1, -2, -3, -4, -5
 PM_K_COUNT = 7

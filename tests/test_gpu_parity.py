@@ -17,7 +17,7 @@ from conftest import assert_same, small_pair
 pytestmark = pytest.mark.gpu
 
 SEMS = [0, 1]
-ENGINES = [1, 2, 3, 4]  # PM_ENGINE_SERIAL, _WAVE, _RUN, _RUNBLK
+ENGINES = [1, 2, 3, 4, 5]  # PM_ENGINE_SERIAL, _WAVE, _RUN, _RUNBLK, _RUNBLK2
 
 
 def mk(pm, sem, engine=0, patch=3, iters=3, lr=1, rows=64, cols=96, batch=1, **kw):
