@@ -36,6 +36,16 @@ namespace pm {
 
 constexpr int kMaxSegWaves = 16;
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its 4 MiB L2).
+// Adjacent chains read almost the same image rows, so chain k of the sweep goes to the block whose
+// XCD owns the band around k: block b -> chain (b % 8) * band + b / 8 (bijective for any count).
+// Speed only: any placement gives the same result.
+__device__ __forceinline__ int xcd_band_index(int b, int nb) {
+  const int xcd = b & 7, j = b >> 3;
+  const int q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 // lane l <- lane l+1 across the whole wavefront (DPP wave_shl:1, gfx9 incl. gfx950); lane 63 has no
 // source and receives 0.
 __device__ __forceinline__ int wave_shl1(int v) {
@@ -254,7 +264,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk(PlaneSet ps, CostP
   float* s_last = lds + 4 * n1;                              // [kMaxSegWaves + 1]
   int* s_changed = (int*)(lds + 4 * n1 + kMaxSegWaves + 1);  // [2], alternating per round
 
-  const int chain = g.c_lo + blockIdx.x;
+  const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   float* s_last = lds + 4 * n1;                                   // [2 * kMaxSegWaves + 1]
   int* s_changed = (int*)(lds + 4 * n1 + 2 * kMaxSegWaves + 1);   // [2]
 
-  const int chain = g.c_lo + blockIdx.x;
+  const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x & 63;
   const int gl = lane & (kGroup - 1);
