@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--patch", type=int, default=PATCH)
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--semantics", type=int, default=0,
+                    help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
     return ap.parse_args()
 
 
@@ -123,7 +125,7 @@ def main():
         "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"1 synthetic {args.cols}x{args.rows} stereo pair per GPU, {args.iters} iterations, "
-                               f"{args.patch}x{args.patch} window, fp32 cost, PM_SEM_CPU, left+right view + cross-check "
+                               f"{args.patch}x{args.patch} window, fp32 cost, {'PM_SEM_CPU' if args.semantics == 0 else 'PM_SEM_GPU (5-tap)'}, left+right view + cross-check "
                                "(BASELINE.json configs[1])",
                    "pairs_per_gpu_per_step": 1, "sharding": "pair index = rank, no collective"},
     }
@@ -155,7 +157,7 @@ def main():
     SR = torch.from_numpy(pair["seed_r"]).to(dev).contiguous()
     DL = torch.empty((args.rows, args.cols), dtype=torch.float32, device=dev)
     DR = torch.empty_like(DL)
-    params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine)
+    params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine)
     eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=1)
 
     def step():

@@ -324,20 +324,20 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
 
 // noise + clamp + cost of the current disparity; PM_SEM_CPU square windows use the LDS-tiled kernel
 void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float amount,
-                       int slots) {
+                       int slots, int keep_zero) {
   const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && getenv("PM_NO_TILED") == nullptr;
   const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
                    (unsigned)slots);
   if (tiled && cp.pw == 3) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<3, 3>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount);
+    hipLaunchKernelGGL((k_noise_cost_tiled<3, 3>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
   } else if (tiled && cp.pw == 5) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<5, 5>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount);
+    hipLaunchKernelGGL((k_noise_cost_tiled<5, 5>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
   } else if (tiled && cp.pw == 7) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<7, 7>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount);
+    hipLaunchKernelGGL((k_noise_cost_tiled<7, 7>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
   } else if (tiled && cp.pw == 9) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<9, 9>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount);
+    hipLaunchKernelGGL((k_noise_cost_tiled<9, 9>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
   } else if (tiled && cp.pw == 11) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<11, 11>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount);
+    hipLaunchKernelGGL((k_noise_cost_tiled<11, 11>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
   } else {
     hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, amount);
   }
@@ -355,7 +355,9 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
     const Interior in = interior(p, ps.rows, ps.cols, cp.pw, cp.ph);
     {
       Launch l(h, PM_K_NOISE);
-      launch_noise_cost(h, ps, cp, in, p.noise_amp[it], slots);
+      // from the second iteration on the cost plane is valid for this window if the window is unchanged
+      const int keep_zero = (it > 0 && cp.pw == last_pw && cp.ph == last_ph) ? 1 : 0;
+      launch_noise_cost(h, ps, cp, in, p.noise_amp[it], slots, keep_zero);
     }
     if (int rc = launch_check(h, "noise_cost")) return rc;
     for (int k = 0; k < 4; ++k)
@@ -818,7 +820,7 @@ int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
   if (int rc = stage_disp_in(h, ps, disp)) return rc;
   const CostParams cp = cost_params(h->params, patch_w, patch_h);
   const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
-  launch_noise_cost(h, ps, cp, in, -1.f, 1);
+  launch_noise_cost(h, ps, cp, in, -1.f, 1, 0);
   if (int rc = launch_check(h, "cost")) return rc;
   for (int k = 0; k < 4; ++k)
     if (pass_mask & (1 << k))

@@ -161,8 +161,13 @@ __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, 
 constexpr int kTileW = 32, kTileH = 8;
 constexpr int kTileRW = 224;  // columns of the target tile held in LDS
 
+// keep_zero != 0: the cost plane already holds cost(d) for this window (it does after any sweep:
+// adoption updates it), so a pixel whose disparity is 0 before the noise -- the noise leaves it 0
+// (patchmatch_gpu.cu:300-303) and the clamp too -- needs no new evaluation.  Exact; saves whole
+// tiles in background regions.
 template <int TPW, int TPH>
-__global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParams cp, Interior in, float amount) {
+__global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParams cp, Interior in, float amount,
+                                                          int keep_zero) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
   __shared__ uint8_t s_l8[TR * LW];
@@ -180,8 +185,10 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
   const size_t o = (size_t)y * pitch + x;
 
   float d = 0.f;
+  bool was_zero = false;
   if (inimg) {
     d = v.disp[o];
+    was_zero = !(d > 0.f);
     if (amount >= 0.f) {
       if (d > 0.f) {
         const float m = ps.noise[o] * amount;
@@ -192,7 +199,11 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
       }
     }
   }
-  const bool interior = inimg && x >= in.x_lo && x <= in.x_hi && y >= in.y_lo && y <= in.y_hi;
+  const bool inside = inimg && x >= in.x_lo && x <= in.x_hi && y >= in.y_lo && y <= in.y_hi;
+  if (keep_zero && inside && was_zero) {  // d == 0 stays 0 and its cost is already stored
+    v.disp[o] = 0.f;
+  }
+  const bool interior = inside && !(keep_zero && was_zero);
   CpuLerp l;
   l.ipx = 0;
   if (interior) {
@@ -216,7 +227,7 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
   __syncthreads();
   lo = min(min(s_red[0], s_red[2]), min(s_red[4], s_red[6]));
   hi_ = max(max(s_red[1], s_red[3]), max(s_red[5], s_red[7]));
-  if (hi_ < lo) {  // no interior pixel in this tile (uniform)
+  if (hi_ < lo) {  // no pixel of this tile needs an evaluation (uniform)
     if (inimg) v.disp[o] = d;
     return;
   }

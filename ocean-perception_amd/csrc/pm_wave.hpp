@@ -137,13 +137,126 @@ __global__ void __launch_bounds__(64) k_sweep_wave_cpu(PlaneSet ps, CostParams c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PM_SEM_GPU sweeps: one wavefront per chain, one LANE per segment of the chain.
+// The reference's rule (PropagateRow/Col, patchmatch_gpu.cu:156-171, :214-229) evaluates a 5-tap cost
+// per step -- too little to spread over lanes, so the lanes of a wavefront take 64 consecutive
+// segments of the chain instead.  Round 1: every lane sweeps its segment from the OLD value of the
+// pixel before it (exact for segment 0).  Later rounds: a lane whose predecessor segment ended on a
+// different value re-runs its segment from the start with that value until the value it produces
+// equals what it had stored (its trajectory merged) or the segment ends (then its own last value may
+// change and trigger the next lane).  Segment k is final after round k+1; the fixpoint is the unique
+// solution of the recurrence, i.e. exactly the sequential sweep (same argument as pm_run.hpp).  The
+// chain's disparity / cost values live in LDS; a single wavefront needs no barriers.
+// grid = (chains, 1, slots), block = 64, dynamic LDS = 4 * (n + 1) + 65 floats.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_sweep_gpu_lanes(PlaneSet ps, CostParams cp, SweepGeom g) {
+  extern __shared__ float lds[];
+  const int n = (g.s_last - g.s_first) * g.dir + 1;
+  const int n1 = (n + 1 + 3) & ~3;
+  float* din = lds;
+  float* cin = lds + n1;
+  float* dout = lds + 2 * n1;
+  float* cout = lds + 3 * n1;
+  float* s_last = lds + 4 * n1;  // [65]
+
+  const int chain = g.c_lo + blockIdx.x;
+  const View v = make_view(ps, blockIdx.z);
+  const int lane = threadIdx.x;
+  const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;
+  const ptrdiff_t first =
+      g.axis == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
+  for (int k = lane; k <= n; k += kWave) {
+    const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+    const float d = v.disp[o];
+    const float cc = k > 0 ? v.cost[o] : 0.f;
+    din[k] = d;
+    cin[k] = cc;
+    dout[k] = d;
+    cout[k] = cc;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS image is complete (one wavefront: no barrier)
+
+  const int len = (n + kWave - 1) / kWave;
+  const int i0 = lane * len, i1 = min(n, i0 + len);
+  const bool active = i0 < n;
+
+  auto step = [&](int i, float prev, float& nd, float& nc) {
+    const int s = g.s_first + i * g.dir;
+    const int x = g.axis == 0 ? s : chain;
+    const int y = g.axis == 0 ? chain : s;
+    const float d0 = din[i + 1], c0 = cin[i + 1];
+    nd = d0;
+    nc = c0;
+    sweep_step(1, x, 1, d0, c0, prev, nd, nc, [&](float xr) { return gpu_cost_lane(v, ps.pitch, x, y, xr, cp); });
+  };
+
+  // ---- round 1 ------------------------------------------------------------------------------------
+  float in_used = active ? din[i0] : 0.f;
+  float prev = in_used;
+  for (int k = 0; k < len; ++k) {
+    const int i = i0 + k;
+    if (active && i < i1) {
+      float nd, nc;
+      step(i, prev, nd, nc);
+      dout[i + 1] = nd;
+      cout[i + 1] = nc;
+      prev = nd;
+    }
+  }
+  float lastv = prev;
+  if (active) s_last[lane + 1] = lastv;
+  if (lane == 0) s_last[0] = din[0];
+
+  // ---- fix-up rounds ---------------------------------------------------------------------------------
+  for (int round = 1; round < kWave; ++round) {
+    const float in = (active && lane > 0) ? s_last[lane] : in_used;
+    const bool redo = active && lane > 0 && in != in_used;
+    if (!__any(redo)) break;
+    bool merged = false;
+    if (redo) {
+      in_used = in;
+      prev = in;
+    }
+    for (int k = 0; k < len; ++k) {
+      const int i = i0 + k;
+      if (redo && !merged && i < i1) {
+        float nd, nc;
+        step(i, prev, nd, nc);
+        if (nd == dout[i + 1]) {
+          merged = true;  // same state as the stored trajectory from here on
+        } else {
+          dout[i + 1] = nd;
+          cout[i + 1] = nc;
+          prev = nd;
+        }
+      }
+    }
+    if (redo && !merged && prev != lastv) {
+      lastv = prev;
+      s_last[lane + 1] = lastv;
+    }
+  }
+
+  for (int k = lane + 1; k <= n; k += kWave) {
+    const float d = dout[k];
+    if (d != din[k]) {
+      const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+      v.disp[o] = d;
+      v.cost[o] = cout[k];
+    }
+  }
+}
+
 inline void launch_sweep_wave(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
                               hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
   if (cp.semantics != 0) {
-    // PM_SEM_GPU: the 5-tap cost is too small to spread over a wavefront; one lane per chain.
-    hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0, stream,
-                       ps, cp, g);
+    // PM_SEM_GPU: the 5-tap cost is too small to spread over a wavefront; lanes take chain segments.
+    const int n = (g.s_last - g.s_first) * g.dir + 1;
+    const int n1 = (n + 1 + 3) & ~3;
+    hipLaunchKernelGGL(k_sweep_gpu_lanes, dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave),
+                       sizeof(float) * (4 * (size_t)n1 + kWave + 1), stream, ps, cp, g);
     return;
   }
   const dim3 grid((unsigned)chains, 1, (unsigned)slots), block(kWave);
