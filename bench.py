@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--patch", type=int, default=PATCH)
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--pairs-per-gpu", type=int, default=1,
+                    help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
     ap.add_argument("--semantics", type=int, default=0,
                     help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
     return ap.parse_args()
@@ -124,10 +126,12 @@ def main():
         "metric": "stereo_pairs_per_sec_1280x720_patchmatch", "unit": "pairs/s", "n_gpus": d.world, "steps": steps,
         "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"1 synthetic {args.cols}x{args.rows} stereo pair per GPU, {args.iters} iterations, "
+        "config": {"workload": f"{max(1, args.pairs_per_gpu)} synthetic {args.cols}x{args.rows} stereo pair(s) per GPU, "
+                               f"{args.iters} iterations, "
                                f"{args.patch}x{args.patch} window, fp32 cost, {'PM_SEM_CPU' if args.semantics == 0 else 'PM_SEM_GPU (5-tap)'}, left+right view + cross-check "
                                "(BASELINE.json configs[1])",
-                   "pairs_per_gpu_per_step": 1, "sharding": "pair index = rank, no collective"},
+                   "pairs_per_gpu_per_step": max(1, args.pairs_per_gpu),
+                   "sharding": "pair index = rank * pairs_per_gpu + i, no collective"},
     }
     if args.dry_run:
         # plumbing only: same barrier / reduction path, no engine, no numbers worth reading
@@ -150,19 +154,22 @@ def main():
 
     torch.cuda.set_device(d.local_rank)
     dev = torch.device(f"cuda:{d.local_rank}")
-    pair = synth.make_pair(d.rank, args.rows, args.cols)
-    L = torch.from_numpy(pair["left"]).to(dev).contiguous()
-    R = torch.from_numpy(pair["right"]).to(dev).contiguous()
-    SL = torch.from_numpy(pair["seed_l"]).to(dev).contiguous()
-    SR = torch.from_numpy(pair["seed_r"]).to(dev).contiguous()
-    DL = torch.empty((args.rows, args.cols), dtype=torch.float32, device=dev)
-    DR = torch.empty_like(DL)
+    nb = max(1, args.pairs_per_gpu)
+    # rank r owns pairs r*nb .. r*nb+nb-1 (a few distinct pairs are generated and repeated to fill the batch)
+    uniq = [synth.make_pair(d.rank * nb + i, args.rows, args.cols) for i in range(min(nb, 4))]
+    pairs = [uniq[i % len(uniq)] for i in range(nb)]
+    pair = pairs[0]
+    stack = lambda k: torch.from_numpy(np.stack([p[k] for p in pairs])).to(dev).contiguous()
+    L, R, SL, SR = stack("left"), stack("right"), stack("seed_l"), stack("seed_r")
+    DLb = torch.empty((nb, args.rows, args.cols), dtype=torch.float32, device=dev)
+    DRb = torch.empty_like(DLb)
+    DL = DLb[0]
     params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine)
-    eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=1)
+    eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=nb)
 
     def step():
-        eng.match_device(1, L.data_ptr(), R.data_ptr(), args.rows, args.cols, SL.data_ptr(), SR.data_ptr(),
-                         DL.data_ptr(), DR.data_ptr())
+        eng.match_device(nb, L.data_ptr(), R.data_ptr(), args.rows, args.cols, SL.data_ptr(), SR.data_ptr(),
+                         DLb.data_ptr(), DRb.data_ptr())
 
     for _ in range(warmup):
         step()
@@ -198,14 +205,15 @@ def main():
     within1 = float((err[DL > 0] < 1.0).float().mean().item()) if fg > 0 else 0.0
 
     if d.rank == 0:
-        px_views = args.rows * args.cols * 2
+        px_views = args.rows * args.cols * 2 * nb
         dom = max(("sweep_row", "sweep_col"), key=lambda k: prof[k][1])
         n_launch, total_ms = prof[dom]
         avg_ms = total_ms / max(n_launch, 1)
         achieved = SWEEP_BYTES_PER_PX * px_views / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
         gpu_ms = sum(v[1] for v in prof.values())
         result.update(
-            value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, ms_per_frame=1e3 * elapsed / steps,
+            value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
+            ms_per_frame=1e3 * elapsed / steps / nb,
             roofline={"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                       "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_PX * px_views, "avg_launch_ms": avg_ms,

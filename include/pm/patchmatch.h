@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2
 #define PM_MAX_ITERS 16
 #define PM_MAX_PATCH 15 /* largest supported window side (odd) */
 
@@ -99,6 +99,18 @@ typedef struct pm_params {
   float functor_tau_grad;         /* 20   (patchmatch_test.cpp:37)                                 */
   uint64_t noise_seed;            /* 123  cv::RNG seed (patchmatch.cpp:146, patchmatch_gpu.cu:341) */
   int left_right_check;           /* 1    right view + MaskOcclusions (patchmatch_gpu.cu:357-372)  */
+
+  /* --- sparse seeding: PatchmatchGpu::SparseInit (patchmatch_gpu.cu:414-442) on the device ------ */
+  int sparse_init;                /* 0: a NULL seed map means "all background"; 1: a NULL seed map is
+                                     computed by SparseInit (what the reference's Match() always does) */
+  int max_features_per_frame;     /* 200   ft::FeatureDetector::Params (feature_detector.hpp:28)       */
+  int min_distance_btw_features;  /* 20    min_distance_btw_tracked_and_detected_features (:31)        */
+  int gftt_block_size;            /* 5     (:33)                                                        */
+  double gftt_quality_level;      /* 0.01  (:32)                                                        */
+  int templ_cols;                 /* 31    ft::StereoMatcher::Params (stereo_matcher.hpp:21)            */
+  int templ_rows;                 /* 11    (:22)                                                        */
+  int max_disp;                   /* 128   (:23)                                                        */
+  double max_matching_cost;       /* 0.15  (:24)                                                        */
 } pm_params;
 
 /* Fills *p with the reference defaults for the given semantics. */
@@ -157,6 +169,10 @@ int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
 /* Patchmatch::RemoveBackground (patchmatch.cpp:314-360) / MaskBackground (patchmatch_gpu.cu:233-270). */
 int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
                          float* disp, int patch_h, int patch_w, float factor);
+/* PatchmatchGpu::SparseInit(iml, imr, dilate_factor) (patchmatch_gpu.h:110-112, patchmatch_gpu.cu:414-442):
+ * GFTT corners, rectified template matching, scatter, (2*(2^f+1)+1)^2 dilation -- all on the device. */
+int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
+                   float* seed);
 /* MaskOcclusions (patchmatch_gpu.cu:273-295). */
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols);
 

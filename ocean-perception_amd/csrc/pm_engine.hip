@@ -19,6 +19,7 @@
 #include "pm_wave.hpp"
 #include "pm_run.hpp"
 #include "pm_run2.hpp"
+#include "pm_seed.hpp"
 
 using namespace pm;
 
@@ -55,6 +56,8 @@ struct pm_handle {
   unsigned long long* counters = nullptr;  // device, 8 words
   bool counters_on = false;                // same-address atomics serialise: opt-in only
   int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
+
+  SeedScratch seed{};  // scratch of the device seeder (pm_seed.hpp)
 
   // staging for the host-buffer entry points: tightly packed [B][rows][cols]
   uint8_t* st_left = nullptr;
@@ -259,6 +262,30 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
   return launch_check(h, "transpose");
 }
 
+SeedParams seed_params(const pm_params& p) {
+  SeedParams sp;
+  sp.max_features = p.max_features_per_frame;
+  sp.min_distance = p.min_distance_btw_features;
+  sp.block_size = p.gftt_block_size;
+  sp.templ_cols = p.templ_cols;
+  sp.templ_rows = p.templ_rows;
+  sp.max_disp = p.max_disp;
+  sp.quality_level = p.gftt_quality_level;
+  sp.max_matching_cost = p.max_matching_cost;
+  return sp;
+}
+
+// SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
+// mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view) {
+  const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
+  const uint8_t* tgt = ps.img8 + ((size_t)b * 4 + (view == 0 ? 1 : 2)) * ps.plane;
+  float* out = ps.disp + ((size_t)b * 2 + view) * ps.plane;
+  PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
+                             h->params.init_dilate_factor, out, ps.pitch, h->stream));
+  return PM_OK;
+}
+
 int ensure_noise(pm_handle* h, int rows, int cols) {
   const int pitch = align_up(cols, 64);
   if (h->noise_rows == rows && h->noise_cols == cols && h->noise_pitch == pitch) return PM_OK;
@@ -404,6 +431,12 @@ int validate_params(pm_handle* h, const pm_params& p) {
       return PM_ERR_INVALID_ARG;
     }
   }
+  if (p.max_features_per_frame < 0 || p.max_features_per_frame > kSeedMaxFeatures || p.gftt_block_size < 1 ||
+      (p.gftt_block_size % 2) == 0 || p.gftt_block_size > 15 || p.templ_cols < 1 || p.templ_rows < 1 ||
+      p.max_disp < p.templ_cols || p.init_dilate_factor < 0 || p.init_dilate_factor > 8) {
+    set_err(h, "seeder parameters out of range");
+    return PM_ERR_INVALID_ARG;
+  }
   for (int i = 0; i < p.patchmatch_iters; ++i)
     if (!(p.noise_amp[i] >= 0.f)) {
       set_err(h, "noise_amp[%d] must be >= 0", i);
@@ -444,6 +477,15 @@ void pm_params_default(pm_params* p, int semantics) {
   p->functor_tau_grad = 20.0f;    // patchmatch_test.cpp:37
   p->noise_seed = 123;            // patchmatch.cpp:146, patchmatch_gpu.cu:341
   p->left_right_check = 1;
+  p->sparse_init = 0;
+  p->max_features_per_frame = 200;   // feature_detector.hpp:28
+  p->min_distance_btw_features = 20; // :31
+  p->gftt_block_size = 5;            // :33
+  p->gftt_quality_level = 0.01;      // :32
+  p->templ_cols = 31;                // stereo_matcher.hpp:21
+  p->templ_rows = 11;                // :22
+  p->max_disp = 128;                 // :23
+  p->max_matching_cost = 0.15;       // :24
 }
 
 const char* pm_status_string(int status) {
@@ -475,7 +517,8 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.stop);
   }
   void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
-                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r};
+                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
+                 h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -541,6 +584,24 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
   PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 8, h->stream));
+  {
+    SeedScratch& sc = h->seed;
+    sc.cap = (int)(plane / 4 + 64);
+    PM_HIP(h, hipMalloc((void**)&sc.dx, sizeof(short) * plane));
+    PM_HIP(h, hipMalloc((void**)&sc.dy, sizeof(short) * plane));
+    PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
+    PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
+    PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
+    PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * 4));
+    PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
+    PM_HIP(h, hipMalloc((void**)&sc.sparse, sizeof(float) * plane));
+    PM_HIP(h, hipMalloc((void**)&sc.tmp, sizeof(float) * plane));
+    sc.sort_tmp = nullptr;
+    sc.sort_tmp_bytes = 0;
+    PM_HIP(h, hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap,
+                                                          0, 64, h->stream));
+    PM_HIP(h, hipMalloc(&sc.sort_tmp, sc.sort_tmp_bytes));
+  }
   const size_t tight = (size_t)max_rows * max_cols;
   PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
@@ -602,6 +663,15 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
                        (size_t)cols);
   }
   if (int rc = launch_check(h, "seed")) return rc;
+  if (h->params.sparse_init) {  // a missing seed map is computed on the device, as the reference's Match() does
+    Launch l(h, PM_K_SEED);
+    for (int b = 0; b < n; ++b) {
+      if (!d_seed_l)
+        if (int rc = run_sparse_init(h, ps, b, 0)) return rc;
+      if (!d_seed_r && n_views > 1)
+        if (int rc = run_sparse_init(h, ps, b, 1)) return rc;
+    }
+  }
   if (int rc = run_views(h, ps, n * n_views)) return rc;
   {
     Launch l(h, PM_K_FINALIZE);
@@ -845,6 +915,20 @@ int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right
   hipLaunchKernelGGL(k_background, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, in, factor, 0);
   if (int rc = launch_check(h, "background")) return rc;
   return stage_out(h, ps, disp, 0);
+}
+
+int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
+                   float* seed) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right || !seed || dilate_factor < 0 || dilate_factor > 8) {
+    set_err(h, "pm_sparse_init: null pointer or dilate_factor outside [0, 8]");
+    return PM_ERR_INVALID_ARG;
+  }
+  PlaneSet ps;
+  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
+  PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
+                             dilate_factor, ps.disp, ps.pitch, h->stream));
+  return stage_out(h, ps, seed, 0);
 }
 
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols) {

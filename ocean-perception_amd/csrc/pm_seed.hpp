@@ -1,0 +1,290 @@
+// pm_seed.hpp -- sparse seeding on the device: the replacement of PatchmatchGpu::SparseInit
+// (src/vehicle/patchmatch_gpu/patchmatch_gpu.cu:414-442), which the reference runs on the CPU twice
+// per Match() through cv::GFTTDetector (feature_tracking/feature_detector.cpp:44-57,89-122) and
+// cv::matchTemplate (feature_tracking/stereo_matcher.cpp:22-116).
+//
+// Pipeline (all on the handle's stream, no host synchronisation):
+//   k_seed_sobel   u8 image -> Sobel dx, dy (int16)
+//   k_seed_eig     block^2 box sums of dx^2, dxdy, dy^2 (exact integers) -> min-eigenvalue response,
+//                  global maximum by atomicMax on the float bit pattern (responses >= 0)
+//   k_seed_nms     quality threshold + 3x3 non-maximum suppression -> candidate keys
+//                  (response bits << 32 | raster index)
+//   hipcub radix sort, descending: strongest first, ties by larger index (cv::goodFeaturesToTrack's
+//                  greaterThanPtr order)
+//   k_seed_select  greedy minimum-distance selection, one wavefront (the accepted list lives in LDS)
+//   k_seed_match   one workgroup per corner: normalised squared difference of the templ_cols x templ_rows
+//                  template against every position of the max_disp x (templ_rows+2) stripe, exact
+//                  integer sums, first minimum
+//   k_seed_scatter + k_seed_dilate_{rows,cols}: sparse map -> (2k+1)^2 max-dilated seed map
+// The arithmetic is this build's definition of the seeder (see oracle/pm_oracle.h): OpenCV's float
+// pipelines are not reproducible without OpenCV; parity is against oracle/pm_seed_oracle.c.
+#pragma once
+
+#include <hipcub/hipcub.hpp>
+
+#include "pm_kernels.hpp"
+
+namespace pm {
+
+struct SeedParams {
+  int max_features, min_distance, block_size;
+  int templ_cols, templ_rows, max_disp;
+  double quality_level, max_matching_cost;
+};
+
+constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list
+
+// Scratch owned by the handle (sized for max_rows x max_cols).
+struct SeedScratch {
+  short* dx;                 // [rows][pitch]
+  short* dy;
+  float* eig;                // [rows][pitch]
+  unsigned long long* keys;  // [cap] candidates, then sorted
+  unsigned long long* keys_sorted;
+  unsigned* counters;        // [0] = max response bits, [1] = candidate count, [2] = accepted count
+  int* kp_xy;                // [kSeedMaxFeatures][2]
+  float* sparse;             // [rows][pitch]
+  float* tmp;                // [rows][pitch]
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int cap;
+};
+
+__global__ void __launch_bounds__(256) k_seed_sobel(const uint8_t* __restrict__ im, int rows, int cols, int pitch,
+                                                    short* __restrict__ dx, short* __restrict__ dy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= cols) return;
+  const uint8_t* r0 = im + (size_t)reflect101(y - 1, rows) * pitch;
+  const uint8_t* r1 = im + (size_t)y * pitch;
+  const uint8_t* r2 = im + (size_t)reflect101(y + 1, rows) * pitch;
+  const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+  dx[(size_t)y * pitch + x] =
+      (short)(((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]));
+  dy[(size_t)y * pitch + x] =
+      (short)(((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]));
+}
+
+// General reflect-101 (the box window may reach further out than one pixel).
+__device__ __forceinline__ int reflect101n(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+  return p;
+}
+
+__global__ void __launch_bounds__(256) k_seed_eig(const short* __restrict__ dx, const short* __restrict__ dy, int rows,
+                                                  int cols, int pitch, int block, float* __restrict__ eig,
+                                                  unsigned* __restrict__ counters) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  float e = 0.f;
+  if (x < cols) {
+    const int h = block / 2;
+    long long sxx = 0, sxy = 0, syy = 0;
+    for (int j = -h; j <= h; ++j) {
+      const size_t ro = (size_t)reflect101n(y + j, rows) * pitch;
+      for (int i = -h; i <= h; ++i) {
+        const size_t o = ro + reflect101n(x + i, cols);
+        const int gx = dx[o], gy = dy[o];
+        sxx += gx * gx;
+        sxy += gx * gy;
+        syy += gy * gy;
+      }
+    }
+    const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+    const float t = a - c;
+    const float tt = t * t, bb = b * b;
+    const float s = a + c;
+    e = s - sqrtf(tt + bb);
+    eig[(size_t)y * pitch + x] = e;
+  }
+  // wave maximum of the positive responses, one atomic per wavefront
+  float m = e > 0.f ? e : 0.f;
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) m = fmaxf(m, __shfl_xor(m, ofs, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&counters[0], __builtin_bit_cast(unsigned, m));
+}
+
+__global__ void __launch_bounds__(256) k_seed_nms(const float* __restrict__ eig, int rows, int cols, int pitch,
+                                                  double quality, unsigned long long* __restrict__ keys,
+                                                  unsigned* __restrict__ counters, int cap) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < 1 || x >= cols - 1 || y < 1 || y >= rows - 1) return;
+  const float maxv = __builtin_bit_cast(float, counters[0]);
+  const float thr = (float)((double)maxv * quality);
+  const float v = eig[(size_t)y * pitch + x];
+  if (!(v > thr)) return;
+  bool is_max = true;
+#pragma unroll
+  for (int j = -1; j <= 1; ++j)
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+      const float u = eig[(size_t)(y + j) * pitch + (x + i)];
+      is_max = is_max && !(u > v);
+    }
+  if (!is_max) return;
+  const unsigned slot = atomicAdd(&counters[1], 1u);
+  if ((int)slot < cap)
+    keys[slot] = ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (unsigned)(y * cols + x);
+}
+
+// One wavefront.  Keys are sorted descending (0 = unused slot).  Accepts a corner when no accepted corner
+// lies closer than min_distance; stops at max_features (cv::goodFeaturesToTrack's greedy loop).
+__global__ void __launch_bounds__(64) k_seed_select(const unsigned long long* __restrict__ keys, int cap, int cols,
+                                                    int min_distance, int max_features, int* __restrict__ kp_xy,
+                                                    unsigned* __restrict__ counters) {
+  __shared__ int s_x[kSeedMaxFeatures], s_y[kSeedMaxFeatures];
+  const int lane = threadIdx.x;
+  const int ncand = min((int)counters[1], cap);
+  const long long md2 = (long long)min_distance * min_distance;
+  int count = 0;
+  for (int base = 0; base < ncand && count < max_features; base += 64) {
+    const unsigned long long mine = base + lane < ncand ? keys[base + lane] : 0ull;
+    const int nk = min(64, ncand - base);
+    for (int k = 0; k < nk && count < max_features; ++k) {
+      const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine & 0xffffffffull), k);
+      const int y = (int)(idx / (unsigned)cols), x = (int)(idx - (unsigned)y * (unsigned)cols);
+      bool bad = false;
+      if (min_distance >= 1)
+        for (int j = lane; j < count; j += 64) {
+          const long long ddx = x - s_x[j], ddy = y - s_y[j];
+          bad = bad || (ddx * ddx + ddy * ddy < md2);
+        }
+      if (!__any(bad)) {
+        if (lane == 0) {
+          s_x[count] = x;
+          s_y[count] = y;
+          kp_xy[2 * count] = x;
+          kp_xy[2 * count + 1] = y;
+        }
+        ++count;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the list entry is visible to the next check
+      }
+    }
+  }
+  if (lane == 0) counters[2] = (unsigned)count;
+}
+
+// One workgroup per accepted corner (StereoMatcher::MatchRectified).  Writes the disparity into the sparse
+// map at the corner (>= 0) -- corners are at least min_distance apart, so no two write the same pixel.
+__global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                    int rows, int cols, int pitch, const int* __restrict__ kp_xy,
+                                                    const unsigned* __restrict__ counters, SeedParams sp,
+                                                    float* __restrict__ sparse) {
+  const int kp = blockIdx.x;
+  if (kp >= (int)counters[2]) return;
+  const int rx = kp_xy[2 * kp], ry = kp_xy[2 * kp + 1];  // integer corners: round() is the identity
+  const int tc = sp.templ_cols, tr = sp.templ_rows, md = sp.max_disp;
+  const int stripe_rows = tr + 2;
+  int ty = ry - (tr - 1) / 2;
+  if (ty < 0 || ty + tr >= rows) return;
+  int offset_x = 0;
+  int tx = rx - (tc - 1) / 2;
+  if (tx < 0) {
+    offset_x = tx;
+    tx = 0;
+  }
+  if (tx + tc >= cols) {
+    if (offset_x != 0) return;
+    offset_x = (tx + tc) - (cols - 1);
+    tx -= offset_x;
+  }
+  const int sy = ry - (stripe_rows - 1) / 2;
+  if (sy < 0 || sy + stripe_rows >= rows) return;
+  int sx = rx + (tc - 1) / 2 - md;
+  if (sx + md > cols - 1) sx -= (sx + md) - (cols - 1);
+  if (sx < 0) sx = 0;
+  if (sx + md > cols || tx < 0) return;
+  const int rw = md - tc + 1, rh = stripe_rows - tr + 1;
+
+  __shared__ unsigned long long s_best[4];
+  unsigned long long best = ~0ull;
+  for (int pos = threadIdx.x; pos < rw * rh; pos += blockDim.x) {
+    const int v = pos / rw, u = pos - v * rw;
+    long long num = 0, i2 = 0, t2 = 0;
+    for (int j = 0; j < tr; ++j) {
+      const uint8_t* T = left + (size_t)(ty + j) * pitch + tx;
+      const uint8_t* I = right + (size_t)(sy + v + j) * pitch + sx + u;
+      for (int i = 0; i < tc; ++i) {
+        const int t = T[i], q = I[i];
+        const int d = t - q;
+        num += d * d;
+        i2 += q * q;
+        t2 += t * t;
+      }
+    }
+    const double den = sqrt((double)t2 * (double)i2);
+    const float r = den > 0.0 ? (float)((double)num / den) : 1.f;
+    // first minimum in row-major order = minimum of (value bits, position) as one 64-bit key (r >= 0)
+    const unsigned long long key = ((unsigned long long)__builtin_bit_cast(unsigned, r) << 32) | (unsigned)pos;
+    best = key < best ? key : best;
+  }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    const unsigned long long o = __shfl_xor(best, ofs, 64);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = s_best[w] < best ? s_best[w] : best;
+    const float minv = __builtin_bit_cast(float, (unsigned)(best >> 32));
+    const int pos = (int)(best & 0xffffffffull);
+    const int bx = pos % rw;
+    const int mx = bx + sx + (tc - 1) / 2 + offset_x;
+    if ((double)minv < sp.max_matching_cost && rx >= mx) sparse[(size_t)ry * pitch + rx] = (float)(rx - mx);
+  }
+}
+
+// Max filter of half-width k along rows / columns, samples outside the image ignored (cv::dilate).
+__global__ void __launch_bounds__(256) k_seed_dilate_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int rows, int cols, int pitch, int k) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= cols) return;
+  const float* r = src + (size_t)y * pitch;
+  const int x0 = max(x - k, 0), x1 = min(x + k, cols - 1);
+  float m = r[x0];
+  for (int i = x0 + 1; i <= x1; ++i) m = fmaxf(m, r[i]);
+  dst[(size_t)y * pitch + x] = m;
+}
+// dst addressing: out_mirror != 0 writes column cols-1-x... (unused: the right view is seeded on the
+// mirrored pair, so its map is already in mirrored coordinates)
+__global__ void __launch_bounds__(256) k_seed_dilate_cols(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int rows, int cols, int pitch, int k, int dst_pitch) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= cols) return;
+  const int y0 = max(y - k, 0), y1 = min(y + k, rows - 1);
+  float m = src[(size_t)y0 * pitch + x];
+  for (int j = y0 + 1; j <= y1; ++j) m = fmaxf(m, src[(size_t)j * pitch + x]);
+  dst[(size_t)y * dst_pitch + x] = m;
+}
+
+// SparseInit(left, right, dilate_factor) for one pair of pitched u8 planes; the seed map is written to
+// `out` (row pitch out_pitch elements).  Enqueue-only.
+inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
+                                   const uint8_t* right, int rows, int cols, int pitch, int dilate_factor, float* out,
+                                   int out_pitch, hipStream_t stream) {
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
+  hipError_t e;
+  if ((e = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned), stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(sc.sparse, 0, sizeof(float) * (size_t)rows * pitch, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_seed_sobel, grid, block, 0, stream, left, rows, cols, pitch, sc.dx, sc.dy);
+  hipLaunchKernelGGL(k_seed_eig, grid, block, 0, stream, sc.dx, sc.dy, rows, cols, pitch, sp.block_size, sc.eig,
+                     sc.counters);
+  hipLaunchKernelGGL(k_seed_nms, grid, block, 0, stream, sc.eig, rows, cols, pitch, sp.quality_level, sc.keys,
+                     sc.counters, sc.cap);
+  size_t tmp_bytes = sc.sort_tmp_bytes;
+  if ((e = hipcub::DeviceRadixSort::SortKeysDescending(sc.sort_tmp, tmp_bytes, sc.keys, sc.keys_sorted, sc.cap, 0, 64,
+                                                       stream)) != hipSuccess)
+    return e;
+  const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
+  hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(64), 0, stream, sc.keys_sorted, sc.cap, cols, sp.min_distance, maxf,
+                     sc.kp_xy, sc.counters);
+  hipLaunchKernelGGL(k_seed_match, dim3((unsigned)(maxf > 0 ? maxf : 1)), dim3(256), 0, stream, left, right, rows,
+                     cols, pitch, sc.kp_xy, sc.counters, sp, sc.sparse);
+  const int k = (1 << dilate_factor) + 1;  // (int)pow(2, f) + 1, patchmatch_gpu.cu:436
+  hipLaunchKernelGGL(k_seed_dilate_rows, grid, block, 0, stream, sc.sparse, sc.tmp, rows, cols, pitch, k);
+  hipLaunchKernelGGL(k_seed_dilate_cols, grid, block, 0, stream, sc.tmp, out, rows, cols, pitch, k, out_pitch);
+  return hipGetLastError();
+}
+
+}  // namespace pm

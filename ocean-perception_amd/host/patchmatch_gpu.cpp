@@ -22,6 +22,16 @@ pm_params PatchmatchGpu::Params::ToC() const {
   p.bg_patch_w = patch_size;
   p.bg_patch_h = patch_size;
   p.left_right_check = left_right_check ? 1 : 0;
+  // like the reference, Match() seeds itself (SparseInit) unless seed maps were supplied through SetSeeds()
+  p.sparse_init = 1;
+  p.max_features_per_frame = detector_params.max_features_per_frame;
+  p.min_distance_btw_features = detector_params.min_distance_btw_tracked_and_detected_features;
+  p.gftt_block_size = detector_params.gftt_block_size;
+  p.gftt_quality_level = detector_params.gftt_quality_level;
+  p.templ_cols = matcher_params.templ_cols;
+  p.templ_rows = matcher_params.templ_rows;
+  p.max_disp = matcher_params.max_disp;
+  p.max_matching_cost = matcher_params.max_matching_cost;
   return p;
 }
 
@@ -89,10 +99,14 @@ void PatchmatchGpu::Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, 
   Check(pm_synchronize(handle_), "pm_synchronize");
 }
 
-Image1f PatchmatchGpu::SparseInit(const Image1b&, const Image1b&, int) {
-  throw std::logic_error(
-      "PatchmatchGpu::SparseInit: the GFTT + template-match seeder is not part of this build; "
-      "provide seed maps through SetSeeds()");
+Image1f PatchmatchGpu::SparseInit(const Image1b& iml, const Image1b& imr, int dilate_factor) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
+    throw std::invalid_argument("PatchmatchGpu::SparseInit: images empty or of different size");
+  EnsurePlan(iml.rows, iml.cols);
+  Image1f seed(iml.rows, iml.cols);
+  Check(pm_sparse_init(handle_, iml.data(), imr.data(), iml.rows, iml.cols, dilate_factor, seed.data()),
+        "pm_sparse_init");
+  return seed;
 }
 
 }  // namespace pm

@@ -121,8 +121,8 @@ class PatchmatchGpu final {
   explicit PatchmatchGpu(const Params& params);
   ~PatchmatchGpu();
 
-  // patchmatch_gpu.h:99-102.  Seeds come from SetSeeds() (explicit input at this boundary);
-  // without seeds every pixel starts as background, as when the reference's seeder finds no match.
+  // patchmatch_gpu.h:99-102.  Like the reference, Match() seeds itself with SparseInit on both views
+  // (on the device); seed maps set through SetSeeds() take precedence.
   void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr);
 
   // patchmatch_gpu.h:104-108 widened to a device-resident pair: raw device pointers to tightly
@@ -134,8 +134,7 @@ class PatchmatchGpu final {
   // left-image and right-image coordinates.  Kept until replaced; pass empty images to clear.
   void SetSeeds(const Image1f& seed_l, const Image1f& seed_r);
 
-  // patchmatch_gpu.h:110-112 -- the GFTT + template-matching seeder needs OpenCV's detector; it is
-  // the next row of the scope table and not part of this build yet.
+  // patchmatch_gpu.h:110-112 -- GFTT corners + rectified template matching + dilation, on the device.
   Image1f SparseInit(const Image1b& iml, const Image1b& imr, int dilate_factor);
 
   // Anything that looks like a cv::Mat_ (rows, cols, step, data).

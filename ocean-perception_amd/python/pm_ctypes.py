@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-PM_ABI_VERSION = 1
+PM_ABI_VERSION = 2
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
@@ -27,7 +27,7 @@ EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
-    "pm_remove_background", "pm_mask_occlusions", "pm_profile_enable", "pm_profile_read",
+    "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
 ]
 
@@ -53,6 +53,15 @@ class PmParams(C.Structure):
         ("functor_tau_grad", C.c_float),
         ("noise_seed", C.c_uint64),
         ("left_right_check", C.c_int),
+        ("sparse_init", C.c_int),
+        ("max_features_per_frame", C.c_int),
+        ("min_distance_btw_features", C.c_int),
+        ("gftt_block_size", C.c_int),
+        ("gftt_quality_level", C.c_double),
+        ("templ_cols", C.c_int),
+        ("templ_rows", C.c_int),
+        ("max_disp", C.c_int),
+        ("max_matching_cost", C.c_double),
     ]
 
 
@@ -110,6 +119,8 @@ def load():
     lib.pm_remove_background.restype = C.c_int
     lib.pm_mask_occlusions.argtypes = [vp, f32p, f32p, C.c_int, C.c_int]
     lib.pm_mask_occlusions.restype = C.c_int
+    lib.pm_sparse_init.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
+    lib.pm_sparse_init.restype = C.c_int
     lib.pm_profile_enable.argtypes = [vp, C.c_int]
     lib.pm_profile_enable.restype = C.c_int
     lib.pm_profile_read.argtypes = [vp, C.POINTER(PmProfile)]
@@ -286,6 +297,14 @@ class Engine:
                                                   d.ctypes.data_as(C.c_void_p), patch_h, patch_w, factor),
                     "pm_remove_background")
         return d
+
+    def sparse_init(self, left, right, dilate_factor=4):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        seed = np.empty(left.shape, np.float32)
+        self._check(self.lib.pm_sparse_init(self.h, pl, pr, left.shape[0], left.shape[1], dilate_factor,
+                                            seed.ctypes.data_as(C.c_void_p)), "pm_sparse_init")
+        return seed
 
     def mask_occlusions(self, disp_l, disp_r):
         dl = np.array(disp_l, dtype=np.float32, order="C", copy=True)

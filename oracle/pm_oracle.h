@@ -145,6 +145,37 @@ void pmo_match_view(const pmo_params* p, const pmo_images* im, float* disp);
 void pmo_match(const pmo_params* p, const uint8_t* left, const uint8_t* right, int rows, int cols,
                const float* seed_l, const float* seed_r, float* disp_l, float* disp_r);
 
+/* ---- sparse seeding: FeatureDetector::Detect + StereoMatcher::MatchRectified + SparseInit ----
+ * The reference delegates to cv::goodFeaturesToTrack and cv::matchTemplate (OpenCV 3.4), whose float
+ * pipelines (scaled Sobel, DFT-based correlation) cannot be reproduced bit for bit without OpenCV.  These
+ * functions restate the ALGORITHMS (min-eigenvalue corners, quality threshold, 3x3 non-maximum suppression,
+ * greedy minimum distance; normalised squared difference, first minimum) on exact integer sums; they are
+ * this build's definition of the seeder, validated functionally (parity unpinned, as for the rest). */
+typedef struct pmo_seed_params {
+  int max_features;         /* 200   feature_detector.hpp:28 max_features_per_frame */
+  int min_distance;         /* 20    :31 min_distance_btw_tracked_and_detected_features */
+  double quality_level;     /* 0.01  :32 gftt_quality_level */
+  int block_size;           /* 5     :33 gftt_block_size */
+  int templ_cols;           /* 31    stereo_matcher.hpp:21 */
+  int templ_rows;           /* 11    :22 */
+  int max_disp;             /* 128   :23 */
+  double max_matching_cost; /* 0.15  :24 */
+} pmo_seed_params;
+
+void pmo_seed_params_default(pmo_seed_params* p);
+/* min-eigenvalue response (cv::cornerMinEigenVal, unscaled): eig = (a+c) - sqrt((a-c)^2 + b^2) in binary32 with
+ * a = Sxx/2, b = Sxy, c = Syy/2, S** = block_size^2 box sums (REFLECT_101) of the Sobel products. */
+void pmo_min_eig_map(const uint8_t* img, int rows, int cols, int block_size, float* eig);
+/* goodFeaturesToTrack as FeatureDetector::Detect configures it (feature_detector.cpp:44-57,89-122);
+ * returns the number of corners written to xs/ys (strongest first). */
+int pmo_gftt_detect(const uint8_t* img, int rows, int cols, const pmo_seed_params* p, int* xs, int* ys, int cap);
+/* StereoMatcher::MatchRectified (stereo_matcher.cpp:22-116): disparity of one keypoint or -1. */
+double pmo_match_rectified(const uint8_t* left, const uint8_t* right, int rows, int cols, float kx, float ky,
+                           const pmo_seed_params* p);
+/* PatchmatchGpu::SparseInit (patchmatch_gpu.cu:414-442): seed map, 0 = unknown. */
+void pmo_sparse_init(const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
+                     const pmo_seed_params* p, float* seed);
+
 #ifdef __cplusplus
 }
 #endif

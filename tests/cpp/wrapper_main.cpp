@@ -54,13 +54,14 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 5; ++i) pm.Match(il, ir, disp, dispr);
     write_raw(dir + "/disp_l.f32", disp);
     write_raw(dir + "/disp_r.f32", dispr);
-    bool threw = false;
-    try {
-      pm.SparseInit(il, ir, 4);
-    } catch (const std::logic_error&) {
-      threw = true;
-    }
-    if (!threw) return 4;
+    // Match() without SetSeeds seeds itself, and SparseInit is callable on its own (patchmatch_gpu.h:110-112)
+    Image1f none;
+    pm.SetSeeds(none, none);
+    Image1f auto_l, auto_r;
+    pm.Match(il, ir, auto_l, auto_r);
+    write_raw(dir + "/auto_l.f32", auto_l);
+    write_raw(dir + "/auto_r.f32", auto_r);
+    write_raw(dir + "/sparse_init.f32", pm.SparseInit(il, ir, 4));
     std::cout << "ok " << disp.rows << "x" << disp.cols << "\n";
     return 0;
   } catch (const std::exception& e) {

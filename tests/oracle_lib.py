@@ -21,6 +21,12 @@ class Functor(C.Structure):
     _fields_ = [("alpha", C.c_float), ("tau_color", C.c_float), ("tau_grad", C.c_float)]
 
 
+class SeedParams(C.Structure):
+    _fields_ = [("max_features", C.c_int), ("min_distance", C.c_int), ("quality_level", C.c_double),
+                ("block_size", C.c_int), ("templ_cols", C.c_int), ("templ_rows", C.c_int), ("max_disp", C.c_int),
+                ("max_matching_cost", C.c_double)]
+
+
 class Params(C.Structure):
     _fields_ = [
         ("semantics", C.c_int), ("n_iters", C.c_int),
@@ -80,6 +86,16 @@ def load():
     lib.pmo_match.argtypes = [C.POINTER(Params), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pmo_flip_h_u8.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.pmo_flip_h_f32.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.pmo_seed_params_default.argtypes = [C.POINTER(SeedParams)]
+    lib.pmo_seed_params_default.restype = None
+    lib.pmo_min_eig_map.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.pmo_min_eig_map.restype = None
+    lib.pmo_gftt_detect.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SeedParams), vp, vp, C.c_int]
+    lib.pmo_gftt_detect.restype = C.c_int
+    lib.pmo_match_rectified.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(SeedParams)]
+    lib.pmo_match_rectified.restype = C.c_double
+    lib.pmo_sparse_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(SeedParams), vp]
+    lib.pmo_sparse_init.restype = None
     for name in ("pmo_params_default", "pmo_rng_fill_uniform", "pmo_rng_raw", "pmo_gradient_magnitude",
                  "pmo_dilate_rect", "pmo_get_rect_subpix_u8", "pmo_get_rect_subpix_f32", "pmo_cpu_add_noise",
                  "pmo_cpu_propagate", "pmo_cpu_remove_background", "pmo_gpu_add_foreground_noise",
@@ -269,3 +285,43 @@ def match(params, left, right, seed_l=None, seed_r=None):
     load().pmo_match(C.byref(params), _p(left), _p(right), rows, cols, _p(sl) if sl is not None else None,
                      _p(sr) if sr is not None else None, _p(dl), _p(dr))
     return dl, (dr if params.left_right_check else None)
+
+
+def seed_params(**kw):
+    p = SeedParams()
+    load().pmo_seed_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def min_eig_map(img, block_size=5):
+    img = c_u8(img)
+    out = np.empty(img.shape, np.float32)
+    load().pmo_min_eig_map(_p(img), img.shape[0], img.shape[1], block_size, _p(out))
+    return out
+
+
+def gftt_detect(img, sp=None):
+    sp = sp or seed_params()
+    img = c_u8(img)
+    cap = max(1, sp.max_features)
+    xs, ys = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    n = load().pmo_gftt_detect(_p(img), img.shape[0], img.shape[1], C.byref(sp), _p(xs), _p(ys), cap)
+    return xs[:n].copy(), ys[:n].copy()
+
+
+def match_rectified(left, right, kx, ky, sp=None):
+    sp = sp or seed_params()
+    left, right = c_u8(left), c_u8(right)
+    return float(load().pmo_match_rectified(_p(left), _p(right), left.shape[0], left.shape[1], kx, ky, C.byref(sp)))
+
+
+def sparse_init(left, right, dilate_factor=4, sp=None):
+    sp = sp or seed_params()
+    left, right = c_u8(left), c_u8(right)
+    out = np.zeros(left.shape, np.float32)
+    load().pmo_sparse_init(_p(left), _p(right), left.shape[0], left.shape[1], dilate_factor, C.byref(sp), _p(out))
+    return out

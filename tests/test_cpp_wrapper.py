@@ -41,7 +41,7 @@ def test_wrapper_builds_with_gxx_and_fails_loudly_without_gpu(wrapper_exe, tmp_p
 @pytest.mark.gpu
 @pytest.mark.parametrize("sem,patch", [(1, 3), (0, 5)])
 def test_wrapper_match_matches_oracle(wrapper_exe, tmp_path, oracle, synth, sem, patch):
-    rows, cols = 60, 94
+    rows, cols = 96, 160  # wide enough for the 128-column matching stripe
     l, r, sl, sr, _ = small_pair(synth, 70 + sem, rows, cols, n_points=30, dilate_factor=2)
     for name, arr in (("left.u8", l), ("right.u8", r), ("seed_l.f32", sl), ("seed_r.f32", sr)):
         np.ascontiguousarray(arr).tofile(os.path.join(tmp_path, name))
@@ -53,3 +53,13 @@ def test_wrapper_match_matches_oracle(wrapper_exe, tmp_path, oracle, synth, sem,
     el, er = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8), l, r, sl, sr)
     assert_same(dl, el, "left")
     assert_same(dr, er, "right")
+    # self-seeded Match() and the stand-alone SparseInit (reference API, patchmatch_gpu.h:99-112)
+    si = np.fromfile(os.path.join(tmp_path, "sparse_init.f32"), np.float32).reshape(rows, cols)
+    osl = oracle.sparse_init(l, r, 4)
+    osr = oracle.sparse_init(r[:, ::-1], l[:, ::-1], 4)[:, ::-1]
+    assert_same(si, osl, "SparseInit")
+    al = np.fromfile(os.path.join(tmp_path, "auto_l.f32"), np.float32).reshape(rows, cols)
+    ar = np.fromfile(os.path.join(tmp_path, "auto_r.f32"), np.float32).reshape(rows, cols)
+    el2, er2 = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8), l, r, osl, osr)
+    assert_same(al, el2, "self-seeded left")
+    assert_same(ar, er2, "self-seeded right")

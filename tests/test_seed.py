@@ -1,0 +1,122 @@
+"""Sparse seeding: the oracle's restatement of FeatureDetector::Detect +
+StereoMatcher::MatchRectified + SparseInit (known answers, functional checks) and, with -m gpu, bit
+parity of the device seeder with it."""
+import numpy as np
+import pytest
+
+from conftest import assert_same, small_pair
+
+
+def test_min_eig_known_answers(oracle):
+    # constant image: no gradient anywhere -> zero response
+    assert not oracle.min_eig_map(np.full((12, 14), 90, np.uint8)).any()
+    # vertical edge: gradient only along x -> the structure tensor is rank 1 -> min eigenvalue 0
+    im = np.zeros((16, 16), np.uint8)
+    im[:, 8:] = 200
+    assert np.all(oracle.min_eig_map(im) == 0)
+    # an isolated corner (bright quadrant) has a positive response near the corner and it is the maximum
+    im = np.zeros((32, 32), np.uint8)
+    im[16:, 16:] = 200
+    e = oracle.min_eig_map(im)
+    y, x = np.unravel_index(np.argmax(e), e.shape)
+    assert e.max() > 0 and abs(y - 16) <= 2 and abs(x - 16) <= 2
+
+
+def test_gftt_rules(oracle, synth):
+    p = synth.make_pair(3, rows=200, cols=320)
+    sp = oracle.seed_params()
+    xs, ys = oracle.gftt_detect(p["left"], sp)
+    assert 0 < len(xs) <= sp.max_features
+    e = oracle.min_eig_map(p["left"])
+    # strongest first; every corner above the quality threshold; local 3x3 maximum; not on the border
+    vals = e[ys, xs]
+    assert np.all(np.diff(vals) <= 0)
+    assert np.all(vals > np.float32(float(e.max()) * sp.quality_level))
+    for x, y in zip(xs, ys):
+        assert 1 <= x < 319 and 1 <= y < 199
+        assert e[y, x] == e[y - 1:y + 2, x - 1:x + 2].max()
+    # pairwise distance >= min_distance (feature_detector.hpp:31)
+    d2 = (xs[:, None] - xs[None, :]) ** 2 + (ys[:, None] - ys[None, :]) ** 2
+    d2[np.arange(len(xs)), np.arange(len(xs))] = 10 ** 9
+    assert d2.min() >= sp.min_distance ** 2
+    # fewer features requested -> a prefix of the same list (greedy in strength order)
+    xs2, ys2 = oracle.gftt_detect(p["left"], oracle.seed_params(max_features=17))
+    assert np.array_equal(xs2, xs[:17]) and np.array_equal(ys2, ys[:17])
+
+
+def test_match_rectified_known_answers(oracle):
+    rng = np.random.default_rng(4)
+    right = rng.integers(0, 256, (60, 300), dtype=np.uint8)
+    left = np.roll(right, 23, axis=1)  # pure shift: disparity 23 everywhere, exact match -> cost 0
+    assert oracle.match_rectified(left, right, 180.0, 30.0) == 23.0
+    assert oracle.match_rectified(left, right, 150.0, 20.0) == 23.0
+    # template or stripe leaving the image vertically: no match (stereo_matcher.cpp:33-36, 64-66)
+    assert oracle.match_rectified(left, right, 180.0, 3.0) == -1.0
+    assert oracle.match_rectified(left, right, 180.0, 56.0) == -1.0
+    # unrelated images: best normalised cost far above max_matching_cost 0.15
+    other = rng.integers(0, 256, (60, 300), dtype=np.uint8)
+    assert oracle.match_rectified(left, other, 180.0, 30.0) == -1.0
+    # a match to the right of the keypoint is rejected (:109 match_is_to_the_left)
+    assert oracle.match_rectified(right, left, 150.0, 30.0) == -1.0
+
+
+def test_sparse_init_functional(oracle, synth):
+    p = synth.make_pair(5, rows=240, cols=376)
+    seed = oracle.sparse_init(p["left"], p["right"], 4)
+    fg = seed > 0
+    assert fg.mean() > 0.5
+    # seeds are dilated integer disparities close to the truth at the corner they came from
+    xs, ys = oracle.gftt_detect(p["left"])
+    d = np.array([oracle.match_rectified(p["left"], p["right"], float(x), float(y)) for x, y in zip(xs, ys)])
+    ok = d >= 0
+    assert ok.mean() > 0.6 and np.median(np.abs(d[ok] - p["gt"][ys[ok], xs[ok]])) < 1.0
+    # dilation with the (2*(2^4+1)+1)^2 = 35x35 rectangle
+    sparse = np.zeros_like(seed)
+    sparse[ys[ok], xs[ok]] = d[ok]
+    assert_same(seed, oracle.dilate_rect(sparse, 17), "dilated scatter")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,idx", [(120, 200, 0), (240, 376, 1), (133, 259, 2)])
+def test_device_sparse_init_matches_oracle(pm, oracle, synth, rows, cols, idx):
+    p = synth.make_pair(idx, rows=rows, cols=cols)
+    with pm.Engine(pm.default_params(1), max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(p["left"], p["right"], 4)
+        got2 = e.sparse_init(p["left"], p["right"], 2)
+        got_r = e.sparse_init(p["right"][:, ::-1], p["left"][:, ::-1], 4)
+    assert_same(got, oracle.sparse_init(p["left"], p["right"], 4), "SparseInit f=4")
+    assert_same(got2, oracle.sparse_init(p["left"], p["right"], 2), "SparseInit f=2")
+    assert_same(got_r, oracle.sparse_init(p["right"][:, ::-1], p["left"][:, ::-1], 4), "SparseInit mirrored pair")
+    assert (got > 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sem", [0, 1])
+def test_self_seeded_match_matches_oracle(pm, oracle, synth, sem):
+    rows, cols = 240, 376   # the reference test's image size (patchmatch_gpu_test.cpp:62-64)
+    p = synth.make_pair(6, rows=rows, cols=cols)
+    l, r = p["left"], p["right"]
+    prm = pm.default_params(sem, patch=5, patchmatch_iters=3, sparse_init=1)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        dl, dr = e.match(l, r, None, None)          # seeds itself on both views, like the reference's Match()
+        dl2, dr2 = e.match(l, r, p["seed_l"], None)  # an explicit left seed map takes precedence
+    osl = oracle.sparse_init(l, r, 4)
+    osr = oracle.sparse_init(r[:, ::-1], l[:, ::-1], 4)[:, ::-1]
+    op = oracle.default_params(sem, patch=5, n_iters=3, nthreads=8)
+    el, er = oracle.match(op, l, r, osl, osr)
+    assert_same(dl, el, "self-seeded left")
+    assert_same(dr, er, "self-seeded right")
+    el2, er2 = oracle.match(op, l, r, p["seed_l"], osr)
+    assert_same(dl2, el2, "explicit left seeds")
+    assert_same(dr2, er2, "self-seeded right with explicit left")
+    fg = dl > 0
+    assert fg.mean() > 0.5 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.97
+
+
+@pytest.mark.gpu
+def test_full_size_seeding(pm, oracle, synth):
+    rows, cols = 720, 1280
+    p = synth.make_pair(0, rows, cols)
+    with pm.Engine(pm.default_params(1), max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(p["left"], p["right"], 4)
+    assert_same(got, oracle.sparse_init(p["left"], p["right"], 4), "1280x720 SparseInit")
