@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
+    ap.add_argument("--self-seed", action="store_true",
+                    help="let Match() compute its seeds with the device SparseInit (side measurement)")
     ap.add_argument("--semantics", type=int, default=0,
                     help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
     return ap.parse_args()
@@ -164,11 +166,13 @@ def main():
     DLb = torch.empty((nb, args.rows, args.cols), dtype=torch.float32, device=dev)
     DRb = torch.empty_like(DLb)
     DL = DLb[0]
-    params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine)
+    params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine,
+                               sparse_init=1 if args.self_seed else 0)
     eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=nb)
 
     def step():
-        eng.match_device(nb, L.data_ptr(), R.data_ptr(), args.rows, args.cols, SL.data_ptr(), SR.data_ptr(),
+        eng.match_device(nb, L.data_ptr(), R.data_ptr(), args.rows, args.cols,
+                         None if args.self_seed else SL.data_ptr(), None if args.self_seed else SR.data_ptr(),
                          DLb.data_ptr(), DRb.data_ptr())
 
     for _ in range(warmup):

@@ -29,6 +29,8 @@ EXPORTS = [
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
+    "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
+    "pm_tile_set_row", "pm_tile_background", "pm_tile_finish",
 ]
 
 
@@ -65,6 +67,10 @@ class PmParams(C.Structure):
     ]
 
 
+class PmTile(C.Structure):
+    _fields_ = [("global_rows", C.c_int), ("band_row0", C.c_int), ("own_row0", C.c_int), ("own_rows", C.c_int)]
+
+
 class PmProfile(C.Structure):
     _fields_ = [("launches", C.c_uint64 * PM_K_COUNT), ("total_ms", C.c_double * PM_K_COUNT)]
 
@@ -83,6 +89,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # A process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64; if this library
+    # is loaded first it pulls in the system runtime, torch later loads its bundled copy, and whichever of
+    # the two initialises second finds no device.  Loading torch first makes this library bind to the
+    # runtime torch brought (same SONAME).  Pure C/C++ callers are unaffected.
+    if os.environ.get("PM_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     u8p, f32p, vp = C.c_void_p, C.c_void_p, C.c_void_p
     lib.pm_params_default.argtypes = [C.POINTER(PmParams), C.c_int]
@@ -121,6 +136,18 @@ def load():
     lib.pm_mask_occlusions.restype = C.c_int
     lib.pm_sparse_init.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
     lib.pm_sparse_init.restype = C.c_int
+    lib.pm_tile_begin.argtypes = [vp, C.POINTER(PmTile), u8p, u8p, C.c_int, C.c_int, f32p, f32p]
+    lib.pm_tile_noise.argtypes = [vp, C.c_int]
+    lib.pm_tile_sweep.argtypes = [vp, C.c_int, C.c_int]
+    lib.pm_tile_snapshot.argtypes = [vp]
+    lib.pm_tile_restore.argtypes = [vp]
+    lib.pm_tile_get_row.argtypes = [vp, C.c_int, f32p]
+    lib.pm_tile_set_row.argtypes = [vp, C.c_int, f32p]
+    lib.pm_tile_background.argtypes = [vp]
+    lib.pm_tile_finish.argtypes = [vp, f32p, f32p]
+    for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
+                 "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish"):
+        getattr(lib, name).restype = C.c_int
     lib.pm_profile_enable.argtypes = [vp, C.c_int]
     lib.pm_profile_enable.restype = C.c_int
     lib.pm_profile_read.argtypes = [vp, C.POINTER(PmProfile)]
@@ -312,6 +339,35 @@ class Engine:
         self._check(self.lib.pm_mask_occlusions(self.h, dl.ctypes.data_as(C.c_void_p), pdr, dl.shape[0],
                                                 dl.shape[1]), "pm_mask_occlusions")
         return dl
+
+    # --- row-tiled mode (device addresses as ints) -----------------------------------------------
+    def tile_begin(self, tile, d_left, d_right, band_rows, cols, d_seed_l, d_seed_r):
+        self._check(self.lib.pm_tile_begin(self.h, C.byref(tile), d_left, d_right, band_rows, cols, d_seed_l,
+                                           d_seed_r), "pm_tile_begin")
+
+    def tile_noise(self, it):
+        self._check(self.lib.pm_tile_noise(self.h, it), "pm_tile_noise")
+
+    def tile_sweep(self, it, k):
+        self._check(self.lib.pm_tile_sweep(self.h, it, k), "pm_tile_sweep")
+
+    def tile_snapshot(self):
+        self._check(self.lib.pm_tile_snapshot(self.h), "pm_tile_snapshot")
+
+    def tile_restore(self):
+        self._check(self.lib.pm_tile_restore(self.h), "pm_tile_restore")
+
+    def tile_get_row(self, image_row, d_dst):
+        self._check(self.lib.pm_tile_get_row(self.h, image_row, d_dst), "pm_tile_get_row")
+
+    def tile_set_row(self, image_row, d_src):
+        self._check(self.lib.pm_tile_set_row(self.h, image_row, d_src), "pm_tile_set_row")
+
+    def tile_background(self):
+        self._check(self.lib.pm_tile_background(self.h), "pm_tile_background")
+
+    def tile_finish(self, d_out_l, d_out_r):
+        self._check(self.lib.pm_tile_finish(self.h, d_out_l, d_out_r), "pm_tile_finish")
 
     def debug_counters_enable(self, on=True):
         self._check(self.lib.pm_debug_counters_enable(self.h, 1 if on else 0), "pm_debug_counters_enable")
