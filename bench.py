@@ -90,6 +90,20 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+def pmc_traffic(kernel_class):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools in DESIGN.md 7: separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command; FETCH_SIZE/WRITE_SIZE are KiB counters of the L2's memory-side requests).  None if the
+    file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        k = t["kernels"][kernel_class]
+        return float(k["fetch_kib"] + k["write_kib"]) * 1024.0
+    except Exception:
+        return None
+
+
 def shard(rank, world, steps):
     """Pair index matched by `rank` at each step: independent pairs, contiguous by rank."""
     return [rank for _ in range(steps)]
@@ -219,7 +233,7 @@ def main():
             value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
             ms_per_frame=1e3 * elapsed / steps / nb,
             roofline={"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
                       "algorithmic_bytes_per_launch": SWEEP_BYTES_PER_PX * px_views, "avg_launch_ms": avg_ms,
                       "launches": n_launch},
             kernels_ms_per_step={k: v[1] / steps for k, v in prof.items()},
