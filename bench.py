@@ -116,7 +116,7 @@ def cpu_baseline(args):
     import oracle_lib as O
     import synth
     p = synth.make_pair(0, args.rows, args.cols)
-    band_rows = min(64, args.rows)
+    band_rows = min(160, args.rows)  # ~10-15 s of single-thread CPU work on the GPU node's host
     y0 = (args.rows - band_rows) // 2
     band = slice(y0, y0 + band_rows)
     prm = O.default_params(O.SEM_CPU, patch=args.patch, n_iters=args.iters, nthreads=1, literal=1, left_right_check=1)

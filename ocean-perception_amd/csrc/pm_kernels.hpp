@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
                                                           int keep_zero) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
-  __shared__ uint8_t s_l8[TR * LW];
-  __shared__ uint8_t s_lg[TR * LW];
+  __shared__ uint8_t s_l8[TR * LW + 4];  // +4: the packed reads take whole dwords
+  __shared__ uint8_t s_lg[TR * LW + 4];
   __shared__ uint8_t s_r8[TR * kTileRW];
   __shared__ float s_rg[TR * kTileRW];
   __shared__ int s_red[8];
@@ -253,27 +253,52 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     }
     __syncthreads();
     if (interior) {
+      // Four taps per v_sad_u8: the window row's reference bytes are consecutive in LDS and are used as
+      // loaded; the four colour samples (byte 2 of the 16.16 fixed-point value) and the four rounded
+      // gradient samples (byte 0 of 0x4B0000nn) are gathered into one register each with v_perm_b32.
       unsigned sc = 0, sg = 0;
       const int rc = l.ipx - lo;
+      constexpr int NG = (PW + 3) / 4;  // groups of four taps; the last one may be partial
 #pragma unroll 1
       for (int i = 0; i < PH; ++i) {
         const uint8_t* lp = s_l8 + (ty + i) * LW + tx;
         const uint8_t* lgp = s_lg + (ty + i) * LW + tx;
         const uint8_t* rp = s_r8 + (ty + i) * kTileRW + rc;
         const float* rg = s_rg + (ty + i) * kTileRW + rc;
+        unsigned lw[NG], lgw[NG];
+        __builtin_memcpy(lw, lp, 4 * NG);    // reads up to 3 bytes past the window inside the tile row: masked below
+        __builtin_memcpy(lgw, lgp, 4 * NG);
         int r0 = rp[0];
         float g0 = rg[0];
 #pragma unroll
-        for (int j = 0; j < PW; ++j) {
-          const int r1 = rp[j + 1];
-          const float g1 = rg[j + 1];
-          sc = cpu_acc_color(sc, lp[j], r0, r1, l);
-          sg = cpu_acc_grad(sg, lgp[j], g0, g1, l);
-          r0 = r1;
-          g0 = g1;
+        for (int q = 0; q < NG; ++q) {
+          unsigned t[4] = {0, 0, 0, 0};
+          unsigned gs[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int j = 4 * q + k;
+            if (j < PW) {
+              const int r1 = rp[j + 1];
+              const float g1 = rg[j + 1];
+              unsigned tt = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
+              t[k] = __umul24((unsigned)r0, (unsigned)l.a11) + tt;
+              float sgr = g0 * l.ia;
+              sgr = sgr + g1 * l.a;
+              sgr = __builtin_amdgcn_fmed3f(sgr, 0.f, 255.f);
+              gs[k] = __builtin_bit_cast(unsigned, sgr + 8388608.f);
+              r0 = r1;
+              g0 = g1;
+            }
+          }
+          // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
+          const unsigned pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | __builtin_amdgcn_perm(t[3], t[2], 0x06020c0cu);
+          const unsigned pg = __builtin_amdgcn_perm(gs[1], gs[0], 0x0c0c0400u) | __builtin_amdgcn_perm(gs[3], gs[2], 0x04000c0cu);
+          const int rem = PW - 4 * q;  // taps in this group
+          const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+          sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc & mask, sc);
+          sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg & mask, sg);
         }
       }
-      sg -= cpu_grad_bias(PW * PH);
       c = cpu_cost_from_sums((int)sc, (int)sg, cp);
     }
   } else if (interior) {

@@ -20,6 +20,13 @@ namespace pm {
 
 constexpr int kGroup = 32;
 
+// Occupancy experiment knob: -DPM_RUNBLK2_MIN_WAVES=8 caps the kernel at 64 VGPRs (8 waves per SIMD).
+#ifdef PM_RUNBLK2_MIN_WAVES
+#define PM_RUNBLK2_BOUNDS __launch_bounds__(64 * kMaxSegWaves, PM_RUNBLK2_MIN_WAVES)
+#else
+#define PM_RUNBLK2_BOUNDS __launch_bounds__(64 * kMaxSegWaves)
+#endif
+
 struct RunStep2 {
   // group-uniform
   int advance;   // positions resolved (0 if the group is idle)
@@ -183,7 +190,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 // Rounds and fix-up exactly as pm_run.hpp::k_runblk, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
 template <int AXIS, int TPW, int TPH>
-__global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
+__global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
   const int n = (g.s_last - g.s_first) * g.dir + 1;
   const int n1 = (n + 1 + 3) & ~3;
