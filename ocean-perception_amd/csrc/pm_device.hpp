@@ -49,6 +49,7 @@ struct View {
   const uint8_t* ttgt8;
   const float* ttgtg;
   const uint8_t* trefg8;
+  const float* trefg;      // transposed refg (PM_SEM_GPU column sweeps)
   const uint16_t* refpk;   // ref8 | refg8 << 8
   const uint16_t* trefpk;  // transposed
   float* disp;
@@ -69,6 +70,7 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.ttgt8 = ps.timg8 + (base4 + itgt) * ps.plane_t;
   w.ttgtg = ps.tg32 + (base4 + itgt) * ps.plane_t;
   w.trefg8 = ps.tg8 + (base4 + iref) * ps.plane_t;
+  w.trefg = ps.tg32 + (base4 + iref) * ps.plane_t;
   w.refpk = ps.pk16 + (base4 + iref) * ps.plane;
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;

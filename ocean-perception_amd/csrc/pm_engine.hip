@@ -346,8 +346,8 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
   int engine = h->params.engine;
   if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK2;
-  if (cp.semantics != PM_SEM_CPU && engine >= PM_ENGINE_RUN)
-    engine = PM_ENGINE_WAVE;  // PM_SEM_GPU: one lane per chain (its 5-tap cost is too small to spread)
+  // PM_SEM_GPU has two parallel engines: lane-per-segment (WAVE) and the shared-tap run step (RUNBLK2)
+  if (cp.semantics != PM_SEM_CPU && (engine == PM_ENGINE_RUN || engine == PM_ENGINE_RUNBLK)) engine = PM_ENGINE_WAVE;
   if (engine == PM_ENGINE_SERIAL) {
     hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0,
                        h->stream, ps, cp, g);

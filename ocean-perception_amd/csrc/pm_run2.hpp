@@ -31,7 +31,7 @@ struct RunStep2 {
   // group-uniform
   int advance;   // positions resolved (0 if the group is idle)
   int rej_pos;   // -1: none
-  float rej_d0;
+  float rej_d0;  // value the position rej_pos holds after the step = candidate of the next step
   // per lane
   int mpos;
   bool adopt;
@@ -189,7 +189,13 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 // One workgroup per chain; wavefront w carries segments 2w (lanes 0-31) and 2w+1 (lanes 32-63).
 // Rounds and fix-up exactly as pm_run.hpp::k_runblk, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
-template <int AXIS, int TPW, int TPH>
+// SEM = 0: PM_SEM_CPU (run_step2 above); SEM = 1: PM_SEM_GPU (run_step2_gpu, pm_run_gpu.hpp).
+template <int SEM, int AXIS, int TPW, int TPH>
+__device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
+                                                  const SweepGeom& g, int chain, bool act, int i, int n_end,
+                                                  float cand, const float* din, const float* cin);
+
+template <int SEM, int AXIS, int TPW, int TPH>
 __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
   const int n = (g.s_last - g.s_first) * g.dir + 1;
@@ -210,7 +216,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   const int nw = blockDim.x >> 6;
   const int nseg = 2 * nw;
   const int sidx = 2 * w + (upper ? 1 : 0);
-  const int nd = run2_nd<AXIS, TPW, TPH>(cp);
+  const int nd = SEM == 0 ? run2_nd<AXIS, TPW, TPH>(cp) : kGroup - 2;
   const int stride = AXIS == 0 ? g.dir : g.dir * ps.pitch;
   const ptrdiff_t first =
       AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
@@ -238,10 +244,10 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     int i = i0;
     while (__any(active && i < i1)) {
       const bool act = active && i < i1;
-      const RunStep2 st = run_step2<AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
+      const RunStep2 st = run_step2_any<SEM, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
       if (st.mpos >= 0 && st.mpos < st.advance) {
-        dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.d0 : cand;
+        dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.rej_d0 : cand;
         cout[i + st.mpos + 1] = st.adopt ? st.cost : st.c0;
       }
       if (st.rej_pos >= 0) cand = st.rej_d0;
@@ -266,14 +272,20 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       bool merged = false;
       while (__any(redo && !merged && i < i1)) {
         const bool act = redo && !merged && i < i1;
-        const RunStep2 st = run_step2<AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
+        const RunStep2 st = run_step2_any<SEM, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
         ++n_fix;
         const bool mine = st.mpos >= 0 && st.mpos < st.advance;
-        const float val = st.mpos == st.rej_pos ? st.d0 : c2;
+        const float val = st.mpos == st.rej_pos ? st.rej_d0 : c2;
         const float spec = mine ? dout[i + st.mpos + 1] : 0.f;
         const unsigned eq = gballot(mine && val == spec, upper);
         int ms = -1;
-        if (eq) ms = g.dir > 0 ? __ffs((int)eq) - 1 : nd - 1 - (31 - __clz((int)eq));
+        if (eq) {  // first merged position in sweep order (lane <-> position mapping of the step function)
+          const int lo_lane = __ffs((int)eq) - 1, hi_lane = 31 - __clz((int)eq);
+          if (SEM == 0)
+            ms = g.dir > 0 ? lo_lane : nd - 1 - hi_lane;
+          else
+            ms = g.dir > 0 ? lo_lane - 1 : nd - hi_lane;
+        }
         const int wlim = ms >= 0 ? ms : st.advance;
         if (st.mpos >= 0 && st.mpos < wlim) {
           dout[i + st.mpos + 1] = val;
@@ -316,7 +328,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   }
 }
 
-template <int AXIS, int TPW, int TPH>
+template <int SEM, int AXIS, int TPW, int TPH>
 inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                           hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
@@ -326,25 +338,43 @@ inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepG
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
   const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + 2 * kMaxSegWaves + 1 + 2);
-  hipLaunchKernelGGL((k_runblk2<AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
+  hipLaunchKernelGGL((k_runblk2<SEM, AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
                      lds_bytes, stream, ps, cp, g, len);
 }
 
 template <int AXIS>
 inline void launch_run2_axis(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                              hipStream_t stream) {
+  if (cp.semantics != 0) {
+    launch_run2_k<1, AXIS, 3, 3>(ps, cp, g, slots, waves, stream);
+    return;
+  }
   const int sq = cp.pw == cp.ph ? cp.pw : 0;
   switch (sq) {
-    case 3: launch_run2_k<AXIS, 3, 3>(ps, cp, g, slots, waves, stream); break;
-    case 5: launch_run2_k<AXIS, 5, 5>(ps, cp, g, slots, waves, stream); break;
-    case 7: launch_run2_k<AXIS, 7, 7>(ps, cp, g, slots, waves, stream); break;
-    case 9: launch_run2_k<AXIS, 9, 9>(ps, cp, g, slots, waves, stream); break;
-    case 11: launch_run2_k<AXIS, 11, 11>(ps, cp, g, slots, waves, stream); break;
-    default: launch_run2_k<AXIS, 0, 0>(ps, cp, g, slots, waves, stream); break;
+    case 3: launch_run2_k<0, AXIS, 3, 3>(ps, cp, g, slots, waves, stream); break;
+    case 5: launch_run2_k<0, AXIS, 5, 5>(ps, cp, g, slots, waves, stream); break;
+    case 7: launch_run2_k<0, AXIS, 7, 7>(ps, cp, g, slots, waves, stream); break;
+    case 9: launch_run2_k<0, AXIS, 9, 9>(ps, cp, g, slots, waves, stream); break;
+    case 11: launch_run2_k<0, AXIS, 11, 11>(ps, cp, g, slots, waves, stream); break;
+    default: launch_run2_k<0, AXIS, 0, 0>(ps, cp, g, slots, waves, stream); break;
   }
 }
 
-// PM_SEM_CPU only, in place.
+}  // namespace pm
+#include "pm_run_gpu.hpp"
+namespace pm {
+
+template <int SEM, int AXIS, int TPW, int TPH>
+__device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
+                                                  const SweepGeom& g, int chain, bool act, int i, int n_end,
+                                                  float cand, const float* din, const float* cin) {
+  if constexpr (SEM == 0)
+    return run_step2<AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+  else
+    return run_step2_gpu<AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+}
+
+// In place.
 inline void launch_sweep_run2(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                               hipStream_t stream) {
   if (g.axis == 0)

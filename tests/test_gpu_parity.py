@@ -80,6 +80,36 @@ def test_gpu_propagate_each_sweep(pm, oracle, synth, engine):
                         f"sweep mask {mask}")
 
 
+@pytest.mark.parametrize("engine", [2, 5])
+@pytest.mark.parametrize("kind", ["random", "plateaus", "huge", "tiny"])
+def test_gpu_propagate_adversarial_fields(pm, oracle, synth, engine, kind):
+    """PM_SEM_GPU sweeps on disparity fields that exercise the clamp (x - d < 1), the single-position slow
+    path, long runs of one value and binade crossings of the sample positions."""
+    rows, cols = 45, 333
+    l, r, _, _, _ = small_pair(synth, 21, rows, cols, n_points=20, dilate_factor=2)
+    ims = oracle.ImageSet(l, r)
+    rng = np.random.default_rng(5)
+    if kind == "random":
+        d = rng.uniform(0.0, 90.0, (rows, cols)).astype(np.float32)
+    elif kind == "plateaus":
+        d = np.repeat(np.repeat(rng.uniform(0.0, 40.0, (rows // 5 + 1, cols // 9 + 1)), 5, 0), 9, 1)
+        d = d[:rows, :cols].astype(np.float32)
+        d[rng.random((rows, cols)) < 0.05] = 0.0
+    elif kind == "huge":  # mostly clamped candidates
+        d = rng.uniform(100.0, 600.0, (rows, cols)).astype(np.float32)
+        d[:, ::7] = 3.25
+    else:  # values around powers of two of x - d, and denormal-small disparities
+        xs = np.arange(cols, dtype=np.float32)[None, :].repeat(rows, 0)
+        pick = rng.choice(np.array([1, 2, 4, 8, 16, 32, 64, 128], np.float32), (rows, cols))
+        d = np.maximum(xs - pick + rng.choice(np.array([-1e-3, 0, 1e-3, 0.5], np.float32), (rows, cols)), 0)
+        d[rng.random((rows, cols)) < 0.1] = 1e-30
+        d = d.astype(np.float32)
+    with mk(pm, 1, engine, rows=rows, cols=cols) as e:
+        for mask in (1, 2, 4, 8, 15):
+            assert_same(e.propagate(l, r, d, 3, 3, mask), oracle.gpu_propagate(ims, d, pass_mask=mask, nthreads=8),
+                        f"{kind} sweep mask {mask}")
+
+
 def test_remove_background_and_mask_occlusions(pm, oracle, synth):
     rows, cols = 50, 90
     l, r, sl, sr, _ = small_pair(synth, 13, rows, cols, n_points=30, dilate_factor=2)
@@ -289,10 +319,11 @@ def test_full_size_baseline_config_properties(pm, oracle, synth):
     assert_same(bdr, er, "64-row band at full width, right")
 
 
-def test_full_size_gpu_semantics_engines_agree(pm, oracle, synth):
+@pytest.mark.parametrize("engine", [2, 5])
+def test_full_size_gpu_semantics_engines_agree(pm, oracle, synth, engine):
     rows, cols = 720, 1280
     p = synth.make_pair(1, rows, cols)
-    with mk(pm, 1, 2, iters=3, rows=rows, cols=cols) as e:
+    with mk(pm, 1, engine, iters=3, rows=rows, cols=cols) as e:
         dl, dr = e.match(p["left"], p["right"], p["seed_l"], p["seed_r"])
     el, er = oracle.match(oparams(oracle, 1, 3, 3), p["left"], p["right"], p["seed_l"], p["seed_r"])
     assert_same(dl, el, "1280x720 PM_SEM_GPU left vs oracle")
