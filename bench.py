@@ -49,6 +49,8 @@ def parse():
                     help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
     ap.add_argument("--self-seed", action="store_true",
                     help="let Match() compute its seeds with the device SparseInit (side measurement)")
+    ap.add_argument("--host-pairs", type=int, default=24,
+                    help="pairs of the untimed host-buffer leg (PCIe-inclusive rates, reported beside `value`); 0 = skip")
     ap.add_argument("--semantics", type=int, default=0,
                     help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
     return ap.parse_args()
@@ -132,6 +134,30 @@ def cpu_baseline(args):
                   f"swept rows {args.rows - 2 * h}/{band_rows - 2 * h}",
         "host_cores": os.cpu_count(),
     }
+
+
+def host_buffer_leg(pm, params, args, pair, device):
+    """PCIe-inclusive rates (never `value`): pageable host images in, host maps out.  `synchronous` is
+    pm_match_u8 call by call (what the reference's Match() does); `pipelined` keeps 3 pairs in flight with
+    pm_submit_u8 / pm_collect, so packing, upload and download overlap the matching of the neighbours."""
+    n = args.host_pairs
+    seeds = (None, None) if args.self_seed else (pair["seed_l"], pair["seed_r"])
+    out = {"pairs": n, "depth": 3, "unit": "pairs/s"}
+    with pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=3) as e:
+        e.match(pair["left"], pair["right"], *seeds)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e.match(pair["left"], pair["right"], *seeds)
+        out["synchronous"] = n / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for i in range(n):
+            if e.in_flight() == 3:
+                e.collect()
+            e.submit(pair["left"], pair["right"], *seeds, tag=i)
+        while e.in_flight():
+            e.collect()
+        out["pipelined"] = n / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -242,6 +268,8 @@ def main():
             check={"deterministic_across_steps": deterministic, "foreground_fraction": fg,
                    "foreground_within_1px_of_truth": within1},
         )
+        if d.world == 1 and args.host_pairs > 0:
+            result["host_buffers"] = host_buffer_leg(pm, params, args, pair, d.local_rank)
         if d.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

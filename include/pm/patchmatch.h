@@ -42,7 +42,8 @@ typedef enum pm_status {
   PM_ERR_SIZE = -2,        /* image larger than the handle was planned for, batch too large */
   PM_ERR_HIP = -3,         /* a HIP runtime call failed; pm_last_error() has the text       */
   PM_ERR_NO_DEVICE = -4,   /* no usable gfx950 device (the engine has NO CPU fallback)      */
-  PM_ERR_NOMEM = -5
+  PM_ERR_NOMEM = -5,
+  PM_ERR_BUSY = -6         /* pm_submit_u8 with max_batch pairs in flight / pm_collect with none */
 } pm_status;
 
 /* Which reference code the sweeps/cost reproduce bit for bit. */
@@ -140,6 +141,19 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
 int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right,
                       int rows, int cols, const float* const* seed_l, const float* const* seed_r,
                       float* const* disp_l, float* const* disp_r);
+
+/* The same Match() for a SEQUENCE of pairs (the per-frame callback loop of
+ * test/stereo_matching/patchmatch_gpu_test.cpp:118-128) with the copies off the critical path:
+ * pm_submit_u8 packs and uploads a pair and enqueues its match without waiting; pm_collect waits for
+ * the OLDEST submitted pair and copies its maps out.  Up to max_batch pairs may be in flight (then
+ * pm_submit_u8 returns PM_ERR_BUSY); results are those of pm_match_u8, in submission order.
+ * `tag` is handed back by the matching pm_collect.  The other host-buffer entry points must not be
+ * called while pairs are in flight (they share the staging buffers). */
+int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                 size_t image_step, const float* seed_l, const float* seed_r, size_t seed_step,
+                 uint64_t tag);
+int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag);
+int pm_in_flight(const pm_handle* h);
 
 /* Replaces void PatchmatchGpu::Match(const cu::GpuMat& ...) (patchmatch_gpu.h:104-108,
  * patchmatch_gpu.cu:379-411) widened to whole pairs: all pointers are DEVICE memory holding n

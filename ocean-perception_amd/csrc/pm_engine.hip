@@ -77,6 +77,17 @@ struct pm_handle {
   void* pinned = nullptr;  // host staging, pinned
   size_t pinned_bytes = 0;
 
+  // pipelined host-buffer path (pm_submit_u8 / pm_collect): slot k of the staging buffers, uploads on
+  // s_in, compute on `stream`, downloads on s_out
+  struct PipeSlot {
+    hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
+    uint64_t tag = 0;
+    int rows = 0, cols = 0;
+  };
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  std::vector<PipeSlot> pipe;
+  int pipe_head = 0, pipe_count = 0;
+
   // profiling
   bool profiling = false;
   std::vector<EventRec> ev_pool;
@@ -508,6 +519,7 @@ const char* pm_status_string(int status) {
     case PM_ERR_HIP: return "HIP runtime error";
     case PM_ERR_NO_DEVICE: return "no usable HIP device";
     case PM_ERR_NOMEM: return "out of memory";
+    case PM_ERR_BUSY: return "pipeline full / nothing to collect";
     default: return "unknown status";
   }
 }
@@ -535,6 +547,15 @@ void pm_destroy(pm_handle* h) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+  if (h->s_out) (void)hipStreamSynchronize(h->s_out);
+  for (auto& sl : h->pipe) {
+    if (sl.in_done) (void)hipEventDestroy(sl.in_done);
+    if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
+    if (sl.out_done) (void)hipEventDestroy(sl.out_done);
+  }
+  if (h->s_in) (void)hipStreamDestroy(h->s_in);
+  if (h->s_out) (void)hipStreamDestroy(h->s_out);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -809,6 +830,145 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
   }
   return PM_OK;
 }
+
+// ---- pipelined host-buffer path ---------------------------------------------------------------------
+// What the Sequence caller of the reference does frame by frame (patchmatch_gpu_test.cpp:118-128) with
+// the copies taken off the critical path: while pair k is matched, pair k+1 is packed and uploaded and
+// pair k-1 is downloaded.  Depth = max_batch of the plan.
+namespace {
+
+int pipe_init(pm_handle* h) {
+  if (!h->pipe.empty()) return PM_OK;
+  PM_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+  PM_HIP(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+  h->pipe.resize((size_t)h->max_batch);
+  for (auto& sl : h->pipe) {
+    PM_HIP(h, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
+    PM_HIP(h, hipEventCreateWithFlags(&sl.compute_done, hipEventDisableTiming));
+    PM_HIP(h, hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
+  }
+  return PM_OK;
+}
+
+struct PinnedSlot {
+  float *sl, *sr, *dl, *dr;
+  uint8_t *l, *r;
+};
+PinnedSlot pinned_slot(pm_handle* h, int slot, size_t px) {
+  const size_t tight = (size_t)h->max_rows * h->max_cols;
+  char* base = (char*)h->pinned + (size_t)slot * tight * (2 + 4 * sizeof(float));
+  PinnedSlot p;
+  p.sl = (float*)base;
+  p.sr = p.sl + px;
+  p.dl = p.sr + px;
+  p.dr = p.dl + px;
+  p.l = (uint8_t*)(p.dr + px);
+  p.r = p.l + px;
+  return p;
+}
+
+}  // namespace
+
+int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
+                 const float* seed_l, const float* seed_r, size_t seed_step, uint64_t tag) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!left || !right) {
+    set_err(h, "pm_submit_u8: null image pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  if (image_step == 0) image_step = (size_t)cols;
+  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
+  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols) {
+    set_err(h, "pm_submit_u8: a row step is smaller than a row");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = pipe_init(h)) return rc;
+  if (h->pipe_count == h->max_batch) {
+    set_err(h, "pm_submit_u8: %d pairs in flight (the plan's max_batch); collect one first", h->pipe_count);
+    return PM_ERR_BUSY;
+  }
+  if (h->noise_rows != rows || h->noise_cols != cols) {
+    // the noise table is staged through the pinned buffer the slots live in
+    if (h->pipe_count > 0) {
+      set_err(h, "pm_submit_u8: image size changed with pairs in flight; collect them first");
+      return PM_ERR_BUSY;
+    }
+    if (int rc = ensure_noise(h, rows, cols)) return rc;
+    PM_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  const int slot = (h->pipe_head + h->pipe_count) % h->max_batch;
+  pm_handle::PipeSlot& sl = h->pipe[(size_t)slot];
+  const size_t px = (size_t)rows * cols;
+  const size_t tight = (size_t)h->max_rows * h->max_cols;
+  const PinnedSlot ps = pinned_slot(h, slot, px);
+  for (int y = 0; y < rows; ++y) {
+    std::memcpy(ps.l + (size_t)y * cols, left + (size_t)y * image_step, (size_t)cols);
+    std::memcpy(ps.r + (size_t)y * cols, right + (size_t)y * image_step, (size_t)cols);
+    if (seed_l) std::memcpy(ps.sl + (size_t)y * cols, (const char*)seed_l + (size_t)y * seed_step, sizeof(float) * cols);
+    if (seed_r) std::memcpy(ps.sr + (size_t)y * cols, (const char*)seed_r + (size_t)y * seed_step, sizeof(float) * cols);
+  }
+  uint8_t* dl8 = h->st_left + slot * tight;
+  uint8_t* dr8 = h->st_right + slot * tight;
+  float* dsl = h->st_seed_l + slot * tight;
+  float* dsr = h->st_seed_r + slot * tight;
+  float* ddl = h->st_disp_l + slot * tight;
+  float* ddr = h->st_disp_r + slot * tight;
+  const bool lr = h->params.left_right_check != 0;
+  PM_HIP(h, hipMemcpyAsync(dl8, ps.l, px, hipMemcpyHostToDevice, h->s_in));
+  PM_HIP(h, hipMemcpyAsync(dr8, ps.r, px, hipMemcpyHostToDevice, h->s_in));
+  if (seed_l) PM_HIP(h, hipMemcpyAsync(dsl, ps.sl, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
+  if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
+  PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
+  PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
+  if (int rc = pm_match_device(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
+                               lr ? ddr : nullptr))
+    return rc;
+  PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
+  PM_HIP(h, hipStreamWaitEvent(h->s_out, sl.compute_done, 0));
+  PM_HIP(h, hipMemcpyAsync(ps.dl, ddl, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
+  if (lr) PM_HIP(h, hipMemcpyAsync(ps.dr, ddr, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
+  PM_HIP(h, hipEventRecord(sl.out_done, h->s_out));
+  sl.tag = tag;
+  sl.rows = rows;
+  sl.cols = cols;
+  ++h->pipe_count;
+  return PM_OK;
+}
+
+int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (h->pipe_count == 0) {
+    set_err(h, "pm_collect: nothing in flight");
+    return PM_ERR_BUSY;
+  }
+  const bool lr = h->params.left_right_check != 0;
+  if (!disp_l || (lr && !disp_r)) {
+    set_err(h, "pm_collect: null output pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  pm_handle::PipeSlot& sl = h->pipe[(size_t)h->pipe_head];
+  const int rows = sl.rows, cols = sl.cols;
+  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
+  if (disp_step < sizeof(float) * (size_t)cols) {
+    set_err(h, "pm_collect: disp_step is smaller than a row");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipEventSynchronize(sl.out_done));
+  const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
+  for (int y = 0; y < rows; ++y) {
+    std::memcpy((char*)disp_l + (size_t)y * disp_step, ps.dl + (size_t)y * cols, sizeof(float) * cols);
+    if (lr) std::memcpy((char*)disp_r + (size_t)y * disp_step, ps.dr + (size_t)y * cols, sizeof(float) * cols);
+  }
+  if (tag) *tag = sl.tag;
+  h->pipe_head = (h->pipe_head + 1) % h->max_batch;
+  --h->pipe_count;
+  return PM_OK;
+}
+
+int pm_in_flight(const pm_handle* h) { return h ? h->pipe_count : 0; }
 
 // ---- single stages ----------------------------------------------------------------------------
 

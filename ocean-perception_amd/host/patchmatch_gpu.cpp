@@ -91,6 +91,30 @@ void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp,
         "pm_match_u8");
 }
 
+bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, uint64_t tag) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
+    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size");
+  if (InFlight() == 0) EnsurePlan(iml.rows, iml.cols);  // re-planning destroys the handle: only when idle
+  const bool seeded_l = !seed_l_.empty() && seed_l_.rows == iml.rows && seed_l_.cols == iml.cols;
+  const bool seeded_r = !seed_r_.empty() && seed_r_.rows == iml.rows && seed_r_.cols == iml.cols;
+  const int rc = pm_submit_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
+                              seeded_l ? seed_l_.data() : nullptr, seeded_r ? seed_r_.data() : nullptr, 0, tag);
+  if (rc == PM_ERR_BUSY) return false;
+  Check(rc, "pm_submit_u8");
+  in_flight_sizes_.emplace_back(iml.rows, iml.cols);
+  return true;
+}
+
+bool PatchmatchGpu::Collect(Image1f& disp, Image1f& dispr, uint64_t* tag) {
+  if (in_flight_sizes_.empty()) return false;
+  const int rows = in_flight_sizes_.front().first, cols = in_flight_sizes_.front().second;
+  if (disp.rows != rows || disp.cols != cols) disp.create(rows, cols);
+  if (dispr.rows != rows || dispr.cols != cols) dispr.create(rows, cols);
+  Check(pm_collect(handle_, disp.data(), dispr.data(), disp.step, tag), "pm_collect");
+  in_flight_sizes_.erase(in_flight_sizes_.begin());
+  return true;
+}
+
 void PatchmatchGpu::Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, int cols, const float* d_seed_l,
                           const float* d_seed_r, float* d_disp, float* d_dispr) {
   EnsurePlan(rows, cols);

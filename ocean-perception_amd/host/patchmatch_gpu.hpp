@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pm/patchmatch.h"
@@ -130,6 +131,14 @@ class PatchmatchGpu final {
   void Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, int cols, const float* d_seed_l,
              const float* d_seed_r, float* d_disp, float* d_dispr);
 
+  // Match() for a sequence of frames (the callback loop of patchmatch_gpu_test.cpp:118-128) with the
+  // copies off the critical path: Submit() returns once the pair is packed and enqueued, Collect() waits
+  // for the oldest submitted pair.  At most Params::max_batch pairs in flight (Submit() returns false
+  // when full).  Results equal Match()'s.
+  bool Submit(const Image1b& iml, const Image1b& imr, uint64_t tag = 0);
+  bool Collect(Image1f& disp, Image1f& dispr, uint64_t* tag = nullptr);
+  int InFlight() const { return handle_ ? pm_in_flight(handle_) : 0; }
+
   // The sparse-init maps Match() starts from (what SparseInit returns, patchmatch_gpu.cu:414-442):
   // left-image and right-image coordinates.  Kept until replaced; pass empty images to clear.
   void SetSeeds(const Image1f& seed_l, const Image1f& seed_r);
@@ -158,6 +167,7 @@ class PatchmatchGpu final {
   pm_handle* handle_ = nullptr;
   int plan_rows_ = 0, plan_cols_ = 0;
   Image1f seed_l_, seed_r_;
+  std::vector<std::pair<int, int>> in_flight_sizes_;  // (rows, cols) of the submitted pairs, oldest first
 };
 
 }  // namespace pm

@@ -15,7 +15,7 @@ PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
 PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUN, PM_ENGINE_RUNBLK, PM_ENGINE_RUNBLK2 = 0, 1, 2, 3, 4, 5
 PM_OK = 0
-PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM = -1, -2, -3, -4, -5
+PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY = -1, -2, -3, -4, -5, -6
 PM_K_COUNT = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +26,7 @@ LIB_PATH = os.environ.get("PM_LIB") or os.path.normpath(os.path.join(_HERE, ".."
 EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
+    "pm_submit_u8", "pm_collect", "pm_in_flight",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
@@ -118,6 +119,12 @@ def load():
     lib.pm_match_batch_u8.restype = C.c_int
     lib.pm_match_device.argtypes = [vp, C.c_int, u8p, u8p, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
     lib.pm_match_device.restype = C.c_int
+    lib.pm_submit_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t, f32p, f32p, C.c_size_t, C.c_uint64]
+    lib.pm_submit_u8.restype = C.c_int
+    lib.pm_collect.argtypes = [vp, f32p, f32p, C.c_size_t, C.POINTER(C.c_uint64)]
+    lib.pm_collect.restype = C.c_int
+    lib.pm_in_flight.argtypes = [vp]
+    lib.pm_in_flight.restype = C.c_int
     lib.pm_synchronize.argtypes = [vp]
     lib.pm_synchronize.restype = C.c_int
     lib.pm_stream.argtypes = [vp]
@@ -277,6 +284,36 @@ class Engine:
         self._check(self.lib.pm_match_batch_u8(self.h, n, pl, pr, rows, cols, psl, psr, pdl, pdr if lr else None),
                     "pm_match_batch_u8")
         return dls, (drs if lr else None)
+
+    # --- pipelined sequence: submit without waiting, collect the oldest --------------------------------
+    def submit(self, left, right, seed_l=None, seed_r=None, tag=0):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        rows, cols = left.shape
+        sl = sr = None
+        psl = psr = None
+        if seed_l is not None:
+            sl, psl = _f32(seed_l)
+        if seed_r is not None:
+            sr, psr = _f32(seed_r)
+        self._shape_q = getattr(self, "_shape_q", [])
+        self._check(self.lib.pm_submit_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, tag), "pm_submit_u8")
+        self._shape_q.append((rows, cols))
+
+    def collect(self):
+        rows, cols = self._shape_q[0] if getattr(self, "_shape_q", None) else (1, 1)
+        dl = np.empty((rows, cols), np.float32)
+        dr = np.empty((rows, cols), np.float32)
+        tag = C.c_uint64(0)
+        lr = bool(self.params.left_right_check)
+        self._check(self.lib.pm_collect(self.h, dl.ctypes.data_as(C.POINTER(C.c_float)),
+                                        dr.ctypes.data_as(C.POINTER(C.c_float)) if lr else None, 0, C.byref(tag)),
+                    "pm_collect")
+        self._shape_q.pop(0)
+        return dl, (dr if lr else None), int(tag.value)
+
+    def in_flight(self):
+        return int(self.lib.pm_in_flight(self.h))
 
     def match_device(self, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
         """All arguments are raw device addresses (ints)."""

@@ -4,6 +4,7 @@
 // against the oracle.  usage: wrapper_main <dir> <rows> <cols> <semantics> <patch> <iters>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -62,6 +63,29 @@ int main(int argc, char** argv) {
     write_raw(dir + "/auto_l.f32", auto_l);
     write_raw(dir + "/auto_r.f32", auto_r);
     write_raw(dir + "/sparse_init.f32", pm.SparseInit(il, ir, 4));
+    // frame loop with the copies off the critical path: Submit()/Collect() return Match()'s maps in order
+    {
+      PatchmatchGpu::Params p3 = params;
+      p3.max_batch = 3;
+      PatchmatchGpu seq(p3);
+      seq.SetSeeds(sl, sr);
+      int collected = 0;
+      Image1f ql, qr;
+      uint64_t tag = 0;
+      for (int i = 0; i < 7; ++i) {
+        while (!seq.Submit(il, ir, 1000 + i)) {
+          if (!seq.Collect(ql, qr, &tag) || tag != (uint64_t)(1000 + collected)) return 4;
+          ++collected;
+          if (std::memcmp(ql.data(), disp.data(), sizeof(float) * (size_t)rows * cols) != 0) return 5;
+        }
+      }
+      while (seq.Collect(ql, qr, &tag)) {
+        if (tag != (uint64_t)(1000 + collected)) return 4;
+        ++collected;
+        if (std::memcmp(qr.data(), dispr.data(), sizeof(float) * (size_t)rows * cols) != 0) return 5;
+      }
+      if (collected != 7) return 6;
+    }
     std::cout << "ok " << disp.rows << "x" << disp.cols << "\n";
     return 0;
   } catch (const std::exception& e) {

@@ -192,6 +192,34 @@ def test_batch_equals_singles(pm, oracle, synth, sem):
 
 
 # ---- edge cases ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth", [1, 3])
+def test_pipelined_sequence_equals_single_matches(pm, oracle, synth, depth):
+    """pm_submit_u8 / pm_collect: results of pm_match_u8, in submission order, with <= max_batch in flight."""
+    rows, cols = 60, 100
+    pairs = [small_pair(synth, 40 + i, rows, cols, n_points=25, dilate_factor=2) for i in range(5)]
+    params = pm.default_params(0, patch=5, patchmatch_iters=2)
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=1) as e:
+        want = [e.match(l, r, sl, sr) for (l, r, sl, sr, _) in pairs]
+    got = []
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=depth) as e:
+        with pytest.raises(pm.PmError) as err:
+            e.collect()
+        assert err.value.status == pm.PM_ERR_BUSY
+        for i, (l, r, sl, sr, _) in enumerate(pairs):
+            if e.in_flight() == depth:
+                with pytest.raises(pm.PmError) as err:
+                    e.submit(l, r, sl, sr, tag=99)
+                assert err.value.status == pm.PM_ERR_BUSY
+                got.append(e.collect())
+            e.submit(l, r, sl, sr, tag=100 + i)
+        while e.in_flight():
+            got.append(e.collect())
+    assert [t for (_, _, t) in got] == [100 + i for i in range(5)]
+    for i, ((dl, dr, _), (wl, wr)) in enumerate(zip(got, want)):
+        assert_same(dl, wl, f"pair {i} left")
+        assert_same(dr, wr, f"pair {i} right")
+
+
 def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
     rows, cols = 33, 47
     l, r, sl, sr, _ = small_pair(synth, 50, rows, cols, n_points=12, dilate_factor=2)
