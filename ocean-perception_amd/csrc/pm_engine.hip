@@ -156,7 +156,7 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.tg32 = h->tg32;
   ps.tg8 = h->tg8;
   ps.pitch_t = align_up(rows, 64);
-  ps.plane_t = (size_t)cols * ps.pitch_t;
+  ps.plane_t = (size_t)(cols + kTransPad) * ps.pitch_t;
   ps.pk16 = h->pk16;
   ps.tpk16 = h->tpk16;
   ps.disp = h->disp;
@@ -341,16 +341,29 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
 }
 
 int runblk_waves_from_env() {
-  // experiment knob: wavefronts (= segments) per chain in PM_ENGINE_RUNBLK
+  // wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2 (tools/sweep_group.sh: 4 is the best or tied at 720p)
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_WAVES");
-    int x = e ? atoi(e) : 8;
+    int x = e ? atoi(e) : 4;
     return x < 1 ? 1 : (x > kMaxSegWaves ? kMaxSegWaves : x);
   }();
   return v;
 }
 
 // One directional sweep, in place.
+// lanes per chain segment of PM_ENGINE_RUNBLK2 (32 or 16); PM_RUNBLK_GROUP overrides.  Measured
+// (tools/sweep_group.sh, 720p): PM_SEM_GPU's 3-lane window wins with 16-lane groups (1.60 vs 1.93 ms per
+// frame), PM_SEM_CPU's 11-lane window with 32 (a 16-lane strip leaves it only 5-6 positions per step).
+int runblk_group(int semantics) {
+  static int v = [] {
+    const char* e = getenv("PM_RUNBLK_GROUP");
+    const int g = e ? atoi(e) : 0;
+    return (g == 16 || g == 32) ? g : 0;
+  }();
+  if (v) return v;
+  return semantics == PM_SEM_CPU ? 32 : 16;
+}
+
 int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
   const int chains = g.c_hi - g.c_lo + 1;
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
@@ -365,7 +378,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), runblk_group(cp.semantics), h->stream);
   } else {
     launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves_from_env() : 1, h->stream);
   }
@@ -597,7 +610,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->img8, B * 4 * plane + 256));
   PM_HIP(h, hipMalloc((void**)&h->g32, sizeof(float) * (B * 4 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->g8, B * 4 * plane + 256));
-  const size_t plane_t = (size_t)max_cols * align_up(max_rows, 64);
+  const size_t plane_t = (size_t)(max_cols + kTransPad) * align_up(max_rows, 64);
   PM_HIP(h, hipMalloc((void**)&h->timg8, B * 4 * plane_t + 256));
   PM_HIP(h, hipMalloc((void**)&h->tg32, sizeof(float) * (B * 4 * plane_t + 64)));
   PM_HIP(h, hipMalloc((void**)&h->tg8, B * 4 * plane_t + 256));

@@ -66,6 +66,11 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
 // Transposes `planes` planes of rows x cols (pitch `sp`) into cols x rows (pitch `dp`) through a
 // 64x64 LDS tile (+1 column of padding: conflict-free for 4-byte elements, 2-way for bytes) so that
 // both the reads and the writes are coalesced.  grid = (ceil(cols/64), ceil(rows/64), planes), block = 256.
+// The transposed planes carry kTransPad extra rows (= image columns cols .. cols + kTransPad - 1) that
+// replicate the last column: a window that leaves the image on the right reads them instead of clamping
+// its column index (cv::getRectSubPix replicates the border), which keeps the column sweep's target row
+// offsets affine in the window column (pm_run2.hpp).
+constexpr int kTransPad = 16;
 template <typename T>
 __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
                                                    int sp, int dp, size_t src_plane, size_t dst_plane) {
@@ -81,7 +86,12 @@ __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T*
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     const int x = x0 + r, y = y0 + tx;
-    if (x < cols && y < rows) d[(size_t)x * dp + y] = tile[tx][r];
+    if (x < cols && y < rows) {
+      const T val = tile[tx][r];
+      d[(size_t)x * dp + y] = val;
+      if (x == cols - 1)
+        for (int p = 1; p <= kTransPad; ++p) d[(size_t)(x + p) * dp + y] = val;
+    }
   }
 }
 

@@ -18,7 +18,7 @@
 
 namespace pm {
 
-constexpr int kGroup = 32;
+constexpr int kGroup = 32;   // default group width; 16 (four segments per wavefront) is the other choice
 
 // Occupancy experiment knob: -DPM_RUNBLK2_MIN_WAVES=8 caps the kernel at 64 VGPRs (8 waves per SIMD).
 #ifdef PM_RUNBLK2_MIN_WAVES
@@ -38,31 +38,80 @@ struct RunStep2 {
   float d0, c0, cost;
 };
 
-template <int AXIS, int TPW, int TPH>
+template <int GS, int AXIS, int TPW, int TPH>
 __device__ __forceinline__ int run2_nd(const CostParams& cp) {
-  return AXIS == 0 ? kGroup - (TPW > 0 ? TPW : cp.pw) : kGroup - (TPH > 0 ? TPH : cp.ph) + 1;
+  return AXIS == 0 ? GS - (TPW > 0 ? TPW : cp.pw) : GS - (TPH > 0 ? TPH : cp.ph) + 1;
 }
 
-// 32-bit ballot of this lane's group.
-__device__ __forceinline__ unsigned gballot(bool p, bool upper) {
+// Ballot of this lane's group (GS = 32 or 16 lanes), in the low GS bits.
+template <int GS>
+__device__ __forceinline__ unsigned gballot(bool p, int gbase) {
   const unsigned long long b = __ballot(p);
-  return upper ? (unsigned)(b >> 32) : (unsigned)b;
+  if (GS == 32) return gbase ? (unsigned)(b >> 32) : (unsigned)b;
+  return (unsigned)(b >> gbase) & 0xffffu;
 }
 
-template <int AXIS, int TPW, int TPH>
+// Buffer descriptors of one view's planes: MUBUF addressing = descriptor base + SGPR offset + VGPR
+// offset + immediate, so a window row costs no VALU address arithmetic -- the row offset rides in the
+// scalar operand, the lane's column in the vector operand (which is the same for every row).
+struct RowBufs {
+  __amdgpu_buffer_rsrc_t ref8, refg8, tgt8, tgtg;
+};
+// Measured (profiles/r01f_ab_loads.txt): on gfx950 the MUBUF form is SLOWER here (7.26 vs 5.80 ms per frame)
+// although it removes ~60 VALU address instructions per step -- the step is bound by load issue/latency,
+// not by VALU count.  Default: plain global loads with the same scalar-row + vector-column addressing;
+// -DPM_RUN2_GLOBAL_LOADS=0 selects the MUBUF form.
+#ifndef PM_RUN2_GLOBAL_LOADS
+#define PM_RUN2_GLOBAL_LOADS 1
+#endif
+__device__ __forceinline__ int win_ld8(__amdgpu_buffer_rsrc_t rs, const uint8_t* base, int voff, int soff) {
+#if PM_RUN2_GLOBAL_LOADS
+  return ld_u8(base, (unsigned)(voff + soff));
+#else
+  return __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0);
+#endif
+}
+// voff4 / soff4 are byte offsets
+__device__ __forceinline__ float win_ldf(__amdgpu_buffer_rsrc_t rs, const float* base, int voff4, int soff4) {
+#if PM_RUN2_GLOBAL_LOADS
+  return ld_f32(base, (unsigned)(voff4 + soff4));
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff4, soff4, 0));
+#endif
+}
+// The same for the transposed planes (column sweeps).
+__device__ __forceinline__ RowBufs make_col_bufs(const View& v, const PlaneSet& ps) {
+  const int bytes = (int)ps.plane_t;
+  RowBufs r;
+  r.ref8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.tref8, 0, bytes, 0x00020000);
+  r.refg8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.trefg8, 0, bytes, 0x00020000);
+  r.tgt8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.ttgt8, 0, bytes, 0x00020000);
+  r.tgtg = __builtin_amdgcn_make_buffer_rsrc((void*)v.ttgtg, 0, bytes * 4, 0x00020000);
+  return r;
+}
+__device__ __forceinline__ RowBufs make_row_bufs(const View& v, const PlaneSet& ps) {
+  const int bytes = (int)ps.plane;
+  RowBufs r;
+  r.ref8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.ref8, 0, bytes, 0x00020000);
+  r.refg8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.refg8, 0, bytes, 0x00020000);
+  r.tgt8 = __builtin_amdgcn_make_buffer_rsrc((void*)v.tgt8, 0, bytes, 0x00020000);
+  r.tgtg = __builtin_amdgcn_make_buffer_rsrc((void*)v.tgtg, 0, bytes * 4, 0x00020000);
+  return r;
+}
+
+template <int GS, int AXIS, int TPW, int TPH>
 __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps, const CostParams& cp,
                                               const SweepGeom& g, int chain, bool act, int i, int n_end, float cand,
                                               const float* din, const float* cin) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int gl = lane & (kGroup - 1);
-  const bool upper = (lane & kGroup) != 0;
-  const int gbase = lane & kGroup;
+  const int gl = lane & (GS - 1);
+  const int gbase = lane & ~(GS - 1);
   const int pitch = ps.pitch, cols = ps.cols, rows = ps.rows;
   const int pw = TPW > 0 ? TPW : cp.pw, ph = TPH > 0 ? TPH : cp.ph;
   const int half_w = pw / 2, half_h = ph / 2;
   const int win = AXIS == 0 ? pw : ph;
   const int half = win / 2;
-  const int nd = run2_nd<AXIS, TPW, TPH>(cp);
+  const int nd = run2_nd<GS, AXIS, TPW, TPH>(cp);
   const int dir = g.dir;
   const float shift = (float)(pw - 1) * 0.5f;
   const unsigned lanes_nd = (1u << nd) - 1u;
@@ -78,7 +127,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   };
   auto glane_of = [&](int m) -> int { return dir > 0 ? m : nd - 1 - m; };
 
-  const unsigned need = gballot(inr && !neutral, upper);
+  const unsigned need = gballot<GS>(inr && !neutral, gbase);
   const bool has_need = need != 0u;
   const int r = has_need ? first_pos(need) : 0;
   const int r_gl = glane_of(r);
@@ -93,7 +142,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   const float a = cx - fl;
   const int delta = (px - half_w) - ipx;
 
-  const unsigned valid_m = gballot(valid, upper);
+  const unsigned valid_m = gballot<GS>(valid, gbase);
   const bool valid_r = has_need && ((valid_m >> r_gl) & 1u);
   const float a_r = __shfl(a, gbase + r_gl, kWave);
   const int delta_r = __shfl(delta, gbase + r_gl, kWave);
@@ -112,17 +161,18 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
     const int c_base = dir > 0 ? c_i - half : c_i - half - (nd - 1);
     unsigned sc = 0, sg = 0;
     if (AXIS == 0) {
-      const unsigned X = (unsigned)min(max(c_base + gl, 0), cols - 1);
-      const unsigned R0 = (unsigned)min(max(c_base + gl - delta_r, 0), cols - 1);
-      const unsigned org = (unsigned)((chain - half_h) * pitch);
-      const unsigned ol = org + X, orr = org + R0;
+      const int X = min(max(c_base + gl, 0), cols - 1);
+      const int R0 = min(max(c_base + gl - delta_r, 0), cols - 1);
+      const int R0x4 = R0 * 4;
+      const RowBufs rb = make_row_bufs(v, ps);
+      const int org = (chain - half_h) * pitch;  // wave-uniform: scalar offsets below
 #pragma unroll
       for (int t = 0; t < ph; ++t) {
-        const unsigned ro = (unsigned)(t * pitch);
-        const int l8 = ld_u8(v.ref8, ol + ro);
-        const int lg = ld_u8(v.refg8, ol + ro);
-        const int r0 = ld_u8(v.tgt8, orr + ro);
-        const float g0 = ld_f32(v.tgtg, (orr + ro) * 4u);
+        const int so = org + t * pitch;
+        const int l8 = win_ld8(rb.ref8, v.ref8, X, so);
+        const int lg = win_ld8(rb.refg8, v.refg8, X, so);
+        const int r0 = win_ld8(rb.tgt8, v.tgt8, R0, so);
+        const float g0 = win_ldf(rb.tgtg, v.tgtg, R0x4, so * 4);
         const int r1 = wave_shl1(r0);
         const float g1 = wave_shl1f(g0);
         sc = cpu_acc_color(sc, l8, r0, r1, l);
@@ -131,19 +181,24 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       sg -= cpu_grad_bias(ph);
     } else {
       const int pt = ps.pitch_t;
-      const unsigned Y = (unsigned)min(max(c_base + gl, 0), rows - 1);
-      // a group that does not evaluate may carry a meaningless delta_r: keep its addresses in range
+      const int Y = min(max(c_base + gl, 0), rows - 1);
+      // a group that does not evaluate may carry a meaningless delta_r: keep its addresses in range.
+      // Window columns beyond cols - 1 read the replicated pad rows of the transposed planes (kTransPad).
       const int ipx_r = min(max((chain - half_w) - delta_r, 0), cols - 1);
-      int r0 = ld_u8(v.ttgt8, (unsigned)(ipx_r * pt) + Y);
-      float g0 = ld_f32(v.ttgtg, ((unsigned)(ipx_r * pt) + Y) * 4u);
+      const int vb = ipx_r * pt + Y;  // group-uniform column, lane's row
+      const int vb4 = vb * 4;
+      const RowBufs cb = make_col_bufs(v, ps);
+      const int lorg = (chain - half_w) * pt;  // wave-uniform: scalar offsets below
+      int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
+      float g0 = win_ldf(cb.tgtg, v.ttgtg, vb4, 0);
 #pragma unroll
       for (int t = 0; t < pw; ++t) {
-        const unsigned lrow = (unsigned)((chain - half_w + t) * pt);  // wave-uniform
-        const unsigned rrow = (unsigned)(min(ipx_r + t + 1, cols - 1) * pt);  // group-uniform
-        const int l8 = ld_u8(v.tref8, lrow + Y);
-        const int lg = ld_u8(v.trefg8, lrow + Y);
-        const int r1 = ld_u8(v.ttgt8, rrow + Y);
-        const float g1 = ld_f32(v.ttgtg, (rrow + Y) * 4u);
+        const int lso = lorg + t * pt;
+        const int rso = (t + 1) * pt;
+        const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
+        const int lg = win_ld8(cb.refg8, v.trefg8, Y, lso);
+        const int r1 = win_ld8(cb.tgt8, v.ttgt8, vb, rso);
+        const float g1 = win_ldf(cb.tgtg, v.ttgtg, vb4, rso * 4);
         sc = cpu_acc_color(sc, l8, r0, r1, l);
         sg = cpu_acc_grad(sg, lg, g0, g1, l);
         r0 = r1;
@@ -158,31 +213,25 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
     st.cost = cpu_cost_from_sums(wsum & 0xffff, (int)((unsigned)wsum >> 16), cp);
   }
 
+  // The run passes a position iff it ends up holding `cand`: already equal, or adopted.  Positions before
+  // r are neutral by the definition of r, so the first position that does not pass is >= r; it is decided
+  // in this step (q_real) if its candidate is not allowed at all (!valid) or was evaluated with its own
+  // bilinear parameters (same); otherwise the next step starts there.  With no position in need every
+  // position in reach passes and q is the end of reach.
   const bool adopt = valid_r && inr && !neutral && same && (st.cost < st.c0);
-  const bool cont = (inr && st.mpos < r) || neutral || adopt;
-  const unsigned stop = gballot(!cont, upper) & lanes_nd;
+  const bool cont = neutral || adopt;
+  const unsigned stop = gballot<GS>(!cont, gbase) & lanes_nd;
   const int q = stop ? first_pos(stop) : nd;
   const int q_gl = glane_of(min(q, nd - 1));
-  const unsigned inr_m = gballot(inr, upper), same_m = gballot(same, upper);
-  const bool q_real = (q < nd) && ((inr_m >> q_gl) & 1u) && (((same_m >> q_gl) & 1u) || !((valid_m >> q_gl) & 1u));
-
-  // outcome (group-uniform selects; see pm_run.hpp::run_step for the case analysis)
-  int advance, rej_pos;
-  if (!has_need) {
-    advance = min(nd, n_end - i);
-    rej_pos = -1;
-  } else if (!valid_r) {
-    advance = r + 1;
-    rej_pos = r;
-  } else {
-    advance = q_real ? q + 1 : q;
-    rej_pos = q_real ? q : -1;
-  }
+  const unsigned decided_m = gballot<GS>(inr && (same || !valid), gbase);
+  const bool q_real = (q < nd) && ((decided_m >> q_gl) & 1u);
+  const int advance = q_real ? q + 1 : q;
+  const int rej_pos = q_real ? q : -1;
   const int src_gl = glane_of(max(rej_pos, 0));
   st.rej_d0 = __shfl(st.d0, gbase + src_gl, kWave);
   st.rej_pos = act ? rej_pos : -1;
   st.advance = act ? advance : 0;
-  st.adopt = adopt && has_need && valid_r && st.mpos < q;
+  st.adopt = adopt && st.mpos < q;
   return st;
 }
 
@@ -190,12 +239,14 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 // Rounds and fix-up exactly as pm_run.hpp::k_runblk, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
 // SEM = 0: PM_SEM_CPU (run_step2 above); SEM = 1: PM_SEM_GPU (run_step2_gpu, pm_run_gpu.hpp).
-template <int SEM, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin);
 
-template <int SEM, int AXIS, int TPW, int TPH>
+constexpr int kMaxSegs = 4 * kMaxSegWaves;  // segments per chain: (64 / GS) per wavefront
+
+template <int SEM, int GS, int AXIS, int TPW, int TPH>
 __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
   const int n = (g.s_last - g.s_first) * g.dir + 1;
@@ -204,19 +255,22 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   float* cin = lds + n1;
   float* dout = lds + 2 * n1;
   float* cout = lds + 3 * n1;
-  float* s_last = lds + 4 * n1;                                   // [2 * kMaxSegWaves + 1]
-  int* s_changed = (int*)(lds + 4 * n1 + 2 * kMaxSegWaves + 1);   // [2]
+  // [nseg + 1] last values + [2] change flags, sized by the launch: at 1280 columns and 4 wavefronts the
+  // block then needs 20 396 B, i.e. EIGHT blocks fit the CU's 160 KB (a fixed-size tail made it seven)
+  float* s_last = lds + 4 * n1;
+  int* s_changed = (int*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1);
 
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x & 63;
-  const int gl = lane & (kGroup - 1);
-  const bool upper = (lane & kGroup) != 0;
+  constexpr int kPerWave = kWave / GS;
+  const int gl = lane & (GS - 1);
+  const int gbase = lane & ~(GS - 1);
   const int w = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
-  const int nseg = 2 * nw;
-  const int sidx = 2 * w + (upper ? 1 : 0);
-  const int nd = SEM == 0 ? run2_nd<AXIS, TPW, TPH>(cp) : kGroup - 2;
+  const int nseg = kPerWave * nw;
+  const int sidx = kPerWave * w + lane / GS;
+  const int nd = SEM == 0 ? run2_nd<GS, AXIS, TPW, TPH>(cp) : GS - 2;
   const int stride = AXIS == 0 ? g.dir : g.dir * ps.pitch;
   const ptrdiff_t first =
       AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
@@ -244,7 +298,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     int i = i0;
     while (__any(active && i < i1)) {
       const bool act = active && i < i1;
-      const RunStep2 st = run_step2_any<SEM, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
+      const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
       if (st.mpos >= 0 && st.mpos < st.advance) {
         dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.rej_d0 : cand;
@@ -272,12 +326,12 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       bool merged = false;
       while (__any(redo && !merged && i < i1)) {
         const bool act = redo && !merged && i < i1;
-        const RunStep2 st = run_step2_any<SEM, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
+        const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
         ++n_fix;
         const bool mine = st.mpos >= 0 && st.mpos < st.advance;
         const float val = st.mpos == st.rej_pos ? st.rej_d0 : c2;
         const float spec = mine ? dout[i + st.mpos + 1] : 0.f;
-        const unsigned eq = gballot(mine && val == spec, upper);
+        const unsigned eq = gballot<GS>(mine && val == spec, gbase);
         int ms = -1;
         if (eq) {  // first merged position in sweep order (lane <-> position mapping of the step function)
           const int lo_lane = __ffs((int)eq) - 1, hi_lane = 31 - __clz((int)eq);
@@ -328,35 +382,38 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   }
 }
 
-template <int SEM, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH>
 inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                           hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
   const int n = (g.s_last - g.s_first) * g.dir + 1;
   int nwv = waves < 1 ? 1 : (waves > kMaxSegWaves ? kMaxSegWaves : waves);
-  int len = (n + 2 * nwv - 1) / (2 * nwv);
+  const int per_block = (kWave / GS) * nwv;
+  int len = (n + per_block - 1) / per_block;
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
-  const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + 2 * kMaxSegWaves + 1 + 2);
-  hipLaunchKernelGGL((k_runblk2<SEM, AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
+  const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
+  hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
                      lds_bytes, stream, ps, cp, g, len);
 }
 
-template <int AXIS>
+// group: 32 or 16 lanes per segment.  16-lane groups need the window to leave positions in a strip
+// (win <= 11); wider or non-square windows use 32.
+template <int GS, int AXIS>
 inline void launch_run2_axis(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                              hipStream_t stream) {
   if (cp.semantics != 0) {
-    launch_run2_k<1, AXIS, 3, 3>(ps, cp, g, slots, waves, stream);
+    launch_run2_k<1, GS, AXIS, 3, 3>(ps, cp, g, slots, waves, stream);
     return;
   }
   const int sq = cp.pw == cp.ph ? cp.pw : 0;
   switch (sq) {
-    case 3: launch_run2_k<0, AXIS, 3, 3>(ps, cp, g, slots, waves, stream); break;
-    case 5: launch_run2_k<0, AXIS, 5, 5>(ps, cp, g, slots, waves, stream); break;
-    case 7: launch_run2_k<0, AXIS, 7, 7>(ps, cp, g, slots, waves, stream); break;
-    case 9: launch_run2_k<0, AXIS, 9, 9>(ps, cp, g, slots, waves, stream); break;
-    case 11: launch_run2_k<0, AXIS, 11, 11>(ps, cp, g, slots, waves, stream); break;
-    default: launch_run2_k<0, AXIS, 0, 0>(ps, cp, g, slots, waves, stream); break;
+    case 3: launch_run2_k<0, GS, AXIS, 3, 3>(ps, cp, g, slots, waves, stream); break;
+    case 5: launch_run2_k<0, GS, AXIS, 5, 5>(ps, cp, g, slots, waves, stream); break;
+    case 7: launch_run2_k<0, GS, AXIS, 7, 7>(ps, cp, g, slots, waves, stream); break;
+    case 9: launch_run2_k<0, GS, AXIS, 9, 9>(ps, cp, g, slots, waves, stream); break;
+    case 11: launch_run2_k<0, GS, AXIS, 11, 11>(ps, cp, g, slots, waves, stream); break;
+    default: launch_run2_k<0, 32, AXIS, 0, 0>(ps, cp, g, slots, waves, stream); break;
   }
 }
 
@@ -364,23 +421,27 @@ inline void launch_run2_axis(const PlaneSet& ps, const CostParams& cp, const Swe
 #include "pm_run_gpu.hpp"
 namespace pm {
 
-template <int SEM, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin) {
   if constexpr (SEM == 0)
-    return run_step2<AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+    return run_step2<GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
   else
-    return run_step2_gpu<AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+    return run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
 }
 
-// In place.
+// In place.  group = lanes per chain segment (32 or 16).
 inline void launch_sweep_run2(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
-                              hipStream_t stream) {
-  if (g.axis == 0)
-    launch_run2_axis<0>(ps, cp, g, slots, waves, stream);
-  else
-    launch_run2_axis<1>(ps, cp, g, slots, waves, stream);
+                              int group, hipStream_t stream) {
+  const bool g16 = group == 16 && (cp.semantics != 0 || (cp.pw == cp.ph && cp.pw <= 11));
+  if (g.axis == 0) {
+    if (g16) launch_run2_axis<16, 0>(ps, cp, g, slots, waves, stream);
+    else launch_run2_axis<32, 0>(ps, cp, g, slots, waves, stream);
+  } else {
+    if (g16) launch_run2_axis<16, 1>(ps, cp, g, slots, waves, stream);
+    else launch_run2_axis<32, 1>(ps, cp, g, slots, waves, stream);
+  }
 }
 
 }  // namespace pm

@@ -48,16 +48,15 @@ __device__ __forceinline__ float gpu_tap_at(const uint8_t* ref8, const float* re
   return gpu_tap(il, gl, r0, r1, g0, g1, tcol, cp);
 }
 
-template <int AXIS>
+template <int GS, int AXIS>
 __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int gl = lane & (kGroup - 1);
-  const bool upper = (lane & kGroup) != 0;
-  const int gbase = lane & kGroup;
+  const int gl = lane & (GS - 1);
+  const int gbase = lane & ~(GS - 1);
   const int pitch = ps.pitch, cols = ps.cols, rows = ps.rows;
-  constexpr int nd = kGroup - 2;  // positions <-> lanes 1..30
+  constexpr int nd = GS - 2;  // positions <-> lanes 1..GS-2
   const int dir = g.dir;
 
   RunStep2 st;
@@ -66,7 +65,7 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
   const bool inr = act && has_pos && (i + st.mpos < n_end);
   st.d0 = inr ? din[i + st.mpos + 1] : 0.f;
   st.c0 = inr ? cin[i + st.mpos + 1] : 0.f;
-  auto first_pos = [&](unsigned m) -> int {  // m != 0, bits of lanes 1..30
+  auto first_pos = [&](unsigned m) -> int {  // m != 0, bits of lanes 1..GS-2
     return dir > 0 ? __ffs((int)m) - 2 : nd - (31 - __clz((int)m));
   };
   auto glane_of = [&](int m) -> int { return dir > 0 ? m + 1 : nd - m; };
@@ -84,11 +83,11 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
   const bool need_eval = inr && !neutral && !same_xr;
   const float newval = fminf(cand, fx - 1.f);
 
-  const unsigned nonneutral = gballot(inr && !neutral, upper);
+  const unsigned nonneutral = gballot<GS>(inr && !neutral, gbase);
   const bool has_need = nonneutral != 0u;
   const int r = has_need ? first_pos(nonneutral) : 0;
   const int r_gl = glane_of(r);
-  const unsigned need_m = gballot(need_eval, upper);
+  const unsigned need_m = gballot<GS>(need_eval, gbase);
   const bool r_eval = has_need && ((need_m >> r_gl) & 1u);
 
   // ---- sample positions and the bitwise consistency of the neighbours ---------------------------
@@ -110,7 +109,7 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
     sR = xu + 1.f;
     wide_ok = (xu >= 1.f) && (sR <= (float)(cols - 1));
   }
-  const unsigned wide_m = gballot(wide_ok, upper);
+  const unsigned wide_m = gballot<GS>(wide_ok, gbase);
   const bool r_wide = r_eval && ((wide_m >> r_gl) & 1u);
   const bool r_slow = r_eval && !r_wide;
 
@@ -199,11 +198,11 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
   const bool before_r = inr && st.mpos < r;
   // slow path: the step ends at r whatever the outcome (the next step continues from r + 1)
   const bool cont = before_r || (pass && !(r_slow && is_r));
-  const unsigned lanes_pos = 0x7ffffffeu;  // lanes 1..30
-  const unsigned stop = gballot(!cont, upper) & lanes_pos;
+  const unsigned lanes_pos = ((1u << (GS - 1)) - 1u) & ~1u;  // lanes 1..GS-2
+  const unsigned stop = gballot<GS>(!cont, gbase) & lanes_pos;
   const int q = stop ? first_pos(stop) : nd;
   const int q_gl = glane_of(min(q, nd - 1));
-  const unsigned inr_m = gballot(inr, upper), evald_m = gballot(evald, upper), same_m = gballot(same_xr, upper);
+  const unsigned inr_m = gballot<GS>(inr, gbase), evald_m = gballot<GS>(evald, gbase), same_m = gballot<GS>(same_xr, gbase);
   // q is decided in this step if it was evaluated or needs no evaluation; otherwise the next step starts there
   const bool q_in = (q < nd) && ((inr_m >> q_gl) & 1u);
   const bool q_real = q_in && (((evald_m >> q_gl) & 1u) || ((same_m >> q_gl) & 1u));
