@@ -143,20 +143,20 @@ __device__ __forceinline__ unsigned cpu_acc_color(unsigned acc, int left, int r0
   t = __umul24((unsigned)r0, (unsigned)l.a11) + t;
   return __builtin_amdgcn_sad_u8((unsigned)left, t >> 16, acc);
 }
-// saturate_cast<uchar>(s) = clamp(rint(s), 0, 255) without a float->int conversion: clamp first
-// (equivalent: rint is monotone and fixes 0 and 255), then add 2^23 -- the sum is 2^23 + rint(s)
-// exactly (ulp 1, ties to even), i.e. the bit pattern 0x4B0000nn.  v_sad_u8 against the plain byte
-// `left_g8` then yields |left_g8 - nn| + 0x4B: a constant 75 per tap, removed once per evaluation by
-// cpu_grad_bias().
-constexpr unsigned kGradTapBias = 0x4Bu;
+// saturate_cast<uchar>(s) = clamp(rint(s), 0, 255), ties to even: exactly what v_cvt_pk_u8_f32 computes
+// (checked on the device for every multiple of 1/16 in [-0.5, 260), the floats next to every .5 tie and
+// +-1e30: tools/probe/cvt_pk_u8.hip), and it drops the byte into a chosen lane of a dword -- one
+// instruction instead of clamp + magic add (+ v_perm when four taps are packed).
 __device__ __forceinline__ unsigned cpu_acc_grad(unsigned acc, int left_g8, float g0, float g1, const CpuLerp& l) {
   float s = g0 * l.ia;
   s = s + g1 * l.a;
-  s = __builtin_amdgcn_fmed3f(s, 0.f, 255.f);
-  s = s + 8388608.f;
-  return __builtin_amdgcn_sad_u8((unsigned)left_g8, __builtin_bit_cast(unsigned, s), acc);
+  return __builtin_amdgcn_sad_u8((unsigned)left_g8, __builtin_amdgcn_cvt_pk_u8_f32(s, 0, 0u), acc);
 }
-__device__ __forceinline__ unsigned cpu_grad_bias(int taps) { return kGradTapBias * (unsigned)taps; }
+// The same with the lerp sum already formed (packed-f32 products, pm_run2.hpp / k_noise_cost_tiled).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cpu_acc_grad_sum(unsigned acc, int left_g8, float s) {
+  return __builtin_amdgcn_sad_u8((unsigned)left_g8, __builtin_amdgcn_cvt_pk_u8_f32(s, 0, 0u), acc);
+}
 // Loads addressed as (wave-uniform plane base) + (32-bit unsigned byte offset): the form that maps
 // to global_load ... v_off, s[base:base+1] -- no 64-bit per-lane address arithmetic, no VGPR pairs.
 // Offsets are relative to one view's plane, i.e. < 4 GiB for any image this engine accepts.

@@ -180,10 +180,16 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
                                                           int keep_zero) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
-  __shared__ uint8_t s_l8[TR * LW + 4];  // +4: the packed reads take whole dwords
-  __shared__ uint8_t s_lg[TR * LW + 4];
-  __shared__ uint8_t s_r8[TR * kTileRW];
+  // byte tiles as dword arrays: window bytes are fetched as ALIGNED dwords and shifted into place
+  // (v_alignbyte_b32).  Unaligned ds_read_b96/b128 made this kernel LDS-bound: SQ_LDS_UNALIGNED_STALL was
+  // 70 % of SQ_LDS_IDX_ACTIVE, which itself equalled the kernel's duration (profiles/r01f_pmc_lds.txt).
+  __shared__ unsigned s_l8w[(TR * LW + 3) / 4 + 4];
+  __shared__ unsigned s_lgw[(TR * LW + 3) / 4 + 4];
+  __shared__ unsigned s_r8w[TR * kTileRW / 4 + 4];
   __shared__ float s_rg[TR * kTileRW];
+  uint8_t* const s_l8 = (uint8_t*)s_l8w;
+  uint8_t* const s_lg = (uint8_t*)s_lgw;
+  uint8_t* const s_r8 = (uint8_t*)s_r8w;
   __shared__ int s_red[8];
 
   const int tid = threadIdx.x, tx = tid & (kTileW - 1), ty = tid / kTileW;
@@ -264,45 +270,70 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     __syncthreads();
     if (interior) {
       // Four taps per v_sad_u8: the window row's reference bytes are consecutive in LDS and are used as
-      // loaded; the four colour samples (byte 2 of the 16.16 fixed-point value) and the four rounded
-      // gradient samples (byte 0 of 0x4B0000nn) are gathered into one register each with v_perm_b32.
+      // loaded; the four colour samples (byte 2 of the 16.16 fixed-point value) are gathered with
+      // v_perm_b32, the four gradient samples are rounded and packed by v_cvt_pk_u8_f32.
       unsigned sc = 0, sg = 0;
       const int rc = l.ipx - lo;
       constexpr int NG = (PW + 3) / 4;  // groups of four taps; the last one may be partial
 #pragma unroll 1
       for (int i = 0; i < PH; ++i) {
-        const uint8_t* lp = s_l8 + (ty + i) * LW + tx;
-        const uint8_t* lgp = s_lg + (ty + i) * LW + tx;
-        const uint8_t* rp = s_r8 + (ty + i) * kTileRW + rc;
         const float* rg = s_rg + (ty + i) * kTileRW + rc;
-        unsigned lw[NG], lgw[NG];
-        __builtin_memcpy(lw, lp, 4 * NG);    // reads up to 3 bytes past the window inside the tile row: masked below
-        __builtin_memcpy(lgw, lgp, 4 * NG);
-        int r0 = rp[0];
-        float g0 = rg[0];
+        // 4 * NG reference bytes from flat byte offset fl, 4 * NR target bytes from fr
+        constexpr int NR = (PW + 4) / 4;  // dwords covering r[0 .. PW]
+        const int fl = (ty + i) * LW + tx, fr = (ty + i) * kTileRW + rc;
+        unsigned lw[NG], lgw[NG], rw[NR];
+        {
+          const unsigned* pl = s_l8w + (fl >> 2);
+          const unsigned* pg = s_lgw + (fl >> 2);
+          const unsigned* pr = s_r8w + (fr >> 2);
+          const unsigned shl = (unsigned)fl & 3u, shr = (unsigned)fr & 3u;
+          unsigned a0 = pl[0], b0 = pg[0], c0 = pr[0];
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            if (q < NG) {
+              const unsigned a1 = pl[q + 1], b1 = pg[q + 1];
+              lw[q] = __builtin_amdgcn_alignbyte(a1, a0, shl);
+              lgw[q] = __builtin_amdgcn_alignbyte(b1, b0, shl);
+              a0 = a1;
+              b0 = b1;
+            }
+            const unsigned c1 = pr[q + 1];
+            rw[q] = __builtin_amdgcn_alignbyte(c1, c0, shr);
+            c0 = c1;
+          }
+        }
+        auto rbyte = [&](int j) -> int { return (int)((rw[j / 4] >> (8 * (j % 4))) & 0xffu); };
+        int r0 = rbyte(0);
+        // gradient lerp g[j] * (1 - a) + g[j + 1] * a: both products of every sample with packed-f32
+        // multiplies (two samples per instruction), one add per tap; each product and each sum is a single
+        // IEEE operation exactly as in the scalar form
+        constexpr int NP = (PW + 2) / 2;  // pairs covering g[0 .. PW]
+        f32x2 ga[NP], gb[NP];
+        const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
+#pragma unroll
+        for (int k2 = 0; k2 < NP; ++k2) {
+          const f32x2 gg = {rg[2 * k2], rg[min(2 * k2 + 1, PW)]};
+          ga[k2] = gg * ia2;
+          gb[k2] = gg * a2;
+        }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
           unsigned t[4] = {0, 0, 0, 0};
-          unsigned gs[4] = {0, 0, 0, 0};
+          unsigned pg = 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int j = 4 * q + k;
             if (j < PW) {
-              const int r1 = rp[j + 1];
-              const float g1 = rg[j + 1];
+              const int r1 = rbyte(j + 1);
               unsigned tt = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
               t[k] = __umul24((unsigned)r0, (unsigned)l.a11) + tt;
-              float sgr = g0 * l.ia;
-              sgr = sgr + g1 * l.a;
-              sgr = __builtin_amdgcn_fmed3f(sgr, 0.f, 255.f);
-              gs[k] = __builtin_bit_cast(unsigned, sgr + 8388608.f);
+              const float sgr = ga[j / 2][j % 2] + gb[(j + 1) / 2][(j + 1) % 2];
+              pg = __builtin_amdgcn_cvt_pk_u8_f32(sgr, k, pg);  // saturate_cast<uchar> into byte k
               r0 = r1;
-              g0 = g1;
             }
           }
           // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
           const unsigned pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | __builtin_amdgcn_perm(t[3], t[2], 0x06020c0cu);
-          const unsigned pg = __builtin_amdgcn_perm(gs[1], gs[0], 0x0c0c0400u) | __builtin_amdgcn_perm(gs[3], gs[2], 0x04000c0cu);
           const int rem = PW - 4 * q;  // taps in this group
           const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
           sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc & mask, sc);

@@ -183,7 +183,6 @@ __device__ __forceinline__ RunStep run_step(const View& v, const PlaneSet& ps, c
       sc = cpu_acc_color(sc, l8, r0, r1, l);
       sg = cpu_acc_grad(sg, lg, g0, g1, l);
     }
-    sg -= cpu_grad_bias(ph);
   } else {
     // lane l <-> image row Y = c_base + l, on the transposed planes: element (x, Y) at x * pitch_t + Y.
     const int pt = ps.pitch_t;
@@ -204,7 +203,6 @@ __device__ __forceinline__ RunStep run_step(const View& v, const PlaneSet& ps, c
       r0 = r1;
       g0 = g1;
     }
-    sg -= cpu_grad_bias(pw);
   }
 
   // ---- window sums: W[l] = line[l] + ... + line[l + win - 1]  (both sums < 2^16, packed) ----------

@@ -61,6 +61,9 @@ struct RowBufs {
 // although it removes ~60 VALU address instructions per step -- the step is bound by load issue/latency,
 // not by VALU count.  Default: plain global loads with the same scalar-row + vector-column addressing;
 // -DPM_RUN2_GLOBAL_LOADS=0 selects the MUBUF form.
+#ifndef PM_RUN2_PK_GRAD
+#define PM_RUN2_PK_GRAD 1
+#endif
 #ifndef PM_RUN2_GLOBAL_LOADS
 #define PM_RUN2_GLOBAL_LOADS 1
 #endif
@@ -166,19 +169,44 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       const int R0x4 = R0 * 4;
       const RowBufs rb = make_row_bufs(v, ps);
       const int org = (chain - half_h) * pitch;  // wave-uniform: scalar offsets below
+      if constexpr (TPH > 0 && PM_RUN2_PK_GRAD) {
+        // gradient lerp g0 * (1 - a) + g1 * a with g1 = the neighbour lane's g0: both products of a lane's
+        // own sample for two rows per packed-f32 multiply, the neighbour's product arrives by DPP inside
+        // the add -- every product and sum is the same single IEEE operation as in cpu_acc_grad
+        int lgv[TPH];
+        float gv[TPH + 1];
 #pragma unroll
-      for (int t = 0; t < ph; ++t) {
-        const int so = org + t * pitch;
-        const int l8 = win_ld8(rb.ref8, v.ref8, X, so);
-        const int lg = win_ld8(rb.refg8, v.refg8, X, so);
-        const int r0 = win_ld8(rb.tgt8, v.tgt8, R0, so);
-        const float g0 = win_ldf(rb.tgtg, v.tgtg, R0x4, so * 4);
-        const int r1 = wave_shl1(r0);
-        const float g1 = wave_shl1f(g0);
-        sc = cpu_acc_color(sc, l8, r0, r1, l);
-        sg = cpu_acc_grad(sg, lg, g0, g1, l);
+        for (int t = 0; t < TPH; ++t) {
+          const int so = org + t * pitch;
+          const int l8 = win_ld8(rb.ref8, v.ref8, X, so);
+          lgv[t] = win_ld8(rb.refg8, v.refg8, X, so);
+          const int r0 = win_ld8(rb.tgt8, v.tgt8, R0, so);
+          gv[t] = win_ldf(rb.tgtg, v.tgtg, R0x4, so * 4);
+          sc = cpu_acc_color(sc, l8, r0, wave_shl1(r0), l);
+        }
+        gv[TPH] = 0.f;
+        const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
+#pragma unroll
+        for (int t = 0; t < TPH; t += 2) {
+          const f32x2 gg = {gv[t], gv[t + 1]};
+          const f32x2 pa = gg * ia2, pb = gg * a2;
+          sg = cpu_acc_grad_sum(sg, lgv[t], pa.x + wave_shl1f(pb.x));
+          if (t + 1 < TPH) sg = cpu_acc_grad_sum(sg, lgv[t + 1], pa.y + wave_shl1f(pb.y));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < ph; ++t) {
+          const int so = org + t * pitch;
+          const int l8 = win_ld8(rb.ref8, v.ref8, X, so);
+          const int lg = win_ld8(rb.refg8, v.refg8, X, so);
+          const int r0 = win_ld8(rb.tgt8, v.tgt8, R0, so);
+          const float g0 = win_ldf(rb.tgtg, v.tgtg, R0x4, so * 4);
+          const int r1 = wave_shl1(r0);
+          const float g1 = wave_shl1f(g0);
+          sc = cpu_acc_color(sc, l8, r0, r1, l);
+          sg = cpu_acc_grad(sg, lg, g0, g1, l);
+        }
       }
-      sg -= cpu_grad_bias(ph);
     } else {
       const int pt = ps.pitch_t;
       const int Y = min(max(c_base + gl, 0), rows - 1);
@@ -190,21 +218,50 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       const RowBufs cb = make_col_bufs(v, ps);
       const int lorg = (chain - half_w) * pt;  // wave-uniform: scalar offsets below
       int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
-      float g0 = win_ldf(cb.tgtg, v.ttgtg, vb4, 0);
+      if constexpr (TPW > 0 && PM_RUN2_PK_GRAD) {
+        // samples g[0 .. PW] of the lane's row; both products per sample with packed-f32 multiplies
+        int lgv[TPW];
+        float gv[TPW + 2];
+        gv[0] = win_ldf(cb.tgtg, v.ttgtg, vb4, 0);
 #pragma unroll
-      for (int t = 0; t < pw; ++t) {
-        const int lso = lorg + t * pt;
-        const int rso = (t + 1) * pt;
-        const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
-        const int lg = win_ld8(cb.refg8, v.trefg8, Y, lso);
-        const int r1 = win_ld8(cb.tgt8, v.ttgt8, vb, rso);
-        const float g1 = win_ldf(cb.tgtg, v.ttgtg, vb4, rso * 4);
-        sc = cpu_acc_color(sc, l8, r0, r1, l);
-        sg = cpu_acc_grad(sg, lg, g0, g1, l);
-        r0 = r1;
-        g0 = g1;
+        for (int t = 0; t < TPW; ++t) {
+          const int lso = lorg + t * pt;
+          const int rso = (t + 1) * pt;
+          const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
+          lgv[t] = win_ld8(cb.refg8, v.trefg8, Y, lso);
+          const int r1 = win_ld8(cb.tgt8, v.ttgt8, vb, rso);
+          gv[t + 1] = win_ldf(cb.tgtg, v.ttgtg, vb4, rso * 4);
+          sc = cpu_acc_color(sc, l8, r0, r1, l);
+          r0 = r1;
+        }
+        gv[TPW + 1] = 0.f;
+        const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
+        f32x2 pa[(TPW + 2) / 2], pb[(TPW + 2) / 2];
+#pragma unroll
+        for (int k = 0; k < (TPW + 2) / 2; ++k) {
+          const f32x2 gg = {gv[2 * k], gv[2 * k + 1]};
+          pa[k] = gg * ia2;
+          pb[k] = gg * a2;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          sg = cpu_acc_grad_sum(sg, lgv[t], pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2]);
+      } else {
+        float g0 = win_ldf(cb.tgtg, v.ttgtg, vb4, 0);
+#pragma unroll
+        for (int t = 0; t < pw; ++t) {
+          const int lso = lorg + t * pt;
+          const int rso = (t + 1) * pt;
+          const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
+          const int lg = win_ld8(cb.refg8, v.trefg8, Y, lso);
+          const int r1 = win_ld8(cb.tgt8, v.ttgt8, vb, rso);
+          const float g1 = win_ldf(cb.tgtg, v.ttgtg, vb4, rso * 4);
+          sc = cpu_acc_color(sc, l8, r0, r1, l);
+          sg = cpu_acc_grad(sg, lg, g0, g1, l);
+          r0 = r1;
+          g0 = g1;
+        }
       }
-      sg -= cpu_grad_bias(pw);
     }
     const int line = (int)(sc | (sg << 16));
     int wsum = line;
