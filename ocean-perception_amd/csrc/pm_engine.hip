@@ -406,6 +406,31 @@ void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
   }
 }
 
+// RemoveBackground / MaskBackground; PM_SEM_CPU square windows use the LDS-tiled kernel
+void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float factor,
+                       int cached, int slots) {
+  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && getenv("PM_NO_TILED") == nullptr;
+  const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
+                   (unsigned)slots);
+#define PM_BG_CASE(W)                                                                                        \
+  case W:                                                                                                    \
+    hipLaunchKernelGGL((k_background_tiled<W, W>), tgrid, dim3(256), 0, h->stream, ps, cp, in, factor, cached); \
+    return;
+  if (tiled) {
+    switch (cp.pw) {
+      PM_BG_CASE(3)
+      PM_BG_CASE(5)
+      PM_BG_CASE(7)
+      PM_BG_CASE(9)
+      PM_BG_CASE(11)
+      default: break;
+    }
+  }
+#undef PM_BG_CASE
+  hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, factor,
+                     cached);
+}
+
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
 int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
@@ -434,8 +459,7 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
     const int cached = (p.patchmatch_iters > 0 && bcp.pw == last_pw && bcp.ph == last_ph) ? 1 : 0;
     const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
     Launch l(h, PM_K_BACKGROUND);
-    hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, bcp, in,
-                       factor, cached);
+    launch_background(h, ps, bcp, in, factor, cached, slots);
   }
   return launch_check(h, "background");
 }
@@ -1099,7 +1123,7 @@ int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right
   if (int rc = stage_disp_in(h, ps, disp)) return rc;
   const CostParams cp = cost_params(h->params, patch_w, patch_h);
   const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
-  hipLaunchKernelGGL(k_background, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, in, factor, 0);
+  launch_background(h, ps, cp, in, factor, 0, 1);
   if (int rc = launch_check(h, "background")) return rc;
   return stage_out(h, ps, disp, 0);
 }
@@ -1324,8 +1348,7 @@ int pm_tile_background(pm_handle* h) {
   const int cached = (last >= 0 && bcp.pw == (p.semantics == PM_SEM_CPU ? p.patch_w[last] : 3) &&
                       bcp.ph == (p.semantics == PM_SEM_CPU ? p.patch_h[last] : 3)) ? 1 : 0;
   const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
-  hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps, bcp, in,
-                     factor, cached);
+  launch_background(h, ps, bcp, in, factor, cached, ps.n_views);
   return launch_check(h, "background");
 }
 

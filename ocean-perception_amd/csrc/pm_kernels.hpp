@@ -428,6 +428,77 @@ __global__ void __launch_bounds__(256) k_background(PlaneSet ps, CostParams cp, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// RemoveBackground for PM_SEM_CPU square windows, tiled.  cost(0) compares the two windows at the SAME
+// position: the bilinear fraction is 0, so the colour sample is the target byte itself
+// ((r0 * 65536 + 32768) >> 16) and the gradient sample is saturate_cast<uchar>(g0 * 1 + g1 * 0) = the
+// target's g8 byte -- cost(0) is a plain byte SAD of two 4-plane windows.  A 32x8 tile stages the
+// (32 + PW - 1) x (8 + PH - 1) bytes of the four u8 planes in LDS (as dwords: aligned reads +
+// v_alignbyte_b32) and every pixel does 2 * ceil(PW / 4) v_sad_u8 per window row.
+// grid = (ceil(cols/32), ceil(rows/8), slots), block = 256.
+// ---------------------------------------------------------------------------------------------
+template <int TPW, int TPH>
+__global__ void __launch_bounds__(256) k_background_tiled(PlaneSet ps, CostParams cp, Interior in, float factor,
+                                                          int cached) {
+  constexpr int PW = TPW, PH = TPH;
+  constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
+  constexpr int NW = (TR * LW + 3) / 4 + 4;
+  __shared__ unsigned s_w[4][NW];  // l8, lg8, r8, rg8
+
+  const int tid = threadIdx.x, tx = tid & (kTileW - 1), ty = tid / kTileW;
+  const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+  const int x = x0 + tx, y = y0 + ty, slot = blockIdx.z;
+  const View v = make_view(ps, slot);
+  const int cols = ps.cols, rows = ps.rows, pitch = ps.pitch;
+  const uint8_t* tgtg8 = v.refg8 + ((v.tgt8 - v.ref8));  // the g8 plane of the target image (same plane order as img8)
+
+  const int ry0 = y0 - PH / 2, lx0 = x0 - PW / 2;
+  for (int e = tid; e < TR * LW; e += 256) {
+    const int rr = e / LW, cc = e - rr * LW;
+    const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
+    const size_t go = (size_t)gy * pitch + gx;
+    ((uint8_t*)s_w[0])[e] = v.ref8[go];
+    ((uint8_t*)s_w[1])[e] = v.refg8[go];
+    ((uint8_t*)s_w[2])[e] = v.tgt8[go];
+    ((uint8_t*)s_w[3])[e] = tgtg8[go];
+  }
+  __syncthreads();
+  if (x < in.x_lo || x > in.x_hi || y < in.y_lo || y > in.y_hi) return;
+
+  constexpr int NG = (PW + 3) / 4;
+  unsigned sc = 0, sg = 0;
+#pragma unroll 1
+  for (int i = 0; i < PH; ++i) {
+    const int fl = (ty + i) * LW + tx;
+    const unsigned sh = (unsigned)fl & 3u;
+    const int w0 = fl >> 2;
+    unsigned a0 = s_w[0][w0], b0 = s_w[1][w0], c0 = s_w[2][w0], d0 = s_w[3][w0];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const unsigned a1 = s_w[0][w0 + q + 1], b1 = s_w[1][w0 + q + 1], c1 = s_w[2][w0 + q + 1], d1 = s_w[3][w0 + q + 1];
+      const int rem = PW - 4 * q;
+      const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+      sc = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(a1, a0, sh) & mask,
+                                   __builtin_amdgcn_alignbyte(c1, c0, sh) & mask, sc);
+      sg = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(b1, b0, sh) & mask,
+                                   __builtin_amdgcn_alignbyte(d1, d0, sh) & mask, sg);
+      a0 = a1;
+      b0 = b1;
+      c0 = c1;
+      d0 = d1;
+    }
+  }
+  const float c_bg = cpu_cost_from_sums((int)sc, (int)sg, cp);
+  const size_t o = (size_t)y * pitch + x;
+  const float d = v.disp[o];
+  const float hi = (float)x - (float)(PW / 2);
+  float dd = d > 0.f ? d : 0.f;
+  dd = dd < hi ? dd : hi;
+  const float c = (cached && dd == d) ? v.cost[o] : cpu_cost_lane(v, pitch, cols, x, y, dd, cp);
+  const float thr = c_bg / factor;
+  if (c > thr) v.disp[o] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: un-mirror the right view (cu::flip, patchmatch_gpu.cu:368) and MaskOcclusions
 // (:273-295) fused with the copy into the caller's tightly packed outputs.
 //   dr = dispr(y, (int)max(x - dl, 0));  zero dl if dr > 1.4*dl || dr < 0.7*dl  (double compare)

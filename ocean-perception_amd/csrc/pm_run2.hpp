@@ -61,6 +61,10 @@ struct RowBufs {
 // although it removes ~60 VALU address instructions per step -- the step is bound by load issue/latency,
 // not by VALU count.  Default: plain global loads with the same scalar-row + vector-column addressing;
 // -DPM_RUN2_GLOBAL_LOADS=0 selects the MUBUF form.
+// 1: the reference pixel's colour and gradient bytes come from the packed u16 plane with one load
+#ifndef PM_RUN2_REF_PK16
+#define PM_RUN2_REF_PK16 1
+#endif
 #ifndef PM_RUN2_PK_GRAD
 #define PM_RUN2_PK_GRAD 1
 #endif
@@ -178,8 +182,14 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 #pragma unroll
         for (int t = 0; t < TPH; ++t) {
           const int so = org + t * pitch;
+#if PM_RUN2_REF_PK16
+          const int pk = ld_u16(v.refpk, (unsigned)((X + so) * 2));
+          const int l8 = pk & 0xff;
+          lgv[t] = pk >> 8;
+#else
           const int l8 = win_ld8(rb.ref8, v.ref8, X, so);
           lgv[t] = win_ld8(rb.refg8, v.refg8, X, so);
+#endif
           const int r0 = win_ld8(rb.tgt8, v.tgt8, R0, so);
           gv[t] = win_ldf(rb.tgtg, v.tgtg, R0x4, so * 4);
           sc = cpu_acc_color(sc, l8, r0, wave_shl1(r0), l);
@@ -227,8 +237,14 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         for (int t = 0; t < TPW; ++t) {
           const int lso = lorg + t * pt;
           const int rso = (t + 1) * pt;
+#if PM_RUN2_REF_PK16
+          const int pk = ld_u16(v.trefpk, (unsigned)((Y + lso) * 2));
+          const int l8 = pk & 0xff;
+          lgv[t] = pk >> 8;
+#else
           const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
           lgv[t] = win_ld8(cb.refg8, v.trefg8, Y, lso);
+#endif
           const int r1 = win_ld8(cb.tgt8, v.ttgt8, vb, rso);
           gv[t + 1] = win_ldf(cb.tgtg, v.ttgtg, vb4, rso * 4);
           sc = cpu_acc_color(sc, l8, r0, r1, l);
