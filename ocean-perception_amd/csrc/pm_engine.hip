@@ -354,17 +354,23 @@ int runblk_waves_from_env() {
 // lanes per chain segment of PM_ENGINE_RUNBLK2 (32 or 16); PM_RUNBLK_GROUP overrides.  Measured
 // (tools/sweep_group.sh, 720p): PM_SEM_GPU's 3-lane window wins with 16-lane groups (1.60 vs 1.93 ms per
 // frame), PM_SEM_CPU's 11-lane window with 32 (a 16-lane strip leaves it only 5-6 positions per step).
-int runblk_group(int semantics) {
+// A tuning choice only (results do not depend on it).  Runs of adopted values get shorter as the noise
+// amplitude decays, and short runs waste most of a 32-lane strip: measured at 720p / 11x11 / amp 32/2^i
+// (tools/sweep_g16_iter.sh) column sweeps win with 16-lane groups from amplitude 4 on, row sweeps (one
+// position fewer per strip: the DPP spare lane) only from 0.5 on.
+int runblk_group(int semantics, int axis, float amp) {
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_GROUP");
     const int g = e ? atoi(e) : 0;
     return (g == 16 || g == 32) ? g : 0;
   }();
   if (v) return v;
-  return semantics == PM_SEM_CPU ? 32 : 16;
+  if (semantics != PM_SEM_CPU) return 16;
+  return amp <= (axis == 0 ? 0.5f : 4.0f) ? 16 : 32;
 }
 
-int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots) {
+int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
+              float amp = 1e30f) {
   const int chains = g.c_hi - g.c_lo + 1;
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
@@ -378,7 +384,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), runblk_group(cp.semantics), h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), runblk_group(cp.semantics, g.axis, amp), h->stream);
   } else {
     launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves_from_env() : 1, h->stream);
   }
@@ -449,7 +455,7 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
     }
     if (int rc = launch_check(h, "noise_cost")) return rc;
     for (int k = 0; k < 4; ++k)
-      if (int rc = run_sweep(h, ps, cp, sweep_geom(p, in, k), slots)) return rc;
+      if (int rc = run_sweep(h, ps, cp, sweep_geom(p, in, k), slots, p.noise_amp[it])) return rc;
     last_pw = cp.pw;
     last_ph = cp.ph;
   }
@@ -1281,7 +1287,7 @@ int pm_tile_sweep(pm_handle* h, int it, int k) {
     g.s_first -= t.band_row0;
     g.s_last -= t.band_row0;
   }
-  return run_sweep(h, ps, cp, g, ps.n_views);
+  return run_sweep(h, ps, cp, g, ps.n_views, p.noise_amp[it]);
 }
 
 int pm_tile_snapshot(pm_handle* h) {
