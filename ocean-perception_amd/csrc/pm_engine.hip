@@ -362,7 +362,7 @@ int runblk_group(int semantics, int axis, float amp) {
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_GROUP");
     const int g = e ? atoi(e) : 0;
-    return (g == 16 || g == 32) ? g : 0;
+    return (g == 8 || g == 16 || g == 32) ? g : 0;
   }();
   if (v) return v;
   if (semantics != PM_SEM_CPU) return 16;

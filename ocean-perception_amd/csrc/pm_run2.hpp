@@ -43,12 +43,12 @@ __device__ __forceinline__ int run2_nd(const CostParams& cp) {
   return AXIS == 0 ? GS - (TPW > 0 ? TPW : cp.pw) : GS - (TPH > 0 ? TPH : cp.ph) + 1;
 }
 
-// Ballot of this lane's group (GS = 32 or 16 lanes), in the low GS bits.
+// Ballot of this lane's group (GS = 32, 16 or 8 lanes), in the low GS bits.
 template <int GS>
 __device__ __forceinline__ unsigned gballot(bool p, int gbase) {
   const unsigned long long b = __ballot(p);
   if (GS == 32) return gbase ? (unsigned)(b >> 32) : (unsigned)b;
-  return (unsigned)(b >> gbase) & 0xffffu;
+  return (unsigned)(b >> gbase) & ((1u << GS) - 1u);
 }
 
 // Buffer descriptors of one view's planes: MUBUF addressing = descriptor base + SGPR offset + VGPR
@@ -317,7 +317,6 @@ __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet&
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin);
 
-constexpr int kMaxSegs = 4 * kMaxSegWaves;  // segments per chain: (64 / GS) per wavefront
 
 template <int SEM, int GS, int AXIS, int TPW, int TPH>
 __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
@@ -504,10 +503,15 @@ __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet&
     return run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
 }
 
-// In place.  group = lanes per chain segment (32 or 16).
+// In place.  group = lanes per chain segment: 32 or 16; 8 for PM_SEM_GPU only (its window is 3 lanes).
 inline void launch_sweep_run2(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                               int group, hipStream_t stream) {
-  const bool g16 = group == 16 && (cp.semantics != 0 || (cp.pw == cp.ph && cp.pw <= 11));
+  if (group == 8 && cp.semantics != 0) {
+    if (g.axis == 0) launch_run2_k<1, 8, 0, 3, 3>(ps, cp, g, slots, waves, stream);
+    else launch_run2_k<1, 8, 1, 3, 3>(ps, cp, g, slots, waves, stream);
+    return;
+  }
+  const bool g16 = group <= 16 && (cp.semantics != 0 || (cp.pw == cp.ph && cp.pw <= 11));
   if (g.axis == 0) {
     if (g16) launch_run2_axis<16, 0>(ps, cp, g, slots, waves, stream);
     else launch_run2_axis<32, 0>(ps, cp, g, slots, waves, stream);
