@@ -19,6 +19,8 @@
 #include "pm_wave.hpp"
 #include "pm_run.hpp"
 #include "pm_run2.hpp"
+#include "pm_imaging.hpp"
+#include "pm/imaging.h"
 #include "pm_seed.hpp"
 
 using namespace pm;
@@ -84,6 +86,7 @@ struct pm_handle {
     uint64_t tag = 0;
     int rows = 0, cols = 0;
   };
+  unsigned* img_scalars = nullptr;  // device: [0] max range (float bits), [1] dark-pixel count (pm/imaging.h)
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -586,7 +589,7 @@ void pm_destroy(pm_handle* h) {
   void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
                  h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->snap_disp,
-                 h->snap_cost};
+                 h->snap_cost, h->img_scalars};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1419,3 +1422,172 @@ int pm_profile_read(pm_handle* h, pm_profile* out) {
 }
 
 }  // extern "C"
+
+// ---- pm/imaging.h: disparity -> range -> range-dependent correction -----------------------------
+namespace {
+
+int imaging_begin(pm_handle* h, const char* what, const void* a, const void* b, int rows, int cols) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!a || !b || rows <= 0 || cols <= 0) {
+    set_err(h, "%s: null pointer or empty image", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (!h->img_scalars) {
+    PM_HIP(h, hipMalloc((void**)&h->img_scalars, sizeof(unsigned) * 4));
+    PM_HIP(h, hipMemsetAsync(h->img_scalars, 0, sizeof(unsigned) * 4, h->stream));
+  }
+  return PM_OK;
+}
+
+inline dim3 stream_grid(size_t n_items) {  // grid-stride: enough blocks to fill 256 CUs a few times over
+  size_t b = (n_items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+inline dim3 reduce_grid(size_t n_items) {  // reductions: one atomic per block, so no more blocks than fill the chip
+  size_t b = (n_items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+BackscatterParams backscatter_params(const float B[3], const float beta_B[3]) {
+  BackscatterParams bp{};
+  for (int c = 0; c < 3; ++c) {
+    bp.B[c] = B ? B[c] : 0.f;
+    bp.beta_B[c] = beta_B ? beta_B[c] : 0.f;
+  }
+  return bp;
+}
+AttenuationParams attenuation_params(const float X[12]) {
+  AttenuationParams ap{};
+  for (int c = 0; c < 3; ++c) {
+    ap.a[c] = X ? X[c] : 0.f;
+    ap.b[c] = X ? X[3 + c] : 0.f;
+    ap.c[c] = X ? X[6 + c] : 0.f;
+    ap.d[c] = X ? X[9 + c] : 0.f;
+  }
+  return ap;
+}
+
+}  // namespace
+
+int pm_disp_to_range(pm_handle* h, const float* d_disp, int rows, int cols, double fx, double baseline,
+                     float* d_range) {
+  if (int rc = imaging_begin(h, "pm_disp_to_range", d_disp, d_range, rows, cols)) return rc;
+  const size_t n = (size_t)rows * cols;
+  hipLaunchKernelGGL(k_disp_to_range, stream_grid(n), dim3(256), 0, h->stream, d_disp, n, fx * baseline, d_range,
+                     (unsigned*)nullptr);
+  return launch_check(h, "disp_to_range");
+}
+
+int pm_remove_backscatter(pm_handle* h, const float* d_bgr, const float* d_range, int rows, int cols,
+                          const float B[3], const float beta_B[3], float* d_out) {
+  if (int rc = imaging_begin(h, "pm_remove_backscatter", d_bgr, d_range, rows, cols)) return rc;
+  if (!B || !beta_B || !d_out) {
+    set_err(h, "pm_remove_backscatter: null parameter");
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t n = (size_t)rows * cols;
+  const int vec = aligned16(d_bgr) && aligned16(d_range) && aligned16(d_out);
+  hipLaunchKernelGGL((k_range_enhance<1>), stream_grid(n / 4 + 1), dim3(256), 0, h->stream, d_bgr, d_range, n, 0.0,
+                     backscatter_params(B, beta_B), attenuation_params(nullptr), (const unsigned*)h->img_scalars,
+                     (float*)nullptr, d_out, vec);
+  return launch_check(h, "remove_backscatter");
+}
+
+int pm_correct_attenuation(pm_handle* h, const float* d_bgr, const float* d_range, int rows, int cols,
+                           const float X[12], float* d_out) {
+  if (int rc = imaging_begin(h, "pm_correct_attenuation", d_bgr, d_range, rows, cols)) return rc;
+  if (!X || !d_out) {
+    set_err(h, "pm_correct_attenuation: null parameter");
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t n = (size_t)rows * cols;
+  PM_HIP(h, hipMemsetAsync(h->img_scalars, 0, sizeof(unsigned), h->stream));
+  hipLaunchKernelGGL(k_range_max, reduce_grid(n), dim3(256), 0, h->stream, d_range, n, h->img_scalars);
+  const int vec = aligned16(d_bgr) && aligned16(d_range) && aligned16(d_out);
+  hipLaunchKernelGGL((k_range_enhance<2>), stream_grid(n / 4 + 1), dim3(256), 0, h->stream, d_bgr, d_range, n, 0.0,
+                     backscatter_params(nullptr, nullptr), attenuation_params(X), (const unsigned*)h->img_scalars,
+                     (float*)nullptr, d_out, vec);
+  return launch_check(h, "correct_attenuation");
+}
+
+int pm_range_enhance(pm_handle* h, const float* d_bgr, const float* d_disp, int rows, int cols, double fx,
+                     double baseline, const float B[3], const float beta_B[3], const float X[12],
+                     float* d_range_out, float* d_out) {
+  if (int rc = imaging_begin(h, "pm_range_enhance", d_bgr, d_disp, rows, cols)) return rc;
+  if (!B || !beta_B || !X || !d_out) {
+    set_err(h, "pm_range_enhance: null parameter");
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t n = (size_t)rows * cols;
+  // pass 1: the largest range (CorrectAttenuation gives it to pixels without range); reads the disparity only
+  PM_HIP(h, hipMemsetD32Async((hipDeviceptr_t)h->img_scalars, 0x7f800000u, 1, h->stream));
+  hipLaunchKernelGGL(k_disp_min_positive, reduce_grid(n / 4 + 1), dim3(256), 0, h->stream, d_disp, n, h->img_scalars,
+                     aligned16(d_disp) ? 1 : 0);
+  const int vec = aligned16(d_bgr) && aligned16(d_disp) && aligned16(d_out) && (!d_range_out || aligned16(d_range_out));
+  hipLaunchKernelGGL((k_range_enhance<7>), stream_grid(n / 4 + 1), dim3(256), 0, h->stream, d_bgr, d_disp, n,
+                     fx * baseline, backscatter_params(B, beta_B), attenuation_params(X),
+                     (const unsigned*)h->img_scalars, d_range_out, d_out, vec);
+  return launch_check(h, "range_enhance");
+}
+
+int pm_compute_intensity(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_gray) {
+  if (int rc = imaging_begin(h, "pm_compute_intensity", d_bgr, d_gray, rows, cols)) return rc;
+  const size_t n = (size_t)rows * cols;
+  hipLaunchKernelGGL(k_intensity, stream_grid(n), dim3(256), 0, h->stream, d_bgr, n, d_gray);
+  return launch_check(h, "intensity");
+}
+
+int pm_find_dark(pm_handle* h, const float* d_intensity, const float* d_range, int rows, int cols, float percentile,
+                 uint8_t* d_mask, float* threshold) {
+  if (int rc = imaging_begin(h, "pm_find_dark", d_intensity, d_range, rows, cols)) return rc;
+  if (!d_mask || !threshold) {
+    set_err(h, "pm_find_dark: null output");
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t n = (size_t)rows * cols;
+  // backscatter.cpp:41-78
+  const float N = (float)(rows * cols);
+  const int n_desired = (int)(percentile * N);
+  auto count_at = [&](float thr, unsigned* out) -> int {
+    PM_HIP(h, hipMemsetAsync(h->img_scalars + 1, 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(k_dark_count, reduce_grid(n), dim3(256), 0, h->stream, d_intensity, d_range, n, thr, d_mask,
+                       h->img_scalars + 1);
+    PM_HIP(h, hipMemcpyAsync(out, h->img_scalars + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    PM_HIP(h, hipStreamSynchronize(h->stream));
+    return PM_OK;
+  };
+  float low = 0.f, high = 0.5f;
+  const float first = (float)(1.5 * percentile);
+  unsigned n_dark = 0;
+  if (int rc = count_at(first, &n_dark)) return rc;
+  if ((int)n_dark < n_desired) {
+    low = first;
+  } else if ((int)n_dark > n_desired) {
+    high = first;
+  } else {
+    *threshold = first;
+    return PM_OK;
+  }
+  for (int iter = 0; iter < 8; ++iter) {
+    const float thr = (high + low) / 2.0f;
+    if (int rc = count_at(thr, &n_dark)) return rc;
+    if ((int)n_dark < n_desired) {
+      low = thr;
+    } else if ((int)n_dark > n_desired) {
+      high = thr;
+    } else {
+      *threshold = thr;
+      return PM_OK;
+    }
+  }
+  *threshold = (high + low) / 2.0f;
+  return PM_OK;
+}

@@ -27,6 +27,8 @@ EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
     "pm_submit_u8", "pm_collect", "pm_in_flight",
+    "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
+    "pm_compute_intensity", "pm_find_dark",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
@@ -125,6 +127,17 @@ def load():
     lib.pm_collect.restype = C.c_int
     lib.pm_in_flight.argtypes = [vp]
     lib.pm_in_flight.restype = C.c_int
+    # pm/imaging.h: raw device addresses
+    f3 = C.POINTER(C.c_float)
+    lib.pm_disp_to_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp]
+    lib.pm_remove_backscatter.argtypes = [vp, vp, vp, C.c_int, C.c_int, f3, f3, vp]
+    lib.pm_correct_attenuation.argtypes = [vp, vp, vp, C.c_int, C.c_int, f3, vp]
+    lib.pm_range_enhance.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, f3, f3, f3, vp, vp]
+    lib.pm_compute_intensity.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.pm_find_dark.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, f3]
+    for name in ("pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
+                 "pm_compute_intensity", "pm_find_dark"):
+        getattr(lib, name).restype = C.c_int
     lib.pm_synchronize.argtypes = [vp]
     lib.pm_synchronize.restype = C.c_int
     lib.pm_stream.argtypes = [vp]
@@ -314,6 +327,37 @@ class Engine:
 
     def in_flight(self):
         return int(self.lib.pm_in_flight(self.h))
+
+    # --- pm/imaging.h (device addresses as ints; float parameter vectors as sequences) ---------------------
+    @staticmethod
+    def _fv(values, n):
+        a = (C.c_float * n)(*[float(v) for v in values])
+        return a
+
+    def disp_to_range(self, d_disp, rows, cols, fx, baseline, d_range):
+        self._check(self.lib.pm_disp_to_range(self.h, d_disp, rows, cols, fx, baseline, d_range), "pm_disp_to_range")
+
+    def remove_backscatter(self, d_bgr, d_range, rows, cols, B, beta_B, d_out):
+        self._check(self.lib.pm_remove_backscatter(self.h, d_bgr, d_range, rows, cols, self._fv(B, 3),
+                                                   self._fv(beta_B, 3), d_out), "pm_remove_backscatter")
+
+    def correct_attenuation(self, d_bgr, d_range, rows, cols, X, d_out):
+        self._check(self.lib.pm_correct_attenuation(self.h, d_bgr, d_range, rows, cols, self._fv(X, 12), d_out),
+                    "pm_correct_attenuation")
+
+    def range_enhance(self, d_bgr, d_disp, rows, cols, fx, baseline, B, beta_B, X, d_range_out, d_out):
+        self._check(self.lib.pm_range_enhance(self.h, d_bgr, d_disp, rows, cols, fx, baseline, self._fv(B, 3),
+                                              self._fv(beta_B, 3), self._fv(X, 12), d_range_out, d_out),
+                    "pm_range_enhance")
+
+    def compute_intensity(self, d_bgr, rows, cols, d_gray):
+        self._check(self.lib.pm_compute_intensity(self.h, d_bgr, rows, cols, d_gray), "pm_compute_intensity")
+
+    def find_dark(self, d_intensity, d_range, rows, cols, percentile, d_mask):
+        thr = C.c_float(0)
+        self._check(self.lib.pm_find_dark(self.h, d_intensity, d_range, rows, cols, percentile, d_mask, C.byref(thr)),
+                    "pm_find_dark")
+        return float(thr.value)
 
     def match_device(self, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
         """All arguments are raw device addresses (ints)."""

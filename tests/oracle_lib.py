@@ -325,3 +325,59 @@ def sparse_init(left, right, dilate_factor=4, sp=None):
     out = np.zeros(left.shape, np.float32)
     load().pmo_sparse_init(_p(left), _p(right), left.shape[0], left.shape[1], dilate_factor, C.byref(sp), _p(out))
     return out
+
+
+# ---- imaging rows: oracle/pm_imaging_oracle.c -------------------------------------------------
+def _img_lib():
+    lib = load()
+    if not getattr(lib, "_img_ready", False):
+        vp = C.c_void_p
+        lib.pmo_disp_to_range.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, vp]
+        lib.pmo_disp_to_range.restype = None
+        lib.pmo_remove_backscatter.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+        lib.pmo_remove_backscatter.restype = None
+        lib.pmo_correct_attenuation.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        lib.pmo_correct_attenuation.restype = None
+        lib.pmo_compute_intensity.argtypes = [vp, C.c_size_t, vp]
+        lib.pmo_compute_intensity.restype = None
+        lib.pmo_find_dark.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp]
+        lib.pmo_find_dark.restype = C.c_float
+        lib._img_ready = True
+    return lib
+
+
+def disp_to_range(disp, fx, baseline):
+    disp = c_f32(disp)
+    out = np.empty_like(disp)
+    _img_lib().pmo_disp_to_range(_p(disp), disp.size, fx, baseline, _p(out))
+    return out
+
+
+def remove_backscatter(bgr, rng, B, beta_B):
+    bgr, rng = c_f32(bgr), c_f32(rng)
+    B, beta_B = c_f32(np.asarray(B, np.float32)), c_f32(np.asarray(beta_B, np.float32))
+    out = np.empty_like(bgr)
+    _img_lib().pmo_remove_backscatter(_p(bgr), _p(rng), rng.size, _p(B), _p(beta_B), _p(out))
+    return out
+
+
+def correct_attenuation(bgr, rng, X):
+    bgr, rng = c_f32(bgr), c_f32(rng)
+    X = c_f32(np.asarray(X, np.float32))
+    out = np.empty_like(bgr)
+    _img_lib().pmo_correct_attenuation(_p(bgr), _p(rng), rng.size, _p(X), _p(out))
+    return out
+
+
+def compute_intensity(bgr):
+    bgr = c_f32(bgr)
+    out = np.empty(bgr.shape[:2], np.float32)
+    _img_lib().pmo_compute_intensity(_p(bgr), out.size, _p(out))
+    return out
+
+
+def find_dark(intensity, rng, percentile):
+    intensity, rng = c_f32(intensity), c_f32(rng)
+    mask = np.empty(intensity.shape, np.uint8)
+    thr = _img_lib().pmo_find_dark(_p(intensity), _p(rng), intensity.shape[0], intensity.shape[1], percentile, _p(mask))
+    return float(thr), mask

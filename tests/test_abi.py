@@ -10,9 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "pm", "patchmatch.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text)))
+    """Every function declared by the public headers include/pm/*.h."""
+    names = set()
+    inc = os.path.join(ROOT, "include", "pm")
+    for header in sorted(os.listdir(inc)):
+        text = open(os.path.join(inc, header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_what_the_binding_lists(pm):
@@ -22,7 +27,7 @@ def test_header_declares_what_the_binding_lists(pm):
 def test_library_exports_every_declared_symbol(pm):
     lib = pm.load()
     for name in declared_functions():
-        assert hasattr(lib, name), f"{name} declared in include/pm/patchmatch.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/pm/*.h but not exported"
 
 
 def test_params_default_matches_reference_defaults(pm):
