@@ -59,6 +59,22 @@ int pm_compute_intensity(pm_handle* h, const float* d_bgr, int rows, int cols, f
 int pm_find_dark(pm_handle* h, const float* d_intensity, const float* d_range, int rows, int cols,
                  float percentile, uint8_t* d_mask, float* threshold);
 
+/* ---- range-free enhancement in FRONT of stereo ---------------------------
+ * The "stereo-ready" chain of test/imaging/enhance_test.cpp:69-73 and test/stereo_matching/sgbm_test.cpp:66-84:
+ *   J    = Normalize(NormalizeColorIlluminant(CastImage3bTo3f(bgr8)))
+ *          (src/vehicle/imaging/normalization.cpp:43-69, :178-185; illuminant.cpp:10-21; image_util.cpp:25-31)
+ *   gray = cv::cvtColor(J, BGR2GRAY), converted to 8 bit (x 255, saturate_cast) -- the image Match() consumes.
+ * d_bgr8: [rows][cols][3] bytes.  d_J ([rows][cols][3] float) and d_gray8 ([rows][cols] bytes) are optional
+ * outputs (at least one).  rows, cols >= 8.  Scratch for the image size is allocated on first use. */
+int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, float* d_J, uint8_t* d_gray8);
+
+/* The two building blocks on float images, for callers that run them separately:
+ * cv::GaussianBlur(src, dst, Size(ksize, ksize), sigma, sigma, BORDER_REPLICATE) for 1-4 interleaved channels
+ * (EstimateIlluminantGaussian = 2 x this, illuminant.cpp:10-21), and imaging::Normalize. */
+int pm_gaussian_blur(pm_handle* h, const float* d_src, int rows, int cols, int channels, int ksize, double sigma,
+                     float* d_dst);
+int pm_normalize(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out);
+
 #ifdef __cplusplus
 }
 #endif

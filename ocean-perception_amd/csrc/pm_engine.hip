@@ -20,6 +20,7 @@
 #include "pm_run.hpp"
 #include "pm_run2.hpp"
 #include "pm_imaging.hpp"
+#include "pm_enhance.hpp"
 #include "pm/imaging.h"
 #include "pm_seed.hpp"
 
@@ -86,7 +87,14 @@ struct pm_handle {
     uint64_t tag = 0;
     int rows = 0, cols = 0;
   };
-  unsigned* img_scalars = nullptr;  // device: [0] max range (float bits), [1] dark-pixel count (pm/imaging.h)
+  unsigned* img_scalars = nullptr;  // device: [0] max range (float bits), [1] dark-pixel count, [2..3] V min / max
+  // stereo-ready enhancement (pm_stereo_ready): row-pass output, bgr / illuminant, Gaussian taps
+  float* enh_tmp = nullptr;
+  float* enh_q = nullptr;
+  float* enh_taps = nullptr;
+  size_t enh_values = 0;  // floats allocated in enh_tmp / enh_q
+  int enh_taps_cap = 0, enh_ksize = 0;
+  double enh_sigma = 0;
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -589,7 +597,7 @@ void pm_destroy(pm_handle* h) {
   void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
                  h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->snap_disp,
-                 h->snap_cost, h->img_scalars};
+                 h->snap_cost, h->img_scalars, h->enh_tmp, h->enh_q, h->enh_taps};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -1590,4 +1598,135 @@ int pm_find_dark(pm_handle* h, const float* d_intensity, const float* d_range, i
   }
   *threshold = (high + low) / 2.0f;
   return PM_OK;
+}
+
+// ---- stereo-ready enhancement ---------------------------------------------------------------------
+namespace {
+
+// cv::getGaussianKernel(n, sigma, CV_32F), uploaded once per (n, sigma)
+int ensure_taps(pm_handle* h, int ksize, double sigma) {
+  if (h->enh_ksize == ksize && h->enh_sigma == sigma && h->enh_taps) return PM_OK;
+  if (ksize > h->enh_taps_cap) {
+    PM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->enh_taps) PM_HIP(h, hipFree(h->enh_taps));
+    h->enh_taps = nullptr;
+    PM_HIP(h, hipMalloc((void**)&h->enh_taps, sizeof(float) * (size_t)ksize));
+    h->enh_taps_cap = ksize;
+  }
+  std::vector<float> k((size_t)ksize);
+  const double scale2x = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < ksize; ++i) {
+    const double x = i - (ksize - 1) * 0.5;
+    k[(size_t)i] = (float)std::exp(scale2x * x * x);
+    sum += k[(size_t)i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < ksize; ++i) k[(size_t)i] = (float)(k[(size_t)i] * sum);
+  PM_HIP(h, hipStreamSynchronize(h->stream));  // the previous taps may still be in use
+  PM_HIP(h, hipMemcpy(h->enh_taps, k.data(), sizeof(float) * (size_t)ksize, hipMemcpyHostToDevice));
+  h->enh_ksize = ksize;
+  h->enh_sigma = sigma;
+  return PM_OK;
+}
+
+int ensure_enh_scratch(pm_handle* h, size_t values) {
+  if (values <= h->enh_values) return PM_OK;
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->enh_tmp) PM_HIP(h, hipFree(h->enh_tmp));
+  if (h->enh_q) PM_HIP(h, hipFree(h->enh_q));
+  h->enh_tmp = h->enh_q = nullptr;
+  h->enh_values = 0;
+  PM_HIP(h, hipMalloc((void**)&h->enh_tmp, sizeof(float) * values));
+  PM_HIP(h, hipMalloc((void**)&h->enh_q, sizeof(float) * values));
+  h->enh_values = values;
+  return PM_OK;
+}
+
+// separable Gaussian, replicate border; divide: dst = orig / (2 * blur) (the illuminant normalisation)
+template <bool SRC_U8>
+int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, int ksize, double sigma, bool divide,
+                 float* d_dst) {
+  if (ksize < 1 || (ksize % 2) == 0 || !(sigma > 0)) {
+    set_err(h, "gaussian: ksize %d must be odd and sigma %g positive", ksize, sigma);
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t values = (size_t)rows * cols * ch;
+  if (int rc = ensure_enh_scratch(h, values)) return rc;
+  if (int rc = ensure_taps(h, ksize, sigma)) return rc;
+  const size_t row_lds = sizeof(float) * (size_t)(256 + ksize - 1) * ch;
+  if (row_lds > 64 * 1024) {
+    set_err(h, "gaussian: kernel of %d taps x %d channels exceeds the row tile", ksize, ch);
+    return PM_ERR_SIZE;
+  }
+  hipLaunchKernelGGL((k_blur_rows<SRC_U8>), dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), row_lds,
+                     h->stream, d_src, rows, cols, ch, ksize, (const float*)h->enh_taps, h->enh_tmp);
+  // column tile: W columns x T rows of outputs, (T + 2c) x W floats of LDS within 64 KB
+  const int c = ksize / 2;
+  int W = 64;
+  while (W > 8 && (size_t)(32 + 2 * c) * W * sizeof(float) > 64 * 1024) W /= 2;
+  int T = (int)(64 * 1024 / (sizeof(float) * W)) - 2 * c;
+  if (T > 256) T = 256;
+  if (T < 256 / W) {
+    set_err(h, "gaussian: kernel of %d taps exceeds the column tile", ksize);
+    return PM_ERR_SIZE;
+  }
+  const int width = cols * ch;
+  const size_t col_lds = sizeof(float) * (size_t)(T + 2 * c) * W;
+  const dim3 cgrid((unsigned)((width + W - 1) / W), (unsigned)((rows + T - 1) / T));
+  if (divide)
+    hipLaunchKernelGGL((k_blur_cols<true, SRC_U8>), cgrid, dim3(256), col_lds, h->stream, (const float*)h->enh_tmp, rows,
+                       width, ksize, (const float*)h->enh_taps, W, T, d_src, d_dst);
+  else
+    hipLaunchKernelGGL((k_blur_cols<false, SRC_U8>), cgrid, dim3(256), col_lds, h->stream, (const float*)h->enh_tmp,
+                       rows, width, ksize, (const float*)h->enh_taps, W, T, d_src, d_dst);
+  return launch_check(h, "gaussian");
+}
+
+// imaging::Normalize on d_q -> J and / or gray8
+int run_normalize(pm_handle* h, const float* d_q, int rows, int cols, float* d_J, uint8_t* d_gray8) {
+  if (rows < 8 || cols < 8) {
+    set_err(h, "normalize: the image must be at least 8x8 (its 1/8 resize would be empty)");
+    return PM_ERR_INVALID_ARG;
+  }
+  const unsigned init[2] = {0x7f7fffffu, 0u};
+  PM_HIP(h, hipMemcpyAsync(h->img_scalars + 2, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  const size_t small = (size_t)(rows / 8) * (cols / 8);
+  hipLaunchKernelGGL(k_value_minmax, reduce_grid(small), dim3(256), 0, h->stream, d_q, rows, cols, h->img_scalars + 2);
+  const size_t n = (size_t)rows * cols;
+  hipLaunchKernelGGL(k_normalize_gray, stream_grid(n), dim3(256), 0, h->stream, d_q, n,
+                     (const unsigned*)(h->img_scalars + 2), d_J, d_gray8);
+  return launch_check(h, "normalize");
+}
+
+}  // namespace
+
+int pm_gaussian_blur(pm_handle* h, const float* d_src, int rows, int cols, int channels, int ksize, double sigma,
+                     float* d_dst) {
+  if (int rc = imaging_begin(h, "pm_gaussian_blur", d_src, d_dst, rows, cols)) return rc;
+  if (channels < 1 || channels > 4) {
+    set_err(h, "pm_gaussian_blur: %d channels", channels);
+    return PM_ERR_INVALID_ARG;
+  }
+  return run_gaussian<false>(h, d_src, rows, cols, channels, ksize, sigma, false, d_dst);
+}
+
+int pm_normalize(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out) {
+  if (int rc = imaging_begin(h, "pm_normalize", d_bgr, d_out, rows, cols)) return rc;
+  return run_normalize(h, d_bgr, rows, cols, d_out, nullptr);
+}
+
+int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, float* d_J, uint8_t* d_gray8) {
+  if (int rc = imaging_begin(h, "pm_stereo_ready", d_bgr8, d_bgr8, rows, cols)) return rc;
+  if (!d_J && !d_gray8) {
+    set_err(h, "pm_stereo_ready: no output requested");
+    return PM_ERR_INVALID_ARG;
+  }
+  // NormalizeColorIlluminant (normalization.cpp:178-185): ksize = NextOddInt(cols / 3), sigma = (float)ksize / 4
+  const int third = cols / 3;
+  const int ksize = third + (1 - third % 2);
+  const double sigma = (double)((float)ksize / 4.0f);
+  if (int rc = ensure_enh_scratch(h, (size_t)rows * cols * 3)) return rc;
+  if (int rc = run_gaussian<true>(h, d_bgr8, rows, cols, 3, ksize, sigma, true, h->enh_q)) return rc;
+  return run_normalize(h, h->enh_q, rows, cols, d_J, d_gray8);
 }

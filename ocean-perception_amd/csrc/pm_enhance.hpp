@@ -1,0 +1,221 @@
+// pm_enhance.hpp -- the range-free "stereo-ready" enhancement in front of stereo (include/pm/imaging.h;
+// SURVEY.md 8f-2): gray = BGR2GRAY(Normalize(NormalizeColorIlluminant(CastImage3bTo3f(bgr8)))), the chain of
+// test/imaging/enhance_test.cpp:69-73 / test/stereo_matching/sgbm_test.cpp:66-84.
+//   NormalizeColorIlluminant  normalization.cpp:178-185  bgr / (2 * GaussianBlur(bgr, NextOddInt(cols/3), ksize/4, REPLICATE))
+//   Normalize                 normalization.cpp:43-69    HSV value stretch by the min / max of a 1/8 bilinear resize
+// Same operation order as oracle/pm_enhance_oracle.c, every float op a single IEEE op: bit-identical results.
+//
+// Kernels: row pass of the separable Gaussian (taps added left to right, window staged in LDS), column pass
+// (centre tap, then symmetric pairs; (T + 2c) x W tile in LDS) fused with the division by the illuminant,
+// min / max of the 1/8-resized value channel, and the per-pixel HSV stretch + gray + 8-bit conversion.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace pm {
+
+__device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- row pass: dst[y][x][q] = sum_t k[t] * src[y][clamp(x - c + t)][q], t = 0 .. ksize-1 in order -------------
+// SRC_U8: the source is the 8-bit image, cast like CastImage3bTo3f (x * (float)(1/255.)).
+// grid = (ceil(cols / 256), rows), block = 256, dynamic LDS = (256 + ksize - 1) * ch floats.
+template <bool SRC_U8>
+__global__ void __launch_bounds__(256) k_blur_rows(const void* __restrict__ src, int rows, int cols, int ch, int ksize,
+                                                   const float* __restrict__ taps, float* __restrict__ dst) {
+  extern __shared__ float lds[];
+  const int y = blockIdx.y, x0 = blockIdx.x * 256, c = ksize / 2;
+  const int span = 256 + ksize - 1;
+  const float cast = (float)(1.0 / 255.0);
+  for (int e = threadIdx.x; e < span * ch; e += 256) {
+    const int p = e / ch, q = e - p * ch;
+    const int sx = clampi_d(x0 - c + p, 0, cols - 1);
+    const size_t o = ((size_t)y * cols + sx) * ch + q;
+    lds[e] = SRC_U8 ? (float)((const uint8_t*)src)[o] * cast : ((const float*)src)[o];
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= cols) return;
+  for (int q = 0; q < ch; ++q) {
+    const float* w = lds + threadIdx.x * ch + q;
+    float s = taps[0] * w[0];
+    for (int t = 1; t < ksize; ++t) s = s + taps[t] * w[t * ch];
+    dst[((size_t)y * cols + x) * ch + q] = s;
+  }
+}
+
+// ---- column pass over the image seen as [rows][width] floats (width = cols * ch):
+// s = k[c] * S[y]; s += k[c + j] * (S[y + j] + S[y - j]), j = 1 .. c.  DIVIDE: the result is the illuminant / 2;
+// the kernel writes orig / (2 * s) (0 where the divisor is 0), orig being the 8-bit (cast) or float source image.
+// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = (T + 2c) * W floats.
+template <bool DIVIDE, bool ORIG_U8>
+__global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp, int rows, int width, int ksize,
+                                                   const float* __restrict__ taps, int W, int T,
+                                                   const void* __restrict__ orig, float* __restrict__ dst) {
+  extern __shared__ float lds[];
+  const int c = ksize / 2;
+  const int x0 = blockIdx.x * W, y0 = blockIdx.y * T;
+  const int span = T + 2 * c;
+  for (int e = threadIdx.x; e < span * W; e += 256) {
+    const int r = e / W, w = e - r * W;
+    const int sy = clampi_d(y0 - c + r, 0, rows - 1), sx = min(x0 + w, width - 1);
+    lds[e] = tmp[(size_t)sy * width + sx];
+  }
+  __syncthreads();
+  const int w = threadIdx.x % W, g = threadIdx.x / W, G = 256 / W;
+  const int x = x0 + w;
+  if (x >= width) return;
+  const float cast = (float)(1.0 / 255.0);
+  for (int yy = g; yy < T && y0 + yy < rows; yy += G) {
+    const float* col = lds + (yy + c) * W + w;
+    float s = taps[c] * col[0];
+    for (int j = 1; j <= c; ++j) s = s + taps[c + j] * (col[j * W] + col[-j * W]);
+    const size_t o = (size_t)(y0 + yy) * width + x;
+    if (DIVIDE) {
+      const float num = ORIG_U8 ? (float)((const uint8_t*)orig)[o] * cast : ((const float*)orig)[o];
+      const float d = s * 2.0f;
+      dst[o] = d != 0.f ? num / d : 0.f;
+    } else {
+      dst[o] = s;
+    }
+  }
+}
+
+// ---- cv::cvtColor BGR2HSV / HSV2BGR on floats -----------------------------------------------------------------------
+__device__ __forceinline__ void bgr2hsv_d(float b, float g, float r, float& h, float& s, float& v) {
+  v = b;
+  float vmin = b;
+  if (g > v) v = g;
+  if (r > v) v = r;
+  if (g < vmin) vmin = g;
+  if (r < vmin) vmin = r;
+  float diff = v - vmin;
+  s = diff / (fabsf(v) + FLT_EPSILON);
+  diff = 60.f / (diff + FLT_EPSILON);
+  if (v == r) h = (g - b) * diff;
+  else if (v == g) h = (b - r) * diff + 120.f;
+  else h = (r - g) * diff + 240.f;
+  if (h < 0.f) h += 360.f;
+}
+
+__device__ __forceinline__ void hsv2bgr_d(float h, float s, float v, float& b, float& g, float& r) {
+  if (s == 0.f) {
+    b = g = r = v;
+    return;
+  }
+  h = h * (6.f / 360.f);
+  if (h < 0.f) {
+    do h += 6.f; while (h < 0.f);
+  } else if (h >= 6.f) {
+    do h -= 6.f; while (h >= 6.f);
+  }
+  int sector = (int)floorf(h);
+  h -= (float)sector;
+  if ((unsigned)sector >= 6u) {
+    sector = 0;
+    h = 0.f;
+  }
+  const float t0 = v, t1 = v * (1.f - s), t2 = v * (1.f - s * h), t3 = v * (1.f - s * (1.f - h));
+  // sector_data = {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}
+  switch (sector) {
+    case 0: b = t1; g = t3; r = t0; break;
+    case 1: b = t1; g = t0; r = t2; break;
+    case 2: b = t3; g = t0; r = t1; break;
+    case 3: b = t0; g = t2; r = t1; break;
+    case 4: b = t0; g = t1; r = t3; break;
+    default: b = t2; g = t1; r = t0; break;
+  }
+}
+
+__device__ __forceinline__ float value_of(const float* __restrict__ q, size_t px) {
+  const float b = q[px * 3], g = q[px * 3 + 1], r = q[px * 3 + 2];
+  float v = b;
+  if (g > v) v = g;
+  if (r > v) v = r;
+  return v;
+}
+
+// One axis of cv::resize INTER_LINEAR (the oracle's linear_coeff)
+__device__ __forceinline__ void linear_coeff_d(int d, int ssize, int dsize, int& s0, float& w0, float& w1) {
+  const double scale = (double)ssize / dsize;
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= ssize - 1) {
+    f = 0.f;
+    s = ssize - 1;
+  }
+  s0 = s;
+  w0 = 1.f - f;
+  w1 = f;
+}
+
+// ---- min / max of resize(V, size / 8); mm[0] = min bits (init 0x7f7fffff), mm[1] = max bits (init 0); V >= 0 ----
+__global__ void __launch_bounds__(256) k_value_minmax(const float* __restrict__ q, int rows, int cols, unsigned* mm) {
+  __shared__ float s_lo[4], s_hi[4];
+  const int dr = rows / 8, dc = cols / 8;
+  float lo = FLT_MAX, hi = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dr * dc; i += gridDim.x * blockDim.x) {
+    const int dy = i / dc, dx = i - dy * dc;
+    int sy, sx;
+    float b0, b1, a0, a1;
+    linear_coeff_d(dy, rows, dr, sy, b0, b1);
+    linear_coeff_d(dx, cols, dc, sx, a0, a1);
+    const int sy1 = min(sy + 1, rows - 1), sx1 = min(sx + 1, cols - 1);
+    const float r0 = value_of(q, (size_t)sy * cols + sx) * a0 + value_of(q, (size_t)sy * cols + sx1) * a1;
+    const float r1 = value_of(q, (size_t)sy1 * cols + sx) * a0 + value_of(q, (size_t)sy1 * cols + sx1) * a1;
+    const float val = r0 * b0 + r1 * b1;
+    lo = val < lo ? val : lo;
+    hi = val > hi ? val : hi;
+  }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, ofs, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, ofs, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    atomicMin(&mm[0], __float_as_uint(lo));
+    atomicMax(&mm[1], __float_as_uint(hi));
+  }
+}
+
+// ---- Normalize's per-pixel part + BGR2GRAY + convertTo(CV_8U, 255) ------------------------------------------------
+// V' = V * (float)(1 / (vmax - vmin)) + (float)(-vmin / (vmax - vmin)); J (optional) and gray8 (optional) out.
+__global__ void __launch_bounds__(256) k_normalize_gray(const float* __restrict__ q, size_t n_px,
+                                                        const unsigned* __restrict__ mm, float* __restrict__ J,
+                                                        uint8_t* __restrict__ gray8) {
+  const double vmin = (double)__uint_as_float(mm[0]), vmax = (double)__uint_as_float(mm[1]);
+  const float alpha = (float)(1.0 / (vmax - vmin)), beta = (float)(-vmin / (vmax - vmin));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (size_t)gridDim.x * blockDim.x) {
+    float h, s, v, b, g, r;
+    bgr2hsv_d(q[i * 3], q[i * 3 + 1], q[i * 3 + 2], h, s, v);
+    v = v * alpha + beta;
+    hsv2bgr_d(h, s, v, b, g, r);
+    if (J) {
+      J[i * 3] = b;
+      J[i * 3 + 1] = g;
+      J[i * 3 + 2] = r;
+    }
+    if (gray8) {
+      float gr = b * 0.114f;
+      gr = gr + g * 0.587f;
+      gr = gr + r * 0.299f;
+      gray8[i] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(gr * 255.f, 0, 0u);  // saturate_cast<uchar>
+    }
+  }
+}
+
+}  // namespace pm

@@ -28,7 +28,7 @@ EXPORTS = [
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
     "pm_submit_u8", "pm_collect", "pm_in_flight",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
-    "pm_compute_intensity", "pm_find_dark",
+    "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
@@ -135,8 +135,11 @@ def load():
     lib.pm_range_enhance.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, f3, f3, f3, vp, vp]
     lib.pm_compute_intensity.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.pm_find_dark.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, f3]
+    lib.pm_stereo_ready.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.pm_gaussian_blur.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
+    lib.pm_normalize.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     for name in ("pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
-                 "pm_compute_intensity", "pm_find_dark"):
+                 "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize"):
         getattr(lib, name).restype = C.c_int
     lib.pm_synchronize.argtypes = [vp]
     lib.pm_synchronize.restype = C.c_int
@@ -358,6 +361,16 @@ class Engine:
         self._check(self.lib.pm_find_dark(self.h, d_intensity, d_range, rows, cols, percentile, d_mask, C.byref(thr)),
                     "pm_find_dark")
         return float(thr.value)
+
+    def stereo_ready(self, d_bgr8, rows, cols, d_J, d_gray8):
+        self._check(self.lib.pm_stereo_ready(self.h, d_bgr8, rows, cols, d_J, d_gray8), "pm_stereo_ready")
+
+    def gaussian_blur(self, d_src, rows, cols, channels, ksize, sigma, d_dst):
+        self._check(self.lib.pm_gaussian_blur(self.h, d_src, rows, cols, channels, ksize, sigma, d_dst),
+                    "pm_gaussian_blur")
+
+    def normalize(self, d_bgr, rows, cols, d_out):
+        self._check(self.lib.pm_normalize(self.h, d_bgr, rows, cols, d_out), "pm_normalize")
 
     def match_device(self, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
         """All arguments are raw device addresses (ints)."""

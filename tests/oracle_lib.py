@@ -381,3 +381,59 @@ def find_dark(intensity, rng, percentile):
     mask = np.empty(intensity.shape, np.uint8)
     thr = _img_lib().pmo_find_dark(_p(intensity), _p(rng), intensity.shape[0], intensity.shape[1], percentile, _p(mask))
     return float(thr), mask
+
+
+# ---- stereo-ready enhancement: oracle/pm_enhance_oracle.c ----------------------------------------
+def _enh_lib():
+    lib = load()
+    if not getattr(lib, "_enh_ready", False):
+        vp = C.c_void_p
+        lib.pmo_gaussian_kernel.argtypes = [C.c_int, C.c_double, vp]
+        lib.pmo_gaussian_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
+        lib.pmo_normalize.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.pmo_normalize_color_illuminant.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.pmo_stereo_ready.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        lib.pmo_value_minmax_eighth.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for n in ("pmo_gaussian_kernel", "pmo_gaussian_blur", "pmo_normalize", "pmo_normalize_color_illuminant",
+                  "pmo_stereo_ready", "pmo_value_minmax_eighth"):
+            getattr(lib, n).restype = None
+        lib._enh_ready = True
+    return lib
+
+
+def gaussian_kernel(n, sigma):
+    k = np.empty(n, np.float32)
+    _enh_lib().pmo_gaussian_kernel(n, sigma, _p(k))
+    return k
+
+
+def gaussian_blur(src, ksize, sigma):
+    src = c_f32(src)
+    rows, cols = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    out = np.empty_like(src)
+    _enh_lib().pmo_gaussian_blur(_p(src), rows, cols, ch, ksize, sigma, _p(out))
+    return out
+
+
+def normalize(bgr):
+    bgr = c_f32(bgr)
+    out = np.empty_like(bgr)
+    _enh_lib().pmo_normalize(_p(bgr), bgr.shape[0], bgr.shape[1], _p(out))
+    return out
+
+
+def value_minmax_eighth(V):
+    V = c_f32(V)
+    lo, hi = C.c_double(0), C.c_double(0)
+    _enh_lib().pmo_value_minmax_eighth(_p(V), V.shape[0], V.shape[1], C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def stereo_ready(bgr8):
+    bgr8 = c_u8(bgr8)
+    rows, cols = bgr8.shape[:2]
+    J = np.empty((rows, cols, 3), np.float32)
+    gray = np.empty((rows, cols), np.uint8)
+    _enh_lib().pmo_stereo_ready(_p(bgr8), rows, cols, _p(J), _p(gray))
+    return J, gray
