@@ -1654,32 +1654,44 @@ int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, in
   const size_t values = (size_t)rows * cols * ch;
   if (int rc = ensure_enh_scratch(h, values)) return rc;
   if (int rc = ensure_taps(h, ksize, sigma)) return rc;
-  const size_t row_lds = sizeof(float) * (size_t)(256 + ksize - 1) * ch;
+  const size_t row_lds = sizeof(float) * ((size_t)(256 + ksize - 1) * ch + ksize);
   if (row_lds > 64 * 1024) {
     set_err(h, "gaussian: kernel of %d taps x %d channels exceeds the row tile", ksize, ch);
     return PM_ERR_SIZE;
   }
-  hipLaunchKernelGGL((k_blur_rows<SRC_U8>), dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), row_lds,
-                     h->stream, d_src, rows, cols, ch, ksize, (const float*)h->enh_taps, h->enh_tmp);
-  // column tile: W columns x T rows of outputs, (T + 2c) x W floats of LDS within 64 KB
+  const dim3 rgrid((unsigned)((cols + 255) / 256), (unsigned)rows);
+  const float* taps = h->enh_taps;
+  switch (ch) {
+    case 1: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 1>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    case 2: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 2>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    case 3: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 3>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    default: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 4>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+  }
+  // column tile: W columns x T rows of outputs, ((T + 2c) x W + c + 1) floats of LDS within 64 KB; a smaller
+  // tile (32 KB) doubles the blocks per CU, which pays more than the extra halo re-reads
   const int c = ksize / 2;
-  int W = 64;
-  while (W > 8 && (size_t)(32 + 2 * c) * W * sizeof(float) > 64 * 1024) W /= 2;
-  int T = (int)(64 * 1024 / (sizeof(float) * W)) - 2 * c;
-  if (T > 256) T = 256;
-  if (T < 256 / W) {
+  int W = 0, T = 0;
+  for (size_t kb : {32, 64}) {
+    const size_t budget = kb * 1024 - sizeof(float) * (size_t)(c + 1);
+    W = 32;
+    while (W > 8 && (size_t)(32 + 2 * c) * W * sizeof(float) > budget) W /= 2;
+    T = (int)(budget / (sizeof(float) * W)) - 2 * c;
+    if (T > 256) T = 256;
+    if (T >= 512 / W) break;
+  }
+  if (T < 512 / W) {
     set_err(h, "gaussian: kernel of %d taps exceeds the column tile", ksize);
     return PM_ERR_SIZE;
   }
   const int width = cols * ch;
-  const size_t col_lds = sizeof(float) * (size_t)(T + 2 * c) * W;
+  const size_t col_lds = sizeof(float) * ((size_t)(T + 2 * c) * W + c + 1);
   const dim3 cgrid((unsigned)((width + W - 1) / W), (unsigned)((rows + T - 1) / T));
   if (divide)
     hipLaunchKernelGGL((k_blur_cols<true, SRC_U8>), cgrid, dim3(256), col_lds, h->stream, (const float*)h->enh_tmp, rows,
-                       width, ksize, (const float*)h->enh_taps, W, T, d_src, d_dst);
+                       width, ksize, taps, W, T, d_src, d_dst);
   else
     hipLaunchKernelGGL((k_blur_cols<false, SRC_U8>), cgrid, dim3(256), col_lds, h->stream, (const float*)h->enh_tmp,
-                       rows, width, ksize, (const float*)h->enh_taps, W, T, d_src, d_dst);
+                       rows, width, ksize, taps, W, T, d_src, d_dst);
   return launch_check(h, "gaussian");
 }
 

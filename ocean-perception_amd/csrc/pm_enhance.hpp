@@ -21,64 +21,93 @@ __device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ?
 
 // ---- row pass: dst[y][x][q] = sum_t k[t] * src[y][clamp(x - c + t)][q], t = 0 .. ksize-1 in order -------------
 // SRC_U8: the source is the 8-bit image, cast like CastImage3bTo3f (x * (float)(1/255.)).
-// grid = (ceil(cols / 256), rows), block = 256, dynamic LDS = (256 + ksize - 1) * ch floats.
-template <bool SRC_U8>
-__global__ void __launch_bounds__(256) k_blur_rows(const void* __restrict__ src, int rows, int cols, int ch, int ksize,
+// One thread per pixel, CH accumulators; the row window and the taps live in LDS.
+// grid = (ceil(cols / 256), rows), block = 256, dynamic LDS = ((256 + ksize - 1) * CH + ksize) floats.
+template <bool SRC_U8, int CH>
+__global__ void __launch_bounds__(256) k_blur_rows(const void* __restrict__ src, int rows, int cols, int ksize,
                                                    const float* __restrict__ taps, float* __restrict__ dst) {
   extern __shared__ float lds[];
   const int y = blockIdx.y, x0 = blockIdx.x * 256, c = ksize / 2;
   const int span = 256 + ksize - 1;
+  float* s_k = lds + span * CH;
   const float cast = (float)(1.0 / 255.0);
-  for (int e = threadIdx.x; e < span * ch; e += 256) {
-    const int p = e / ch, q = e - p * ch;
+  for (int e = threadIdx.x; e < span * CH; e += 256) {
+    const int p = e / CH, q = e - p * CH;
     const int sx = clampi_d(x0 - c + p, 0, cols - 1);
-    const size_t o = ((size_t)y * cols + sx) * ch + q;
+    const size_t o = ((size_t)y * cols + sx) * CH + q;
     lds[e] = SRC_U8 ? (float)((const uint8_t*)src)[o] * cast : ((const float*)src)[o];
   }
+  for (int e = threadIdx.x; e < ksize; e += 256) s_k[e] = taps[e];
   __syncthreads();
   const int x = x0 + threadIdx.x;
   if (x >= cols) return;
-  for (int q = 0; q < ch; ++q) {
-    const float* w = lds + threadIdx.x * ch + q;
-    float s = taps[0] * w[0];
-    for (int t = 1; t < ksize; ++t) s = s + taps[t] * w[t * ch];
-    dst[((size_t)y * cols + x) * ch + q] = s;
+  const float* w = lds + threadIdx.x * CH;
+  float s[CH];
+  {
+    const float k0 = s_k[0];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) s[q] = k0 * w[q];
   }
+#pragma unroll 4
+  for (int t = 1; t < ksize; ++t) {
+    const float kt = s_k[t];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) s[q] = s[q] + kt * w[t * CH + q];
+  }
+#pragma unroll
+  for (int q = 0; q < CH; ++q) dst[((size_t)y * cols + x) * CH + q] = s[q];
 }
 
 // ---- column pass over the image seen as [rows][width] floats (width = cols * ch):
 // s = k[c] * S[y]; s += k[c + j] * (S[y + j] + S[y - j]), j = 1 .. c.  DIVIDE: the result is the illuminant / 2;
 // the kernel writes orig / (2 * s) (0 where the divisor is 0), orig being the 8-bit (cast) or float source image.
-// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = (T + 2c) * W floats.
+// A thread owns TWO adjacent columns (packed-f32 adds and multiplies: the same IEEE operations, two per
+// instruction) and walks its share of the tile's T output rows.
+// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = ((T + 2c) * W + c + 1) floats, W even.
 template <bool DIVIDE, bool ORIG_U8>
 __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp, int rows, int width, int ksize,
                                                    const float* __restrict__ taps, int W, int T,
                                                    const void* __restrict__ orig, float* __restrict__ dst) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
   extern __shared__ float lds[];
   const int c = ksize / 2;
   const int x0 = blockIdx.x * W, y0 = blockIdx.y * T;
   const int span = T + 2 * c;
+  float* s_k = lds + span * W;  // taps[c .. ksize-1]
   for (int e = threadIdx.x; e < span * W; e += 256) {
     const int r = e / W, w = e - r * W;
     const int sy = clampi_d(y0 - c + r, 0, rows - 1), sx = min(x0 + w, width - 1);
     lds[e] = tmp[(size_t)sy * width + sx];
   }
+  for (int e = threadIdx.x; e <= c; e += 256) s_k[e] = taps[c + e];
   __syncthreads();
-  const int w = threadIdx.x % W, g = threadIdx.x / W, G = 256 / W;
+  const int W2 = W / 2;
+  const int w = (threadIdx.x % W2) * 2, g = threadIdx.x / W2, G = 256 / W2;
   const int x = x0 + w;
   if (x >= width) return;
   const float cast = (float)(1.0 / 255.0);
   for (int yy = g; yy < T && y0 + yy < rows; yy += G) {
     const float* col = lds + (yy + c) * W + w;
-    float s = taps[c] * col[0];
-    for (int j = 1; j <= c; ++j) s = s + taps[c + j] * (col[j * W] + col[-j * W]);
+    const float kc = s_k[0];
+    f2 s = *(const f2*)col * (f2){kc, kc};
+#pragma unroll 4
+    for (int j = 1; j <= c; ++j) {
+      const float kj = s_k[j];
+      const f2 pair = *(const f2*)(col + j * W) + *(const f2*)(col - j * W);
+      s = s + pair * (f2){kj, kj};
+    }
     const size_t o = (size_t)(y0 + yy) * width + x;
-    if (DIVIDE) {
-      const float num = ORIG_U8 ? (float)((const uint8_t*)orig)[o] * cast : ((const float*)orig)[o];
-      const float d = s * 2.0f;
-      dst[o] = d != 0.f ? num / d : 0.f;
-    } else {
-      dst[o] = s;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (x + u >= width) break;
+      const float sv = u == 0 ? s.x : s.y;
+      if (DIVIDE) {
+        const float num = ORIG_U8 ? (float)((const uint8_t*)orig)[o + u] * cast : ((const float*)orig)[o + u];
+        const float d = sv * 2.0f;
+        dst[o + u] = d != 0.f ? num / d : 0.f;
+      } else {
+        dst[o + u] = sv;
+      }
     }
   }
 }
