@@ -62,7 +62,9 @@ int pm_find_dark(pm_handle* h, const float* d_intensity, const float* d_range, i
 /* ---- range-free enhancement in FRONT of stereo ---------------------------
  * The "stereo-ready" chain of test/imaging/enhance_test.cpp:69-73 and test/stereo_matching/sgbm_test.cpp:66-84:
  *   J    = Normalize(NormalizeColorIlluminant(CastImage3bTo3f(bgr8)))
- *          (src/vehicle/imaging/normalization.cpp:43-69, :178-185; illuminant.cpp:10-21; image_util.cpp:25-31)
+ *          (src/vehicle/imaging/normalization.cpp:43-69, :178-185; illuminant.cpp:10-21; image_util.cpp:25-31;
+ *          as written there: NormalizeColorIlluminant ends with a Normalize of its own, so the value channel is
+ *          stretched twice)
  *   gray = cv::cvtColor(J, BGR2GRAY), converted to 8 bit (x 255, saturate_cast) -- the image Match() consumes.
  * d_bgr8: [rows][cols][3] bytes.  d_J ([rows][cols][3] float) and d_gray8 ([rows][cols] bytes) are optional
  * outputs (at least one).  rows, cols >= 8.  Scratch for the image size is allocated on first use. */
@@ -74,6 +76,17 @@ int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, flo
 int pm_gaussian_blur(pm_handle* h, const float* d_src, int rows, int cols, int channels, int ksize, double sigma,
                      float* d_dst);
 int pm_normalize(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out);
+/* imaging::NormalizeColorIlluminant on a float image (normalization.cpp:178-185). */
+int pm_normalize_color_illuminant(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out);
+
+/* ---- device buffers for host code that does not include HIP (host/imaging.hpp uses them) ------------------
+ * pm_device_malloc / pm_device_free wrap hipMalloc / hipFree on the handle's device; pm_upload / pm_download are
+ * stream-ordered copies on the handle's stream from / to pageable host memory (pm_download returns after the
+ * data has arrived). */
+int pm_device_malloc(pm_handle* h, size_t bytes, void** d_ptr);
+int pm_device_free(pm_handle* h, void* d_ptr);
+int pm_upload(pm_handle* h, void* d_dst, const void* src, size_t bytes);
+int pm_download(pm_handle* h, void* dst, const void* d_src, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -351,14 +351,16 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
   return PM_OK;
 }
 
-int runblk_waves_from_env() {
-  // wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2 (tools/sweep_group.sh: 4 is the best or tied at 720p)
+// Wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
+// 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
+int runblk_waves(int chain_len) {
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_WAVES");
-    int x = e ? atoi(e) : 4;
-    return x < 1 ? 1 : (x > kMaxSegWaves ? kMaxSegWaves : x);
+    int x = e ? atoi(e) : 0;
+    return x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
   }();
-  return v;
+  if (v) return v;
+  return chain_len > 1600 ? 8 : 4;
 }
 
 // One directional sweep, in place.
@@ -385,6 +387,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   const int chains = g.c_hi - g.c_lo + 1;
   if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
   Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
+  const int chain_len = (g.s_last - g.s_first) * g.dir + 1;
   int engine = h->params.engine;
   if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK2;
   // PM_SEM_GPU has two parallel engines: lane-per-segment (WAVE) and the shared-tap run step (RUNBLK2)
@@ -395,9 +398,9 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves_from_env(), runblk_group(cp.semantics, g.axis, amp), h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len), runblk_group(cp.semantics, g.axis, amp), h->stream);
   } else {
-    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves_from_env() : 1, h->stream);
+    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves(chain_len) : 1, h->stream);
   }
   return launch_check(h, "sweep");
 }
@@ -1740,5 +1743,54 @@ int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, flo
   const double sigma = (double)((float)ksize / 4.0f);
   if (int rc = ensure_enh_scratch(h, (size_t)rows * cols * 3)) return rc;
   if (int rc = run_gaussian<true>(h, d_bgr8, rows, cols, 3, ksize, sigma, true, h->enh_q)) return rc;
-  return run_normalize(h, h->enh_q, rows, cols, d_J, d_gray8);
+  // enhance_test.cpp:69 applies Normalize to NormalizeColorIlluminant's result, which already ends with a
+  // Normalize (normalization.cpp:184): two value stretches.  The row-pass scratch is free again: it takes the first.
+  if (int rc = run_normalize(h, h->enh_q, rows, cols, h->enh_tmp, nullptr)) return rc;
+  return run_normalize(h, h->enh_tmp, rows, cols, d_J, d_gray8);
+}
+
+int pm_normalize_color_illuminant(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out) {
+  if (int rc = imaging_begin(h, "pm_normalize_color_illuminant", d_bgr, d_out, rows, cols)) return rc;
+  const int third = cols / 3;
+  const int ksize = third + (1 - third % 2);
+  const double sigma = (double)((float)ksize / 4.0f);
+  if (int rc = ensure_enh_scratch(h, (size_t)rows * cols * 3)) return rc;
+  if (int rc = run_gaussian<false>(h, d_bgr, rows, cols, 3, ksize, sigma, true, h->enh_q)) return rc;
+  return run_normalize(h, h->enh_q, rows, cols, d_out, nullptr);
+}
+
+int pm_device_malloc(pm_handle* h, size_t bytes, void** d_ptr) {
+  if (!h || !d_ptr) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  *d_ptr = nullptr;
+  if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) {
+    set_err(h, "pm_device_malloc: %zu bytes", bytes);
+    return PM_ERR_NOMEM;
+  }
+  return PM_OK;
+}
+
+int pm_device_free(pm_handle* h, void* d_ptr) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!d_ptr) return PM_OK;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  PM_HIP(h, hipFree(d_ptr));
+  return PM_OK;
+}
+
+int pm_upload(pm_handle* h, void* d_dst, const void* src, size_t bytes) {
+  if (!h || !d_dst || !src) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));  // pageable source: the caller may reuse it right away
+  return PM_OK;
+}
+
+int pm_download(pm_handle* h, void* dst, const void* d_src, size_t bytes) {
+  if (!h || !dst || !d_src) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
 }

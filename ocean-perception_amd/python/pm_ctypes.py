@@ -29,6 +29,7 @@ EXPORTS = [
     "pm_submit_u8", "pm_collect", "pm_in_flight",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
+    "pm_normalize_color_illuminant", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
@@ -138,6 +139,14 @@ def load():
     lib.pm_stereo_ready.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.pm_gaussian_blur.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
     lib.pm_normalize.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.pm_normalize_color_illuminant.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.pm_normalize_color_illuminant.restype = C.c_int
+    lib.pm_device_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.pm_device_free.argtypes = [vp, vp]
+    lib.pm_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.pm_download.argtypes = [vp, vp, vp, C.c_size_t]
+    for name in ("pm_device_malloc", "pm_device_free", "pm_upload", "pm_download"):
+        getattr(lib, name).restype = C.c_int
     for name in ("pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
                  "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize"):
         getattr(lib, name).restype = C.c_int

@@ -213,7 +213,11 @@ void pmo_stereo_ready(const uint8_t* bgr8, int rows, int cols, float* J_out, uin
   float* I = (float*)malloc(sizeof(float) * n * 3);
   float* J = (float*)malloc(sizeof(float) * n * 3);
   pmo_cast_3b_to_3f(bgr8, n * 3, I);
+  /* enhance_test.cpp:69: Normalize(NormalizeColorIlluminant(I)) -- NormalizeColorIlluminant already ends with a
+   * Normalize (normalization.cpp:184), so the value channel is stretched twice */
   pmo_normalize_color_illuminant(I, rows, cols, J);
+  memcpy(I, J, sizeof(float) * n * 3);
+  pmo_normalize(I, rows, cols, J);
   for (size_t i = 0; i < n; ++i) {
     float g = J[i * 3] * 0.114f;
     g = g + J[i * 3 + 1] * 0.587f;
