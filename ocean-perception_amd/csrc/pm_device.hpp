@@ -33,6 +33,7 @@ struct PlaneSet {
   unsigned long long* counters;  // [8] work counters (see pm_debug_counters), one atomic per wavefront
   int rows, cols, pitch;
   int n_views;         // 1 or 2
+  int view_fixed;      // -1: slot = pair * n_views + view; 0 / 1: slot = pair, this view only (per-view streams)
   size_t plane;        // rows * pitch
 };
 
@@ -57,7 +58,8 @@ struct View {
 };
 
 __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
-  const int b = slot / ps.n_views, v = slot - b * ps.n_views;
+  const int b = ps.view_fixed >= 0 ? slot : slot / ps.n_views;
+  const int v = ps.view_fixed >= 0 ? ps.view_fixed : slot - b * ps.n_views;
   const int iref = v == 0 ? 0 : 3, itgt = v == 0 ? 1 : 2;
   const size_t base4 = (size_t)b * 4;
   View w;

@@ -87,6 +87,10 @@ struct pm_handle {
     uint64_t tag = 0;
     int rows = 0, cols = 0;
   };
+  // per-view streams: the two views are independent until the cross-check, so their launch chains run on
+  // two streams and one view's kernels fill the CUs the other view's kernel tails leave idle
+  hipStream_t view_stream[2] = {nullptr, nullptr};
+  hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
   unsigned* img_scalars = nullptr;  // device: [0] max range (float bits), [1] dark-pixel count, [2..3] V min / max
   // stereo-ready enhancement (pm_stereo_ready): row-pass output, bgr / illuminant, Gaussian taps
   float* enh_tmp = nullptr;
@@ -178,6 +182,7 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.cols = cols;
   ps.pitch = align_up(cols, 64);
   ps.n_views = n_views;
+  ps.view_fixed = -1;
   ps.plane = (size_t)rows * ps.pitch;
   return ps;
 }
@@ -353,13 +358,19 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
 
 // Wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
 // 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
-int runblk_waves(int chain_len) {
-  static int v = [] {
-    const char* e = getenv("PM_RUNBLK_WAVES");
-    int x = e ? atoi(e) : 0;
-    return x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
-  }();
-  if (v) return v;
+int runblk_waves(int chain_len, int axis) {
+  static int v[2] = {-1, -1};
+  if (v[0] < 0) {
+    const char* names[2] = {"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_COL"};
+    const char* both = getenv("PM_RUNBLK_WAVES");
+    for (int a = 0; a < 2; ++a) {
+      const char* e = getenv(names[a]);
+      if (!e) e = both;
+      int x = e ? atoi(e) : 0;
+      v[a] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
+    }
+  }
+  if (v[axis]) return v[axis];
   return chain_len > 1600 ? 8 : 4;
 }
 
@@ -398,9 +409,9 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len), runblk_group(cp.semantics, g.axis, amp), h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis), runblk_group(cp.semantics, g.axis, amp), h->stream);
   } else {
-    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves(chain_len) : 1, h->stream);
+    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves(chain_len, g.axis) : 1, h->stream);
   }
   return launch_check(h, "sweep");
 }
@@ -453,7 +464,7 @@ void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
 
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
-int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
+int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots) {
   const pm_params& p = h->params;
   CostParams cp{};
   int last_pw = 0, last_ph = 0;
@@ -482,6 +493,46 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
     launch_background(h, ps, bcp, in, factor, cached, slots);
   }
   return launch_check(h, "background");
+}
+
+bool view_streams_enabled() {
+  static bool v = [] {
+    const char* e = getenv("PM_VIEW_STREAMS");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
+int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
+  if (ps.n_views != 2 || !view_streams_enabled()) return run_one_view_set(h, ps, slots);
+  if (!h->view_fork) {
+    PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
+    for (int v = 0; v < 2; ++v) {
+      PM_HIP(h, hipStreamCreateWithFlags(&h->view_stream[v], hipStreamNonBlocking));
+      PM_HIP(h, hipEventCreateWithFlags(&h->view_join[v], hipEventDisableTiming));
+    }
+  }
+  hipStream_t main_stream = h->stream;
+  PM_HIP(h, hipEventRecord(h->view_fork, main_stream));
+  int rc = PM_OK;
+  for (int v = 0; v < 2 && rc == PM_OK; ++v) {
+    PlaneSet pv = ps;
+    pv.view_fixed = v;
+    if (hipStreamWaitEvent(h->view_stream[v], h->view_fork, 0) != hipSuccess) {
+      rc = PM_ERR_HIP;
+      break;
+    }
+    h->stream = h->view_stream[v];  // every launch helper enqueues on h->stream
+    rc = run_one_view_set(h, pv, slots / 2);
+    h->stream = main_stream;
+    if (rc == PM_OK && hipEventRecord(h->view_join[v], h->view_stream[v]) != hipSuccess) rc = PM_ERR_HIP;
+  }
+  if (rc != PM_OK) {
+    if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
+    return rc;
+  }
+  for (int v = 0; v < 2; ++v) PM_HIP(h, hipStreamWaitEvent(main_stream, h->view_join[v], 0));
+  return PM_OK;
 }
 
 int validate_params(pm_handle* h, const pm_params& p) {
@@ -604,6 +655,12 @@ void pm_destroy(pm_handle* h) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  for (int v = 0; v < 2; ++v) {
+    if (h->view_stream[v]) (void)hipStreamSynchronize(h->view_stream[v]);
+    if (h->view_join[v]) (void)hipEventDestroy(h->view_join[v]);
+    if (h->view_stream[v]) (void)hipStreamDestroy(h->view_stream[v]);
+  }
+  if (h->view_fork) (void)hipEventDestroy(h->view_fork);
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   for (auto& sl : h->pipe) {

@@ -292,7 +292,9 @@ def test_device_entry_point_with_torch_buffers(pm, oracle, synth):
         e.match_device(2, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
                        DR.data_ptr())
         prof = e.profile_read()
-    assert prof["sweep_row"][0] == 4 and prof["sweep_col"][0] == 4 and prof["noise_cost"][0] == 2
+    # 2 iterations x 2 row sweeps (and column sweeps), x 2 when the views run on their own streams (default)
+    assert prof["sweep_row"][0] in (4, 8) and prof["sweep_col"][0] == prof["sweep_row"][0]
+    assert prof["noise_cost"][0] == prof["sweep_row"][0] // 2
     assert prof["sweep_row"][1] > 0
     for i, p in enumerate(pairs):
         el, er = oracle.match(oparams(oracle, 0, 5, 2), p[0], p[1], p[2], p[3])

@@ -3,25 +3,25 @@
 
 usage: tools/make_traffic.py <fetch.csv> <write.csv> <out.json>
 Per-launch averages in KiB for the dominant kernels (the counters report KiB; summed over XCD instances)."""
-import csv, collections, json, sys
+import csv, collections, json, re, sys
+
+
+CLASSES = (("sweep_row", r"k_runblk2<\d+, \d+, 0,"), ("sweep_col", r"k_runblk2<\d+, \d+, 1,"),
+           ("noise_cost", r"k_noise_cost_tiled"))
 
 
 def per_launch(path, counter):
-    tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+    """class -> (mean counter value per launch over all kernels of the class, kernel names, launches)"""
+    tot, disp, names = collections.defaultdict(float), collections.defaultdict(set), collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"]
-        tot[k] += float(r["Counter_Value"])
-        disp[k].add(r["Dispatch_Id"])
-    return {k: tot[k] / len(disp[k]) for k in tot}
-
-
-def pick(d, *subs):
-    for k, v in d.items():
-        if all(s in k for s in subs):
-            return k, v
-    return None, None
+        for cls, pat in CLASSES:
+            if re.search(pat, r["Kernel_Name"]):
+                tot[cls] += float(r["Counter_Value"])
+                disp[cls].add(r["Dispatch_Id"])
+                names[cls].add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
+    return {c: (tot[c] / len(disp[c]), sorted(names[c]), len(disp[c])) for c in tot}
 
 
 def main():
@@ -29,12 +29,10 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
                      "--warmup 1 --no-cpu-baseline --host-pairs 0; per-launch averages, KiB; FETCH_SIZE is uncalibrated "
                      "for 1-4 B/lane loads (MI355X_MICROARCH.md HBM section)", "kernels": {}}
-    for name, subs in (("sweep_row", ("k_runblk2<0, 32, 0,",)), ("sweep_col", ("k_runblk2<0, 32, 1,",)),
-                       ("noise_cost", ("k_noise_cost_tiled",))):
-        kf, f = pick(fetch, *subs)
-        kw, w = pick(write, *subs)
-        if kf:
-            out["kernels"][name] = {"kernel": kf.split("(")[0].replace("void ", ""), "fetch_kib": f, "write_kib": w}
+    for cls, _ in CLASSES:
+        if cls in fetch:
+            out["kernels"][cls] = {"kernels": fetch[cls][1], "launches_sampled": fetch[cls][2],
+                                   "fetch_kib": fetch[cls][0], "write_kib": write.get(cls, (None,))[0]}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
