@@ -60,7 +60,9 @@ struct pm_handle {
   bool counters_on = false;                // same-address atomics serialise: opt-in only
   int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
 
-  SeedScratch seed{};  // scratch of the device seeder (pm_seed.hpp)
+  SeedScratch seed{};   // scratch of the device seeder (pm_seed.hpp)
+  SeedScratch seed2{};  // second set for the right view's seeder (allocated on first use; per-view streams)
+  bool need_seed[2] = {false, false};  // set by pm_match_device: views whose seed map the device computes
 
   // row-tiled mode (pm_tile_*)
   bool tile_on = false;
@@ -312,11 +314,34 @@ SeedParams seed_params(const pm_params& p) {
 
 // SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
 // mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
-int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view) {
+int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
+  const size_t plane = (size_t)h->max_rows * h->max_pitch;
+  sc.cap = (int)(plane / 4 + 64);
+  PM_HIP(h, hipMalloc((void**)&sc.dx, sizeof(short) * plane));
+  PM_HIP(h, hipMalloc((void**)&sc.dy, sizeof(short) * plane));
+  PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
+  PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
+  PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
+  PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * 4));
+  PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
+  PM_HIP(h, hipMalloc((void**)&sc.sparse, sizeof(float) * plane));
+  PM_HIP(h, hipMalloc((void**)&sc.tmp, sizeof(float) * plane));
+  sc.sort_tmp = nullptr;
+  sc.sort_tmp_bytes = 0;
+  PM_HIP(h, hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap,
+                                                        0, 64, h->stream));
+  PM_HIP(h, hipMalloc(&sc.sort_tmp, sc.sort_tmp_bytes));
+  return PM_OK;
+}
+
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0) {
+  if (scratch == 1 && !h->seed2.dx)
+    if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
+  SeedScratch& sc = scratch == 1 ? h->seed2 : h->seed;
   const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
   const uint8_t* tgt = ps.img8 + ((size_t)b * 4 + (view == 0 ? 1 : 2)) * ps.plane;
   float* out = ps.disp + ((size_t)b * 2 + view) * ps.plane;
-  PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
+  PM_HIP(h, seed_sparse_init(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
                              h->params.init_dilate_factor, out, ps.pitch, h->stream));
   return PM_OK;
 }
@@ -503,8 +528,20 @@ bool view_streams_enabled() {
   return v;
 }
 
+int seed_views(pm_handle* h, const PlaneSet& ps, int n_pairs, int view, int scratch) {
+  if (!h->need_seed[view]) return PM_OK;
+  Launch l(h, PM_K_SEED);
+  for (int b = 0; b < n_pairs; ++b)
+    if (int rc = run_sparse_init(h, ps, b, view, scratch)) return rc;
+  return PM_OK;
+}
+
 int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
-  if (ps.n_views != 2 || !view_streams_enabled()) return run_one_view_set(h, ps, slots);
+  if (ps.n_views != 2 || !view_streams_enabled()) {
+    for (int v = 0; v < ps.n_views; ++v)
+      if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
+    return run_one_view_set(h, ps, slots);
+  }
   if (!h->view_fork) {
     PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
     for (int v = 0; v < 2; ++v) {
@@ -523,7 +560,8 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
       break;
     }
     h->stream = h->view_stream[v];  // every launch helper enqueues on h->stream
-    rc = run_one_view_set(h, pv, slots / 2);
+    rc = seed_views(h, ps, slots / 2, v, v);
+    if (rc == PM_OK) rc = run_one_view_set(h, pv, slots / 2);
     h->stream = main_stream;
     if (rc == PM_OK && hipEventRecord(h->view_join[v], h->view_stream[v]) != hipSuccess) rc = PM_ERR_HIP;
   }
@@ -650,7 +688,9 @@ void pm_destroy(pm_handle* h) {
   }
   void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
-                 h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->snap_disp,
+                 h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->seed2.dx, h->seed2.dy,
+                 h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.sparse,
+                 h->seed2.tmp, h->seed2.sort_tmp, h->snap_disp,
                  h->snap_cost, h->img_scalars, h->enh_tmp, h->enh_q, h->enh_taps};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -733,24 +773,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   h->noise_capacity = plane;
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
   PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 8, h->stream));
-  {
-    SeedScratch& sc = h->seed;
-    sc.cap = (int)(plane / 4 + 64);
-    PM_HIP(h, hipMalloc((void**)&sc.dx, sizeof(short) * plane));
-    PM_HIP(h, hipMalloc((void**)&sc.dy, sizeof(short) * plane));
-    PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
-    PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
-    PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
-    PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * 4));
-    PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
-    PM_HIP(h, hipMalloc((void**)&sc.sparse, sizeof(float) * plane));
-    PM_HIP(h, hipMalloc((void**)&sc.tmp, sizeof(float) * plane));
-    sc.sort_tmp = nullptr;
-    sc.sort_tmp_bytes = 0;
-    PM_HIP(h, hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap,
-                                                          0, 64, h->stream));
-    PM_HIP(h, hipMalloc(&sc.sort_tmp, sc.sort_tmp_bytes));
-  }
+  if (int rc = alloc_seed_scratch(h, h->seed)) return rc;
   const size_t tight = (size_t)max_rows * max_cols;
   PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
@@ -812,15 +835,10 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
                        (size_t)cols);
   }
   if (int rc = launch_check(h, "seed")) return rc;
-  if (h->params.sparse_init) {  // a missing seed map is computed on the device, as the reference's Match() does
-    Launch l(h, PM_K_SEED);
-    for (int b = 0; b < n; ++b) {
-      if (!d_seed_l)
-        if (int rc = run_sparse_init(h, ps, b, 0)) return rc;
-      if (!d_seed_r && n_views > 1)
-        if (int rc = run_sparse_init(h, ps, b, 1)) return rc;
-    }
-  }
+  // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
+  // the two views' seeders overlap on their own streams)
+  h->need_seed[0] = h->params.sparse_init && !d_seed_l;
+  h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
   if (int rc = run_views(h, ps, n * n_views)) return rc;
   {
     Launch l(h, PM_K_FINALIZE);
