@@ -407,7 +407,7 @@ int runblk_waves(int chain_len, int axis) {
 // amplitude decays, and short runs waste most of a 32-lane strip: measured at 720p / 11x11 / amp 32/2^i
 // (tools/sweep_g16_iter.sh) column sweeps win with 16-lane groups from amplitude 4 on, row sweeps (one
 // position fewer per strip: the DPP spare lane) only from 0.5 on.
-int runblk_group(int semantics, int axis, float amp) {
+int runblk_group(int semantics, int axis, float amp, int win) {
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_GROUP");
     const int g = e ? atoi(e) : 0;
@@ -415,6 +415,7 @@ int runblk_group(int semantics, int axis, float amp) {
   }();
   if (v) return v;
   if (semantics != PM_SEM_CPU) return 16;
+  if (win <= 5) return 16;  // small windows leave 11+ positions in a 16-lane strip: 16 wins at every amplitude
   return amp <= (axis == 0 ? 0.5f : 4.0f) ? 16 : 32;
 }
 
@@ -434,7 +435,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis), runblk_group(cp.semantics, g.axis, amp), h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis), runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph), h->stream);
   } else {
     launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves(chain_len, g.axis) : 1, h->stream);
   }

@@ -511,6 +511,7 @@ inline void launch_sweep_run2(const PlaneSet& ps, const CostParams& cp, const Sw
     else launch_run2_k<1, 8, 1, 3, 3>(ps, cp, g, slots, waves, stream);
     return;
   }
+  // (8-lane groups for PM_SEM_CPU 3x3 windows were tried: bit-identical, but 2.82 vs 2.66 ms per frame with 16)
   const bool g16 = group <= 16 && (cp.semantics != 0 || (cp.pw == cp.ph && cp.pw <= 11));
   if (g.axis == 0) {
     if (g16) launch_run2_axis<16, 0>(ps, cp, g, slots, waves, stream);
