@@ -772,8 +772,8 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
   h->noise_capacity = plane;
-  PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 8));
-  PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 8, h->stream));
+  PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 16));  // [8..13]: timing builds only
+  PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 16, h->stream));
   if (int rc = alloc_seed_scratch(h, h->seed)) return rc;
   const size_t tight = (size_t)max_rows * max_cols;
   PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
@@ -1480,7 +1480,18 @@ int pm_debug_counters(pm_handle* h, uint64_t out[8]) {
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   PM_HIP(h, hipMemcpy(out, h->counters, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
-  PM_HIP(h, hipMemset(h->counters, 0, sizeof(uint64_t) * 8));
+#ifdef PM_RUN2_TIMING
+  {
+    uint64_t t[8];
+    PM_HIP(h, hipMemcpy(t, h->counters + 8, sizeof(t), hipMemcpyDeviceToHost));
+    if (t[5])
+      fprintf(stderr, "run2 timing (cycles per sampled round-1 step): lds+ballot %.0f, loads+lines %.0f, window+cost %.0f, "
+                      "decide %.0f, loop %.0f; steps %llu\n",
+              (double)t[0] / t[5], (double)t[1] / t[5], (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5],
+              (unsigned long long)t[5]);
+  }
+#endif
+  PM_HIP(h, hipMemset(h->counters, 0, sizeof(uint64_t) * 16));
   return PM_OK;
 }
 

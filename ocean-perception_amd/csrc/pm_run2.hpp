@@ -36,7 +36,15 @@ struct RunStep2 {
   int mpos;
   bool adopt;
   float d0, c0, cost;
+#ifdef PM_RUN2_TIMING
+  long long t[5];  // s_memtime at: entry, after the need ballot, after the line sums, after the cost, at return
+#endif
 };
+#ifdef PM_RUN2_TIMING
+#define PM_T(k) st.t[k] = clock64()
+#else
+#define PM_T(k)
+#endif
 
 template <int GS, int AXIS, int TPW, int TPH>
 __device__ __forceinline__ int run2_nd(const CostParams& cp) {
@@ -124,6 +132,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   const unsigned lanes_nd = (1u << nd) - 1u;
 
   RunStep2 st;
+  PM_T(0);
   st.mpos = dir > 0 ? gl : nd - 1 - gl;
   const bool inr = act && (gl < nd) && (i + st.mpos < n_end);
   st.d0 = inr ? din[i + st.mpos + 1] : 0.f;
@@ -138,6 +147,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   const bool has_need = need != 0u;
   const int r = has_need ? first_pos(need) : 0;
   const int r_gl = glane_of(r);
+  PM_T(1);
 
   const int pos = g.s_first + (i + st.mpos) * dir;
   const int px = AXIS == 0 ? pos : chain;
@@ -151,8 +161,17 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 
   const unsigned valid_m = gballot<GS>(valid, gbase);
   const bool valid_r = has_need && ((valid_m >> r_gl) & 1u);
-  const float a_r = __shfl(a, gbase + r_gl, kWave);
-  const int delta_r = __shfl(delta, gbase + r_gl, kWave);
+  // Reference bilinear parameters = those of the step's FIRST position, computed from (i, cand) alone with the
+  // same float operations -- group-uniform without any cross-lane traffic, so the window loads do not wait for
+  // a ds_bpermute round trip.  A position whose own (a, delta) differ (x - d crossed a binade since position
+  // 0) is not decided in this step; if that is r itself the step just advances to r and the next one starts
+  // there (then r IS the first position).  Column sweeps: x is the chain, all positions agree by construction.
+  const int px0 = AXIS == 0 ? g.s_first + i * dir : chain;
+  float cx0 = (float)px0 - cand;
+  cx0 = cx0 - shift;
+  const float fl0 = floorf(cx0);
+  const float a_r = cx0 - fl0;
+  const int delta_r = (px0 - half_w) - (int)fl0;
   const bool same = valid && (a == a_r) && (delta == delta_r);
 
   st.cost = 0.f;
@@ -280,11 +299,16 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       }
     }
     const int line = (int)(sc | (sg << 16));
+    PM_T(2);
     int wsum = line;
 #pragma unroll
     for (int t = 1; t < win; ++t) wsum = line + wave_shl1(wsum);
     st.cost = cpu_cost_from_sums(wsum & 0xffff, (int)((unsigned)wsum >> 16), cp);
   }
+#ifdef PM_RUN2_TIMING
+  else st.t[2] = clock64();
+#endif
+  PM_T(3);
 
   // The run passes a position iff it ends up holding `cand`: already equal, or adopted.  Positions before
   // r are neutral by the definition of r, so the first position that does not pass is >= r; it is decided
@@ -305,6 +329,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   st.rej_pos = act ? rej_pos : -1;
   st.advance = act ? advance : 0;
   st.adopt = adopt && st.mpos < q;
+  PM_T(4);
   return st;
 }
 
@@ -362,6 +387,9 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   const int i1 = min(n, i0 + seg_len);
   const bool active = i0 < n;
   unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
+#ifdef PM_RUN2_TIMING
+  long long tph[5] = {0, 0, 0, 0, 0}, t_prev_end = 0;
+#endif
 
   // ---- round 1 ------------------------------------------------------------------------------------
   float in_used = active ? din[i0] : 0.f;
@@ -372,6 +400,13 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       const bool act = active && i < i1;
       const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
+#ifdef PM_RUN2_TIMING
+      if constexpr (SEM == 0) {
+        for (int k = 0; k < 4; ++k) tph[k] += st.t[k + 1] - st.t[k];
+        if (t_prev_end) tph[4] += st.t[0] - t_prev_end;  // loop part between two steps (LDS writes, bookkeeping)
+        t_prev_end = st.t[4];
+      }
+#endif
       if (st.mpos >= 0 && st.mpos < st.advance) {
         dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.rej_d0 : cand;
         cout[i + st.mpos + 1] = st.adopt ? st.cost : st.c0;
@@ -436,6 +471,12 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     if (!s_changed[round & 1]) break;
   }
   __syncthreads();
+#ifdef PM_RUN2_TIMING
+  if (ps.counters && lane == 0 && w == 0 && blockIdx.x % 16 == 0) {  // a sample of wavefronts: phase cycles of round 1
+    for (int k = 0; k < 5; ++k) atomicAdd(&ps.counters[8 + k], (unsigned long long)tph[k]);
+    atomicAdd(&ps.counters[13], (unsigned long long)n_steps);
+  }
+#endif
   if (ps.counters && lane == 0) {
     const int base = AXIS * 4;
     atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);
