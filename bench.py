@@ -157,6 +157,22 @@ def host_buffer_leg(pm, params, args, pair, device):
         while e.in_flight():
             e.collect()
         out["pipelined"] = n / (time.perf_counter() - t0)
+    # two handles, pairs alternating between them: two matches (four view streams) share the chip
+    with pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=2) as e0, \
+            pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=2) as e1:
+        engs = (e0, e1)
+        for e in engs:
+            e.match(pair["left"], pair["right"], *seeds)
+        t0 = time.perf_counter()
+        for i in range(n):
+            e = engs[i & 1]
+            if e.in_flight() == 2:
+                e.collect()
+            e.submit(pair["left"], pair["right"], *seeds, tag=i)
+        for e in engs:
+            while e.in_flight():
+                e.collect()
+        out["pipelined_two_handles"] = n / (time.perf_counter() - t0)
     return out
 
 
