@@ -142,6 +142,20 @@ Raster DecodePnm(const std::vector<uint8_t>& file, const std::string& path) {
 int ReadImage(const std::string& path, Image1b* gray, Image3b* color) {
   const std::vector<uint8_t> file = ReadFile(path);
   Raster r;
+  if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8) {
+    // IMREAD_ANYCOLOR: a 3-component JPEG comes back as BGR, a 1-component one as gray
+    bool three = false;
+    for (size_t i = 2; i + 9 < file.size() && file[i] == 0xFF;) {
+      const int m = file[i + 1];
+      if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+        three = file[i + 9] == 3;
+        break;
+      }
+      if (m == 0xDA) break;
+      i += 2 + (((size_t)file[i + 2] << 8) | file[i + 3]);
+    }
+    return DecodeJpeg(file.data(), file.size(), three, gray, color);
+  }
   if (file.size() >= 2 && file[0] == 'P' && (file[1] == '5' || file[1] == '6')) r = DecodePnm(file, path);
   else r = DecodePng(file, path);
   if (r.ch <= 2) {  // gray [+ alpha]

@@ -5,8 +5,8 @@
 //   EurocDataset                              src/vehicle/dataset/euroc_dataset.cpp:12-19,116-165 (ParseStereo)
 //   MaybeConvertToGray                        src/vehicle/vision_core/image_util.cpp:52-61
 // with an own image reader in place of cv::imread (8-bit PNG through zlib, binary PGM / PPM).  IMU, depth, range
-// and ground-truth streams are not on the stereo path and are not mirrored.  JPEG (the LCM image_t path,
-// lcm_util/decode_image.cpp:11-32) is not supported: no JPEG decoder is available to this build.
+// and ground-truth streams are not on the stereo path and are not mirrored.  JPEG files / LCM image_t payloads
+// (lcm_util/decode_image.cpp:11-32) go through the own baseline decoder in jpeg.cpp.
 #pragma once
 
 #include <cstdint>
@@ -35,10 +35,14 @@ struct StereoImage final {
 typedef StereoImage<Image1b> StereoImage1b;
 typedef StereoImage<Image3b> StereoImage3b;
 
-// cv::imread(path, cv::IMREAD_ANYCOLOR) for the formats above: one channel -> gray, otherwise BGR (alpha dropped).
+// cv::imread(path, cv::IMREAD_ANYCOLOR) for PNG / PNM / JPEG: one channel -> gray, otherwise BGR (alpha dropped).
 // Exactly one of *gray / *color is filled; returns the channel count (1 or 3).  Throws std::runtime_error on
 // unreadable or unsupported files (16-bit, palette, interlaced PNG; ASCII PNM).
 int ReadImage(const std::string& path, Image1b* gray, Image3b* color);
+// cv::imdecode for a JPEG held in memory (lcm_util/decode_image.cpp:11-32: DecodeJPG) -- baseline / extended
+// sequential Huffman, 8 bit, 1 or 3 components.  want_color == false is IMREAD_GRAYSCALE: the luma plane as the
+// decoder library delivers it (no colour conversion); true: BGR.  Returns the channel count written.
+int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Image3b* color);
 // cv::cvtColor(BGR2GRAY) on 8-bit images: (1868 B + 9617 G + 4899 R + 8192) >> 14.
 Image1b ConvertToGray(const Image3b& bgr);
 }  // namespace core

@@ -2,12 +2,15 @@
 // stereo pairs back into a callback that matches them -- here through the mirrored EurocDataset, the own PNG
 // reader and the pipelined Submit()/Collect().  Modes:
 //   dataset_main read <image> <out.raw>                 decode one image, write gray or BGR bytes, print "rows cols ch"
+//   dataset_main readgray <jpeg> <out.raw>              IMREAD_GRAYSCALE of a JPEG (luma plane)
 //   dataset_main play <euroc_root> <out_dir> <iters>    match every pair, write disp_<i>.f32 (left view)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <string>
+#include <vector>
 
 #include "dataset.hpp"
 
@@ -30,6 +33,16 @@ int main(int argc, char** argv) {
         std::ofstream fg(std::string(argv[3]) + ".gray", std::ios::binary);
         fg.write(reinterpret_cast<const char*>(g.data()), (std::streamsize)g.rows * g.cols);
       }
+      return 0;
+    }
+    if (mode == "readgray") {  // cv::imread(path, IMREAD_GRAYSCALE) of a JPEG: the luma plane
+      std::ifstream in(argv[2], std::ios::binary);
+      std::vector<char> buf((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+      core::Image1b gray;
+      core::DecodeJpeg(reinterpret_cast<const uint8_t*>(buf.data()), buf.size(), false, &gray, nullptr);
+      std::ofstream f(argv[3], std::ios::binary);
+      f.write(reinterpret_cast<const char*>(gray.data()), (std::streamsize)gray.rows * gray.cols);
+      std::printf("%d %d 1\n", gray.rows, gray.cols);
       return 0;
     }
     if (mode == "play" && argc >= 5) {

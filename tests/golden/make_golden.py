@@ -6,8 +6,9 @@
 
 Fixtures are data: inputs + expected outputs.  The CADDY fixture holds the two JPEGs of the
 reference's test/resources (caddy_32_{left,right}.jpg, used by its sgbm/feature tests and named by
-BASELINE.json configs[0]) decoded ONCE to 8-bit gray with PIL -- the decoded arrays define the
-fixture (a JPEG decoder / gray conversion other than OpenCV's differs by a few levels), plus an
+BASELINE.json configs[0]) decoded ONCE to 8-bit gray -- the luma plane as the JPEG library delivers it
+(JCS_GRAYSCALE, what cv::imread(path, GRAYSCALE) requests; Pillow's libjpeg-turbo via Image.draft("L"),
+bit-identical to the build's own decoder host/jpeg.cpp, tests/test_dataset.py) -- plus an
 explicit seed map (block-matched on a sparse grid below; the reference's GFTT seeder needs OpenCV)
 and per-row checksums of the oracle's disparity map for the 7x7 / 3-iteration configuration.
 """
@@ -75,8 +76,12 @@ def block_match_seeds(left, right, n=200, tw=31, th=11, max_disp=98, dilate_fact
 def caddy():
     from PIL import Image
     res = "/root/reference/test/resources"
-    left = np.asarray(Image.open(os.path.join(res, "caddy_32_left.jpg")).convert("L"), dtype=np.uint8)
-    right = np.asarray(Image.open(os.path.join(res, "caddy_32_right.jpg")).convert("L"), dtype=np.uint8)
+    def luma(name):
+        im = Image.open(os.path.join(res, name))
+        im.draft("L", im.size)
+        return np.asarray(im, dtype=np.uint8)
+
+    left, right = luma("caddy_32_left.jpg"), luma("caddy_32_right.jpg")
     assert left.shape == (480, 640), left.shape
     seed_l = block_match_seeds(left, right)
     seed_r = np.zeros_like(seed_l)

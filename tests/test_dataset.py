@@ -116,6 +116,59 @@ def test_image_reader_png_and_pnm(dataset_exe, tmp_path):
     assert r.returncode == 10 and "PNG" in r.stdout
 
 
+def _pil():
+    return pytest.importorskip("PIL.Image")
+
+
+@pytest.mark.parametrize("size,subsampling,quality", [((64, 48), 2, 90), ((53, 37), 2, 75), ((53, 37), 1, 85),
+                                                      ((40, 30), 0, 95), ((17, 9), 2, 60), ((129, 65), 2, 30)])
+def test_jpeg_decoder_matches_libjpeg_turbo(dataset_exe, tmp_path, size, subsampling, quality):
+    """The own baseline JPEG decoder against Pillow's (libjpeg-turbo, accurate integer IDCT, fancy upsampling):
+    luma plane (IMREAD_GRAYSCALE) and BGR output, bit for bit.  No GPU involved."""
+    Image = _pil()
+    w, h = size
+    rng = np.random.default_rng(w * h + subsampling)
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([127 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 127 + 90 * np.cos(xx / 3.0 + yy / 11.0),
+                    60 + 2.0 * xx + rng.normal(0, 12, (h, w))], -1).clip(0, 255).astype(np.uint8)
+    p = os.path.join(tmp_path, "c.jpg")
+    Image.fromarray(rgb).save(p, quality=quality, subsampling=subsampling)
+    want_rgb = np.asarray(Image.open(p).convert("RGB"))
+    im = Image.open(p)
+    im.draft("L", im.size)  # the decoder's own grayscale output = the luma plane
+    want_y = np.asarray(im)
+    assert want_y.shape == (h, w)
+    got, _ = _read(dataset_exe, p, tmp_path)
+    assert got.shape == (h, w, 3)
+    assert np.array_equal(got, want_rgb[..., ::-1]), np.abs(got.astype(int) - want_rgb[..., ::-1].astype(int)).max()
+    out = os.path.join(tmp_path, "y.raw")
+    r = subprocess.run([dataset_exe, "readgray", p, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(h, w), want_y)
+    # a grayscale JPEG
+    pg = os.path.join(tmp_path, "g.jpg")
+    Image.fromarray(rgb[..., 1]).save(pg, quality=quality)
+    got, _ = _read(dataset_exe, pg, tmp_path)
+    assert np.array_equal(got, np.asarray(Image.open(pg)))
+
+
+def test_jpeg_decoder_on_the_reference_test_images(dataset_exe, tmp_path):
+    """test/resources/caddy_32_{left,right}_small.jpg of the reference (fixtures: tests/golden/): the inputs of its
+    stereo tests are JPEGs read with cv::imread(..., GRAYSCALE)."""
+    Image = _pil()
+    for name in ("caddy_32_left_small.jpg", "caddy_32_right_small.jpg"):
+        p = os.path.join(ROOT, "tests", "golden", name)
+        im = Image.open(p)
+        im.draft("L", im.size)
+        want = np.asarray(im)
+        out = os.path.join(tmp_path, "y.raw")
+        r = subprocess.run([dataset_exe, "readgray", p, out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(out, np.uint8).reshape(want.shape), want)
+        got, _ = _read(dataset_exe, p, tmp_path)
+        assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB"))[..., ::-1])
+
+
 @pytest.mark.gpu
 def test_euroc_playback_through_the_pipelined_matcher(dataset_exe, tmp_path, oracle, synth):
     rows, cols, n = 64, 112, 5
