@@ -74,6 +74,32 @@ def test_oracle_stereo_ready_flattens_the_colour_cast():
     assert np.abs(gray.astype(np.float32) - np.clip(np.rint(g * 255), 0, 255)).max() <= 1
 
 
+def test_oracle_against_independent_implementations():
+    """scipy's separable correlation (replicate border) and the standard library's colorsys agree with the
+    oracle's Gaussian blur and HSV round trip to float accuracy (different summation order / formulas)."""
+    import colorsys
+    from scipy import ndimage
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0, 1, (40, 56, 3)).astype(np.float32)
+    k = O.gaussian_kernel(21, 21 / 4.0).astype(np.float64)
+    ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0,
+                              mode="nearest")
+    assert np.allclose(O.gaussian_blur(img, 21, 21 / 4.0), ref, rtol=0, atol=2e-6)
+    # Normalize with a known stretch: V' = (V - lo) / (hi - lo), hue and saturation kept (colorsys)
+    out = O.normalize(img)
+    lo, hi = O.value_minmax_eighth(img.max(-1))
+    for (y, x) in [(0, 0), (7, 13), (20, 41), (39, 55), (11, 2)]:
+        b, g, r = (float(c) for c in img[y, x])
+        h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        rr, gg, bb = colorsys.hsv_to_rgb(h, s, (v - lo) / (hi - lo))
+        assert np.allclose(out[y, x], (bb, gg, rr), rtol=0, atol=3e-5), (y, x)
+    # the 1/8 bilinear resize is an average of 4 neighbours at the centre of each 8x8 cell
+    V = rng.uniform(0, 1, (32, 48)).astype(np.float32)
+    cells = np.stack([V[8 * j + 3:8 * j + 5, 8 * i + 3:8 * i + 5].mean() for j in range(4) for i in range(6)])
+    lo, hi = O.value_minmax_eighth(V)
+    assert abs(lo - cells.min()) < 1e-6 and abs(hi - cells.max()) < 1e-6
+
+
 # ---- device parity ------------------------------------------------------------------------------------------
 def _dev(t, a):
     return t.from_numpy(np.ascontiguousarray(a)).cuda()
