@@ -65,9 +65,9 @@ __device__ __forceinline__ unsigned gballot(bool p, int gbase) {
 struct RowBufs {
   __amdgpu_buffer_rsrc_t ref8, refg8, tgt8, tgtg;
 };
-// Measured (profiles/r01f_ab_loads.txt): on gfx950 the MUBUF form is SLOWER here (7.26 vs 5.80 ms per frame)
-// although it removes ~60 VALU address instructions per step -- the step is bound by load issue/latency,
-// not by VALU count.  Default: plain global loads with the same scalar-row + vector-column addressing;
+// Measured (profiles/r01f_ab_loads.txt): the MUBUF form was SLOWER in the lockstep configuration (7.26 vs 5.80 ms
+// per frame) although it removes ~60 VALU address instructions per step, and is on par under per-view streams
+// (4.08 vs 4.12 ms).  Default: plain global loads with the same scalar-row + vector-column addressing;
 // -DPM_RUN2_GLOBAL_LOADS=0 selects the MUBUF form.
 // 1: the reference pixel's colour and gradient bytes come from the packed u16 plane with one load
 #ifndef PM_RUN2_REF_PK16
