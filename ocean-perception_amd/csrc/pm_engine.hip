@@ -416,7 +416,14 @@ int runblk_group(int semantics, int axis, float amp, int win) {
   if (v) return v;
   if (semantics != PM_SEM_CPU) return 16;
   if (win <= 5) return 16;  // small windows leave 11+ positions in a 16-lane strip: 16 wins at every amplitude
-  return amp <= (axis == 0 ? 0.5f : 4.0f) ? 16 : 32;
+  static float thr[2] = {-1.f, -1.f};
+  if (thr[0] < 0.f) {
+    const char* er = getenv("PM_G16_ROW_AMP");
+    const char* ec = getenv("PM_G16_COL_AMP");
+    thr[0] = er ? (float)atof(er) : 0.5f;
+    thr[1] = ec ? (float)atof(ec) : 4.0f;
+  }
+  return amp <= thr[axis] ? 16 : 32;
 }
 
 int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
