@@ -434,6 +434,10 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   const int chain_len = (g.s_last - g.s_first) * g.dir + 1;
   int engine = h->params.engine;
   if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK2;
+  // the chain engines hold a chain in LDS: beyond the CU's capacity only the serial engine remains
+  if (engine != PM_ENGINE_SERIAL && !(engine == PM_ENGINE_WAVE && cp.semantics == PM_SEM_CPU) &&
+      chain_lds_bytes(chain_len, 4 * kMaxSegWaves + 4) > kChainLdsMax)
+    engine = PM_ENGINE_SERIAL;
   // PM_SEM_GPU has two parallel engines: lane-per-segment (WAVE) and the shared-tap run step (RUNBLK2)
   if (cp.semantics != PM_SEM_CPU && (engine == PM_ENGINE_RUN || engine == PM_ENGINE_RUNBLK)) engine = PM_ENGINE_WAVE;
   if (engine == PM_ENGINE_SERIAL) {

@@ -36,6 +36,7 @@ namespace pm {
 
 constexpr int kMaxSegWaves = 16;
 
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its 4 MiB L2).
 // Adjacent chains read almost the same image rows, so chain k of the sweep goes to the block whose
 // XCD owns the band around k: block b -> chain (b % 8) * band + b / 8 (bijective for any count).
@@ -389,6 +390,7 @@ inline void launch_run_k(const PlaneSet& ps, const CostParams& cp, const SweepGe
   if (len < 16) len = 16;  // tiny chains: fewer waves do work
   const int n1 = (n + 1 + 3) & ~3;
   const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + kMaxSegWaves + 1 + 2);
+  allow_big_lds(k_runblk<AXIS, TPW, TPH>, lds_bytes);
   hipLaunchKernelGGL((k_runblk<AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
                      lds_bytes, stream, ps, cp, g, len);
 }

@@ -506,6 +506,7 @@ inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepG
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
   const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
+  allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH>, lds_bytes);
   hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
                      lds_bytes, stream, ps, cp, g, len);
 }

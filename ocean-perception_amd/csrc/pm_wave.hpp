@@ -255,6 +255,7 @@ inline void launch_sweep_wave(const PlaneSet& ps, const CostParams& cp, const Sw
     // PM_SEM_GPU: the 5-tap cost is too small to spread over a wavefront; lanes take chain segments.
     const int n = (g.s_last - g.s_first) * g.dir + 1;
     const int n1 = (n + 1 + 3) & ~3;
+    allow_big_lds(k_sweep_gpu_lanes, sizeof(float) * (4 * (size_t)n1 + kWave + 1));
     hipLaunchKernelGGL(k_sweep_gpu_lanes, dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave),
                        sizeof(float) * (4 * (size_t)n1 + kWave + 1), stream, ps, cp, g);
     return;

@@ -302,6 +302,24 @@ def test_device_entry_point_with_torch_buffers(pm, oracle, synth):
         assert_same(DR[i].cpu().numpy(), er, f"pair {i} right")
 
 
+@pytest.mark.parametrize("sem", SEMS)
+@pytest.mark.parametrize("rows,cols", [(24, 6000), (6000, 24), (20, 11000)])
+def test_very_long_chains(pm, oracle, synth, sem, rows, cols):
+    """Chains longer than 64 KB of LDS state (raised per-kernel limit) and longer than the CU's LDS (serial
+    fallback): still the oracle's maps.  Long axis 6000: 96 KB per chain; 11000: beyond 160 KB."""
+    rng = np.random.default_rng(rows + cols)
+    base = rng.integers(0, 256, (rows, cols + 40), dtype=np.uint8)
+    left, right = np.ascontiguousarray(base[:, 20:20 + cols]), np.ascontiguousarray(base[:, 14:14 + cols])  # d = 6
+    seed = np.zeros((rows, cols), np.float32)
+    seed[rows // 2 - 2:rows // 2 + 3, ::97] = 6.0
+    seed_r = seed.copy()
+    with mk(pm, sem, patch=5, iters=2, rows=rows, cols=cols) as e:
+        dl, dr = e.match(left, right, seed, seed_r)
+    el, er = oracle.match(oparams(oracle, sem, 5, 2), left, right, seed, seed_r)
+    assert_same(dl, el, "left")
+    assert_same(dr, er, "right")
+
+
 # ---- full size: properties and engine-vs-engine ------------------------------------------------------------
 def test_full_size_baseline_config_properties(pm, oracle, synth):
     """BASELINE.json configs[1]: one 1280x720 pair, 8 iterations, 11x11 window."""
