@@ -384,18 +384,21 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
 // Wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
 // 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
 int runblk_waves(int chain_len, int axis) {
-  static int v[2] = {-1, -1};
-  if (v[0] < 0) {
-    const char* names[2] = {"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_COL"};
-    const char* both = getenv("PM_RUNBLK_WAVES");
-    for (int a = 0; a < 2; ++a) {
-      const char* e = getenv(names[a]);
-      if (!e) e = both;
-      int x = e ? atoi(e) : 0;
-      v[a] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
+  struct Knobs {
+    int v[2];
+    Knobs() {
+      const char* names[2] = {"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_COL"};
+      const char* both = getenv("PM_RUNBLK_WAVES");
+      for (int a = 0; a < 2; ++a) {
+        const char* e = getenv(names[a]);
+        if (!e) e = both;
+        const int x = e ? atoi(e) : 0;
+        v[a] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
+      }
     }
-  }
-  if (v[axis]) return v[axis];
+  };
+  static const Knobs k;  // initialised once, thread-safe
+  if (k.v[axis]) return k.v[axis];
   return chain_len > 1600 ? 8 : 4;
 }
 
@@ -416,13 +419,17 @@ int runblk_group(int semantics, int axis, float amp, int win) {
   if (v) return v;
   if (semantics != PM_SEM_CPU) return 16;
   if (win <= 5) return 16;  // small windows leave 11+ positions in a 16-lane strip: 16 wins at every amplitude
-  static float thr[2] = {-1.f, -1.f};
-  if (thr[0] < 0.f) {
-    const char* er = getenv("PM_G16_ROW_AMP");
-    const char* ec = getenv("PM_G16_COL_AMP");
-    thr[0] = er ? (float)atof(er) : 0.5f;
-    thr[1] = ec ? (float)atof(ec) : 4.0f;
-  }
+  struct Thr {
+    float t[2];
+    Thr() {
+      const char* er = getenv("PM_G16_ROW_AMP");
+      const char* ec = getenv("PM_G16_COL_AMP");
+      t[0] = er ? (float)atof(er) : 0.5f;
+      t[1] = ec ? (float)atof(ec) : 4.0f;
+    }
+  };
+  static const Thr thr_knobs;
+  const float* thr = thr_knobs.t;
   return amp <= thr[axis] ? 16 : 32;
 }
 
