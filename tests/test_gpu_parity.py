@@ -320,6 +320,47 @@ def test_very_long_chains(pm, oracle, synth, sem, rows, cols):
     assert_same(dr, er, "right")
 
 
+def test_random_configurations_match_the_oracle(pm, oracle, synth):
+    """Property test (hypothesis, fixed seed): random small sizes, windows, iteration counts, noise schedules,
+    group widths and both semantics -- the default engine equals the oracle bit for bit."""
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+
+    @hyp.settings(max_examples=80, deadline=None, derandomize=True, database=None,
+                  suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(rows=st.integers(8, 44), cols=st.integers(8, 90), sem=st.sampled_from([0, 1]),
+               patch=st.sampled_from([3, 5, 7, 9, 11]), iters=st.integers(0, 4),
+               amp0=st.sampled_from([32.0, 6.0, 1.0, 0.25]), lr=st.booleans(), seed=st.integers(0, 10 ** 6),
+               density=st.sampled_from([0, 3, 25]))
+    def run(rows, cols, sem, patch, iters, amp0, lr, seed, density):
+        hyp.assume(rows > patch + 2 and cols > patch + 2)
+        rng = np.random.default_rng(seed)
+        d_true = int(rng.integers(0, max(1, min(12, cols // 4))))
+        base = rng.integers(0, 256, (rows, cols + d_true), dtype=np.uint8)
+        base = (base.astype(np.float32) * 0.5 + np.roll(base, 1, 1) * 0.5).astype(np.uint8)  # some structure
+        left = np.ascontiguousarray(base[:, d_true:d_true + cols])
+        right = np.ascontiguousarray(base[:, :cols])
+        seed_l = np.zeros((rows, cols), np.float32)
+        if density:
+            ys, xs = rng.integers(0, rows, density), rng.integers(0, cols, density)
+            seed_l[ys, xs] = rng.uniform(0.5, max(1.0, d_true + 2.0), density).astype(np.float32)
+        seed_r = np.ascontiguousarray(seed_l[:, ::-1]) if lr else None
+        params = pm.default_params(sem, patch=patch, patchmatch_iters=iters, left_right_check=1 if lr else 0)
+        op = oparams(oracle, sem, patch, iters)
+        op.left_right_check = 1 if lr else 0
+        for i in range(iters):
+            params.noise_amp[i] = amp0 / (2 ** i)
+            op.noise_amp[i] = amp0 / (2 ** i)
+        with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
+            dl, dr = e.match(left, right, seed_l, seed_r)
+        el, er = oracle.match(op, left, right, seed_l, seed_r)
+        assert_same(dl, el, f"left {rows}x{cols} sem{sem} p{patch} it{iters} amp{amp0} lr{lr}")
+        if lr:
+            assert_same(dr, er, "right")
+
+    run()
+
+
 # ---- full size: properties and engine-vs-engine ------------------------------------------------------------
 def test_full_size_baseline_config_properties(pm, oracle, synth):
     """BASELINE.json configs[1]: one 1280x720 pair, 8 iterations, 11x11 window."""
