@@ -1762,18 +1762,18 @@ int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, in
   const size_t values = (size_t)rows * cols * ch;
   if (int rc = ensure_enh_scratch(h, values)) return rc;
   if (int rc = ensure_taps(h, ksize, sigma)) return rc;
-  const size_t row_lds = sizeof(float) * ((size_t)(256 + ksize - 1) * ch + ksize);
+  const size_t row_lds = sizeof(float) * ((size_t)(blur_skew(kBlurRowPx + ksize - 1) + 1) * ch + ksize);
   if (row_lds > 64 * 1024) {
     set_err(h, "gaussian: kernel of %d taps x %d channels exceeds the row tile", ksize, ch);
     return PM_ERR_SIZE;
   }
-  const dim3 rgrid((unsigned)((cols + 255) / 256), (unsigned)rows);
+  const dim3 rgrid((unsigned)((cols + kBlurRowPx - 1) / kBlurRowPx), (unsigned)rows);
   const float* taps = h->enh_taps;
   switch (ch) {
-    case 1: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 1>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
-    case 2: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 2>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
-    case 3: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 3>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
-    default: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 4>), rgrid, dim3(256), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    case 1: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 1>), rgrid, dim3(kBlurRowThreads), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    case 2: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 2>), rgrid, dim3(kBlurRowThreads), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    case 3: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 3>), rgrid, dim3(kBlurRowThreads), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
+    default: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 4>), rgrid, dim3(kBlurRowThreads), row_lds, h->stream, d_src, rows, cols, ksize, taps, h->enh_tmp); break;
   }
   // column tile: W columns x T rows of outputs, ((T + 2c) x W + c + 1) floats of LDS within 64 KB; a smaller
   // tile (32 KB) doubles the blocks per CU, which pays more than the extra halo re-reads

@@ -21,41 +21,100 @@ __device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ?
 
 // ---- row pass: dst[y][x][q] = sum_t k[t] * src[y][clamp(x - c + t)][q], t = 0 .. ksize-1 in order -------------
 // SRC_U8: the source is the 8-bit image, cast like CastImage3bTo3f (x * (float)(1/255.)).
-// One thread per pixel, CH accumulators; the row window and the taps live in LDS.
-// grid = (ceil(cols / 256), rows), block = 256, dynamic LDS = ((256 + ksize - 1) * CH + ksize) floats.
+// One thread per FOUR consecutive pixels: every window sample is read from LDS once and feeds four outputs with
+// four different taps (register blocking: the first version, one pixel per thread, was LDS-bandwidth bound --
+// 3 x 427 reads per pixel).  Each output still adds its taps in ascending order, so the result is unchanged.
+// LDS is planar per channel with one pad word every 32 (lane stride 4 would hit 8 banks only).
+// grid = (ceil(cols / 512), rows), block = 128, dynamic LDS = (CH * (skew(512 + ksize - 1) + 1) + ksize) floats.
+constexpr int kBlurRowThreads = 128;
+constexpr int kBlurRowPx = 4 * kBlurRowThreads;
+__host__ __device__ inline int blur_skew(int p) { return p + (p >> 5); }
 template <bool SRC_U8, int CH>
-__global__ void __launch_bounds__(256) k_blur_rows(const void* __restrict__ src, int rows, int cols, int ksize,
-                                                   const float* __restrict__ taps, float* __restrict__ dst) {
+__global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __restrict__ src, int rows, int cols,
+                                                               int ksize, const float* __restrict__ taps,
+                                                               float* __restrict__ dst) {
   extern __shared__ float lds[];
-  const int y = blockIdx.y, x0 = blockIdx.x * 256, c = ksize / 2;
-  const int span = 256 + ksize - 1;
-  float* s_k = lds + span * CH;
+  constexpr int R = 4;
+  const int y = blockIdx.y, x0 = blockIdx.x * kBlurRowPx, c = ksize / 2;
+  const int span = kBlurRowPx + ksize - 1;
+  const int plane = blur_skew(span) + 1;
+  float* s_k = lds + plane * CH;
   const float cast = (float)(1.0 / 255.0);
-  for (int e = threadIdx.x; e < span * CH; e += 256) {
+  for (int e = threadIdx.x; e < span * CH; e += kBlurRowThreads) {
     const int p = e / CH, q = e - p * CH;
     const int sx = clampi_d(x0 - c + p, 0, cols - 1);
     const size_t o = ((size_t)y * cols + sx) * CH + q;
-    lds[e] = SRC_U8 ? (float)((const uint8_t*)src)[o] * cast : ((const float*)src)[o];
+    lds[q * plane + blur_skew(p)] = SRC_U8 ? (float)((const uint8_t*)src)[o] * cast : ((const float*)src)[o];
   }
-  for (int e = threadIdx.x; e < ksize; e += 256) s_k[e] = taps[e];
+  for (int e = threadIdx.x; e < ksize; e += kBlurRowThreads) s_k[e] = taps[e];
   __syncthreads();
-  const int x = x0 + threadIdx.x;
-  if (x >= cols) return;
-  const float* w = lds + threadIdx.x * CH;
-  float s[CH];
+  const int p0 = threadIdx.x * R;  // first output pixel of this thread, relative to x0
+  if (x0 + p0 >= cols) return;
+  float s[R][CH];
+  // window position u (sample x0 - c + p0 + u) contributes tap j = u - r to output r.
+  // prologue u < R: the first taps of outputs 0 .. u (the sum starts WITH k[0] * w, it is not added to 0)
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int sp = blur_skew(p0 + u);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const float w = lds[q * plane + sp];
+#pragma unroll
+      for (int r = 0; r <= u; ++r) {
+        const float prod = s_k[u - r] * w;
+        s[r][q] = (u == r) ? prod : s[r][q] + prod;
+      }
+    }
+  }
+  // main part: every output has a tap at this position.  Outputs are paired (0,1) and (2,3): packed-f32
+  // multiply and add, the same two IEEE operations per tap as the scalar form.
   {
-    const float k0 = s_k[0];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[2][CH];
 #pragma unroll
-    for (int q = 0; q < CH; ++q) s[q] = k0 * w[q];
+    for (int q = 0; q < CH; ++q) {
+      a[0][q] = (f2){s[0][q], s[1][q]};
+      a[1][q] = (f2){s[2][q], s[3][q]};
+    }
+#pragma unroll 2
+    for (int u = R; u < ksize; ++u) {
+      const int sp = blur_skew(p0 + u);
+      const f2 k01 = {s_k[u], s_k[u - 1]}, k23 = {s_k[u - 2], s_k[u - 3]};
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const float w = lds[q * plane + sp];
+        const f2 ww = {w, w};
+        a[0][q] = a[0][q] + k01 * ww;
+        a[1][q] = a[1][q] + k23 * ww;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      s[0][q] = a[0][q].x;
+      s[1][q] = a[0][q].y;
+      s[2][q] = a[1][q].x;
+      s[3][q] = a[1][q].y;
+    }
   }
-#pragma unroll 4
-  for (int t = 1; t < ksize; ++t) {
-    const float kt = s_k[t];
+  // epilogue: the last taps of outputs 1 .. R-1
 #pragma unroll
-    for (int q = 0; q < CH; ++q) s[q] = s[q] + kt * w[t * CH + q];
+  for (int v = 0; v < R - 1; ++v) {
+    const int u = ksize + v;
+    const int sp = blur_skew(p0 + u);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const float w = lds[q * plane + sp];
+#pragma unroll
+      for (int r = v + 1; r < R; ++r) s[r][q] = s[r][q] + s_k[u - r] * w;
+    }
   }
 #pragma unroll
-  for (int q = 0; q < CH; ++q) dst[((size_t)y * cols + x) * CH + q] = s[q];
+  for (int r = 0; r < R; ++r) {
+    const int x = x0 + p0 + r;
+    if (x < cols)
+#pragma unroll
+      for (int q = 0; q < CH; ++q) dst[((size_t)y * cols + x) * CH + q] = s[r][q];
+  }
 }
 
 // ---- column pass over the image seen as [rows][width] floats (width = cols * ch):
