@@ -88,6 +88,7 @@ struct CostParams {
   // PM_SEM_CPU: L1GradientCostFunction (test/stereo_matching/patchmatch_test.cpp:30-45)
   float alpha, one_minus_alpha, tau_color, tau_grad;
   double inv_n;  // 1./(pw*ph): cv::mean multiplies the sum by the reciprocal in double
+  float inv_n_hi, inv_n_lo;  // inv_n split into two floats (mean_from_sum)
   // PM_SEM_GPU: L1GradientCost3x3 (patchmatch_gpu.cu:72-114)
   float g_alpha, g_one_minus_alpha;
 };
@@ -183,10 +184,21 @@ __device__ __forceinline__ void load_pair_f32(const float* base, unsigned byte_o
   b = v.y;
 }
 
+// (float)((double)sum * inv_n) without f64 conversions: sum * (hi + lo) with the rounding error of the leading
+// product recovered by one FMA.  Equal to the double form for EVERY window 3..15 x 3..15 and every sum
+// 0 .. 255 * pw * ph (exhaustive check: tests/test_oracle_primitives.py::test_mean_from_sum_is_exact).
+__device__ __forceinline__ float mean_from_sum(int sum, const CostParams& cp) {
+  const float sf = (float)sum;
+  const float p = sf * cp.inv_n_hi;
+  const float e1 = __builtin_fmaf(sf, cp.inv_n_hi, -p);
+  const float e2 = sf * cp.inv_n_lo;
+  return p + (e1 + e2);
+}
+
 // mean = (float)(sum * (1./N)); cost = alpha*min(mean_c, tau_c) + (1-alpha)*min(mean_g, tau_g).
 __device__ __forceinline__ float cpu_cost_from_sums(int sc, int sg, const CostParams& cp) {
-  const float mc = (float)((double)sc * cp.inv_n);
-  const float mg = (float)((double)sg * cp.inv_n);
+  const float mc = mean_from_sum(sc, cp);
+  const float mg = mean_from_sum(sg, cp);
   const float ec = fminf(mc, cp.tau_color);
   const float eg = fminf(mg, cp.tau_grad);
   const float t0 = cp.alpha * ec;

@@ -199,6 +199,8 @@ CostParams cost_params(const pm_params& p, int pw, int ph) {
   cp.tau_color = p.functor_tau_color;
   cp.tau_grad = p.functor_tau_grad;
   cp.inv_n = 1. / (double)(cp.pw * cp.ph);
+  cp.inv_n_hi = (float)cp.inv_n;
+  cp.inv_n_lo = (float)(cp.inv_n - (double)cp.inv_n_hi);
   cp.g_alpha = p.cost_alpha;
   cp.g_one_minus_alpha = 1.f - p.cost_alpha;
   return cp;

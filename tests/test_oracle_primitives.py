@@ -112,3 +112,22 @@ def test_gpu_get_subpixel(oracle):
     for _ in range(200):
         r, c = float(np.float32(rng.uniform(0, 5))), float(np.float32(rng.uniform(0, 8)))
         assert oracle.gpu_get_subpixel(im, r, c) == pyref.gpu_get_subpixel(im, r, c)
+
+
+def test_mean_from_sum_is_exact():
+    """The device computes cv::mean's (float)(sum * (1./N)) without f64: p = s*hi, e = fma(s, hi, -p) + s*lo,
+    mean = p + e (pm_device.hpp::mean_from_sum).  Exhaustive over every supported window and every possible sum."""
+    for pw in range(3, 16, 2):
+        for ph in range(3, 16, 2):
+            n = pw * ph
+            c = np.float64(1.0) / np.float64(n)
+            hi = np.float32(c)
+            lo = np.float32(c - np.float64(hi))
+            s = np.arange(0, 255 * n + 1, dtype=np.int64)
+            want = (s.astype(np.float64) * c).astype(np.float32)
+            sf = s.astype(np.float32)
+            p = (sf * hi).astype(np.float32)
+            e1 = (sf.astype(np.float64) * np.float64(hi) - p.astype(np.float64)).astype(np.float32)  # the FMA, exact
+            e2 = (sf * lo).astype(np.float32)
+            got = (p + (e1 + e2).astype(np.float32)).astype(np.float32)
+            assert np.array_equal(got, want), (pw, ph)
