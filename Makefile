@@ -7,7 +7,7 @@ PKG     := ocean-perception_amd
 # bit-identical to the CPU path (hipcc's default is fp-contract=fast).
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-pass-failed
 LIB     := $(PKG)/lib/libvehicle_pm_gpu.so
-SRCS    := $(PKG)/csrc/pm_engine.hip $(PKG)/host/patchmatch_gpu.cpp $(PKG)/host/imaging.cpp $(PKG)/host/dataset.cpp $(PKG)/host/jpeg.cpp
+SRCS    := $(PKG)/csrc/pm_engine.hip $(PKG)/csrc/pm_imaging.hip $(PKG)/host/patchmatch_gpu.cpp $(PKG)/host/imaging.cpp $(PKG)/host/dataset.cpp $(PKG)/host/jpeg.cpp
 HDRS    := include/pm/patchmatch.h $(wildcard $(PKG)/csrc/*.hpp) $(wildcard $(PKG)/host/*.hpp)
 
 all: $(LIB) oracle

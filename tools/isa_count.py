@@ -8,11 +8,24 @@ VMEM / LDS instructions of the whole body and of its largest loop."""
 import os, re, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = "/tmp/isa/pm_engine.s"
+OUT = "/tmp/isa/all_units.s"
 
 
 def build():
     os.makedirs("/tmp/isa", exist_ok=True)
+    parts = []
+    for unit in ("pm_engine", "pm_imaging"):
+        out = "/tmp/isa/%s.s" % unit
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
+               "-I" + ROOT + "/include", "-I" + ROOT + "/ocean-perception_amd/csrc",
+               "-I" + ROOT + "/ocean-perception_amd/host", "-S", "--cuda-device-only", "-o", out,
+               ROOT + "/ocean-perception_amd/csrc/%s.hip" % unit]
+        subprocess.run(cmd, check=True)
+        parts.append(open(out).read())
+    open(OUT, "w").write("\n".join(parts))
+    return
+
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
            "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
            "-I" + ROOT + "/include", "-I" + ROOT + "/ocean-perception_amd/csrc", "-I" + ROOT + "/ocean-perception_amd/host",
