@@ -49,6 +49,8 @@ def parse():
                     help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
     ap.add_argument("--self-seed", action="store_true",
                     help="let Match() compute its seeds with the device SparseInit (side measurement)")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="experiment: no per-kernel HIP events in the timed region (the roofline object is then empty)")
     ap.add_argument("--host-pairs", type=int, default=24,
                     help="pairs of the untimed host-buffer leg (PCIe-inclusive rates, reported beside `value`); 0 = skip")
     ap.add_argument("--semantics", type=int, default=0,
@@ -236,7 +238,7 @@ def main():
     eng.synchronize()
     ref = DL.clone()
     eng.profile_read()
-    eng.profile_enable(True)
+    eng.profile_enable(not args.no_profile)
 
     torch.cuda.synchronize()
     d.barrier()
