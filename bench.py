@@ -49,6 +49,9 @@ def parse():
                     help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
     ap.add_argument("--self-seed", action="store_true",
                     help="let Match() compute its seeds with the device SparseInit (side measurement)")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="per-kernel HIP events are recorded on every n-th timed step (the ~180 event records of a "
+                         "fully timed step cost 6 %% of the step; 1 = every step)")
     ap.add_argument("--no-profile", action="store_true",
                     help="experiment: no per-kernel HIP events in the timed region (the roofline object is then empty)")
     ap.add_argument("--host-pairs", type=int, default=24,
@@ -238,13 +241,17 @@ def main():
     eng.synchronize()
     ref = DL.clone()
     eng.profile_read()
-    eng.profile_enable(not args.no_profile)
+    every = max(1, args.profile_every)
+    n_prof = 0
 
     torch.cuda.synchronize()
     d.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in shard(d.rank, d.world, steps):
+    for i, _ in enumerate(shard(d.rank, d.world, steps)):
+        timed = (not args.no_profile) and i % every == 0
+        eng.profile_enable(timed)
+        n_prof += 1 if timed else 0
         step()
     eng.synchronize()
     torch.cuda.synchronize()
@@ -273,7 +280,7 @@ def main():
         avg_ms = total_ms / max(n_launch, 1)
         # a class runs 2 sweeps per iteration over every pixel of both views; with the views on their own streams
         # (default) a launch covers one view, and two launches run concurrently on the chip
-        launches_per_step = n_launch / max(steps, 1)
+        launches_per_step = n_launch / max(n_prof, 1)
         concurrency = max(1, round(launches_per_step / (2 * args.iters)))
         bytes_per_launch = SWEEP_BYTES_PER_PX * px_views / concurrency
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
@@ -284,12 +291,13 @@ def main():
             roofline={"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
                       "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                      "launches": n_launch, "concurrent_launches": concurrency,
+                      "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
                       "achieved_all_concurrent": achieved * concurrency,
-                      "note": "per-launch figure as specified; `concurrent_launches` launches of this class (one per "
-                              "view, own streams) share the chip, so the chip-level rate is achieved_all_concurrent"},
-            kernels_ms_per_step={k: v[1] / steps for k, v in prof.items()},
-            gpu_busy_ms_per_step=gpu_ms / steps,
+                      "note": "per-launch figure as specified, HIP events on every --profile-every-th timed step "
+                              "(`profiled_steps` of them); `concurrent_launches` launches of this class (one per view, "
+                              "own streams) share the chip, so the chip-level rate is achieved_all_concurrent"},
+            kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items()},
+            gpu_busy_ms_per_step=gpu_ms / max(n_prof, 1),
             run_engine_counters_per_step=counters,
             check={"deterministic_across_steps": deterministic, "foreground_fraction": fg,
                    "foreground_within_1px_of_truth": within1},
