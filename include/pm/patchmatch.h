@@ -163,6 +163,13 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
                     int cols, const float* d_seed_l, const float* d_seed_r, float* d_disp_l,
                     float* d_disp_r);
 int pm_synchronize(pm_handle* h);
+/* Optional: record the calls made between pm_capture_begin and pm_capture_end (e.g. one pm_match_device with fixed
+ * device pointers and image size; the handle must already have matched that size once) into a HIP graph instead
+ * of executing them, then launch the whole DAG -- both view streams -- with pm_replay.  Results are those of the
+ * recorded calls on whatever the device buffers hold at replay time.  Profiling must be off while capturing. */
+int pm_capture_begin(pm_handle* h);
+int pm_capture_end(pm_handle* h);
+int pm_replay(pm_handle* h);
 /* The hipStream_t the handle enqueues on (as void*), for event timing by the caller. */
 void* pm_stream(pm_handle* h);
 

@@ -92,6 +92,8 @@ struct pm_handle {
   hipStream_t view_stream[2] = {nullptr, nullptr};
   hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
+  hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
+  bool capturing = false;
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -695,6 +697,7 @@ void pm_destroy(pm_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   pm_internal::release_imaging(h);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->ev_pool) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
@@ -815,6 +818,51 @@ int pm_synchronize(pm_handle* h) {
 }
 
 void* pm_stream(pm_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+// ---- HIP-graph replay of a recorded call sequence -----------------------------------------------------------
+// Everything enqueued between pm_capture_begin and pm_capture_end (typically one pm_match_device with fixed
+// device pointers) is recorded into a HIP graph instead of being executed -- the fork / join of the per-view
+// streams included -- and pm_replay launches the whole DAG with one call.
+int pm_capture_begin(pm_handle* h) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (h->profiling) {
+    set_err(h, "pm_capture_begin: per-kernel profiling must be off while capturing");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  h->capturing = true;
+  return PM_OK;
+}
+
+int pm_capture_end(pm_handle* h) {
+  if (!h || !h->capturing) return PM_ERR_INVALID_ARG;
+  h->capturing = false;
+  hipGraph_t graph = nullptr;
+  PM_HIP(h, hipStreamEndCapture(h->stream, &graph));
+  if (h->graph_exec) {
+    (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+  }
+  const hipError_t e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    set_err(h, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return PM_ERR_HIP;
+  }
+  return PM_OK;
+}
+
+int pm_replay(pm_handle* h) {
+  if (!h || !h->graph_exec) {
+    if (h) set_err(h, "pm_replay: nothing captured");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipGraphLaunch(h->graph_exec, h->stream));
+  return PM_OK;
+}
 
 int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                     const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {

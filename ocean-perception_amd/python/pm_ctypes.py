@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("PM_LIB") or os.path.normpath(os.path.join(_HERE, ".."
 EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
-    "pm_submit_u8", "pm_collect", "pm_in_flight",
+    "pm_submit_u8", "pm_collect", "pm_in_flight", "pm_capture_begin", "pm_capture_end", "pm_replay",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
     "pm_normalize_color_illuminant", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
@@ -149,6 +149,9 @@ def load():
         getattr(lib, name).restype = C.c_int
     for name in ("pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
                  "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize"):
+        getattr(lib, name).restype = C.c_int
+    for name in ("pm_capture_begin", "pm_capture_end", "pm_replay"):
+        getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = C.c_int
     lib.pm_synchronize.argtypes = [vp]
     lib.pm_synchronize.restype = C.c_int
@@ -385,6 +388,15 @@ class Engine:
         """All arguments are raw device addresses (ints)."""
         self._check(self.lib.pm_match_device(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
                                              d_disp_r), "pm_match_device")
+
+    def capture_begin(self):
+        self._check(self.lib.pm_capture_begin(self.h), "pm_capture_begin")
+
+    def capture_end(self):
+        self._check(self.lib.pm_capture_end(self.h), "pm_capture_end")
+
+    def replay(self):
+        self._check(self.lib.pm_replay(self.h), "pm_replay")
 
     def synchronize(self):
         self._check(self.lib.pm_synchronize(self.h), "pm_synchronize")

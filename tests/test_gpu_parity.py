@@ -320,6 +320,36 @@ def test_very_long_chains(pm, oracle, synth, sem, rows, cols):
     assert_same(dr, er, "right")
 
 
+def test_graph_replay_equals_direct_calls(pm, oracle, synth):
+    """pm_capture_begin / pm_capture_end / pm_replay: the recorded Match() (both view streams) as one HIP graph."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 64, 96
+    dev = torch.device("cuda:0")
+    pa = small_pair(synth, 91, rows, cols, n_points=25, dilate_factor=2)
+    pb = small_pair(synth, 92, rows, cols, n_points=25, dilate_factor=2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    L, R, SL, SR = t(pa[0]), t(pa[1]), t(pa[2]), t(pa[3])
+    DL, DR = torch.empty_like(SL), torch.empty_like(SR)
+    with mk(pm, 0, patch=5, iters=2, rows=rows, cols=cols) as e:
+        run = lambda: e.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(),
+                                     DL.data_ptr(), DR.data_ptr())
+        with pytest.raises(pm.PmError):
+            e.replay()  # nothing captured yet
+        run()
+        e.synchronize()
+        e.capture_begin()
+        run()
+        e.capture_end()
+        # new inputs in the same buffers: the replay works on what the buffers hold now
+        L.copy_(t(pb[0])); R.copy_(t(pb[1])); SL.copy_(t(pb[2])); SR.copy_(t(pb[3]))
+        torch.cuda.synchronize()
+        e.replay()
+        e.synchronize()
+    el, er = oracle.match(oparams(oracle, 0, 5, 2), pb[0], pb[1], pb[2], pb[3])
+    assert_same(DL.cpu().numpy(), el, "replayed left")
+    assert_same(DR.cpu().numpy(), er, "replayed right")
+
+
 def test_random_configurations_match_the_oracle(pm, oracle, synth):
     """Property test (hypothesis, fixed seed): random small sizes, windows, iteration counts, noise schedules,
     group widths and both semantics -- the default engine equals the oracle bit for bit."""
