@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 2
+#define PM_ABI_VERSION 3
 #define PM_MAX_ITERS 16
 #define PM_MAX_PATCH 15 /* largest supported window side (odd) */
 
@@ -58,6 +58,17 @@ typedef enum pm_semantics {
    * stripe per row / column. */
   PM_SEM_GPU = 1
 } pm_semantics;
+
+/* What a pixel's state is.
+ *   PM_MODE_SCALAR  one disparity per pixel: the reference's algorithm (semantics above), the parity target.
+ *   PM_MODE_PLANES  a slanted plane per pixel (a, b, z) + its cost: random plane initialisation, red-black
+ *                   spatial propagation, view propagation, random plane refinement, P x P windowed cost --
+ *                   the kernels BASELINE.json's north_star names.  The reference has no counterpart
+ *                   (patchmatch_gpu.cu:379-411 is scalar); the algorithm is defined by
+ *                   oracle/pm_planes_oracle.h and reproduced bit for bit on the same seeded random numbers. */
+typedef enum pm_mode { PM_MODE_SCALAR = 0, PM_MODE_PLANES = 1 } pm_mode;
+/* Storage type of the plane / cost planes in PM_MODE_PLANES (BASELINE configs[4]: fp16 planes/cost). */
+typedef enum pm_state_dtype { PM_STATE_F32 = 0, PM_STATE_F16 = 1 } pm_state_dtype;
 
 /* How the directional sweeps are executed on the device (results are identical). */
 typedef enum pm_engine {
@@ -112,6 +123,18 @@ typedef struct pm_params {
   int templ_rows;                 /* 11    (:22)                                                        */
   int max_disp;                   /* 128   (:23)                                                        */
   double max_matching_cost;       /* 0.15  (:24)                                                        */
+
+  /* --- PM_MODE_PLANES (no reference counterpart; defaults of oracle/pm_planes_oracle.c) ------------------
+   * Shared with the scalar mode: patchmatch_iters, patch_w[0] (square window), noise_amp[i] (dz of the first
+   * refinement step of iteration i), functor_*, noise_seed, max_disp (disparities live in [0, max_disp]),
+   * left_right_check, sparse_init / seed maps (a seed > 0 fixes a pixel's initial disparity). */
+  int mode;                       /* pm_mode, 0                                                          */
+  int state_dtype;                /* pm_state_dtype, 0                                                   */
+  int plane_refine_steps;         /* 3     candidates per pixel and iteration, ranges halving             */
+  float plane_slope_max;          /* 1.0   |a|, |b| bound                                                 */
+  float plane_slope_init;         /* 0.25  initial slopes uniform in +-this                               */
+  float plane_slope_per_disp;     /* 1/64  slope range of a refinement step = dz * this                   */
+  float plane_lr_tol;             /* 1.0   |dl - dr| above which the left disparity is zeroed             */
 } pm_params;
 
 /* Fills *p with the reference defaults for the given semantics. */
@@ -225,6 +248,25 @@ int pm_tile_background(pm_handle* h);
 /* cross-check + un-mirror; writes the owned rows only: [own_rows][cols] each */
 int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own);
 
+/* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------
+ * pm_match_u8 / pm_match_batch_u8 / pm_submit_u8 / pm_match_device run the whole schedule
+ *   begin; for it < patchmatch_iters: {red, black} per view, view 0, view 1, refine per view; finish
+ * when params.mode == PM_MODE_PLANES.  These entry points run one stage each (tests, tools). */
+enum { PM_PL_SPATIAL = 1, PM_PL_VIEW = 2, PM_PL_REFINE = 3 };
+/* prep + random plane initialisation (+ its cost) of n pairs; seeds as in pm_match_device */
+int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                    const float* d_seed_l, const float* d_seed_r);
+/* stage = PM_PL_SPATIAL: arg = colour (0 red: x + y even, 1 black), both views;
+ *         PM_PL_VIEW:    arg = the view that receives candidates from the other one;
+ *         PM_PL_REFINE:  arg = iteration (selects noise_amp[arg] and the random numbers), both views */
+int pm_planes_step(pm_handle* h, int stage, int arg);
+/* planes of (pair, view) as four tightly packed rows x cols float maps a, b, z, cost: HOST buffer of
+ * 4 * rows * cols floats (view 1 is in mirrored coordinates, as the engine holds it) */
+int pm_planes_read(pm_handle* h, int pair, int view, float* planes);
+int pm_planes_write(pm_handle* h, int pair, int view, const float* planes);
+/* disparity maps (right map un-mirrored) + consistency mask: [n][rows][cols] device floats */
+int pm_planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r);
+
 /* ---- per-kernel timing (hipEvents on the handle's stream) ---------------------------------- */
 
 enum {
@@ -235,7 +277,11 @@ enum {
   PM_K_SWEEP_COL = 4,
   PM_K_BACKGROUND = 5,
   PM_K_FINALIZE = 6, /* un-mirror + MaskOcclusions                     */
-  PM_K_COUNT = 7
+  PM_K_PL_INIT = 7,    /* PM_MODE_PLANES: random plane initialisation + cost */
+  PM_K_PL_SPATIAL = 8, /* red / black spatial propagation                    */
+  PM_K_PL_VIEW = 9,    /* view propagation                                   */
+  PM_K_PL_REFINE = 10, /* random plane refinement                            */
+  PM_K_COUNT = 11
 };
 typedef struct pm_profile {
   uint64_t launches[PM_K_COUNT];

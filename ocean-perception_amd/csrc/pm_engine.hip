@@ -21,6 +21,7 @@
 #include "pm_run2.hpp"
 #include "pm_internal.hpp"
 #include "pm_seed.hpp"
+#include "pm_planes.hpp"
 
 using namespace pm;
 
@@ -57,6 +58,11 @@ struct pm_handle {
   unsigned long long* counters = nullptr;  // device, 8 words
   bool counters_on = false;                // same-address atomics serialise: opt-in only
   int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
+
+  // PM_MODE_PLANES: [max_batch][2 views][a, b, z, cost][rows][pitch], f32 or f16 (pm_planes.hpp)
+  void* planes_state = nullptr;
+  int pl_rows = 0, pl_cols = 0, pl_n = 0;  // what pm_planes_begin last prepared
+  bool pl_on = false;
 
   SeedScratch seed{};   // scratch of the device seeder (pm_seed.hpp)
   SeedScratch seed2{};  // second set for the right view's seeder (allocated on first use; per-view streams)
@@ -616,7 +622,8 @@ int validate_params(pm_handle* h, const pm_params& p) {
   }
   if (p.max_features_per_frame < 0 || p.max_features_per_frame > kSeedMaxFeatures || p.gftt_block_size < 1 ||
       (p.gftt_block_size % 2) == 0 || p.gftt_block_size > 15 || p.templ_cols < 1 || p.templ_rows < 1 ||
-      p.max_disp < p.templ_cols || p.init_dilate_factor < 0 || p.init_dilate_factor > 8) {
+      ((p.mode != PM_MODE_PLANES || p.sparse_init) && p.max_disp < p.templ_cols) || p.init_dilate_factor < 0 ||
+      p.init_dilate_factor > 8) {
     set_err(h, "seeder parameters out of range");
     return PM_ERR_INVALID_ARG;
   }
@@ -625,7 +632,162 @@ int validate_params(pm_handle* h, const pm_params& p) {
       set_err(h, "noise_amp[%d] must be >= 0", i);
       return PM_ERR_INVALID_ARG;
     }
+  if (p.mode != PM_MODE_SCALAR && p.mode != PM_MODE_PLANES) {
+    set_err(h, "unknown mode %d", p.mode);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.mode == PM_MODE_PLANES) {
+    const int w = p.patch_w[0];
+    if (w < 3 || w > PM_MAX_PATCH || (w % 2) == 0 || p.patch_h[0] != w) {
+      set_err(h, "PM_MODE_PLANES: window patch_w[0] x patch_h[0] must be square, odd and within [3, %d]", PM_MAX_PATCH);
+      return PM_ERR_INVALID_ARG;
+    }
+    if ((p.state_dtype != PM_STATE_F32 && p.state_dtype != PM_STATE_F16) || p.plane_refine_steps < 0 ||
+        p.plane_refine_steps > 16 || !(p.plane_slope_max > 0.f) || !(p.plane_slope_max <= 4.f) ||
+        !(p.plane_slope_init >= 0.f) || !(p.plane_slope_init <= p.plane_slope_max) ||
+        !(p.plane_slope_per_disp >= 0.f) || !(p.plane_lr_tol >= 0.f) || p.max_disp < 1 || p.max_disp > 1024) {
+      set_err(h, "PM_MODE_PLANES: plane parameters out of range");
+      return PM_ERR_INVALID_ARG;
+    }
+  }
   return PM_OK;
+}
+
+// ---- PM_MODE_PLANES ------------------------------------------------------------------------------------------
+
+PlanesParams planes_params(const pm_params& p) {
+  PlanesParams pp;
+  pp.patch = p.patch_w[0];
+  pp.max_disp = p.max_disp;
+  pp.refine_steps = p.plane_refine_steps;
+  // the bound itself must be a fixed point of the state's rounding (oracle: slope_bound)
+  pp.slope_max = p.state_dtype == PM_STATE_F16 ? (float)(_Float16)p.plane_slope_max : p.plane_slope_max;
+  // columns a window can reach beyond [x - h - max_disp, x + h]: h * (|a| + |b|) on either side, + rounding slack
+  pp.margin = (int)std::ceil(2.0 * (pp.patch / 2) * (double)pp.slope_max) + 2;
+  pp.slope_init = p.plane_slope_init;
+  pp.slope_per_disp = p.plane_slope_per_disp;
+  pp.alpha = p.functor_alpha;
+  pp.one_minus_alpha = 1.f - p.functor_alpha;
+  pp.tau_color = p.functor_tau_color;
+  pp.tau_grad = p.functor_tau_grad;
+  pp.inv_n = 1.0f / (float)(pp.patch * pp.patch);
+  pp.lr_tol = p.plane_lr_tol;
+  pp.seed = p.noise_seed;
+  pp.n_views = p.left_right_check ? 2 : 1;
+  return pp;
+}
+
+int planes_alloc(pm_handle* h) {
+  if (h->planes_state) return PM_OK;
+  const size_t plane = (size_t)h->max_rows * h->max_pitch;
+  const size_t bytes = sizeof(float) * ((size_t)h->max_batch * 2 * 4 * plane + 64);
+  PM_HIP(h, hipMalloc(&h->planes_state, bytes));
+  PM_HIP(h, hipMemsetAsync(h->planes_state, 0, bytes, h->stream));
+  return PM_OK;
+}
+
+template <int STAGE>
+int planes_stage(pm_handle* h, const PlaneSet& ps, const PlArgs& ar, int slots, int klass, const char* what) {
+  Launch l(h, klass);
+  const hipError_t e = pl_launch<STAGE>(ps, h->planes_state, h->params.state_dtype == PM_STATE_F16,
+                                        planes_params(h->params), ar, slots, h->stream);
+  if (e != hipSuccess) {
+    set_err(h, "launch of planes %s failed: %s", what, hipGetErrorString(e));
+    return PM_ERR_HIP;
+  }
+  return PM_OK;
+}
+
+int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
+  const int nv = ps.n_views;
+  PlArgs ar{};
+  ar.stage = stage;
+  ar.arg = arg;
+  ar.view_fixed = -1;
+  switch (stage) {
+    case PM_PL_SPATIAL:
+      return planes_stage<PL_SPATIAL>(h, ps, ar, n * nv, PM_K_PL_SPATIAL, "spatial propagation");
+    case PM_PL_VIEW:
+      if (nv < 2) return PM_OK;
+      ar.view_fixed = arg;
+      return planes_stage<PL_VIEW>(h, ps, ar, n, PM_K_PL_VIEW, "view propagation");
+    case PM_PL_REFINE:
+      ar.refine_amp = h->params.noise_amp[arg];
+      return planes_stage<PL_REFINE>(h, ps, ar, n * nv, PM_K_PL_REFINE, "refinement");
+    default:
+      set_err(h, "unknown planes stage %d", stage);
+      return PM_ERR_INVALID_ARG;
+  }
+}
+
+// prep (images, gradients, packed planes) + seeds + random initialisation of n pairs
+int planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                 const float* d_seed_l, const float* d_seed_r) {
+  if (int rc = planes_alloc(h)) return rc;
+  const int nv = h->params.left_right_check ? 2 : 1;
+  PlaneSet ps = plane_set(h, rows, cols, nv);
+  {
+    Launch l(h, PM_K_PREP);
+    hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, (size_t)cols);
+  }
+  if (int rc = launch_check(h, "prep")) return rc;
+  const float* sl = d_seed_l;
+  const float* sr = d_seed_r;
+  PlArgs ar{};
+  if (h->params.sparse_init) {
+    // SparseInit on the device (patchmatch_gpu.cu:414-442) into the scalar engine's disparity planes, from
+    // which the initialisation kernel takes the seeds (view 1's plane is already in mirrored coordinates)
+    for (int v = 0; v < nv; ++v) {
+      if (v == 0 ? sl != nullptr : sr != nullptr) continue;
+      Launch l(h, PM_K_SEED);
+      for (int b = 0; b < n; ++b)
+        if (int rc = run_sparse_init(h, ps, b, v, 0)) return rc;
+      ar.seed_in_disp |= 1 << v;
+    }
+  }
+  ar.stage = PL_INIT;
+  ar.view_fixed = -1;
+  ar.seed_l = sl;
+  ar.seed_r = sr;
+  if (int rc = planes_stage<PL_INIT>(h, ps, ar, n * nv, PM_K_PL_INIT, "initialisation")) return rc;
+  h->pl_rows = rows;
+  h->pl_cols = cols;
+  h->pl_n = n;
+  h->pl_on = true;
+  return PM_OK;
+}
+
+int planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r) {
+  const int nv = h->params.left_right_check ? 2 : 1;
+  const PlaneSet ps = plane_set(h, h->pl_rows, h->pl_cols, nv);
+  const PlanesParams pp = planes_params(h->params);
+  Launch l(h, PM_K_FINALIZE);
+  if (h->params.state_dtype == PM_STATE_F16) {
+    PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane};
+    hipLaunchKernelGGL(k_planes_finish<_Float16>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps,
+                       st, pp, d_disp_l, d_disp_r, (size_t)ps.cols);
+  } else {
+    PlaneState<float> st{(float*)h->planes_state, ps.plane};
+    hipLaunchKernelGGL(k_planes_finish<float>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps, st,
+                       pp, d_disp_l, d_disp_r, (size_t)ps.cols);
+  }
+  return launch_check(h, "planes finish");
+}
+
+// The whole schedule of oracle/pm_planes_oracle.c::pmo_planes_match.
+int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                 const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+  if (int rc = planes_begin(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r)) return rc;
+  const int nv = h->params.left_right_check ? 2 : 1;
+  const PlaneSet ps = plane_set(h, rows, cols, nv);
+  for (int it = 0; it < h->params.patchmatch_iters; ++it) {
+    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 0)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 1)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_VIEW, 0)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_VIEW, 1)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_REFINE, it)) return rc;
+  }
+  return planes_finish(h, d_disp_l, d_disp_r);
 }
 
 }  // namespace
@@ -669,6 +831,13 @@ void pm_params_default(pm_params* p, int semantics) {
   p->templ_rows = 11;                // :22
   p->max_disp = 128;                 // :23
   p->max_matching_cost = 0.15;       // :24
+  p->mode = PM_MODE_SCALAR;
+  p->state_dtype = PM_STATE_F32;
+  p->plane_refine_steps = 3;         // oracle/pm_planes_oracle.c: pmo_planes_params_default
+  p->plane_slope_max = 1.0f;
+  p->plane_slope_init = 0.25f;
+  p->plane_slope_per_disp = 1.0f / 64.0f;
+  p->plane_lr_tol = 1.0f;
 }
 
 const char* pm_status_string(int status) {
@@ -686,7 +855,8 @@ const char* pm_status_string(int status) {
 
 const char* pm_kernel_name(int k) {
   static const char* names[PM_K_COUNT] = {"prep", "seed", "noise_cost", "sweep_row", "sweep_col", "background",
-                                          "finalize"};
+                                          "finalize", "planes_init", "planes_spatial", "planes_view",
+                                          "planes_refine"};
   return (k >= 0 && k < PM_K_COUNT) ? names[k] : "?";
 }
 
@@ -707,7 +877,7 @@ void pm_destroy(pm_handle* h) {
                  h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->seed2.dx, h->seed2.dy,
                  h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.sparse,
                  h->seed2.tmp, h->seed2.sort_tmp, h->snap_disp,
-                 h->snap_cost};
+                 h->snap_cost, h->planes_state};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -790,6 +960,8 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 16));  // [8..13]: timing builds only
   PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 16, h->stream));
   if (int rc = alloc_seed_scratch(h, h->seed)) return rc;
+  if (params->mode == PM_MODE_PLANES)
+    if (int rc = planes_alloc(h)) return rc;
   const size_t tight = (size_t)max_rows * max_cols;
   PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
@@ -878,6 +1050,8 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
     set_err(h, "pm_match_device: disp_r required when left_right_check is set");
     return PM_ERR_INVALID_ARG;
   }
+  if (h->params.mode == PM_MODE_PLANES)
+    return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   PlaneSet ps = plane_set(h, rows, cols, n_views);
   {
@@ -1525,6 +1699,100 @@ int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own) {
     PM_HIP(h, hipMemcpyAsync(d_disp_r_own, h->st_disp_r + ofs, bytes, hipMemcpyDeviceToDevice, h->stream));
   h->tile_on = false;
   return PM_OK;
+}
+
+// ---- PM_MODE_PLANES, stage by stage ------------------------------------------------------------------------
+
+namespace {
+int planes_check(pm_handle* h, const char* what, bool need_begin) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (h->params.mode != PM_MODE_PLANES) {
+    set_err(h, "%s: the handle was created with mode != PM_MODE_PLANES", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (need_begin && !h->pl_on) {
+    set_err(h, "%s: call pm_planes_begin (or a Match) first", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  return PM_OK;
+}
+}  // namespace
+
+int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                    const float* d_seed_l, const float* d_seed_r) {
+  if (int rc = planes_check(h, "pm_planes_begin", false)) return rc;
+  if (!d_left || !d_right) {
+    set_err(h, "pm_planes_begin: null image pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, n)) return rc;
+  return planes_begin(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r);
+}
+
+int pm_planes_step(pm_handle* h, int stage, int arg) {
+  if (int rc = planes_check(h, "pm_planes_step", true)) return rc;
+  const int nv = h->params.left_right_check ? 2 : 1;
+  const bool ok = (stage == PM_PL_SPATIAL && (arg == 0 || arg == 1)) ||
+                  (stage == PM_PL_VIEW && (arg == 0 || arg == 1)) ||
+                  (stage == PM_PL_REFINE && arg >= 0 && arg < PM_MAX_ITERS);
+  if (!ok) {
+    set_err(h, "pm_planes_step: stage %d / argument %d out of range", stage, arg);
+    return PM_ERR_INVALID_ARG;
+  }
+  return planes_step(h, plane_set(h, h->pl_rows, h->pl_cols, nv), h->pl_n, stage, arg);
+}
+
+static int planes_rw(pm_handle* h, int pair, int view, float* planes, int to_state, const char* what) {
+  if (int rc = planes_check(h, what, true)) return rc;
+  if (!planes || pair < 0 || pair >= h->pl_n || view < 0 || view > 1) {
+    set_err(h, "%s: null buffer or pair / view out of range", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  const int nv = h->params.left_right_check ? 2 : 1;
+  const PlaneSet ps = plane_set(h, h->pl_rows, h->pl_cols, nv);
+  const size_t count = 4 * (size_t)ps.rows * ps.cols;
+  // staged through the disparity staging buffers (4 * rows * cols floats fit st_disp_l .. only when max_batch
+  // allows; a scratch allocation keeps this tool path independent of the plan)
+  float* d_buf = nullptr;
+  PM_HIP(h, hipMalloc((void**)&d_buf, sizeof(float) * count));
+  int rc = PM_OK;
+  if (to_state && hipMemcpyAsync(d_buf, planes, sizeof(float) * count, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    rc = PM_ERR_HIP;
+  if (rc == PM_OK) {
+    const dim3 grid((unsigned)((ps.cols + 255) / 256), (unsigned)ps.rows, 4);
+    if (h->params.state_dtype == PM_STATE_F16) {
+      PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane};
+      hipLaunchKernelGGL(k_planes_copy<_Float16>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
+    } else {
+      PlaneState<float> st{(float*)h->planes_state, ps.plane};
+      hipLaunchKernelGGL(k_planes_copy<float>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
+    }
+    rc = launch_check(h, what);
+  }
+  if (rc == PM_OK && !to_state &&
+      hipMemcpyAsync(planes, d_buf, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+    rc = PM_ERR_HIP;
+  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == PM_OK) rc = PM_ERR_HIP;
+  (void)hipFree(d_buf);
+  if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "%s: copy failed", what);
+  return rc;
+}
+
+int pm_planes_read(pm_handle* h, int pair, int view, float* planes) {
+  return planes_rw(h, pair, view, planes, 0, "pm_planes_read");
+}
+int pm_planes_write(pm_handle* h, int pair, int view, const float* planes) {
+  return planes_rw(h, pair, view, const_cast<float*>(planes), 1, "pm_planes_write");
+}
+
+int pm_planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r) {
+  if (int rc = planes_check(h, "pm_planes_finish", true)) return rc;
+  if (!d_disp_l || (h->params.left_right_check && !d_disp_r)) {
+    set_err(h, "pm_planes_finish: null output");
+    return PM_ERR_INVALID_ARG;
+  }
+  return planes_finish(h, d_disp_l, d_disp_r);
 }
 
 // ---- profiling ----------------------------------------------------------------------------------

@@ -1,0 +1,453 @@
+// pm_planes.hpp -- PM_MODE_PLANES: slanted-plane PatchMatch stereo kernels for gfx950.
+//
+// BASELINE.json's north_star names random slanted-plane initialisation, red-black spatial propagation, view
+// propagation, random plane refinement and a per-pixel windowed match cost.  The reference has no such code
+// (its device entry point, src/vehicle/patchmatch_gpu/patchmatch_gpu.cu:379-411, keeps one scalar disparity
+// per pixel); the algorithm is DEFINED by oracle/pm_planes_oracle.{h,c} and these kernels reproduce that
+// definition bit for bit.  What is shared with the reference path: the images / Sobel gradient planes of
+// k_prep, the cost functor's form (test/stereo_matching/patchmatch_test.cpp:30-45), cv::RNG's
+// multiply-with-carry step, "right view = same algorithm on the mirrored (R, L) pair" (patchmatch_gpu.cu:357-368).
+//
+// State per pixel and view, SoA in HBM ([rows][pitch] each, f32 or f16): plane (a, b, z) in pixel-local form
+// (z = disparity AT the pixel, d(x+dx, y+dy) = z + a*dx + b*dy) and the cost of that plane.
+//
+// One kernel template, four stages.  A block owns a tile of 8 rows x 32 pixels (x 64 columns for the red-black
+// stage, whose lanes hold only the pixels of the active colour), stages in LDS
+//   * the reference window bytes of the tile (colour and saturated gradient, (TW+P-1) x (8+P-1)),
+//   * the target rows over the whole column range any admissible plane can reach
+//     (TW + P-1 + max_disp + slope margin; one dword per pixel: colour | gradient << 16),
+//   * for the red-black stage the planes of the tile with a 1-pixel ring (neighbour candidates),
+// and every lane then evaluates its candidates out of LDS.  The window cost is integer arithmetic:
+// 16.16 fixed-point column per tap, 8-bit lerp weights applied to both channels with ONE multiply-add pair
+// (the channels sit 16 bits apart in the dword and cannot carry into each other), four taps per v_sad_u8.
+#pragma once
+
+#include "pm_kernels.hpp"
+
+namespace pm {
+
+enum { PL_INIT = 0, PL_SPATIAL = 1, PL_VIEW = 2, PL_REFINE = 3 };
+enum { PL_RAND_INIT = 0, PL_RAND_REFINE = 1 };  // `stage` of the random key (oracle: ST_INIT / ST_REFINE)
+
+constexpr int kPlTileH = 8;
+
+struct PlanesParams {
+  int patch, max_disp, refine_steps, margin;
+  float slope_max;  // effective bound (f16-representable in f16 mode)
+  float slope_init, slope_per_disp;
+  float alpha, one_minus_alpha, tau_color, tau_grad, inv_n;
+  float lr_tol;
+  unsigned long long seed;
+  int n_views;
+};
+
+// State of all slots: slot (pair, view) holds 4 arrays of `plane` elements: a, b, z, cost.
+template <typename ST>
+struct PlaneState {
+  ST* base;
+  size_t plane;  // rows * pitch
+  __device__ __forceinline__ ST* arr(int pair, int view, int k) const {
+    return base + (((size_t)pair * 2 + view) * 4 + k) * plane;
+  }
+};
+
+template <typename ST>
+__device__ __forceinline__ float pl_quant(float v) {
+  if constexpr (sizeof(ST) == 2) return (float)(_Float16)v;
+  else return v;
+}
+template <typename ST>
+__device__ __forceinline__ float pl_load(const ST* p, size_t o) { return (float)p[o]; }
+template <typename ST>
+__device__ __forceinline__ void pl_store(ST* p, size_t o, float v) { p[o] = (ST)v; }
+
+// oracle: pmo_planes_rand
+__device__ __forceinline__ unsigned pl_rand(unsigned long long seed, int stage, int it, int k, int view, int draw,
+                                            int x, int y) {
+  const unsigned long long tag = (unsigned long long)stage | ((unsigned long long)it << 4) |
+                                 ((unsigned long long)k << 12) | ((unsigned long long)view << 20) |
+                                 ((unsigned long long)draw << 24);
+  unsigned long long s = seed + 0x9E3779B97F4A7C15ull * (tag + 1);
+  s ^= ((unsigned long long)(unsigned)y << 32) | (unsigned long long)(unsigned)x;
+  s ^= s >> 30;
+  s *= 0xBF58476D1CE4E5B9ull;
+  s ^= s >> 27;
+  s *= 0x94D049BB133111EBull;
+  s ^= s >> 31;
+  s = (unsigned long long)(unsigned)s * 4164903690u + (s >> 32);
+  return (unsigned)s;
+}
+__device__ __forceinline__ float pl_pm1(unsigned r) { return (float)(int)r * 4.656612873077392578125e-10f; }
+__device__ __forceinline__ float pl_u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }
+
+__device__ __forceinline__ float pl_clamp_slope(float v, float smax) { return fminf(fmaxf(v, -smax), smax); }
+
+// LDS images of one tile.
+struct PlTile {
+  const unsigned* tgt;  // [TR][rw] dwords: colour | gradient << 16 of target column xs_lo + index
+  const unsigned* rc;   // reference colour bytes, flat [(TR) * lw] as dwords
+  const unsigned* rg;   // reference gradient bytes
+  int rw, lw;
+};
+
+// Window cost of plane (a, b, z) for the pixel at tile position (lx, ty); xrel = its column - h - xs_lo.
+// oracle: pmo_planes_cost.
+template <int P>
+__device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
+                                         const PlanesParams& pp) {
+  constexpr int h = P / 2;
+  constexpr int NG = (P + 3) / 4;
+  const int Z = __float2int_rn(z * 65536.0f), A = __float2int_rn(a * 65536.0f), B = __float2int_rn(b * 65536.0f);
+  int xrow = (xrel << 16) - Z + A * h + B * h;  // tap (0, 0)
+  const int stepj = 65536 - A;
+  unsigned sc = 0, sg = 0;
+  const unsigned* trow = t.tgt + ty * t.rw;
+  int fl = ty * t.lw + lx;
+#pragma unroll 1
+  for (int i = 0; i < P; ++i) {
+    unsigned lw[NG], lgw[NG];
+    {
+      const unsigned* pl = t.rc + (fl >> 2);
+      const unsigned* pg = t.rg + (fl >> 2);
+      const unsigned sh = (unsigned)fl & 3u;
+      unsigned a0 = pl[0], b0 = pg[0];
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const unsigned a1 = pl[q + 1], b1 = pg[q + 1];
+        lw[q] = __builtin_amdgcn_alignbyte(a1, a0, sh);
+        lgw[q] = __builtin_amdgcn_alignbyte(b1, b0, sh);
+        a0 = a1;
+        b0 = b1;
+      }
+    }
+    int X = xrow;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      unsigned s[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (4 * q + k < P) {
+          const int idx = X >> 16;
+          const unsigned w1 = ((unsigned)X >> 8) & 255u, w0 = 256u - w1;
+          const unsigned p0 = trow[idx], p1 = trow[idx + 1];
+          s[k] = __umul24(p0, w0) + (__umul24(p1, w1) + 0x00800080u);
+          X += stepj;
+        }
+      }
+      // bytes 1 / 3 of every s[k] are the colour / gradient samples: gather four of each
+      const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
+      const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
+      const unsigned pc = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+      const unsigned pg = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+      const int rem = P - 4 * q;
+      const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+      sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc & mask, sc);
+      sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg & mask, sg);
+    }
+    xrow -= B;
+    trow += t.rw;
+    fl += t.lw;
+  }
+  const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
+  const float t0 = pp.alpha * fminf(mc, pp.tau_color);
+  const float t1 = pp.one_minus_alpha * fminf(mg, pp.tau_grad);
+  return t0 + t1;
+}
+
+// Pixel state in registers + the candidate rule (oracle: offer()).
+struct PlPix {
+  float a, b, z, c;
+};
+template <int P, typename ST>
+__device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xrel, int x, bool on, float ca, float cb,
+                                         float cz, PlPix& px, const PlanesParams& pp) {
+  ca = pl_quant<ST>(ca);
+  cb = pl_quant<ST>(cb);
+  cz = pl_quant<ST>(cz);
+  const float zmax = fminf((float)pp.max_disp, (float)x);
+  const bool need = on && cz >= 0.0f && cz <= zmax && !(ca == px.a && cb == px.b && cz == px.z);
+  if (!__any(need)) return;  // wave-uniform skip
+  // lanes without a candidate evaluate a harmless plane (their result is discarded)
+  const float c = pl_quant<ST>(pl_cost<P>(t, lx, ty, xrel, need ? ca : 0.f, need ? cb : 0.f, need ? cz : 0.f, pp));
+  if (need && c < px.c) {
+    px.a = ca;
+    px.b = cb;
+    px.z = cz;
+    px.c = c;
+  }
+}
+
+struct PlArgs {
+  int stage;
+  int arg;         // SPATIAL: parity; VIEW: the view; REFINE: iteration
+  int view_fixed;  // >= 0: blockIdx.z = pair, this view; -1: blockIdx.z = pair * n_views + view
+  float refine_amp;
+  const float* seed_l;  // INIT: tightly packed [n][rows][cols] seed maps in left / right image coordinates, or null
+  const float* seed_r;
+  // INIT: bit v set = view v's seeds are in the scalar engine's disparity plane of (pair, v) (pitched, view 1
+  // already mirrored): where the device SparseInit leaves them
+  int seed_in_disp;
+};
+
+// grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 256, dynamic LDS = pl_lds_bytes().
+template <int P, int STAGE, typename ST>
+__global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
+  constexpr int h = P / 2;
+  constexpr int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  constexpr int TR = kPlTileH + P - 1;
+  constexpr int LW = TW + P - 1;
+  constexpr int NREF = (TR * LW + 3) / 4 + 4;
+  extern __shared__ unsigned pl_lds[];
+  const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
+  unsigned* s_rc = pl_lds;
+  unsigned* s_rg = pl_lds + NREF;
+  unsigned* s_tgt = pl_lds + 2 * NREF;
+  float* s_pl = (float*)(s_tgt + TR * rw);  // SPATIAL only: [3][kPlTileH + 2][TW + 2]
+
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kPlTileH;
+  const int pair = ar.view_fixed >= 0 ? (int)blockIdx.z : (int)blockIdx.z / pp.n_views;
+  const int view = ar.view_fixed >= 0 ? ar.view_fixed : (int)blockIdx.z - pair * pp.n_views;
+  const int rows = ps.rows, cols = ps.cols, pitch = ps.pitch;
+  const int y = y0 + ty;
+  const int lx = STAGE == PL_SPATIAL ? 2 * tx + ((y + ar.arg) & 1) : tx;
+  const int x = x0 + lx;
+  const bool on = x < cols && y < rows;
+
+  // images of this view: reference / target packed planes (colour | gradient << 8)
+  const int iref = view == 0 ? 0 : 3, itgt = view == 0 ? 1 : 2;
+  const uint16_t* refpk = ps.pk16 + ((size_t)pair * 4 + iref) * ps.plane;
+  const uint16_t* tgtpk = ps.pk16 + ((size_t)pair * 4 + itgt) * ps.plane;
+
+  // ---- fill ------------------------------------------------------------------------------------------
+  {
+    uint8_t* rc8 = (uint8_t*)s_rc;
+    uint8_t* rg8 = (uint8_t*)s_rg;
+    const int ry0 = y0 - h, lx0 = x0 - h;
+    for (int e = tid; e < TR * LW; e += 256) {
+      const int rr = e / LW, cc = e - rr * LW;
+      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
+      const unsigned pk = refpk[(size_t)gy * pitch + gx];
+      rc8[e] = (uint8_t)(pk & 0xffu);
+      rg8[e] = (uint8_t)(pk >> 8);
+    }
+    const int xs_lo = x0 - h - pp.max_disp - pp.margin;
+    for (int e = tid; e < TR * rw; e += 256) {
+      const int rr = e / rw, cc = e - rr * rw;
+      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(xs_lo + cc, 0), cols - 1);
+      const unsigned pk = tgtpk[(size_t)gy * pitch + gx];
+      s_tgt[e] = (pk & 0xffu) | ((pk & 0xff00u) << 8);
+    }
+  }
+  ST* const pa = st.arr(pair, view, 0);
+  ST* const pb = st.arr(pair, view, 1);
+  ST* const pz = st.arr(pair, view, 2);
+  ST* const pc = st.arr(pair, view, 3);
+  if constexpr (STAGE == PL_SPATIAL) {
+    constexpr int PW2 = TW + 2, PH2 = kPlTileH + 2;
+    for (int e = tid; e < PW2 * PH2; e += 256) {
+      const int rr = e / PW2, cc = e - rr * PW2;
+      const int gy = min(max(y0 - 1 + rr, 0), rows - 1), gx = min(max(x0 - 1 + cc, 0), cols - 1);
+      const size_t o = (size_t)gy * pitch + gx;
+      s_pl[e] = pl_load(pa, o);
+      s_pl[PW2 * PH2 + e] = pl_load(pb, o);
+      s_pl[2 * PW2 * PH2 + e] = pl_load(pz, o);
+    }
+  }
+  __syncthreads();
+
+  PlTile t;
+  t.tgt = s_tgt;
+  t.rc = s_rc;
+  t.rg = s_rg;
+  t.rw = rw;
+  t.lw = LW;
+  const int xrel = lx + pp.max_disp + pp.margin;
+  const size_t o = (size_t)y * pitch + x;
+  const float smax = pp.slope_max;
+
+  PlPix px = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (STAGE == PL_INIT) {
+    const float zmax = fminf((float)pp.max_disp, (float)x);
+    const float* seed = view == 0 ? ar.seed_l : ar.seed_r;
+    float s = 0.f;
+    if (((ar.seed_in_disp >> view) & 1) && on) {
+      s = ps.disp[((size_t)pair * 2 + view) * ps.plane + o];
+    } else if (seed && on) {
+      // the right view's seed map is given in right-image coordinates: view 1 works on the mirrored pair
+      const int sx = view == 0 ? x : cols - 1 - x;
+      s = seed[(size_t)pair * rows * cols + (size_t)y * cols + sx];
+    }
+    const float u = pl_u01(pl_rand(pp.seed, PL_RAND_INIT, 0, 0, view, 0, x, y));
+    float z = s > 0.0f ? fminf(s, zmax) : u * zmax;
+    float a = pp.slope_init * pl_pm1(pl_rand(pp.seed, PL_RAND_INIT, 0, 0, view, 1, x, y));
+    float b = pp.slope_init * pl_pm1(pl_rand(pp.seed, PL_RAND_INIT, 0, 0, view, 2, x, y));
+    a = pl_quant<ST>(pl_clamp_slope(a, smax));
+    b = pl_quant<ST>(pl_clamp_slope(b, smax));
+    z = pl_quant<ST>(z);
+    if (!(z <= zmax)) z = 0.0f;
+    px.a = a;
+    px.b = b;
+    px.z = z;
+    px.c = pl_quant<ST>(pl_cost<P>(t, lx, ty, xrel, on ? a : 0.f, on ? b : 0.f, on ? z : 0.f, pp));
+  } else {
+    if (on) {
+      px.a = pl_load(pa, o);
+      px.b = pl_load(pb, o);
+      px.z = pl_load(pz, o);
+      px.c = pl_load(pc, o);
+    }
+    if constexpr (STAGE == PL_SPATIAL) {
+      constexpr int PW2 = TW + 2, PH2 = kPlTileH + 2;
+      const float* sa = s_pl;
+      const float* sb = s_pl + PW2 * PH2;
+      const float* sz = s_pl + 2 * PW2 * PH2;
+      const int c = (ty + 1) * PW2 + lx + 1;
+      // left, right, up, down: the neighbour's plane evaluated at this pixel
+      {
+        const float na = sa[c - 1], nb = sb[c - 1], nz = sz[c - 1];
+        pl_offer<P, ST>(t, lx, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp);
+      }
+      {
+        const float na = sa[c + 1], nb = sb[c + 1], nz = sz[c + 1];
+        pl_offer<P, ST>(t, lx, ty, xrel, x, on && x < cols - 1, na, nb, nz - na, px, pp);
+      }
+      {
+        const float na = sa[c - PW2], nb = sb[c - PW2], nz = sz[c - PW2];
+        pl_offer<P, ST>(t, lx, ty, xrel, x, on && y > 0, na, nb, nz + nb, px, pp);
+      }
+      {
+        const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
+        pl_offer<P, ST>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
+      }
+    } else if constexpr (STAGE == PL_VIEW) {
+      const ST* oa = st.arr(pair, 1 - view, 0);
+      const ST* ob = st.arr(pair, 1 - view, 1);
+      const ST* oz = st.arr(pair, 1 - view, 2);
+      const float xo = (float)(cols - 1 - x) + px.z;
+      const int xoi = min(max(__float2int_rn(xo), 0), cols - 1);
+      float ao = 0.f, bo = 0.f, zo = 0.f;
+      if (on) {
+        const size_t oo = (size_t)y * pitch + xoi;
+        ao = pl_load(oa, oo);
+        bo = pl_load(ob, oo);
+        zo = pl_load(oz, oo);
+      }
+      const float den = 1.0f - ao;
+      const bool ok = on && den >= 0.25f;
+      const float dsafe = ok ? den : 1.0f;
+      const float na = (-ao) / dsafe, nb = bo / dsafe;
+      const float xc = (float)(cols - 1 - xoi) + zo;
+      const float dx = (float)x - xc;
+      const float tt = na * dx;
+      const float nz = zo + tt;
+      pl_offer<P, ST>(t, lx, ty, xrel, x, ok, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
+    } else {  // PL_REFINE
+      float dz = ar.refine_amp;
+      for (int k = 0; k < pp.refine_steps; ++k) {
+        const float ds = dz * pp.slope_per_disp;
+        const float u0 = pl_pm1(pl_rand(pp.seed, PL_RAND_REFINE, ar.arg, k, view, 0, x, y));
+        const float u1 = pl_pm1(pl_rand(pp.seed, PL_RAND_REFINE, ar.arg, k, view, 1, x, y));
+        const float u2 = pl_pm1(pl_rand(pp.seed, PL_RAND_REFINE, ar.arg, k, view, 2, x, y));
+        const float t0 = dz * u0, t1 = ds * u1, t2 = ds * u2;
+        const float nz = px.z + t0, na = px.a + t1, nb = px.b + t2;
+        pl_offer<P, ST>(t, lx, ty, xrel, x, on, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
+        dz = dz * 0.5f;
+      }
+    }
+  }
+  if (on) {
+    pl_store(pa, o, px.a);
+    pl_store(pb, o, px.b);
+    pl_store(pz, o, px.z);
+    pl_store(pc, o, px.c);
+  }
+}
+
+template <int STAGE>
+inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
+  const int h = P / 2;
+  const int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  const int TR = kPlTileH + P - 1, LW = TW + P - 1;
+  const int nref = (TR * LW + 3) / 4 + 4;
+  const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
+  size_t words = 2 * (size_t)nref + (size_t)TR * rw + 4;
+  if (STAGE == PL_SPATIAL) words += 3 * (size_t)(kPlTileH + 2) * (TW + 2);
+  return words * 4;
+}
+
+template <int P, int STAGE, typename ST>
+inline hipError_t pl_launch_t(const PlaneSet& ps, void* state, const PlanesParams& pp, const PlArgs& ar, int slots,
+                              hipStream_t stream) {
+  const int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  const size_t lds = pl_lds_bytes<STAGE>(P, pp);
+  if (lds > kChainLdsMax) return hipErrorInvalidValue;
+  allow_big_lds(k_planes<P, STAGE, ST>, lds);
+  PlaneState<ST> st;
+  st.base = (ST*)state;
+  st.plane = ps.plane;
+  const dim3 grid((unsigned)((ps.cols + TW - 1) / TW), (unsigned)((ps.rows + kPlTileH - 1) / kPlTileH), (unsigned)slots);
+  hipLaunchKernelGGL((k_planes<P, STAGE, ST>), grid, dim3(256), lds, stream, ps, st, pp, ar);
+  return hipGetLastError();
+}
+
+template <int P, int STAGE>
+inline hipError_t pl_launch_p(const PlaneSet& ps, void* state, bool f16, const PlanesParams& pp, const PlArgs& ar,
+                              int slots, hipStream_t stream) {
+  return f16 ? pl_launch_t<P, STAGE, _Float16>(ps, state, pp, ar, slots, stream)
+             : pl_launch_t<P, STAGE, float>(ps, state, pp, ar, slots, stream);
+}
+
+template <int STAGE>
+inline hipError_t pl_launch(const PlaneSet& ps, void* state, bool f16, const PlanesParams& pp, const PlArgs& ar,
+                            int slots, hipStream_t stream) {
+  switch (pp.patch) {
+    case 3: return pl_launch_p<3, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 5: return pl_launch_p<5, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 7: return pl_launch_p<7, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 9: return pl_launch_p<9, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 11: return pl_launch_p<11, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 13: return pl_launch_p<13, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    case 15: return pl_launch_p<15, STAGE>(ps, state, f16, pp, ar, slots, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Disparity maps out (view 1 un-mirrored) + left/right consistency mask on the left map
+// (the role of MaskOcclusions, patchmatch_gpu.cu:273-295; rule: |dl - dr| > lr_tol).  grid = pixel grid x pairs.
+template <typename ST>
+__global__ void __launch_bounds__(256) k_planes_finish(PlaneSet ps, PlaneState<ST> st, PlanesParams pp,
+                                                       float* __restrict__ out_l, float* __restrict__ out_r,
+                                                       size_t out_stride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= ps.cols) return;
+  const size_t op = (size_t)ps.rows * out_stride;
+  const ST* z0 = st.arr(b, 0, 2) + (size_t)y * ps.pitch;
+  float dl = (float)z0[x];
+  if (pp.n_views > 1) {
+    const ST* z1 = st.arr(b, 1, 2) + (size_t)y * ps.pitch;
+    const float fx = (float)x - dl;
+    const int xt = min(max(__float2int_rn(fx), 0), ps.cols - 1);
+    const float dr = (float)z1[ps.cols - 1 - xt];
+    const float df = dl - dr;
+    if (fabsf(df) > pp.lr_tol) dl = 0.0f;
+    if (out_r) out_r[(size_t)b * op + (size_t)y * out_stride + x] = (float)z1[ps.cols - 1 - x];
+  }
+  out_l[(size_t)b * op + (size_t)y * out_stride + x] = dl;
+}
+
+// state <-> tightly packed f32 host-side planes (pm_planes_read / pm_planes_write)
+template <typename ST>
+__global__ void __launch_bounds__(256) k_planes_copy(PlaneSet ps, PlaneState<ST> st, int pair, int view, float* buf,
+                                                     int to_state) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, k = blockIdx.z;
+  if (x >= ps.cols) return;
+  ST* p = st.arr(pair, view, k) + (size_t)y * ps.pitch + x;
+  float* q = buf + ((size_t)k * ps.rows + y) * ps.cols + x;
+  if (to_state) *p = (ST)*q;
+  else *q = (float)*p;
+}
+
+}  // namespace pm

@@ -9,14 +9,17 @@ import os
 
 import numpy as np
 
-PM_ABI_VERSION = 2
+PM_ABI_VERSION = 3
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
 PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUN, PM_ENGINE_RUNBLK, PM_ENGINE_RUNBLK2 = 0, 1, 2, 3, 4, 5
 PM_OK = 0
 PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY = -1, -2, -3, -4, -5, -6
-PM_K_COUNT = 7
+PM_K_COUNT = 11
+PM_MODE_SCALAR, PM_MODE_PLANES = 0, 1
+PM_STATE_F32, PM_STATE_F16 = 0, 1
+PM_PL_SPATIAL, PM_PL_VIEW, PM_PL_REFINE = 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB: experiment knob to load another build of the same library (e.g. a different unroll factor)
@@ -35,6 +38,7 @@ EXPORTS = [
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish",
+    "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
 ]
 
 
@@ -68,6 +72,13 @@ class PmParams(C.Structure):
         ("templ_rows", C.c_int),
         ("max_disp", C.c_int),
         ("max_matching_cost", C.c_double),
+        ("mode", C.c_int),
+        ("state_dtype", C.c_int),
+        ("plane_refine_steps", C.c_int),
+        ("plane_slope_max", C.c_float),
+        ("plane_slope_init", C.c_float),
+        ("plane_slope_per_disp", C.c_float),
+        ("plane_lr_tol", C.c_float),
     ]
 
 
@@ -183,6 +194,13 @@ def load():
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
                  "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish"):
         getattr(lib, name).restype = C.c_int
+    lib.pm_planes_begin.argtypes = [vp, C.c_int, u8p, u8p, C.c_int, C.c_int, f32p, f32p]
+    lib.pm_planes_step.argtypes = [vp, C.c_int, C.c_int]
+    lib.pm_planes_read.argtypes = [vp, C.c_int, C.c_int, f32p]
+    lib.pm_planes_write.argtypes = [vp, C.c_int, C.c_int, f32p]
+    lib.pm_planes_finish.argtypes = [vp, f32p, f32p]
+    for name in ("pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish"):
+        getattr(lib, name).restype = C.c_int
     lib.pm_profile_enable.argtypes = [vp, C.c_int]
     lib.pm_profile_enable.restype = C.c_int
     lib.pm_profile_read.argtypes = [vp, C.POINTER(PmProfile)]
@@ -282,6 +300,7 @@ class Engine:
         dl = np.empty((rows, cols), np.float32)
         dr = np.empty((rows, cols), np.float32)
         lr = bool(self.params.left_right_check)
+        self._pl_shape = (rows, cols)
         self._check(self.lib.pm_match_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, dl.ctypes.data_as(C.c_void_p),
                                          dr.ctypes.data_as(C.c_void_p) if lr else None, 0), "pm_match_u8")
         return (dl, dr) if lr else (dl, None)
@@ -386,6 +405,7 @@ class Engine:
 
     def match_device(self, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
         """All arguments are raw device addresses (ints)."""
+        self._pl_shape = (rows, cols)
         self._check(self.lib.pm_match_device(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
                                              d_disp_r), "pm_match_device")
 
@@ -483,6 +503,29 @@ class Engine:
 
     def tile_finish(self, d_out_l, d_out_r):
         self._check(self.lib.pm_tile_finish(self.h, d_out_l, d_out_r), "pm_tile_finish")
+
+    # --- PM_MODE_PLANES stage by stage (device addresses as ints) ---------------------------------------
+    def planes_begin(self, n, d_left, d_right, rows, cols, d_seed_l=None, d_seed_r=None):
+        self._pl_shape = (rows, cols)
+        self._check(self.lib.pm_planes_begin(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r),
+                    "pm_planes_begin")
+
+    def planes_step(self, stage, arg):
+        self._check(self.lib.pm_planes_step(self.h, stage, arg), "pm_planes_step")
+
+    def planes_read(self, pair, view):
+        """(4, rows, cols) float32: a, b, z, cost of (pair, view); view 1 in mirrored coordinates."""
+        rows, cols = self._pl_shape
+        out = np.empty((4, rows, cols), np.float32)
+        self._check(self.lib.pm_planes_read(self.h, pair, view, out.ctypes.data_as(C.c_void_p)), "pm_planes_read")
+        return out
+
+    def planes_write(self, pair, view, planes):
+        a, p = _f32(planes)
+        self._check(self.lib.pm_planes_write(self.h, pair, view, p), "pm_planes_write")
+
+    def planes_finish(self, d_disp_l, d_disp_r):
+        self._check(self.lib.pm_planes_finish(self.h, d_disp_l, d_disp_r), "pm_planes_finish")
 
     def debug_counters_enable(self, on=True):
         self._check(self.lib.pm_debug_counters_enable(self.h, 1 if on else 0), "pm_debug_counters_enable")

@@ -48,6 +48,19 @@ def synthetic():
          disp_l=dl, disp_r=dr, sem=0, iters=4, lr=1, bg_patch=3, **{k: np.array(v) for k, v in sched.items()})
 
 
+def planes():
+    # PM_MODE_PLANES has no reference counterpart: the fixture pins this build's own definition
+    # (oracle/pm_planes_oracle.c) against regressions, for f32 and f16 state
+    p = synth.make_pair(102, rows=64, cols=96, d_max=20.0)
+    out = dict(left=p["left"], right=p["right"], patch=7, iters=3, max_disp=24)
+    for f16 in (0, 1):
+        prm = O.planes_params(n_iters=3, nthreads=8, state_f16=f16, patch=7, max_disp=24)
+        dl, dr = O.planes_match(prm, p["left"], p["right"])
+        out[f"disp_l_f{16 if f16 else 32}"] = dl
+        out[f"disp_r_f{16 if f16 else 32}"] = dr
+    save("planes_64x96", **out)
+
+
 def block_match_seeds(left, right, n=200, tw=31, th=11, max_disp=98, dilate_factor=4):
     """Sparse SAD block matching on a regular grid -> dilated seed map (stand-in for SparseInit)."""
     rows, cols = left.shape
@@ -94,6 +107,10 @@ def caddy():
 
 
 if __name__ == "__main__":
+    if "--planes-only" in sys.argv:
+        planes()
+        sys.exit(0)
     synthetic()
+    planes()
     if "--caddy" in sys.argv:
         caddy()

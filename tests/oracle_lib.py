@@ -437,3 +437,126 @@ def stereo_ready(bgr8):
     gray = np.empty((rows, cols), np.uint8)
     _enh_lib().pmo_stereo_ready(_p(bgr8), rows, cols, _p(J), _p(gray))
     return J, gray
+
+
+# ---- PM_MODE_PLANES definition (oracle/pm_planes_oracle.c) ----------------------------------------------------
+PMO_PL_MAX_ITERS = 16
+
+
+class PlanesParams(C.Structure):
+    _fields_ = [
+        ("n_iters", C.c_int), ("patch", C.c_int), ("max_disp", C.c_int), ("refine_steps", C.c_int),
+        ("refine_amp", C.c_float * PMO_PL_MAX_ITERS),
+        ("slope_max", C.c_float), ("slope_init", C.c_float), ("slope_per_disp", C.c_float),
+        ("alpha", C.c_float), ("tau_color", C.c_float), ("tau_grad", C.c_float),
+        ("seed", C.c_uint64), ("left_right_check", C.c_int), ("lr_tol", C.c_float), ("state_f16", C.c_int),
+        ("nthreads", C.c_int),
+    ]
+
+
+class PlanesView(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("ref8", C.c_void_p), ("refg8", C.c_void_p),
+                ("tgt8", C.c_void_p), ("tgtg8", C.c_void_p)]
+
+
+class PlanesState(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("z", C.c_void_p), ("cost", C.c_void_p)]
+
+
+_planes_ready = False
+
+
+def _planes_lib():
+    global _planes_ready
+    lib = load()
+    if not _planes_ready:
+        vp = C.c_void_p
+        PP, PV, PS = C.POINTER(PlanesParams), C.POINTER(PlanesView), C.POINTER(PlanesState)
+        lib.pmo_planes_params_default.argtypes = [PP]
+        lib.pmo_planes_rand.argtypes = [C.c_uint64] + [C.c_int] * 7
+        lib.pmo_planes_rand.restype = C.c_uint32
+        lib.pmo_planes_quant_f16.argtypes = [C.c_float]
+        lib.pmo_planes_quant_f16.restype = C.c_float
+        lib.pmo_planes_cost.argtypes = [PP, PV, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+        lib.pmo_planes_cost.restype = C.c_float
+        lib.pmo_planes_init.argtypes = [PP, PV, C.c_int, vp, PS]
+        lib.pmo_planes_spatial.argtypes = [PP, PV, PS, C.c_int]
+        lib.pmo_planes_view_prop.argtypes = [PP, PV, PS, PS]
+        lib.pmo_planes_refine.argtypes = [PP, PV, C.c_int, C.c_int, PS]
+        lib.pmo_planes_match.argtypes = [PP, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        lib.pmo_planes_prepare.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        _planes_ready = True
+    return lib
+
+
+def planes_params(**kw):
+    p = PlanesParams()
+    _planes_lib().pmo_planes_params_default(C.byref(p))
+    amp = kw.pop("refine_amp", None)
+    if amp is not None:
+        for i, v in enumerate(amp):
+            p.refine_amp[i] = v
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def planes_rand(seed, stage, it, k, view, draw, x, y):
+    return int(_planes_lib().pmo_planes_rand(seed, stage, it, k, view, draw, x, y))
+
+
+def planes_quant_f16(v):
+    return float(_planes_lib().pmo_planes_quant_f16(float(v)))
+
+
+class PlanesViews:
+    """The u8 planes of both views of a pair + state arrays; keeps every buffer alive."""
+
+    def __init__(self, left, right):
+        left, right = c_u8(left), c_u8(right)
+        self.rows, self.cols = left.shape
+        n = left.size
+        self.buf = [np.zeros((4, self.rows, self.cols), np.uint8) for _ in range(2)]
+        _planes_lib().pmo_planes_prepare(_p(left), _p(right), self.rows, self.cols, _p(self.buf[0]), _p(self.buf[1]))
+        self.view = []
+        for v in range(2):
+            b = self.buf[v]
+            self.view.append(PlanesView(self.rows, self.cols, b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data,
+                                        b[3].ctypes.data))
+        self.planes = [np.zeros((4, self.rows, self.cols), np.float32) for _ in range(2)]
+        self.state = [PlanesState(*[self.planes[v][k].ctypes.data for k in range(4)]) for v in range(2)]
+
+    def cost(self, p, view, x, y, a, b, z):
+        return float(_planes_lib().pmo_planes_cost(C.byref(p), C.byref(self.view[view]), x, y, a, b, z))
+
+    def init(self, p, view, seed=None):
+        s = c_f32(seed) if seed is not None else None
+        _planes_lib().pmo_planes_init(C.byref(p), C.byref(self.view[view]), view, _p(s) if s is not None else None,
+                                      C.byref(self.state[view]))
+
+    def spatial(self, p, view, parity):
+        _planes_lib().pmo_planes_spatial(C.byref(p), C.byref(self.view[view]), C.byref(self.state[view]), parity)
+
+    def view_prop(self, p, view):
+        _planes_lib().pmo_planes_view_prop(C.byref(p), C.byref(self.view[view]), C.byref(self.state[view]),
+                                           C.byref(self.state[1 - view]))
+
+    def refine(self, p, view, it):
+        _planes_lib().pmo_planes_refine(C.byref(p), C.byref(self.view[view]), view, it, C.byref(self.state[view]))
+
+
+def planes_match(p, left, right, seed_l=None, seed_r=None, want_planes=False):
+    left, right = c_u8(left), c_u8(right)
+    rows, cols = left.shape
+    sl = c_f32(seed_l) if seed_l is not None else None
+    sr = c_f32(seed_r) if seed_r is not None else None
+    dl = np.zeros((rows, cols), np.float32)
+    dr = np.zeros((rows, cols), np.float32)
+    nv = 2 if p.left_right_check else 1
+    planes = np.zeros((nv, 4, rows, cols), np.float32) if want_planes else None
+    _planes_lib().pmo_planes_match(C.byref(p), _p(left), _p(right), rows, cols, _p(sl) if sl is not None else None,
+                                   _p(sr) if sr is not None else None, _p(dl), _p(dr),
+                                   _p(planes) if planes is not None else None)
+    return (dl, dr, planes) if want_planes else (dl, dr)

@@ -1,0 +1,377 @@
+"""PM_MODE_PLANES: slanted-plane PatchMatch (random init, red-black spatial propagation, view propagation, random
+plane refinement, windowed cost) -- the kernels BASELINE.json's north_star names.
+
+The reference has no such code (src/vehicle/patchmatch_gpu/patchmatch_gpu.cu:379-411 keeps a scalar disparity), so
+the checker is this build's own CPU definition, oracle/pm_planes_oracle.c.  Bars:
+  * HIP == definition bit for bit on the same seeded random numbers, stage by stage and end to end, for f32 AND f16
+    state (the f16 rounding points are part of the definition, so f16 is exact too);
+  * quality against the synthetic ground truth, with the tolerance stated in the test: f32 planes >= 97 % of the
+    valid pixels within 1 px; f16 state may lose at most 0.5 percentage points against f32.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_same
+
+ROWS, COLS = 72, 200  # not multiples of the 8 x 32 / 8 x 64 tiles
+
+
+def okw(pm_params):
+    """pm_params (ctypes) -> keyword arguments of the oracle's parameter struct."""
+    it = pm_params.patchmatch_iters
+    return dict(n_iters=it, patch=pm_params.patch_w[0], max_disp=pm_params.max_disp,
+                refine_steps=pm_params.plane_refine_steps, refine_amp=[pm_params.noise_amp[i] for i in range(16)],
+                slope_max=pm_params.plane_slope_max, slope_init=pm_params.plane_slope_init,
+                slope_per_disp=pm_params.plane_slope_per_disp, alpha=pm_params.functor_alpha,
+                tau_color=pm_params.functor_tau_color, tau_grad=pm_params.functor_tau_grad,
+                seed=pm_params.noise_seed, left_right_check=pm_params.left_right_check,
+                lr_tol=pm_params.plane_lr_tol, state_f16=pm_params.state_dtype, nthreads=8)
+
+
+def pparams(pm, patch=11, iters=2, f16=0, **kw):
+    kw.setdefault("state_dtype", f16)
+    kw.setdefault("mode", pm.PM_MODE_PLANES)
+    return pm.default_params(0, patch=patch, patchmatch_iters=iters, **kw)
+
+
+# ---- the definition itself (CPU) ---------------------------------------------------------------------------------
+def test_rand_is_a_pure_function_of_its_key(oracle):
+    a = [oracle.planes_rand(123, 1, 2, 1, 0, d, 17, 5) for d in range(3)]
+    assert a == [oracle.planes_rand(123, 1, 2, 1, 0, d, 17, 5) for d in range(3)]
+    assert len({oracle.planes_rand(123, 1, 2, 1, 0, 0, x, 5) for x in range(256)}) == 256
+    # python restatement of the key mix + one cv::RNG multiply-with-carry step
+    M = (1 << 64) - 1
+
+    def ref(seed, stage, it, k, view, draw, x, y):
+        tag = stage | (it << 4) | (k << 12) | (view << 20) | (draw << 24)
+        s = (seed + 0x9E3779B97F4A7C15 * (tag + 1)) & M
+        s ^= (y << 32) | x
+        s ^= s >> 30
+        s = (s * 0xBF58476D1CE4E5B9) & M
+        s ^= s >> 27
+        s = (s * 0x94D049BB133111EB) & M
+        s ^= s >> 31
+        s = ((s & 0xffffffff) * 4164903690 + (s >> 32)) & M
+        return s & 0xffffffff
+
+    for key in [(123, 0, 0, 0, 0, 0, 0, 0), (123, 1, 7, 2, 1, 2, 1279, 719), (99, 1, 3, 0, 1, 1, 40, 41)]:
+        assert oracle.planes_rand(*key) == ref(*key)
+    # roughly uniform
+    v = np.array([oracle.planes_rand(123, 0, 0, 0, 0, 0, x, y) for y in range(64) for x in range(64)], np.float64)
+    assert abs(v.mean() / 2 ** 32 - 0.5) < 0.02
+
+
+def test_quant_f16_equals_numpy_float16(oracle):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([
+        rng.normal(0, 1, 2000), rng.uniform(-70000, 70000, 2000), rng.uniform(-1e-4, 1e-4, 2000),
+        rng.uniform(-7e-8, 7e-8, 500), np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, 2.0 ** -24, 2.0 ** -25,
+                                                   2.0 ** -25 * 1.0001, 2.0 ** -14, 1.0 + 2.0 ** -11,
+                                                   1.0 + 3 * 2.0 ** -11, 128.0625, 127.96875])]).astype(np.float32)
+    # every f16 midpoint in a few binades (ties to even)
+    h = np.arange(0x3c00, 0x3c40, dtype=np.uint16).view(np.float16).astype(np.float32)
+    vals = np.concatenate([vals, (h[:-1] + h[1:]) / 2]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).astype(np.float32)
+    got = np.array([oracle.planes_quant_f16(v) for v in vals], np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_cost_of_the_true_plane_is_zero_on_a_shifted_texture(oracle):
+    rng = np.random.default_rng(2)
+    right = rng.integers(0, 256, (40, 120), dtype=np.uint8)
+    left = np.roll(right, 7, axis=1)  # left(x) = right(x - 7)
+    v = oracle.PlanesViews(left, right)
+    p = oracle.planes_params(patch=11)
+    assert v.cost(p, 0, 60, 20, 0.0, 0.0, 7.0) == 0.0
+    assert v.cost(p, 0, 60, 20, 0.0, 0.0, 9.0) > 5.0
+    # hand value for a 3x3 window of constant images: |10 - 30| colour, zero gradient
+    l2 = np.full((8, 16), 10, np.uint8)
+    r2 = np.full((8, 16), 30, np.uint8)
+    v2 = oracle.PlanesViews(l2, r2)
+    p3 = oracle.planes_params(patch=3)
+    assert v2.cost(p3, 0, 8, 4, 0.1, -0.2, 1.5) == np.float32(np.float32(0.7) * np.float32(np.float32(180) * np.float32(1.0 / 9)))
+
+
+def test_definition_recovers_the_synthetic_truth_and_f16_costs_little(oracle, synth):
+    p = synth.make_pair(3, 120, 240)
+    res = {}
+    for f16 in (0, 1):
+        prm = oracle.planes_params(n_iters=6, nthreads=8, state_f16=f16)
+        dl, dr = oracle.planes_match(prm, p["left"], p["right"])
+        ok = dl > 0
+        err = np.abs(dl - p["gt"])
+        res[f16] = ((err[ok] < 1).mean(), ok.mean())
+        assert res[f16][1] > 0.5
+    assert res[0][0] >= 0.97, res                  # stated tolerance: >= 97 % of valid pixels within 1 px
+    assert res[1][0] >= res[0][0] - 0.005, res     # f16 state: at most 0.5 points worse
+    # thread count does not matter
+    prm1 = oracle.planes_params(n_iters=2, nthreads=1)
+    prm8 = oracle.planes_params(n_iters=2, nthreads=8)
+    a = oracle.planes_match(prm1, p["left"][:48, :96], p["right"][:48, :96])
+    b = oracle.planes_match(prm8, p["left"][:48, :96], p["right"][:48, :96])
+    assert_same(a[0], b[0], "threads")
+
+
+def test_golden_planes_fixture(oracle):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "planes_64x96.npz"))
+    for f16 in (0, 1):
+        prm = oracle.planes_params(n_iters=3, nthreads=4, state_f16=f16, patch=7, max_disp=24)
+        dl, dr = oracle.planes_match(prm, g["left"], g["right"])
+        assert_same(dl, g[f"disp_l_f{16 if f16 else 32}"], "golden left")
+        assert_same(dr, g[f"disp_r_f{16 if f16 else 32}"], "golden right")
+
+
+# ---- HIP vs definition --------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def dev_pair(pair_list):
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda k, dt: torch.from_numpy(np.stack([p[k] for p in pair_list])).to(dev).to(dt).contiguous()
+    return t("left", torch.uint8), t("right", torch.uint8), t("seed_l", torch.float32), t("seed_r", torch.float32)
+
+
+@gpu
+@pytest.mark.parametrize("f16", [0, 1])
+@pytest.mark.parametrize("seeded", [False, True])
+def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded):
+    """NS-1 random plane initialisation, NS-2 red-black propagation, NS-3 view propagation, NS-4 refinement."""
+    import torch
+    p = synth.make_pair(11, ROWS, COLS, n_points=30, dilate_factor=2)
+    prm = pparams(pm, iters=2, f16=f16, max_disp=48)
+    op = oracle.planes_params(**okw(prm))
+    L, R, SL, SR = dev_pair([p])
+    ov = oracle.PlanesViews(p["left"], p["right"])
+    names = "a b z cost".split()
+
+    def check(e, what):
+        torch.cuda.synchronize()
+        for v in range(2):
+            got = e.planes_read(0, v)
+            for k in range(4):
+                assert_same(got[k], ov.planes[v][k], f"{what}: view {v} {names[k]}")
+
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        e.planes_begin(1, L.data_ptr(), R.data_ptr(), ROWS, COLS, SL.data_ptr() if seeded else None,
+                       SR.data_ptr() if seeded else None)
+        for v in range(2):
+            seed = None
+            if seeded:
+                seed = p["seed_l"] if v == 0 else p["seed_r"][:, ::-1]
+            ov.init(op, v, seed)
+        check(e, "init")
+        for it in range(2):
+            for par in (0, 1):
+                e.planes_step(pm.PM_PL_SPATIAL, par)
+                for v in range(2):
+                    ov.spatial(op, v, par)
+                check(e, f"spatial it {it} colour {par}")
+            for v in range(2):
+                e.planes_step(pm.PM_PL_VIEW, v)
+                ov.view_prop(op, v)
+                check(e, f"view propagation it {it} into view {v}")
+            e.planes_step(pm.PM_PL_REFINE, it)
+            for v in range(2):
+                ov.refine(op, v, it)
+            check(e, f"refine it {it}")
+
+
+@gpu
+def test_stages_on_injected_adversarial_planes(pm, oracle, synth):
+    """Planes at the bounds (slopes +-slope_max, z = 0 / max_disp / beyond the column), steep planes next to flat
+    ones, equal neighbours: written into the engine and into the definition, then every stage once."""
+    import torch
+    p = synth.make_pair(12, ROWS, COLS)
+    prm = pparams(pm, iters=1, max_disp=40)
+    op = oracle.planes_params(**okw(prm))
+    L, R, _, _ = dev_pair([p])
+    ov = oracle.PlanesViews(p["left"], p["right"])
+    rng = np.random.default_rng(5)
+    ys, xs = np.mgrid[0:ROWS, 0:COLS]
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        e.planes_begin(1, L.data_ptr(), R.data_ptr(), ROWS, COLS)
+        for v in range(2):
+            a = rng.choice(np.array([-1.0, 1.0, 0.0, 0.999, -0.5], np.float32), (ROWS, COLS))
+            b = rng.choice(np.array([-1.0, 1.0, 0.0, 0.25], np.float32), (ROWS, COLS))
+            z = rng.choice(np.array([0.0, 40.0, 39.99, 12.5, 3.0], np.float32), (ROWS, COLS))
+            z = np.minimum(z, xs.astype(np.float32))  # keep the state admissible (0 <= z <= min(max_disp, x))
+            a[:, 50:60] = 0.25
+            b[:, 50:60] = 0.0
+            z[:, 50:60] = 10.0  # a block of identical planes (equal candidates are never evaluated)
+            ov.planes[v][0], ov.planes[v][1], ov.planes[v][2] = a, b, z
+            for yy in range(ROWS):
+                for xx in range(COLS):
+                    ov.planes[v][3][yy, xx] = ov.cost(op, v, xx, yy, a[yy, xx], b[yy, xx], z[yy, xx])
+            e.planes_write(0, v, ov.planes[v])
+        for stage, args in ((pm.PM_PL_SPATIAL, (0, 1)), (pm.PM_PL_VIEW, (0, 1)), (pm.PM_PL_REFINE, (0,))):
+            for arg in args:
+                e.planes_step(stage, arg)
+                if stage == pm.PM_PL_SPATIAL:
+                    for v in range(2):
+                        ov.spatial(op, v, arg)
+                elif stage == pm.PM_PL_VIEW:
+                    ov.view_prop(op, arg)
+                else:
+                    for v in range(2):
+                        ov.refine(op, v, arg)
+                torch.cuda.synchronize()
+                for v in range(2):
+                    got = e.planes_read(0, v)
+                    for k in range(4):
+                        assert_same(got[k], ov.planes[v][k], f"stage {stage} arg {arg} view {v} plane {k}")
+
+
+@gpu
+@pytest.mark.parametrize("f16", [0, 1])
+@pytest.mark.parametrize("patch,max_disp", [(11, 64), (7, 32), (5, 128), (3, 16), (15, 40)])
+def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp):
+    p = synth.make_pair(20 + patch, ROWS, COLS)
+    prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp)
+    want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"])
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        got = e.match(p["left"], p["right"])
+    assert_same(got[0], want[0], "left map")
+    assert_same(got[1], want[1], "right map")
+
+
+@gpu
+def test_match_variants(pm, oracle, synth):
+    """seed maps, one view only, other schedule / slopes / seed, batch == singles, pipelined entry point."""
+    pairs = [synth.make_pair(30 + i, ROWS, COLS, n_points=40, dilate_factor=2) for i in range(3)]
+    p = pairs[0]
+    # seeded
+    prm = pparams(pm, iters=2, max_disp=48)
+    want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"], p["seed_l"], p["seed_r"])
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        got = e.match(p["left"], p["right"], p["seed_l"], p["seed_r"])
+    assert_same(got[0], want[0], "seeded left")
+    assert_same(got[1], want[1], "seeded right")
+    # one view, no consistency mask
+    prm = pparams(pm, iters=2, max_disp=48, left_right_check=0)
+    want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"])
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        got = e.match(p["left"], p["right"])
+    assert_same(got[0], want[0], "one view")
+    # other constants
+    prm = pparams(pm, iters=2, max_disp=48, plane_refine_steps=5, plane_slope_max=0.5, plane_slope_init=0.5,
+                  plane_slope_per_disp=0.03, plane_lr_tol=0.5, noise_seed=77, noise_amp=[8, 3, 1] + [0.5] * 13,
+                  functor_alpha=0.5, functor_tau_color=30.0, functor_tau_grad=40.0)
+    want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"])
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
+        got = e.match(p["left"], p["right"])
+    assert_same(got[0], want[0], "other constants left")
+    assert_same(got[1], want[1], "other constants right")
+    # batch of 3 == 3 singles == pipelined
+    prm = pparams(pm, iters=2, max_disp=48)
+    op = oracle.planes_params(**okw(prm))
+    with pm.Engine(prm, max_rows=ROWS, max_cols=COLS, max_batch=3) as e:
+        dls, drs = e.match_batch([q["left"] for q in pairs], [q["right"] for q in pairs])
+        for i, q in enumerate(pairs):
+            e.submit(q["left"], q["right"], tag=i)
+        piped = [e.collect() for _ in pairs]
+    for i, q in enumerate(pairs):
+        want = oracle.planes_match(op, q["left"], q["right"])
+        assert_same(dls[i], want[0], f"batch left {i}")
+        assert_same(drs[i], want[1], f"batch right {i}")
+        assert_same(piped[i][0], want[0], f"pipelined left {i}")
+        assert piped[i][2] == i
+
+
+@gpu
+def test_self_seeded_planes_match(pm, oracle, synth):
+    """sparse_init = 1: the device SparseInit (patchmatch_gpu.cu:414-442) feeds the plane initialisation."""
+    p = synth.make_pair(41, 96, 256)
+    prm = pparams(pm, iters=2, max_disp=64, sparse_init=1, init_dilate_factor=2)
+    sp = oracle.seed_params(max_disp=64)  # the seeder shares max_disp with the plane search
+    sl = oracle.sparse_init(p["left"], p["right"], 2, sp)
+    sr_m = oracle.sparse_init(p["right"][:, ::-1], p["left"][:, ::-1], 2, sp)
+    want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"], sl,
+                               np.ascontiguousarray(sr_m[:, ::-1]))
+    with pm.Engine(prm, max_rows=96, max_cols=256) as e:
+        got = e.match(p["left"], p["right"])
+    assert_same(got[0], want[0], "self-seeded left")
+    assert_same(got[1], want[1], "self-seeded right")
+
+
+@gpu
+def test_golden_planes_fixture_on_device(pm):
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "planes_64x96.npz"))
+    for f16 in (0, 1):
+        prm = pparams(pm, patch=7, iters=3, f16=f16, max_disp=24)
+        with pm.Engine(prm, max_rows=64, max_cols=96) as e:
+            dl, dr = e.match(g["left"], g["right"])
+        assert_same(dl, g[f"disp_l_f{16 if f16 else 32}"], "golden left")
+        assert_same(dr, g[f"disp_r_f{16 if f16 else 32}"], "golden right")
+
+
+@gpu
+def test_parameter_errors(pm):
+    for kw in (dict(patch=4), dict(plane_slope_max=0.0), dict(state_dtype=2), dict(max_disp=0), dict(mode=2),
+               dict(plane_refine_steps=-1)):
+        with pytest.raises(pm.PmError) as ei:
+            pm.Engine(pparams(pm, **kw), max_rows=64, max_cols=64)
+        assert ei.value.status == pm.PM_ERR_INVALID_ARG
+    # stage entry points refuse a scalar-mode handle, and a planes handle before pm_planes_begin
+    with pm.Engine(pm.default_params(0), max_rows=64, max_cols=64) as e:
+        with pytest.raises(pm.PmError):
+            e.planes_step(pm.PM_PL_SPATIAL, 0)
+    with pm.Engine(pparams(pm), max_rows=64, max_cols=64) as e:
+        with pytest.raises(pm.PmError):
+            e.planes_step(pm.PM_PL_SPATIAL, 0)
+
+
+@gpu
+@pytest.mark.parametrize("f16", [0, 1])
+def test_full_size_properties(pm, oracle, synth, f16):
+    """1280x720, 8 iterations, 11x11 (BASELINE configs[1] / configs[4] shapes): run-to-run determinism, quality
+    against the synthetic truth (>= 97 % of valid pixels within 1 px; f16 within 0.5 points of f32 is checked at
+    small size against the definition), a 40-row band of pixels re-costed by the definition, and the consistency
+    mask's own invariant."""
+    import torch
+    rows, cols = 720, 1280
+    p = synth.make_pair(0, rows, cols)
+    prm = pparams(pm, iters=8, f16=f16)
+    op = oracle.planes_params(**okw(prm))
+    L, R, _, _ = dev_pair([p])
+    dev = L.device
+    DL = torch.empty((1, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        e.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+        e.synchronize()
+        first = DL.clone()
+        e.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+        e.synchronize()
+        assert torch.equal(first, DL)
+        planes = [e.planes_read(0, v) for v in range(2)]
+    dl, dr = DL[0].cpu().numpy(), DR[0].cpu().numpy()
+    ok = dl > 0
+    err = np.abs(dl - p["gt"])
+    assert ok.mean() > 0.8
+    assert (err[ok] < 1).mean() >= 0.97
+    # state invariants: admissible planes, stored cost == cost of the stored plane under the definition
+    xs = np.arange(cols, dtype=np.float32)[None, :]
+    ov = oracle.PlanesViews(p["left"], p["right"])
+    for v in range(2):
+        a, b, z, c = planes[v]
+        assert (np.abs(a) <= 1).all() and (np.abs(b) <= 1).all()
+        assert (z >= 0).all() and (z <= np.minimum(128.0, xs)).all()
+        for y in range(340, 380, 13):
+            for x in range(7, cols, 97):
+                want = ov.cost(op, v, x, y, a[y, x], b[y, x], z[y, x])
+                if f16:
+                    want = oracle.planes_quant_f16(want)
+                assert c[y, x] == np.float32(want), (v, x, y)
+    # output maps are the z planes; masked pixels are exactly those failing |dl - dr(x - dl)| <= tol
+    assert_same(dr, planes[1][2][:, ::-1], "right map = mirrored z of view 1")
+    z0 = planes[0][2]
+    xt = np.clip(np.rint(np.arange(cols, dtype=np.float32)[None, :] - z0).astype(np.int64), 0, cols - 1)
+    drs = np.take_along_axis(dr, xt, axis=1)
+    keep = np.abs(z0 - drs) <= 1.0
+    assert_same(dl, np.where(keep, z0, 0).astype(np.float32), "consistency mask")
