@@ -11,11 +11,12 @@
 // State per pixel and view, SoA in HBM ([rows][pitch] each, f32 or f16): plane (a, b, z) in pixel-local form
 // (z = disparity AT the pixel, d(x+dx, y+dy) = z + a*dx + b*dy) and the cost of that plane.
 //
-// One kernel template, four stages.  A block owns a tile of 8 rows x 32 pixels (x 64 columns for the red-black
-// stage, whose lanes hold only the pixels of the active colour), stages in LDS
+// One kernel template, four stages.  A block of 512 threads owns a tile of 8 rows x 64 pixels (x 128 columns for the
+// red-black stage, whose lanes hold only the pixels of the active colour), stages in LDS
 //   * the reference window bytes of the tile (colour and saturated gradient, (TW+P-1) x (8+P-1)),
 //   * the target rows over the whole column range any admissible plane can reach
-//     (TW + P-1 + max_disp + slope margin; one dword per pixel: colour | gradient << 16),
+//     (TW + P-1 + max_disp + slope margin; 8 bytes per column: the pixel AND its right neighbour, each as
+//     colour | gradient << 16, so that one aligned ds_read_b64 fetches both bilinear taps),
 //   * for the red-black stage the planes of the tile with a 1-pixel ring (neighbour candidates),
 // and every lane then evaluates its candidates out of LDS.  The window cost is integer arithmetic:
 // 16.16 fixed-point column per tap, 8-bit lerp weights applied to both channels with ONE multiply-add pair
@@ -83,8 +84,11 @@ __device__ __forceinline__ float pl_u01(unsigned r) { return (float)(r >> 8) * 5
 __device__ __forceinline__ float pl_clamp_slope(float v, float smax) { return fminf(fmaxf(v, -smax), smax); }
 
 // LDS images of one tile.
+typedef unsigned pl_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) pl_u2 pl_lds_u2;
 struct PlTile {
-  const unsigned* tgt;  // [TR][rw] dwords: colour | gradient << 16 of target column xs_lo + index
+  int tgt_entry0;       // ABSOLUTE LDS address / 8 of the target tile: [TR][rw] 8-byte entries
+                        // {P(c), P(c + 1)}, P = colour | gradient << 16, c = xs_lo + index
   const unsigned* rc;   // reference colour bytes, flat [(TR) * lw] as dwords
   const unsigned* rg;   // reference gradient bytes
   int rw, lw;
@@ -92,19 +96,37 @@ struct PlTile {
 
 // Window cost of plane (a, b, z) for the pixel at tile position (lx, ty); xrel = its column - h - xs_lo.
 // oracle: pmo_planes_cost.
+// The 16.16 column of a tap carries the LDS entry index of its row in the integer part (t.tgt_entry0 + row * rw is
+// folded into it), so the byte address of the tap's 8-byte entry is ((X >> 16) << 3) -- one SDWA shift -- and the
+// low half is untouched: bits 8..15 are the lerp weight.
 template <int P>
 __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                          const PlanesParams& pp) {
   constexpr int h = P / 2;
   constexpr int NG = (P + 3) / 4;
   const int Z = __float2int_rn(z * 65536.0f), A = __float2int_rn(a * 65536.0f), B = __float2int_rn(b * 65536.0f);
-  int xrow = (xrel << 16) - Z + A * h + B * h;  // tap (0, 0)
-  const int stepj = 65536 - A;
+  int xrow = ((xrel + t.tgt_entry0 + ty * t.rw) << 16) - Z + A * h + B * h;  // tap (0, 0)
+  int stepj = 65536 - A;
+  // opaque to the optimiser: otherwise it splits j * stepj into j * 65536 - j * A and spends three adds per tap
+  asm volatile("" : "+v"(stepj));
+  int xoff[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) xoff[j] = j * stepj;
+  const int rowstep = (t.rw << 16) - B;
   unsigned sc = 0, sg = 0;
-  const unsigned* trow = t.tgt + ty * t.rw;
   int fl = ty * t.lw + lx;
 #pragma unroll 1
   for (int i = 0; i < P; ++i) {
+    // all LDS reads of the window row first (target pairs, then reference bytes), arithmetic afterwards: the
+    // reads of a row are in flight together instead of one wait per tap
+    pl_u2 tp[P];
+    unsigned wq[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int X = xrow + xoff[j];
+      tp[j] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)X >> 16) << 3);  // absolute LDS byte address
+      wq[j] = ((unsigned)X >> 8) & 255u;
+    }
     unsigned lw[NG], lgw[NG];
     {
       const unsigned* pl = t.rc + (fl >> 2);
@@ -120,32 +142,29 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
         b0 = b1;
       }
     }
-    int X = xrow;
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       unsigned s[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (4 * q + k < P) {
-          const int idx = X >> 16;
-          const unsigned w1 = ((unsigned)X >> 8) & 255u, w0 = 256u - w1;
-          const unsigned p0 = trow[idx], p1 = trow[idx + 1];
-          s[k] = __umul24(p0, w0) + (__umul24(p1, w1) + 0x00800080u);
-          X += stepj;
+        const int j = 4 * q + k;
+        if (j < P) {
+          const unsigned w1 = wq[j], w0 = 256u - w1;
+          s[k] = __umul24(tp[j].x, w0) + (__umul24(tp[j].y, w1) + 0x00800080u);
         }
       }
-      // bytes 1 / 3 of every s[k] are the colour / gradient samples: gather four of each
+      // bytes 1 / 3 of every s[k] are the colour / gradient samples: gather four of each (a tap the window
+      // does not have contributes s = 0, i.e. sample bytes 0: only the reference side needs the mask)
       const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
       const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
       const unsigned pc = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
       const unsigned pg = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
       const int rem = P - 4 * q;
       const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
-      sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc & mask, sc);
-      sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg & mask, sg);
+      sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc, sc);
+      sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg, sg);
     }
-    xrow -= B;
-    trow += t.rw;
+    xrow += rowstep;
     fl += t.lw;
   }
   const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
@@ -189,22 +208,23 @@ struct PlArgs {
   int seed_in_disp;
 };
 
-// grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 256, dynamic LDS = pl_lds_bytes().
+// grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 512, dynamic LDS = pl_lds_bytes().
+constexpr int kPlThreads = 512;
 template <int P, int STAGE, typename ST>
-__global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
+__global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
   constexpr int h = P / 2;
-  constexpr int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  constexpr int TW = STAGE == PL_SPATIAL ? 128 : 64;  // 64 lanes per tile row either way
   constexpr int TR = kPlTileH + P - 1;
   constexpr int LW = TW + P - 1;
-  constexpr int NREF = (TR * LW + 3) / 4 + 4;
-  extern __shared__ unsigned pl_lds[];
+  constexpr int NREF = ((TR * LW + 3) / 4 + 4 + 1) & ~1;
+  extern __shared__ __attribute__((aligned(16))) unsigned pl_lds[];
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
   unsigned* s_rc = pl_lds;
   unsigned* s_rg = pl_lds + NREF;
-  unsigned* s_tgt = pl_lds + 2 * NREF;
-  float* s_pl = (float*)(s_tgt + TR * rw);  // SPATIAL only: [3][kPlTileH + 2][TW + 2]
+  pl_u2* s_tgt = (pl_u2*)(pl_lds + 2 * NREF);  // NREF is even: 8-byte aligned
+  float* s_pl = (float*)(s_tgt + TR * rw);     // SPATIAL only: [3][kPlTileH + 2][TW + 2]
 
-  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kPlTileH;
   const int pair = ar.view_fixed >= 0 ? (int)blockIdx.z : (int)blockIdx.z / pp.n_views;
   const int view = ar.view_fixed >= 0 ? ar.view_fixed : (int)blockIdx.z - pair * pp.n_views;
@@ -219,24 +239,30 @@ __global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, 
   const uint16_t* refpk = ps.pk16 + ((size_t)pair * 4 + iref) * ps.plane;
   const uint16_t* tgtpk = ps.pk16 + ((size_t)pair * 4 + itgt) * ps.plane;
 
-  // ---- fill ------------------------------------------------------------------------------------------
+  // ---- fill: wavefront w takes tile rows w, w + 8, ...; lanes walk along the row (coalesced u16 reads) --------
   {
     uint8_t* rc8 = (uint8_t*)s_rc;
     uint8_t* rg8 = (uint8_t*)s_rg;
     const int ry0 = y0 - h, lx0 = x0 - h;
-    for (int e = tid; e < TR * LW; e += 256) {
-      const int rr = e / LW, cc = e - rr * LW;
-      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
-      const unsigned pk = refpk[(size_t)gy * pitch + gx];
-      rc8[e] = (uint8_t)(pk & 0xffu);
-      rg8[e] = (uint8_t)(pk >> 8);
-    }
     const int xs_lo = x0 - h - pp.max_disp - pp.margin;
-    for (int e = tid; e < TR * rw; e += 256) {
-      const int rr = e / rw, cc = e - rr * rw;
-      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(xs_lo + cc, 0), cols - 1);
-      const unsigned pk = tgtpk[(size_t)gy * pitch + gx];
-      s_tgt[e] = (pk & 0xffu) | ((pk & 0xff00u) << 8);
+    for (int rr = ty; rr < TR; rr += kPlThreads / 64) {
+      const int gy = min(max(ry0 + rr, 0), rows - 1);
+      const uint16_t* rrow = refpk + (size_t)gy * pitch;
+      const uint16_t* trw = tgtpk + (size_t)gy * pitch;
+      for (int cc = tx; cc < LW; cc += 64) {
+        const unsigned pk = rrow[min(max(lx0 + cc, 0), cols - 1)];
+        rc8[rr * LW + cc] = (uint8_t)(pk & 0xffu);
+        rg8[rr * LW + cc] = (uint8_t)(pk >> 8);
+      }
+      pl_u2* trow = s_tgt + rr * rw;
+      for (int cc = tx; cc < rw; cc += 64) {
+        const unsigned pk0 = trw[min(max(xs_lo + cc, 0), cols - 1)];
+        const unsigned pk1 = trw[min(max(xs_lo + cc + 1, 0), cols - 1)];
+        pl_u2 v;
+        v.x = (pk0 & 0xffu) | ((pk0 & 0xff00u) << 8);
+        v.y = (pk1 & 0xffu) | ((pk1 & 0xff00u) << 8);
+        trow[cc] = v;
+      }
     }
   }
   ST* const pa = st.arr(pair, view, 0);
@@ -245,7 +271,7 @@ __global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, 
   ST* const pc = st.arr(pair, view, 3);
   if constexpr (STAGE == PL_SPATIAL) {
     constexpr int PW2 = TW + 2, PH2 = kPlTileH + 2;
-    for (int e = tid; e < PW2 * PH2; e += 256) {
+    for (int e = tid; e < PW2 * PH2; e += kPlThreads) {
       const int rr = e / PW2, cc = e - rr * PW2;
       const int gy = min(max(y0 - 1 + rr, 0), rows - 1), gx = min(max(x0 - 1 + cc, 0), cols - 1);
       const size_t o = (size_t)gy * pitch + gx;
@@ -257,7 +283,8 @@ __global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, 
   __syncthreads();
 
   PlTile t;
-  t.tgt = s_tgt;
+  // absolute LDS address of the target tile in 8-byte units (the dynamic LDS block is 16-byte aligned)
+  t.tgt_entry0 = (int)((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)pl_lds >> 3) + NREF;
   t.rc = s_rc;
   t.rg = s_rg;
   t.rw = rw;
@@ -367,11 +394,11 @@ __global__ void __launch_bounds__(256) k_planes(PlaneSet ps, PlaneState<ST> st, 
 template <int STAGE>
 inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
   const int h = P / 2;
-  const int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  const int TW = STAGE == PL_SPATIAL ? 128 : 64;
   const int TR = kPlTileH + P - 1, LW = TW + P - 1;
-  const int nref = (TR * LW + 3) / 4 + 4;
+  const int nref = ((TR * LW + 3) / 4 + 4 + 1) & ~1;
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
-  size_t words = 2 * (size_t)nref + (size_t)TR * rw + 4;
+  size_t words = 2 * (size_t)nref + 2 * (size_t)TR * rw + 4;
   if (STAGE == PL_SPATIAL) words += 3 * (size_t)(kPlTileH + 2) * (TW + 2);
   return words * 4;
 }
@@ -379,7 +406,7 @@ inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
 template <int P, int STAGE, typename ST>
 inline hipError_t pl_launch_t(const PlaneSet& ps, void* state, const PlanesParams& pp, const PlArgs& ar, int slots,
                               hipStream_t stream) {
-  const int TW = STAGE == PL_SPATIAL ? 64 : 32;
+  const int TW = STAGE == PL_SPATIAL ? 128 : 64;
   const size_t lds = pl_lds_bytes<STAGE>(P, pp);
   if (lds > kChainLdsMax) return hipErrorInvalidValue;
   allow_big_lds(k_planes<P, STAGE, ST>, lds);
@@ -387,7 +414,7 @@ inline hipError_t pl_launch_t(const PlaneSet& ps, void* state, const PlanesParam
   st.base = (ST*)state;
   st.plane = ps.plane;
   const dim3 grid((unsigned)((ps.cols + TW - 1) / TW), (unsigned)((ps.rows + kPlTileH - 1) / kPlTileH), (unsigned)slots);
-  hipLaunchKernelGGL((k_planes<P, STAGE, ST>), grid, dim3(256), lds, stream, ps, st, pp, ar);
+  hipLaunchKernelGGL((k_planes<P, STAGE, ST>), grid, dim3(kPlThreads), lds, stream, ps, st, pp, ar);
   return hipGetLastError();
 }
 
