@@ -72,12 +72,13 @@ typedef enum pm_state_dtype { PM_STATE_F32 = 0, PM_STATE_F16 = 1 } pm_state_dtyp
 
 /* How the directional sweeps are executed on the device (results are identical). */
 typedef enum pm_engine {
-  PM_ENGINE_AUTO = 0,   /* = PM_ENGINE_RUNBLK2 for PM_SEM_CPU, PM_ENGINE_WAVE for PM_SEM_GPU                  */
+  PM_ENGINE_AUTO = 0,   /* = PM_ENGINE_RUNBLK2 for both semantics                                              */
   PM_ENGINE_SERIAL = 1, /* one lane per row/column chain, strictly sequential: correctness anchor         */
-  PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes                  */
-  PM_ENGINE_RUN = 3,    /* one wavefront per chain, a whole adoption run (<= 64-pw positions) per step    */
-  PM_ENGINE_RUNBLK = 4, /* workgroup per chain, wavefront per segment, in-kernel fix-up to a fixpoint     */
-  PM_ENGINE_RUNBLK2 = 5 /* as RUNBLK with two segments per wavefront (32-lane strips)                      */
+  PM_ENGINE_WAVE = 2,   /* one wavefront per chain, window taps spread over the 64 lanes (PM_SEM_GPU: one  */
+                        /* lane per chain segment): second, independent anchor                             */
+  /* 3, 4: one-segment-per-wavefront run engines of round 1, retired (PM_ERR_INVALID_ARG)                  */
+  PM_ENGINE_RUNBLK2 = 5 /* workgroup per chain, a whole adoption run per step, two or four chain segments  */
+                        /* per wavefront, in-kernel fix-up to a fixpoint: the product engine               */
 } pm_engine;
 
 /*
@@ -185,6 +186,23 @@ int pm_in_flight(const pm_handle* h);
 int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows,
                     int cols, const float* d_seed_l, const float* d_seed_r, float* d_disp_l,
                     float* d_disp_r);
+/* Replaces void PatchmatchGpu::Match(const cu::GpuMat& iml, const cu::GpuMat& imr, const cu::GpuMat& Gl,
+ * const cu::GpuMat& Gr, cu::GpuMat& disp) (patchmatch_gpu.h:104-108, patchmatch_gpu.cu:379-411) as it stands: ONE
+ * view, caller-supplied gradients, `disp` holds the sparse-init map on entry and the result on return.
+ * All pointers are DEVICE memory of CV_32F layout: rows x cols floats, `step` = row stride in BYTES (GpuMat::step,
+ * 0 = tightly packed); d_iml / d_imr hold the 8-bit image values as floats (convertTo, patchmatch_gpu.cu:346-349).
+ * `stream` (a hipStream_t, or NULL for the handle's own stream) is the caller's stream: the work is ordered after
+ * what that stream holds at the time of the call, and work the caller enqueues afterwards is ordered after it.
+ * Iterations {noise, 4 sweeps} + background mask under the handle's semantics; no cross-check (one view).
+ * PM_MODE_SCALAR only. */
+int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, const float* d_Gl,
+                         const float* d_Gr, int rows, int cols, size_t step, float* d_disp, size_t disp_step,
+                         void* stream);
+/* Replaces the unit-noise image the reference's host Match() creates on first use and its device Match()
+ * silently depends on (patchmatch_gpu.cu:339-344 vs :395): installs a caller-supplied HOST table of
+ * rows x cols floats (tightly packed) in place of cv::RNG(noise_seed) uniform [-1, 1).  It stays until a call
+ * with another image size regenerates the default table. */
+int pm_set_unit_noise(pm_handle* h, const float* noise, int rows, int cols);
 int pm_synchronize(pm_handle* h);
 /* Optional: record the calls made between pm_capture_begin and pm_capture_end (e.g. one pm_match_device with fixed
  * device pointers and image size; the handle must already have matched that size once) into a HIP graph instead

@@ -17,7 +17,6 @@
 
 #include "pm_kernels.hpp"
 #include "pm_wave.hpp"
-#include "pm_run.hpp"
 #include "pm_run2.hpp"
 #include "pm_internal.hpp"
 #include "pm_seed.hpp"
@@ -100,6 +99,8 @@ struct pm_handle {
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
   bool capturing = false;
+  bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
+  hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -352,6 +353,10 @@ int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scrat
 int ensure_noise(pm_handle* h, int rows, int cols) {
   const int pitch = align_up(cols, 64);
   if (h->noise_rows == rows && h->noise_cols == cols && h->noise_pitch == pitch) return PM_OK;
+  if (h->capturing) {  // building the table synchronises and copies: not capturable
+    set_err(h, "the noise table for %dx%d does not exist yet: match this size once before capturing", cols, rows);
+    return PM_ERR_BUSY;
+  }
   const size_t count = (size_t)rows * pitch;
   PM_HIP(h, hipStreamSynchronize(h->stream));
   if (count > h->noise_capacity) {
@@ -382,7 +387,7 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
   return PM_OK;
 }
 
-// Wavefronts per chain in PM_ENGINE_RUNBLK / RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
+// Wavefronts per chain in PM_ENGINE_RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
 // 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
 int runblk_waves(int chain_len, int axis) {
   struct Knobs {
@@ -447,16 +452,14 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
       chain_lds_bytes(chain_len, 4 * kMaxSegWaves + 4) > kChainLdsMax)
     engine = PM_ENGINE_SERIAL;
   // PM_SEM_GPU has two parallel engines: lane-per-segment (WAVE) and the shared-tap run step (RUNBLK2)
-  if (cp.semantics != PM_SEM_CPU && (engine == PM_ENGINE_RUN || engine == PM_ENGINE_RUNBLK)) engine = PM_ENGINE_WAVE;
   if (engine == PM_ENGINE_SERIAL) {
     hipLaunchKernelGGL(k_sweep_serial, dim3((unsigned)((chains + 63) / 64), 1, (unsigned)slots), dim3(64), 0,
                        h->stream, ps, cp, g);
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
-  } else if (engine == PM_ENGINE_RUNBLK2) {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis), runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph), h->stream);
   } else {
-    launch_sweep_run(ps, cp, g, slots, engine == PM_ENGINE_RUNBLK ? runblk_waves(chain_len, g.axis) : 1, h->stream);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis),
+                      runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph), h->stream);
   }
   return launch_check(h, "sweep");
 }
@@ -464,7 +467,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
 // noise + clamp + cost of the current disparity; PM_SEM_CPU square windows use the LDS-tiled kernel
 void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float amount,
                        int slots, int keep_zero) {
-  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && getenv("PM_NO_TILED") == nullptr;
+  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
   const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
                    (unsigned)slots);
   if (tiled && cp.pw == 3) {
@@ -485,7 +488,7 @@ void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
 // RemoveBackground / MaskBackground; PM_SEM_CPU square windows use the LDS-tiled kernel
 void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float factor,
                        int cached, int slots) {
-  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && getenv("PM_NO_TILED") == nullptr;
+  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
   const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
                    (unsigned)slots);
 #define PM_BG_CASE(W)                                                                                        \
@@ -603,7 +606,8 @@ int validate_params(pm_handle* h, const pm_params& p) {
     set_err(h, "unknown semantics %d", p.semantics);
     return PM_ERR_INVALID_ARG;
   }
-  if (p.engine < PM_ENGINE_AUTO || p.engine > PM_ENGINE_RUNBLK2) {
+  if (p.engine != PM_ENGINE_AUTO && p.engine != PM_ENGINE_SERIAL && p.engine != PM_ENGINE_WAVE &&
+      p.engine != PM_ENGINE_RUNBLK2) {
     set_err(h, "unknown engine %d", p.engine);
     return PM_ERR_INVALID_ARG;
   }
@@ -792,6 +796,23 @@ int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
 
 }  // namespace
 
+namespace {
+// Ends a capture in progress and throws the partial graph away (error paths, pm_destroy).
+void abort_capture(pm_handle* h) {
+  if (!h->capturing) return;
+  h->capturing = false;
+  hipGraph_t graph = nullptr;
+  (void)hipStreamEndCapture(h->stream, &graph);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+}
+int refuse_while_capturing(pm_handle* h, const char* what) {
+  if (!h->capturing) return PM_OK;
+  set_err(h, "%s: not allowed between pm_capture_begin and pm_capture_end", what);
+  return PM_ERR_BUSY;
+}
+}  // namespace
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -865,8 +886,11 @@ const char* pm_last_error(const pm_handle* h) { return h ? h->err : "null handle
 void pm_destroy(pm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  abort_capture(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   pm_internal::release_imaging(h);
+  if (h->ext_fork) (void)hipEventDestroy(h->ext_fork);
+  if (h->ext_join) (void)hipEventDestroy(h->ext_join);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->ev_pool) {
     (void)hipEventDestroy(r.start);
@@ -911,6 +935,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   *out = h;
   h->params = *params;
   h->device = device;
+  h->no_tiled = getenv("PM_NO_TILED") != nullptr;
   if (int rc = validate_params(h, *params)) return rc;
 
   int count = 0;
@@ -984,6 +1009,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
 
 int pm_synchronize(pm_handle* h) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_synchronize")) return rc;
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   return PM_OK;
@@ -1001,8 +1027,19 @@ int pm_capture_begin(pm_handle* h) {
     set_err(h, "pm_capture_begin: per-kernel profiling must be off while capturing");
     return PM_ERR_INVALID_ARG;
   }
+  if (h->capturing) {
+    set_err(h, "pm_capture_begin: already capturing");
+    return PM_ERR_BUSY;
+  }
+  if (h->pipe_count > 0) {
+    set_err(h, "pm_capture_begin: pairs are in flight (pm_collect them first)");
+    return PM_ERR_BUSY;
+  }
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
+  // lazily created resources must exist before the capture starts (creating them is not capturable)
+  if (h->params.sparse_init && !h->seed2.dx)
+    if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
   PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   h->capturing = true;
   return PM_OK;
@@ -1036,9 +1073,8 @@ int pm_replay(pm_handle* h) {
   return PM_OK;
 }
 
-int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                    const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
-  if (!h) return PM_ERR_INVALID_ARG;
+static int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                             const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
   if (!d_left || !d_right || !d_disp_l) {
     set_err(h, "pm_match_device: null image or output pointer");
     return PM_ERR_INVALID_ARG;
@@ -1083,10 +1119,100 @@ int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
   return launch_check(h, "finalize");
 }
 
+int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                    const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  const int rc = match_device_impl(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
+  if (rc != PM_OK) abort_capture(h);  // a failed call must not leave the stream in capture mode
+  return rc;
+}
+
+int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, const float* d_Gl, const float* d_Gr,
+                         int rows, int cols, size_t step, float* d_disp, size_t disp_step, void* stream) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_match_view_device")) return rc;
+  if (!d_iml || !d_imr || !d_Gl || !d_Gr || !d_disp) {
+    set_err(h, "pm_match_view_device: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (h->params.mode != PM_MODE_SCALAR) {
+    set_err(h, "pm_match_view_device: scalar-disparity mode only");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  if (step == 0) step = sizeof(float) * (size_t)cols;
+  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
+  if (step < sizeof(float) * (size_t)cols || disp_step < sizeof(float) * (size_t)cols || (step % sizeof(float)) ||
+      (disp_step % sizeof(float))) {
+    set_err(h, "pm_match_view_device: a row step is smaller than a row or not a multiple of 4");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  hipStream_t user = (hipStream_t)stream;
+  const bool foreign = user != nullptr && user != h->stream;
+  if (foreign) {
+    if (!h->ext_fork) {
+      PM_HIP(h, hipEventCreateWithFlags(&h->ext_fork, hipEventDisableTiming));
+      PM_HIP(h, hipEventCreateWithFlags(&h->ext_join, hipEventDisableTiming));
+    }
+    PM_HIP(h, hipEventRecord(h->ext_fork, user));
+    PM_HIP(h, hipStreamWaitEvent(h->stream, h->ext_fork, 0));
+  }
+  PlaneSet ps = plane_set(h, rows, cols, 1);
+  {
+    Launch l(h, PM_K_PREP);
+    hipLaunchKernelGGL(k_prep_view, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_iml, d_imr, d_Gl, d_Gr,
+                       step / sizeof(float));
+  }
+  if (int rc = launch_check(h, "prep_view")) return rc;
+  {
+    Launch l(h, PM_K_PREP);
+    if (int rc = run_transpose(h, ps, 1)) return rc;
+  }
+  {
+    Launch l(h, PM_K_SEED);
+    hipLaunchKernelGGL(k_copy_disp_strided, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_disp,
+                       disp_step / sizeof(float), 0);
+  }
+  if (int rc = launch_check(h, "seed")) return rc;
+  h->need_seed[0] = h->need_seed[1] = false;
+  if (int rc = run_one_view_set(h, ps, 1)) return rc;
+  {
+    Launch l(h, PM_K_FINALIZE);
+    hipLaunchKernelGGL(k_copy_disp_strided, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_disp,
+                       disp_step / sizeof(float), 1);
+  }
+  if (int rc = launch_check(h, "copy out")) return rc;
+  if (foreign) {
+    PM_HIP(h, hipEventRecord(h->ext_join, h->stream));
+    PM_HIP(h, hipStreamWaitEvent(user, h->ext_join, 0));
+  }
+  return PM_OK;
+}
+
+int pm_set_unit_noise(pm_handle* h, const float* noise, int rows, int cols) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_set_unit_noise")) return rc;
+  if (!noise) {
+    set_err(h, "pm_set_unit_noise: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = ensure_noise(h, rows, cols)) return rc;  // allocation + bookkeeping for this size
+  const int pitch = align_up(cols, 64);
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  PM_HIP(h, hipMemcpy2D(h->noise, sizeof(float) * (size_t)pitch, noise, sizeof(float) * (size_t)cols,
+                        sizeof(float) * (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
+  return PM_OK;
+}
+
 int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int rows,
                       int cols, const float* const* seed_l, const float* const* seed_r, float* const* disp_l,
                       float* const* disp_r) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_match_batch_u8")) return rc;
   if (!left || !right || !disp_l) {
     set_err(h, "pm_match_batch_u8: null pointer array");
     return PM_ERR_INVALID_ARG;
@@ -1107,6 +1233,19 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
   uint8_t* pl = (uint8_t*)(pdr + n * px);
   uint8_t* pr = pl + n * px;
   bool any_sl = false, any_sr = false;
+  // With sparse_init a missing seed map means "seed this view on the device", which is decided per call, not per
+  // pair: a batch must give the seed map of a view for every pair or for none.
+  if (h->params.sparse_init) {
+    int nl = 0, nr = 0;
+    for (int i = 0; i < n; ++i) {
+      nl += (seed_l && seed_l[i]) ? 1 : 0;
+      nr += (seed_r && seed_r[i]) ? 1 : 0;
+    }
+    if ((nl != 0 && nl != n) || (nr != 0 && nr != n)) {
+      set_err(h, "pm_match_batch_u8: with sparse_init a view's seed maps must be given for all pairs or for none");
+      return PM_ERR_INVALID_ARG;
+    }
+  }
   for (int i = 0; i < n; ++i) {
     if (!left[i] || !right[i] || !disp_l[i] || (lr && !disp_r[i])) {
       set_err(h, "pm_match_batch_u8: null pointer for pair %d", i);
@@ -1131,7 +1270,7 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
   PM_HIP(h, hipMemcpyAsync(h->st_right, pr, n * px, hipMemcpyHostToDevice, h->stream));
   if (any_sl) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
   if (any_sr) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
-  if (int rc = pm_match_device(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
+  if (int rc = match_device_impl(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
                                any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
   PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
@@ -1148,6 +1287,7 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
                 const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
                 size_t disp_step) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_match_u8")) return rc;
   if (!left || !right || !disp_l) {
     set_err(h, "pm_match_u8: null image or output pointer");
     return PM_ERR_INVALID_ARG;
@@ -1185,7 +1325,7 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
   PM_HIP(h, hipMemcpyAsync(h->st_right, pr, px, hipMemcpyHostToDevice, h->stream));
   if (seed_l) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
   if (seed_r) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  if (int rc = pm_match_device(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
+  if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
                                seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
   PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
@@ -1239,6 +1379,7 @@ PinnedSlot pinned_slot(pm_handle* h, int slot, size_t px) {
 int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
                  const float* seed_l, const float* seed_r, size_t seed_step, uint64_t tag) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_submit_u8")) return rc;
   if (!left || !right) {
     set_err(h, "pm_submit_u8: null image pointer");
     return PM_ERR_INVALID_ARG;
@@ -1289,7 +1430,7 @@ int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
   if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
   PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
   PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
-  if (int rc = pm_match_device(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
+  if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
                                lr ? ddr : nullptr))
     return rc;
   PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
@@ -1306,6 +1447,7 @@ int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
 
 int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_collect")) return rc;
   if (h->pipe_count == 0) {
     set_err(h, "pm_collect: nothing in flight");
     return PM_ERR_BUSY;
@@ -1378,6 +1520,7 @@ int stage_out(pm_handle* h, const PlaneSet& ps, float* dst, int which) {
 
 int pm_gradient_magnitude(pm_handle* h, const uint8_t* image, int rows, int cols, float* grad) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_gradient_magnitude")) return rc;
   if (!image || !grad) {
     set_err(h, "pm_gradient_magnitude: null pointer");
     return PM_ERR_INVALID_ARG;
@@ -1389,6 +1532,7 @@ int pm_gradient_magnitude(pm_handle* h, const uint8_t* image, int rows, int cols
 
 int pm_unit_noise(pm_handle* h, int rows, int cols, float* noise) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_unit_noise")) return rc;
   if (!noise) {
     set_err(h, "pm_unit_noise: null pointer");
     return PM_ERR_INVALID_ARG;
@@ -1401,6 +1545,7 @@ int pm_unit_noise(pm_handle* h, int rows, int cols, float* noise) {
 
 int pm_add_noise(pm_handle* h, float* disp, int rows, int cols, float amount) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_add_noise")) return rc;
   if (!disp || !(amount >= 0.f)) {
     set_err(h, "pm_add_noise: null pointer or negative amount");
     return PM_ERR_INVALID_ARG;
@@ -1420,6 +1565,7 @@ int pm_add_noise(pm_handle* h, float* disp, int rows, int cols, float amount) {
 int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
                  int patch_h, int patch_w, int pass_mask) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_propagate")) return rc;
   if (!left || !right || !disp) {
     set_err(h, "pm_propagate: null pointer");
     return PM_ERR_INVALID_ARG;
@@ -1442,6 +1588,7 @@ int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
 int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
                          int patch_h, int patch_w, float factor) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_remove_background")) return rc;
   if (!left || !right || !disp || !(factor > 0.f)) {
     set_err(h, "pm_remove_background: null pointer or non-positive factor");
     return PM_ERR_INVALID_ARG;
@@ -1461,6 +1608,7 @@ int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right
 int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
                    float* seed) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_sparse_init")) return rc;
   if (!left || !right || !seed || dilate_factor < 0 || dilate_factor > 8) {
     set_err(h, "pm_sparse_init: null pointer or dilate_factor outside [0, 8]");
     return PM_ERR_INVALID_ARG;
@@ -1474,6 +1622,7 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
 
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_mask_occlusions")) return rc;
   if (!disp_l || !disp_r) {
     set_err(h, "pm_mask_occlusions: null pointer");
     return PM_ERR_INVALID_ARG;
@@ -1825,12 +1974,15 @@ int pm_debug_counters(pm_handle* h, uint64_t out[8]) {
 
 int pm_profile_enable(pm_handle* h, int on) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (on)
+    if (int rc = refuse_while_capturing(h, "pm_profile_enable")) return rc;  // events would be recorded into the graph
   h->profiling = on != 0;
   return PM_OK;
 }
 
 int pm_profile_read(pm_handle* h, pm_profile* out) {
   if (!h || !out) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_profile_read")) return rc;
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < h->ev_used; ++i) {

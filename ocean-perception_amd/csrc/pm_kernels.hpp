@@ -63,6 +63,32 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
   }
 }
 
+// One view from caller-supplied FLOAT images and gradients -- the inputs of
+// PatchmatchGpu::Match(const cu::GpuMat& iml, imr, Gl, Gr, cu::GpuMat& disp) (patchmatch_gpu.h:104-108): iml / imr hold
+// the 8-bit image values as floats, as convertTo(CV_32F) leaves them (patchmatch_gpu.cu:346-349), Gl / Gr their
+// gradient magnitudes.  Fills planes 0 (reference) and 1 (target) of pair 0; `stride` in elements.
+__global__ void __launch_bounds__(256) k_prep_view(PlaneSet ps, const float* __restrict__ iml,
+                                                   const float* __restrict__ imr, const float* __restrict__ gl,
+                                                   const float* __restrict__ gr, size_t stride) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ps.cols) return;
+  const float* im[2] = {iml, imr};
+  const float* gm[2] = {gl, gr};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const size_t si = (size_t)y * stride + x;
+    const uint8_t p = (uint8_t)sat_u8(im[i][si]);
+    const float g = gm[i][si];
+    const uint8_t g8 = (uint8_t)sat_u8(g);
+    const size_t o = (size_t)i * ps.plane + (size_t)y * ps.pitch + x;
+    ps.img8[o] = p;
+    ps.g32[o] = g;
+    ps.g8[o] = g8;
+    ps.pk16[o] = (uint16_t)(p | ((unsigned)g8 << 8));
+  }
+}
+
 // Transposes `planes` planes of rows x cols (pitch `sp`) into cols x rows (pitch `dp`) through a
 // 64x64 LDS tile (+1 column of padding: conflict-free for 4-byte elements, 2-way for bytes) so that
 // both the reads and the writes are coalesced.  grid = (ceil(cols/64), ceil(rows/64), planes), block = 256.
@@ -547,12 +573,21 @@ __global__ void __launch_bounds__(256) k_mask_occlusions(float* __restrict__ dis
   if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) displ[(size_t)y * cols + x] = 0.f;
 }
 
-// Plain copies between tightly packed caller planes and the pitched disparity plane of view 0.
+// Plain copies between caller planes and the pitched disparity plane of view 0.
 __global__ void __launch_bounds__(256) k_copy_in(PlaneSet ps, const float* __restrict__ src) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
   ps.disp[(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
+}
+// caller plane with its own row stride (elements); to_caller != 0 copies the other way
+__global__ void __launch_bounds__(256) k_copy_disp_strided(PlaneSet ps, float* __restrict__ buf, size_t stride,
+                                                           int to_caller) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= ps.cols) return;
+  if (to_caller) buf[(size_t)y * stride + x] = ps.disp[(size_t)y * ps.pitch + x];
+  else ps.disp[(size_t)y * ps.pitch + x] = buf[(size_t)y * stride + x];
 }
 __global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict__ dst, int which) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,9 +9,9 @@
 // group-uniform here and lives in vector registers; cross-lane traffic stays inside a group:
 // ballots are split into their 32-bit halves, broadcasts use ds_bpermute.  The DPP neighbour tap and
 // the sliding window sum may cross from lane 31 into lane 32, which only touches lines no position of
-// group 0 uses (its last lane is the spare one, exactly as lane 63 was).
-// Semantics, exactness arguments and the fix-up scheme are those of pm_run.hpp; results are
-// bit-identical and checked against the other engines and the oracle.
+// group 0 uses (its last lane is the spare one).
+// The run step itself, its exactness arguments and the fix-up scheme are described in pm_run.hpp; results are
+// bit-identical to the serial and wave engines and the oracle.
 #pragma once
 
 #include "pm_run.hpp"
@@ -334,7 +334,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 }
 
 // One workgroup per chain; wavefront w carries segments 2w (lanes 0-31) and 2w+1 (lanes 32-63).
-// Rounds and fix-up exactly as pm_run.hpp::k_runblk, per group.
+// Rounds and fix-up as described in pm_run.hpp, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
 // SEM = 0: PM_SEM_CPU (run_step2 above); SEM = 1: PM_SEM_GPU (run_step2_gpu, pm_run_gpu.hpp).
 template <int SEM, int GS, int AXIS, int TPW, int TPH>

@@ -75,6 +75,7 @@ int DecodeSymbol(BitReader& br, const Huff& h) {
   return h.vals[h.valptr[len] + code - h.mincode[len]];
 }
 
+// t is 1..16 here: callers reject larger categories (baseline allows DC <= 11, AC <= 10; the extended process 15/14)
 int Extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
 const int kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -291,7 +292,8 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
       while (o < slen) {
         const int pq = seg[o] >> 4, tq = seg[o] & 15;
         ++o;
-        if (tq > 3) throw std::runtime_error("JPEG: bad quantisation table id");
+        if (tq > 3 || pq > 1) throw std::runtime_error("JPEG: bad quantisation table id");
+        if (o + (pq ? 128 : 64) > slen) throw std::runtime_error("JPEG: truncated quantisation table");
         for (int i = 0; i < 64; ++i) {
           qt[tq][kZigzag[i]] = pq ? Be16(seg + o) : seg[o];
           o += pq ? 2 : 1;
@@ -302,18 +304,22 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
       while (o < slen) {
         const int tc = seg[o] >> 4, th = seg[o] & 15;
         ++o;
+        if (o + 16 > slen) throw std::runtime_error("JPEG: truncated Huffman table");
         int total = 0;
         for (int i = 0; i < 16; ++i) total += seg[o + i];
-        if (th > 3 || total > 256) throw std::runtime_error("JPEG: bad Huffman table");
+        if (tc > 1 || th > 3 || total > 256 || o + 16 + total > slen) throw std::runtime_error("JPEG: bad Huffman table");
         build(tc ? hac[th] : hdc[th], seg + o, seg + o + 16, total);
         o += 16 + total;
       }
     } else if (m == 0xC0 || m == 0xC1) {
+      if (have_frame) throw std::runtime_error("JPEG: second frame header");  // planes are sized by the first
+      if (slen < 6) throw std::runtime_error("JPEG: truncated frame header");
       if (seg[0] != 8) throw std::runtime_error("JPEG: only 8-bit samples are supported");
       height = Be16(seg + 1);
       width = Be16(seg + 3);
       const int nc = seg[5];
       if ((nc != 1 && nc != 3) || width <= 0 || height <= 0) throw std::runtime_error("JPEG: unsupported frame");
+      if (slen < 6 + 3 * nc) throw std::runtime_error("JPEG: truncated frame header");
       comps.resize((size_t)nc);
       for (int i = 0; i < nc; ++i) {
         comps[i].id = seg[6 + 3 * i];
@@ -329,10 +335,14 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
     } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
       throw std::runtime_error("JPEG: progressive / lossless / arithmetic coding is not supported");
     } else if (m == 0xDD) {
+      if (slen < 2) throw std::runtime_error("JPEG: truncated restart interval");
       restart = Be16(seg);
     } else if (m == 0xDA) {
       if (!have_frame) throw std::runtime_error("JPEG: scan before frame header");
+      if (slen < 1) throw std::runtime_error("JPEG: truncated scan header");
       const int ns = seg[0];
+      if (ns < 1 || ns > (int)comps.size() || slen < 1 + 2 * ns + 3)
+        throw std::runtime_error("JPEG: bad scan header");
       std::vector<int> order;
       for (int i = 0; i < ns; ++i) {
         const int cid = seg[1 + 2 * i];
@@ -340,8 +350,12 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
         for (size_t k = 0; k < comps.size(); ++k)
           if (comps[k].id == cid) idx = (int)k;
         if (idx < 0) throw std::runtime_error("JPEG: scan names an unknown component");
-        comps[(size_t)idx].td = seg[2 + 2 * i] >> 4;
-        comps[(size_t)idx].ta = seg[2 + 2 * i] & 15;
+        for (int prev : order)
+          if (prev == idx) throw std::runtime_error("JPEG: scan names a component twice");
+        const int td = seg[2 + 2 * i] >> 4, ta = seg[2 + 2 * i] & 15;
+        if (td > 3 || ta > 3) throw std::runtime_error("JPEG: bad Huffman table selector");
+        comps[(size_t)idx].td = td;
+        comps[(size_t)idx].ta = ta;
         order.push_back(idx);
       }
       // geometry
@@ -363,6 +377,7 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
         const Huff& ac = hac[c.ta];
         if (!dc.present || !ac.present) throw std::runtime_error("JPEG: missing Huffman table");
         const int t = DecodeSymbol(br, dc);
+        if (t > 15) throw std::runtime_error("JPEG: bad DC category");  // 8-bit samples: at most 11 (15 tolerated)
         const int diff = t ? Extend(br.bits(t), t) : 0;
         c.pred += diff;
         coef[0] = c.pred * qt[c.tq][0];

@@ -15,6 +15,8 @@ pm_params PatchmatchGpu::Params::ToC() const {
   p.init_dilate_factor = init_dilate_factor;
   p.cost_improve_factor = cost_improve_factor;
   p.engine = engine;
+  p.mode = mode;
+  p.state_dtype = state_dtype;
   for (int i = 0; i < PM_MAX_ITERS; ++i) {
     p.patch_w[i] = patch_size;
     p.patch_h[i] = patch_size;
@@ -52,6 +54,11 @@ void PatchmatchGpu::Check(int status, const char* what) const {
 // (patchmatch_gpu.cu:339-344); here a size that exceeds the plan re-plans explicitly.
 void PatchmatchGpu::EnsurePlan(int rows, int cols) {
   if (handle_ && rows <= plan_rows_ && cols <= plan_cols_) return;
+  if (InFlight() > 0)  // re-planning destroys the handle the submitted pairs live in
+    throw std::runtime_error("PatchmatchGpu: image larger than the plan while pairs are in flight; Collect() them first");
+  // grow to the envelope of everything seen so far: alternating 720x1280 / 1280x720 inputs re-plan once, not per call
+  rows = rows > plan_rows_ ? rows : plan_rows_;
+  cols = cols > plan_cols_ ? cols : plan_cols_;
   if (handle_) {
     pm_destroy(handle_);
     handle_ = nullptr;
@@ -81,12 +88,16 @@ void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp,
     throw std::invalid_argument("PatchmatchGpu::Match: left seed map does not match the image size");
   if (!seed_r_.empty() && (seed_r_.rows != iml.rows || seed_r_.cols != iml.cols))
     throw std::invalid_argument("PatchmatchGpu::Match: right seed map does not match the image size");
+  if (iml.step != imr.step) throw std::invalid_argument("PatchmatchGpu::Match: the two images have different row steps");
+  if (!seed_l_.empty() && !seed_r_.empty() && seed_l_.step != seed_r_.step)
+    throw std::invalid_argument("PatchmatchGpu::Match: the two seed maps have different row steps");
   EnsurePlan(iml.rows, iml.cols);
   // like GpuMat::download (patchmatch_gpu.cu:374-375) the outputs are (re)allocated to the image size
   if (disp.rows != iml.rows || disp.cols != iml.cols) disp.create(iml.rows, iml.cols);
   if (dispr.rows != iml.rows || dispr.cols != iml.cols) dispr.create(iml.rows, iml.cols);
+  const size_t seed_step = !seed_l_.empty() ? seed_l_.step : (!seed_r_.empty() ? seed_r_.step : 0);
   Check(pm_match_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
-                    seed_l_.empty() ? nullptr : seed_l_.data(), seed_r_.empty() ? nullptr : seed_r_.data(), 0,
+                    seed_l_.empty() ? nullptr : seed_l_.data(), seed_r_.empty() ? nullptr : seed_r_.data(), seed_step,
                     disp.data(), dispr.data(), disp.step),
         "pm_match_u8");
 }
@@ -123,9 +134,24 @@ void PatchmatchGpu::Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, 
   Check(pm_synchronize(handle_), "pm_synchronize");
 }
 
+void PatchmatchGpu::Match(const GpuImage1f& iml, const GpuImage1f& imr, const GpuImage1f& Gl, const GpuImage1f& Gr,
+                          GpuImage1f& disp, void* stream) {
+  const auto same = [&](const GpuImage1f& m) { return m.data && m.rows == iml.rows && m.cols == iml.cols; };
+  if (!same(iml) || !same(imr) || !same(Gl) || !same(Gr) || !same(disp))
+    throw std::invalid_argument("PatchmatchGpu::Match(GpuImage1f...): images empty or of different size");
+  if (imr.step != iml.step || Gl.step != iml.step || Gr.step != iml.step)
+    throw std::invalid_argument("PatchmatchGpu::Match(GpuImage1f...): images and gradients must share one row step");
+  EnsurePlan(iml.rows, iml.cols);
+  Check(pm_match_view_device(handle_, iml.data, imr.data, Gl.data, Gr.data, iml.rows, iml.cols, iml.step, disp.data,
+                             disp.step, stream),
+        "pm_match_view_device");
+}
+
 Image1f PatchmatchGpu::SparseInit(const Image1b& iml, const Image1b& imr, int dilate_factor) {
   if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
     throw std::invalid_argument("PatchmatchGpu::SparseInit: images empty or of different size");
+  if (iml.step != (size_t)iml.cols || imr.step != (size_t)imr.cols)
+    throw std::invalid_argument("PatchmatchGpu::SparseInit: images must be continuous (step == cols)");
   EnsurePlan(iml.rows, iml.cols);
   Image1f seed(iml.rows, iml.cols);
   Check(pm_sparse_init(handle_, iml.data(), imr.data(), iml.rows, iml.cols, dilate_factor, seed.data()),

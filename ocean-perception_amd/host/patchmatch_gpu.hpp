@@ -59,31 +59,44 @@ typedef Image<float> Image1f;
 
 namespace ft {
 
-// Field names and defaults of ft::FeatureDetector::Params
-// (src/vehicle/feature_tracking/feature_detector.hpp:22-47) and ft::StereoMatcher::Params
-// (src/vehicle/feature_tracking/stereo_matcher.hpp:17-29): the configuration of the sparse seeder.
-struct FeatureDetectorParams {
-  int max_features_per_frame = 200;
-  int min_distance_btw_tracked_and_detected_features = 20;
-  double gftt_quality_level = 0.01;
-  int gftt_block_size = 5;
-  bool gftt_use_harris_corner_detector = false;
-  double gftt_k = 0.04;
-  bool subpixel_corners = false;
-  int subpix_winsize = 10;
-  int subpix_zerozone = -1;
-  int subpix_maxiters = 10;
-  float subpix_epsilon = 0.01f;
+// ft::FeatureDetector::Params (src/vehicle/feature_tracking/feature_detector.hpp:19-47) and
+// ft::StereoMatcher::Params (src/vehicle/feature_tracking/stereo_matcher.hpp:15-29): the configuration of the
+// sparse seeder, nested in their classes exactly as the reference nests them (PatchmatchGpu::Params holds a
+// `ft::FeatureDetector::Params detector_params` and a `ft::StereoMatcher::Params matcher_params`,
+// patchmatch_gpu.h:82-83).  The classes themselves carry no behaviour here: detection and matching run on the
+// device inside the engine (pm_sparse_init).
+class FeatureDetector final {
+ public:
+  struct Params final {
+    int max_features_per_frame = 200;
+    int min_distance_btw_tracked_and_detected_features = 20;
+    double gftt_quality_level = 0.01;
+    int gftt_block_size = 5;
+    bool gftt_use_harris_corner_detector = false;
+    double gftt_k = 0.04;
+    bool subpixel_corners = false;
+    int subpix_winsize = 10;
+    int subpix_zerozone = -1;
+    int subpix_maxiters = 10;
+    float subpix_epsilon = 0.01f;
+  };
 };
 
-struct StereoMatcherParams {
-  int templ_cols = 31;
-  int templ_rows = 11;
-  int max_disp = 128;
-  double max_matching_cost = 0.15;
-  bool bidirectional = false;
-  bool subpixel_refinement = false;
+class StereoMatcher final {
+ public:
+  struct Params final {
+    int templ_cols = 31;
+    int templ_rows = 11;
+    int max_disp = 128;
+    double max_matching_cost = 0.15;
+    bool bidirectional = false;
+    bool subpixel_refinement = false;
+  };
 };
+
+// round-1 spellings
+typedef FeatureDetector::Params FeatureDetectorParams;
+typedef StereoMatcher::Params StereoMatcherParams;
 
 }  // namespace ft
 
@@ -96,8 +109,8 @@ class PatchmatchGpu final {
  public:
   struct Params final {
     // --- reference fields (patchmatch_gpu.h:82-88) ---
-    ft::FeatureDetectorParams detector_params;
-    ft::StereoMatcherParams matcher_params;
+    ft::FeatureDetector::Params detector_params;
+    ft::StereoMatcher::Params matcher_params;
     float cost_alpha = 0.9f;
     int patchmatch_iters = 3;
     int init_dilate_factor = 4;
@@ -107,6 +120,8 @@ class PatchmatchGpu final {
     int semantics = PM_SEM_GPU;  // which reference code is reproduced; PM_SEM_CPU = stereo_matching/patchmatch.cpp
     int engine = PM_ENGINE_AUTO;
     int patch_size = 3;          // PM_SEM_CPU window side for every iteration and the background mask
+    int mode = PM_MODE_SCALAR;   // PM_MODE_PLANES: slanted-plane state (include/pm/patchmatch.h)
+    int state_dtype = PM_STATE_F32;
     bool left_right_check = true;
     int device = 0;
     int max_rows = 0, max_cols = 0;  // 0: plan on the first Match()
@@ -130,6 +145,16 @@ class PatchmatchGpu final {
   // packed planes.  Gl/Gr of the reference are computed inside the engine.
   void Match(const uint8_t* d_iml, const uint8_t* d_imr, int rows, int cols, const float* d_seed_l,
              const float* d_seed_r, float* d_disp, float* d_dispr);
+
+  // patchmatch_gpu.h:104-108 as it stands: one view, caller-supplied gradients, `disp` = sparse-init map in,
+  // result out.  GpuImage1f is what the call needs of a cu::GpuMat (CV_32F): device pointer, size, step in bytes.
+  struct GpuImage1f {
+    float* data = nullptr;
+    int rows = 0, cols = 0;
+    size_t step = 0;
+  };
+  void Match(const GpuImage1f& iml, const GpuImage1f& imr, const GpuImage1f& Gl, const GpuImage1f& Gr,
+             GpuImage1f& disp, void* stream = nullptr);
 
   // Match() for a sequence of frames (the callback loop of patchmatch_gpu_test.cpp:118-128) with the
   // copies off the critical path: Submit() returns once the pair is packed and enqueued, Collect() waits

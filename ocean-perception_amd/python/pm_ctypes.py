@@ -13,7 +13,7 @@ PM_ABI_VERSION = 3
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
-PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUN, PM_ENGINE_RUNBLK, PM_ENGINE_RUNBLK2 = 0, 1, 2, 3, 4, 5
+PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUNBLK2 = 0, 1, 2, 5
 PM_OK = 0
 PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY = -1, -2, -3, -4, -5, -6
 PM_K_COUNT = 11
@@ -38,6 +38,7 @@ EXPORTS = [
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish",
+    "pm_match_view_device", "pm_set_unit_noise",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
 ]
 
@@ -194,6 +195,10 @@ def load():
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
                  "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish"):
         getattr(lib, name).restype = C.c_int
+    lib.pm_match_view_device.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_size_t, f32p, C.c_size_t, vp]
+    lib.pm_match_view_device.restype = C.c_int
+    lib.pm_set_unit_noise.argtypes = [vp, f32p, C.c_int, C.c_int]
+    lib.pm_set_unit_noise.restype = C.c_int
     lib.pm_planes_begin.argtypes = [vp, C.c_int, u8p, u8p, C.c_int, C.c_int, f32p, f32p]
     lib.pm_planes_step.argtypes = [vp, C.c_int, C.c_int]
     lib.pm_planes_read.argtypes = [vp, C.c_int, C.c_int, f32p]
@@ -408,6 +413,15 @@ class Engine:
         self._pl_shape = (rows, cols)
         self._check(self.lib.pm_match_device(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
                                              d_disp_r), "pm_match_device")
+
+    def match_view_device(self, d_iml, d_imr, d_gl, d_gr, rows, cols, step, d_disp, disp_step=0, stream=None):
+        """One view with caller-supplied float images and gradients (device addresses as ints)."""
+        self._check(self.lib.pm_match_view_device(self.h, d_iml, d_imr, d_gl, d_gr, rows, cols, step, d_disp,
+                                                  disp_step, stream), "pm_match_view_device")
+
+    def set_unit_noise(self, noise):
+        a, p = _f32(noise)
+        self._check(self.lib.pm_set_unit_noise(self.h, p, a.shape[0], a.shape[1]), "pm_set_unit_noise")
 
     def capture_begin(self):
         self._check(self.lib.pm_capture_begin(self.h), "pm_capture_begin")

@@ -9,7 +9,11 @@
 #include <iostream>
 #include <string>
 
+#include <type_traits>
+#include <vector>
+
 #include "patchmatch_gpu.hpp"
+#include "pm/imaging.h"
 
 using namespace bm::pm;
 using bm::core::Image1b;
@@ -85,6 +89,51 @@ int main(int argc, char** argv) {
         if (std::memcmp(qr.data(), dispr.data(), sizeof(float) * (size_t)rows * cols) != 0) return 5;
       }
       if (collected != 7) return 6;
+    }
+    // the nested parameter types carry the reference's names (patchmatch_gpu.h:82-83)
+    static_assert(std::is_same<decltype(params.detector_params), bm::ft::FeatureDetector::Params>::value, "nested Params");
+    static_assert(std::is_same<decltype(params.matcher_params), bm::ft::StereoMatcher::Params>::value, "nested Params");
+    // PatchmatchGpu::Match(GpuMat iml, imr, Gl, Gr, GpuMat& disp) (patchmatch_gpu.h:104-108): one view, gradients
+    // from the caller, disp = sparse-init map in / result out; device buffers through pm/imaging.h's helpers
+    {
+      const size_t n = (size_t)rows * cols, bytes = n * sizeof(float);
+      std::vector<float> fl(n), fr(n), gl(n), gr(n);
+      for (size_t i = 0; i < n; ++i) {
+        fl[i] = (float)il.data()[i];
+        fr[i] = (float)ir.data()[i];
+      }
+      if (pm_gradient_magnitude(pm.handle(), il.data(), rows, cols, gl.data()) != PM_OK ||
+          pm_gradient_magnitude(pm.handle(), ir.data(), rows, cols, gr.data()) != PM_OK)
+        return 7;
+      PatchmatchGpu::GpuImage1f dv[5];
+      const float* host[5] = {fl.data(), fr.data(), gl.data(), gr.data(), sl.data()};
+      for (int k = 0; k < 5; ++k) {
+        void* d = nullptr;
+        if (pm_device_malloc(pm.handle(), bytes, &d) != PM_OK || pm_upload(pm.handle(), d, host[k], bytes) != PM_OK)
+          return 7;
+        dv[k].data = (float*)d;
+        dv[k].rows = rows;
+        dv[k].cols = cols;
+        dv[k].step = sizeof(float) * (size_t)cols;
+      }
+      pm.Match(dv[0], dv[1], dv[2], dv[3], dv[4]);
+      Image1f view(rows, cols);
+      if (pm_download(pm.handle(), view.data(), dv[4].data, bytes) != PM_OK) return 7;
+      write_raw(dir + "/view_l.f32", view);
+      for (int k = 0; k < 5; ++k) pm_device_free(pm.handle(), dv[k].data);
+    }
+    // a larger image re-plans to the envelope of the sizes seen; the old size still works afterwards
+    {
+      Image1b big_l(rows + 8, cols), big_r(rows + 8, cols);
+      std::memset(big_l.data(), 0, (size_t)(rows + 8) * cols);
+      std::memset(big_r.data(), 0, (size_t)(rows + 8) * cols);
+      Image1f bd, bdr, again, againr;
+      pm.SetSeeds(none, none);
+      pm.Match(big_l, big_r, bd, bdr);
+      if (bd.rows != rows + 8) return 8;
+      pm.SetSeeds(sl, sr);
+      pm.Match(il, ir, again, againr);
+      if (std::memcmp(again.data(), disp.data(), sizeof(float) * (size_t)rows * cols) != 0) return 9;
     }
     std::cout << "ok " << disp.rows << "x" << disp.cols << "\n";
     return 0;

@@ -63,3 +63,7 @@ def test_wrapper_match_matches_oracle(wrapper_exe, tmp_path, oracle, synth, sem,
     el2, er2 = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8), l, r, osl, osr)
     assert_same(al, el2, "self-seeded left")
     assert_same(ar, er2, "self-seeded right")
+    # the one-view device overload with caller-supplied gradients (patchmatch_gpu.h:104-108)
+    vl = np.fromfile(os.path.join(tmp_path, "view_l.f32"), np.float32).reshape(rows, cols)
+    ev = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8, left_right_check=0), l, r, sl, None)
+    assert_same(vl, ev[0], "Match(GpuImage1f...)")

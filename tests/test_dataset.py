@@ -169,6 +169,32 @@ def test_jpeg_decoder_on_the_reference_test_images(dataset_exe, tmp_path):
         assert np.array_equal(got, np.asarray(Image.open(p).convert("RGB"))[..., ::-1])
 
 
+def test_jpeg_decoder_rejects_malformed_input_under_asan(tmp_path):
+    """Every truncation, 3000 random mutations and crafted header fields (table selectors > 3, scan component
+    counts 0 / too large, a second frame header, short table segments, DC categories >= 16) of two small JPEGs go
+    through the decoder built with AddressSanitizer + UBSan (CPU build): each input is decoded or rejected with an
+    exception, never a sanitizer report.  The reference uses cv::imdecode (lcm_util/decode_image.cpp:11-32)."""
+    Image = _pil()
+    exe = os.path.join(tmp_path, "jpeg_fuzz")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"),
+           os.path.join(ROOT, "tests", "cpp", "jpeg_fuzz_main.cpp"), os.path.join(PKG, "host", "jpeg.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:24, 0:40]
+    rgb = np.stack([127 + 100 * np.sin(xx / 5.0), 127 + 90 * np.cos(yy / 3.0), rng.integers(0, 255, (24, 40))],
+                   -1).clip(0, 255).astype(np.uint8)
+    for i, kw in enumerate((dict(quality=80, subsampling=2), dict(quality=60, subsampling=0))):
+        p = os.path.join(tmp_path, f"s{i}.jpg")
+        Image.fromarray(rgb).save(p, **kw)
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+        r = subprocess.run([exe, p, "3000"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+        ok, bad = map(int, r.stdout.split()[1:3])
+        assert ok > 100 and bad > 500, r.stdout  # both paths were exercised
+
+
 @pytest.mark.gpu
 def test_euroc_playback_through_the_pipelined_matcher(dataset_exe, tmp_path, oracle, synth):
     rows, cols, n = 64, 112, 5

@@ -17,7 +17,7 @@ from conftest import assert_same, small_pair
 pytestmark = pytest.mark.gpu
 
 SEMS = [0, 1]
-ENGINES = [1, 2, 3, 4, 5]  # PM_ENGINE_SERIAL, _WAVE, _RUN, _RUNBLK, _RUNBLK2
+ENGINES = [1, 2, 5]  # PM_ENGINE_SERIAL, _WAVE (anchors), _RUNBLK2 (product)
 
 
 def mk(pm, sem, engine=0, patch=3, iters=3, lr=1, rows=64, cols=96, batch=1, **kw):
@@ -348,6 +348,118 @@ def test_graph_replay_equals_direct_calls(pm, oracle, synth):
     el, er = oracle.match(oparams(oracle, 0, 5, 2), pb[0], pb[1], pb[2], pb[3])
     assert_same(DL.cpu().numpy(), el, "replayed left")
     assert_same(DR.cpu().numpy(), er, "replayed right")
+
+
+def test_capture_error_paths_leave_the_handle_usable(pm, oracle, synth):
+    """A call that fails while capturing ends the capture; calls that would synchronise or record events are
+    refused with PM_ERR_BUSY between pm_capture_begin and pm_capture_end."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 64, 96
+    dev = torch.device("cuda:0")
+    pa = small_pair(synth, 93, rows, cols, n_points=25, dilate_factor=2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    L, R, SL, SR = t(pa[0]), t(pa[1]), t(pa[2]), t(pa[3])
+    DL, DR = torch.empty_like(SL), torch.empty_like(SR)
+    with mk(pm, 0, patch=5, iters=2, rows=rows, cols=cols) as e:
+        run = lambda r_=rows, c_=cols: e.match_device(1, L.data_ptr(), R.data_ptr(), r_, c_, SL.data_ptr(),
+                                                        SR.data_ptr(), DL.data_ptr(), DR.data_ptr())
+        # 1) capturing a size that was never matched: the noise table cannot be built inside a capture
+        e.capture_begin()
+        with pytest.raises(pm.PmError) as ei:
+            run()
+        assert ei.value.status == pm.PM_ERR_BUSY
+        with pytest.raises(pm.PmError):
+            e.capture_end()  # the failed call already ended the capture
+        run()                # ... and the handle still works
+        e.synchronize()
+        el, er = oracle.match(oparams(oracle, 0, 5, 2), *pa[:4])
+        assert_same(DL.cpu().numpy(), el, "after an aborted capture")
+        # 2) refused while capturing
+        e.capture_begin()
+        for call in (e.synchronize, lambda: e.profile_enable(True), e.profile_read,
+                     lambda: e.match(pa[0], pa[1], pa[2], pa[3]), lambda: e.gradient_magnitude(pa[0]), e.capture_begin):
+            with pytest.raises(pm.PmError) as ei:
+                call()
+            assert ei.value.status == pm.PM_ERR_BUSY
+        run()
+        e.capture_end()
+        e.replay()
+        e.synchronize()
+        assert_same(DL.cpu().numpy(), el, "replay after refused calls")
+        # 3) an oversized request inside a capture fails cleanly too
+        e.capture_begin()
+        with pytest.raises(pm.PmError) as ei:
+            run(rows + 8, cols)
+        assert ei.value.status == pm.PM_ERR_SIZE
+        run()
+        e.synchronize()
+    # destroying a handle in the middle of a capture must not hang or crash
+    e2 = mk(pm, 0, patch=5, iters=1, rows=rows, cols=cols)
+    e2.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
+                    DR.data_ptr())
+    e2.synchronize()
+    e2.capture_begin()
+    e2.close()
+
+
+@pytest.mark.parametrize("sem", SEMS)
+def test_one_view_device_match_with_caller_gradients(pm, oracle, synth, sem):
+    """PatchmatchGpu::Match(GpuMat iml, imr, Gl, Gr, GpuMat& disp) (patchmatch_gpu.h:104-108): float images and
+    gradients with a row step, disp = seed in / result out, enqueued behind the caller's stream."""
+    torch = pytest.importorskip("torch")
+    rows, cols, padc = 64, 96, 104
+    dev = torch.device("cuda:0")
+    l, r, sl, sr, _ = small_pair(synth, 94 + sem, rows, cols, n_points=25, dilate_factor=2)
+
+    def padded(a):
+        buf = torch.full((rows, padc), -7.0, dtype=torch.float32, device=dev)
+        buf[:, :cols] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        return buf
+
+    with mk(pm, sem, patch=5, iters=3, rows=rows, cols=cols) as e:
+        gl, gr = e.gradient_magnitude(l), e.gradient_magnitude(r)
+        IL, IR, GL, GR, D = padded(l), padded(r), padded(gl), padded(gr), padded(sl)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            D2 = D.clone()  # produced on the caller's stream: the call must wait for it
+            e.match_view_device(IL.data_ptr(), IR.data_ptr(), GL.data_ptr(), GR.data_ptr(), rows, cols, padc * 4,
+                                D2.data_ptr(), padc * 4, stream=side.cuda_stream)
+            out = D2.clone()  # consumed on the caller's stream: must see the result
+        side.synchronize()
+        e.match_view_device(IL.data_ptr(), IR.data_ptr(), GL.data_ptr(), GR.data_ptr(), rows, cols, padc * 4,
+                            D.data_ptr(), padc * 4)
+        e.synchronize()
+        with pytest.raises(pm.PmError):
+            e.match_view_device(IL.data_ptr(), IR.data_ptr(), GL.data_ptr(), GR.data_ptr(), rows, cols, cols * 4 - 4,
+                                D.data_ptr())
+    want = oracle.match(oparams(oracle, sem, 5, 3, lr=0), l, r, sl, None)[0]
+    assert_same(D[:, :cols].cpu().numpy(), want, "one view, own stream")
+    assert_same(out[:, :cols].cpu().numpy(), want, "one view, caller's stream")
+    assert (D[:, cols:] == -7.0).all()  # the padding behind a row is not touched
+
+
+def test_set_unit_noise_and_seed_rules(pm, oracle, synth):
+    rows, cols = 48, 80
+    l, r, sl, sr, _ = small_pair(synth, 96, rows, cols, n_points=20, dilate_factor=2)
+    with mk(pm, 1, iters=3, rows=rows, cols=cols) as e:
+        base = e.match(l, r, sl, sr)
+        e.set_unit_noise(e.unit_noise(rows, cols))  # the table the engine already uses: nothing changes
+        again = e.match(l, r, sl, sr)
+        assert_same(again[0], base[0], "same table")
+        e.set_unit_noise(np.zeros((rows, cols), np.float32))  # no noise at all == amplitude 0 in the oracle
+        quiet = e.match(l, r, sl, sr)
+    want = oracle.match(oparams(oracle, 1, 3, 3, noise_amp=[0.0] * 16), l, r, sl, sr)
+    assert_same(quiet[0], want[0], "zero noise table, left")
+    assert_same(quiet[1], want[1], "zero noise table, right")
+    # with sparse_init a batch gives a view's seed maps for all pairs or for none
+    with mk(pm, 1, iters=1, rows=rows, cols=cols, batch=2, sparse_init=1) as e:
+        with pytest.raises(pm.PmError) as ei:
+            e.match_batch([l, l], [r, r], [sl, None], None)
+        assert ei.value.status == pm.PM_ERR_INVALID_ARG
+    # the retired engines are refused
+    for eng in (3, 4, 6):
+        with pytest.raises(pm.PmError):
+            mk(pm, 0, engine=eng)
 
 
 def test_random_configurations_match_the_oracle(pm, oracle, synth):
