@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: PatchMatch stereo Match() on MI355X.
 
-Workload (BASELINE.json configs[1]): one 1280x720 synthetic stereo pair per GPU, 8 iterations,
-11x11 window, fp32 cost, reference-CPU semantics (PM_SEM_CPU), left + right view + cross-check.
-A "step" is one Match() through the C ABI entry point pm_match_device with the u8 pair and the seed
-maps already resident in HBM and the disparity maps written to HBM.
+Headline workload (BASELINE.json configs[1]): one 1280x720 synthetic stereo pair per GPU, 8 iterations,
+11x11 window, fp32 cost, reference-CPU semantics (PM_SEM_CPU, the parity-bearing scalar mode), left + right
+view + cross-check.  A "step" is one Match() through the C ABI entry point pm_match_device with the u8 pair and
+the seed maps already resident in HBM and the disparity maps written to HBM; the timed steps rotate over four
+distinct resident pairs, so the inputs are not the same cache-hot pair every step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank r matches pair r (stereo pairs are independent: no data-path collective, weak scaling).  The K
-timed steps are bracketed by barrier + synchronize on both sides; rank 0 prints ONE JSON line with
-the whole-job pairs/s (max elapsed over ranks), the roofline of the dominant kernel (per-launch
-duration from HIP events recorded by the engine on its own stream during the timed steps) and the
-CPU baseline (the oracle -- a port of the reference CPU path -- timed on this host, rank 0, N=1).
+Rank r matches its own pairs (stereo pairs are independent: no data-path collective, weak scaling).  The K
+timed steps are bracketed by barrier + synchronize on both sides; rank 0 prints ONE JSON line with the whole-job
+pairs/s (max elapsed over ranks), the roofline of the dominant kernel (per-launch duration from HIP events
+recorded by the engine on its own stream during the timed steps) and the CPU baseline (the oracle -- a port of
+the reference CPU path -- timed on this host, rank 0, N=1).
+
+Side legs in the same line (rank 0, N=1, never `value`):
+    planes            the slanted-plane mode (north_star kernels) at the same shape: fp32 state (configs[1] shape) and
+                      fp16 state behind the on-device stereo-ready enhancement (configs[4] shape)
+    host_buffers      PCIe-inclusive rates of the host-buffer entry points
+Other workloads: --mode planes [--state f16] [--enhance] makes the plane mode the timed one; --pairs-per-gpu 32 is
+configs[2]'s per-GPU share; --tiled runs configs[3] (one 4096x2160 pair row-tiled over the ranks).
 """
 import argparse
 import json
@@ -26,9 +34,13 @@ sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
 
 ROWS, COLS, ITERS, PATCH = 720, 1280, 8, 11
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured streaming
-# Algorithmic bytes of one directional sweep: per pixel and view the sweep reads the four
-# f32-equivalent image planes once (16 B), reads the disparity (4 B) and writes it (4 B).
+# Algorithmic bytes.  Scalar mode: a directional sweep reads the four f32-equivalent image planes once
+# (16 B), reads the disparity (4 B) and writes it (4 B) per pixel and view; a whole pair is N * (78 + 216 * I).
 SWEEP_BYTES_PER_PX = 24
+# Plane mode: state = 12 B plane + 4 B cost per pixel and view (8 B with fp16 state); per iteration and view the
+# spatial stage moves 48 B/px (two colour launches of 24), view propagation 64, refinement 48: N * (74 + 320 * I).
+PLANE_STAGE_BYTES = {"planes_spatial": 48, "planes_view": 64, "planes_refine": 48}
+N_ROTATE = 4  # distinct device-resident pairs the timed steps rotate over
 
 
 def parse():
@@ -58,6 +70,15 @@ def parse():
                     help="pairs of the untimed host-buffer leg (PCIe-inclusive rates, reported beside `value`); 0 = skip")
     ap.add_argument("--semantics", type=int, default=0,
                     help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
+    ap.add_argument("--mode", choices=("scalar", "planes"), default="scalar",
+                    help="scalar = the reference's algorithm (headline); planes = slanted-plane mode as the timed workload")
+    ap.add_argument("--state", choices=("f32", "f16"), default="f32", help="plane / cost storage type (--mode planes)")
+    ap.add_argument("--enhance", action="store_true",
+                    help="--mode planes: inputs are BGR images, the stereo-ready enhancement (pm_stereo_ready) of both "
+                         "runs on the device in front of every Match (BASELINE configs[4])")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the plane-mode side legs of the default run")
+    ap.add_argument("--tiled", action="store_true",
+                    help="BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks (see python/tiled.py)")
     return ap.parse_args()
 
 
@@ -111,14 +132,16 @@ def pmc_traffic(kernel_class):
         return None
 
 
-def shard(rank, world, steps):
-    """Pair index matched by `rank` at each step: independent pairs, contiguous by rank."""
-    return [rank for _ in range(steps)]
+def shard(rank, world, steps, nb):
+    """Pair indices matched by `rank` at each step: independent pairs, contiguous by rank; the steps rotate over
+    N_ROTATE distinct pairs of the rank's share."""
+    return [[rank * nb * N_ROTATE + (s % N_ROTATE) * nb + i for i in range(nb)] for s in range(steps)]
 
 
 def cpu_baseline(args):
-    """The oracle (port of src/vehicle/stereo_matching/patchmatch.cpp + the test recipe, literal call
-    structure, single thread like the reference) on a bounded sample of the same workload."""
+    """The oracle (port of src/vehicle/stereo_matching/patchmatch.cpp + the test recipe, literal call structure)
+    on bounded samples of the same workload: single-threaded like the reference (a 160-row full-width band, the
+    swept rows scaled up) and on all host cores (the whole frame; rows / columns of a sweep are independent)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     import synth
@@ -132,13 +155,40 @@ def cpu_baseline(args):
     t = time.perf_counter() - t0
     h = args.patch // 2
     scale = (args.rows - 2 * h) / float(band_rows - 2 * h)  # swept rows of the full image / of the band
+    ncpu = os.cpu_count() or 1
+    nthr = min(ncpu, 16)  # the GPU box's CPU share for one GPU is 16 cores; more threads only oversubscribe it
+    prm_all = O.default_params(O.SEM_CPU, patch=args.patch, n_iters=args.iters, nthreads=nthr, literal=1,
+                               left_right_check=1)
+    t0 = time.perf_counter()
+    O.match(prm_all, p["left"], p["right"], p["seed_l"], p["seed_r"])
+    t_all = time.perf_counter() - t0
     return {
         "value": 1.0 / (t * scale), "unit": "pairs/s", "cores": 1, "kind": "port",
-        "sample": f"oracle (literal getRectSubPix+functor port, 1 thread) on a {band_rows}-row full-width band of "
-                  f"pair 0, both views, {args.iters} iterations, {args.patch}x{args.patch}: {t:.2f} s; scaled by "
-                  f"swept rows {args.rows - 2 * h}/{band_rows - 2 * h}",
-        "host_cores": os.cpu_count(),
+        "sample": f"oracle (literal getRectSubPix+functor port, 1 thread: the reference CPU path has no threading) on a "
+                  f"{band_rows}-row full-width band of pair 0, both views, {args.iters} iterations, "
+                  f"{args.patch}x{args.patch}: {t:.2f} s; scaled by swept rows {args.rows - 2 * h}/{band_rows - 2 * h}",
+        "all_cores": {"value": 1.0 / t_all, "unit": "pairs/s", "cores": nthr, "kind": "port",
+                      "sample": f"the same oracle on the WHOLE {args.cols}x{args.rows} frame with {nthr} OpenMP threads "
+                                f"(rows / columns of a sweep in parallel; the box's CPU share for one GPU is 16 cores "
+                                f"of {ncpu}): {t_all:.2f} s, unscaled"},
+        "host_cores": ncpu,
     }
+
+
+def cpu_baseline_planes(args, f16):
+    """The plane mode's CPU definition (oracle/pm_planes_oracle.c) on all host cores, whole frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import synth
+    p = synth.make_pair(0, args.rows, args.cols)
+    nthr = min(os.cpu_count() or 1, 16)
+    prm = O.planes_params(n_iters=args.iters, patch=args.patch, nthreads=nthr, state_f16=1 if f16 else 0)
+    t0 = time.perf_counter()
+    O.planes_match(prm, p["left"], p["right"])
+    t = time.perf_counter() - t0
+    return {"value": 1.0 / t, "unit": "pairs/s", "cores": nthr, "kind": "port",
+            "sample": f"oracle/pm_planes_oracle.c (this mode's own CPU definition; the reference has no slanted-plane "
+                      f"code) on the whole {args.cols}x{args.rows} frame, {nthr} OpenMP threads: {t:.2f} s"}
 
 
 def host_buffer_leg(pm, params, args, pair, device):
@@ -181,32 +231,218 @@ def host_buffer_leg(pm, params, args, pair, device):
     return out
 
 
+def to_bgr(gray, seed):
+    """A synthetic underwater-looking BGR image whose stereo-ready enhancement is well defined: the gray pattern
+    under a smooth coloured illuminant (blue-green cast, vignette)."""
+    import numpy as np
+    rows, cols = gray.shape
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    vig = 0.55 + 0.45 * np.exp(-(((xx - cols / 2) / (0.6 * cols)) ** 2 + ((yy - rows / 2) / (0.6 * rows)) ** 2))
+    g = gray.astype(np.float32)
+    rng = np.random.default_rng(seed)
+    gains = (1.0, 0.85, 0.55)  # B, G, R
+    bgr = np.stack([np.clip(g * gains[c] * vig + rng.normal(0, 0.6, g.shape), 0, 255) for c in range(3)], -1)
+    return np.rint(bgr).astype(np.uint8)
+
+
+class Workload:
+    """Device-resident inputs/outputs of one rank and the step function of the selected mode."""
+
+    def __init__(self, args, pm, torch, np, synth, dev, local_rank, rank, mode, state, enhance):
+        self.args, self.pm, self.torch, self.mode, self.enhance = args, pm, torch, mode, enhance
+        nb = max(1, args.pairs_per_gpu)
+        self.nb = nb
+        # rank r owns pairs r*nb*N_ROTATE ...: N_ROTATE groups of nb pairs (a few distinct pairs are generated and
+        # repeated inside a group to fill a large batch)
+        uniq = [synth.make_pair(rank * N_ROTATE * min(nb, 4) + i, args.rows, args.cols) for i in range(N_ROTATE * min(nb, 4))]
+        self.pairs = uniq
+        groups = [[uniq[g * min(nb, 4) + (i % min(nb, 4))] for i in range(nb)] for g in range(N_ROTATE)]
+        stack = lambda grp, k: torch.from_numpy(np.stack([p[k] for p in grp])).to(dev).contiguous()
+        self.L = [stack(g, "left") for g in groups]
+        self.R = [stack(g, "right") for g in groups]
+        self.SL = [stack(g, "seed_l") for g in groups]
+        self.SR = [stack(g, "seed_r") for g in groups]
+        self.gt0 = torch.from_numpy(groups[0][0]["gt"]).to(dev)
+        self.DL = torch.empty((nb, args.rows, args.cols), dtype=torch.float32, device=dev)
+        self.DR = torch.empty_like(self.DL)
+        if mode == "planes":
+            self.params = pm.default_params(0, patch=args.patch, patchmatch_iters=args.iters, mode=pm.PM_MODE_PLANES,
+                                            state_dtype=pm.PM_STATE_F16 if state == "f16" else pm.PM_STATE_F32,
+                                            sparse_init=1 if args.self_seed else 0)
+        else:
+            self.params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters,
+                                            engine=args.engine, sparse_init=1 if args.self_seed else 0)
+        self.eng = pm.Engine(self.params, device=local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=nb)
+        if enhance:
+            # BGR inputs; the enhanced gray images are produced on the device, on the engine's stream, in front of
+            # every Match (no host round trip): pm_stereo_ready (imaging::Normalize(NormalizeColorIlluminant(.)) -> gray)
+            self.BL = [torch.from_numpy(np.stack([to_bgr(p["left"], 1) for p in g])).to(dev).contiguous() for g in groups]
+            self.BR = [torch.from_numpy(np.stack([to_bgr(p["right"], 2) for p in g])).to(dev).contiguous() for g in groups]
+            self.J = torch.empty((args.rows, args.cols, 3), dtype=torch.float32, device=dev)
+            self.GL = torch.empty((nb, args.rows, args.cols), dtype=torch.uint8, device=dev)
+            self.GR = torch.empty_like(self.GL)
+
+    def step(self, s):
+        a, e, g = self.args, self.eng, s % N_ROTATE
+        seeded = self.mode == "scalar" and not a.self_seed
+        if self.enhance:
+            px = a.rows * a.cols
+            for i in range(self.nb):
+                e.stereo_ready(self.BL[g].data_ptr() + 3 * px * i, a.rows, a.cols, self.J.data_ptr(),
+                               self.GL.data_ptr() + px * i)
+                e.stereo_ready(self.BR[g].data_ptr() + 3 * px * i, a.rows, a.cols, self.J.data_ptr(),
+                               self.GR.data_ptr() + px * i)
+            left, right = self.GL.data_ptr(), self.GR.data_ptr()
+        else:
+            left, right = self.L[g].data_ptr(), self.R[g].data_ptr()
+        e.match_device(self.nb, left, right, a.rows, a.cols, self.SL[g].data_ptr() if seeded else None,
+                       self.SR[g].data_ptr() if seeded else None, self.DL.data_ptr(), self.DR.data_ptr())
+
+    def quality(self):
+        d = self.DL[0]
+        ok = d > 0
+        fg = float(ok.float().mean().item())
+        err = (d - self.gt0).abs()
+        return {"foreground_fraction": fg,
+                "foreground_within_1px_of_truth": float((err[ok] < 1.0).float().mean().item()) if fg > 0 else 0.0}
+
+
+def roofline_of(args, prof, n_prof, nb, mode, state):
+    px_views = args.rows * args.cols * 2 * nb
+    if mode == "planes":
+        dom = max(PLANE_STAGE_BYTES, key=lambda k: prof[k][1])
+        n_launch, total_ms = prof[dom]
+        avg_ms = total_ms / max(n_launch, 1)
+        launches_per_iter = {"planes_spatial": 2, "planes_view": 2, "planes_refine": 1}[dom]
+        scale = 0.5 if state == "f16" else 1.0  # "with fp16 state replace 16 -> 8 B" (SURVEY 8d)
+        bytes_per_launch = PLANE_STAGE_BYTES[dom] * scale * px_views / launches_per_iter
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
+        return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
+                "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48, view 64, "
+                           "refine 48 (halved for fp16 state)",
+                "note": "the window cost makes these kernels VALU-bound (about 100 vector instructions per window row "
+                        "and candidate, DESIGN.md): the HBM fraction is the figure BASELINE.json asks for, not the "
+                        "binding roof"}
+    dom = max(("sweep_row", "sweep_col"), key=lambda k: prof[k][1])
+    n_launch, total_ms = prof[dom]
+    avg_ms = total_ms / max(n_launch, 1)
+    # a class runs 2 sweeps per iteration over every pixel of both views; with the views on their own streams
+    # (default) a launch covers one view, and two launches run concurrently on the chip
+    launches_per_step = n_launch / max(n_prof, 1)
+    concurrency = max(1, round(launches_per_step / (2 * args.iters)))
+    bytes_per_launch = SWEEP_BYTES_PER_PX * px_views / concurrency
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+            "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
+            "achieved_all_concurrent": achieved * concurrency,
+            "formula": "N * (78 + 216 * I) B per pair, scalar state; 24 B per px and view and sweep",
+            "note": "per-launch figure as specified, HIP events on every --profile-every-th timed step "
+                    "(`profiled_steps` of them); `concurrent_launches` launches of this class (one per view, "
+                    "own streams) share the chip, so the chip-level rate is achieved_all_concurrent"}
+
+
+def timed_loop(w, d, steps, warmup, every, no_profile):
+    torch = w.torch
+    eng = w.eng
+    for s in range(warmup):
+        w.step(s)
+    eng.synchronize()
+    eng.profile_read()
+    n_prof = 0
+    torch.cuda.synchronize()
+    d.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        timed = (not no_profile) and s % every == 0
+        eng.profile_enable(timed)
+        n_prof += 1 if timed else 0
+        w.step(s)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    d.barrier()
+    torch.cuda.synchronize()
+    elapsed = d.max_over_ranks(elapsed_local)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    return elapsed, prof, n_prof
+
+
+def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
+    """One plane-mode measurement for the default run's JSON line (rank 0, N=1)."""
+    class NoDist:
+        def barrier(self):
+            pass
+
+        def max_over_ranks(self, v):
+            return v
+    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance)
+    steps = 8
+    elapsed, prof, n_prof = timed_loop(w, NoDist(), steps, 2, 2, False)
+    w.step(0)
+    w.eng.synchronize()
+    out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
+                       f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images on the device in "
+                                                      "front of every Match (BASELINE configs[4] per-GPU shape)" if enhance
+                                                      else " (BASELINE configs[1] shape)"),
+           "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
+           "dtype": "u8 window cost, " + state + " state",
+           "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state),
+           "kernels_ms_per_step": {k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
+           "check": w.quality()}
+    w.eng.close()
+    return out
+
+
+def run_tiled(args, d):
+    """BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks; delegates to python/tiled.py."""
+    import tiled
+    tiled.bench(args, d)
+
+
 def main():
     args = parse()
     d = Dist(args)
     steps, warmup = args.steps, args.warmup
+    nb = max(1, args.pairs_per_gpu)
+    planes = args.mode == "planes"
+    sem_name = "PM_SEM_CPU" if args.semantics == 0 else "PM_SEM_GPU (5-tap)"
+    if planes:
+        what = (f"PM_MODE_PLANES (random plane init, red-black / view propagation, refinement), {args.state} state"
+                + (", BGR inputs enhanced on the device (BASELINE.json configs[4] per-GPU shape)" if args.enhance else ""))
+    else:
+        what = f"fp32 cost, {sem_name}"
     result = {
         "metric": "stereo_pairs_per_sec_1280x720_patchmatch", "unit": "pairs/s", "n_gpus": d.world, "steps": steps,
-        "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("u8 window cost, " + args.state + " state") if planes else "f32",
         "data": "synthetic",
-        "config": {"workload": f"{max(1, args.pairs_per_gpu)} synthetic {args.cols}x{args.rows} stereo pair(s) per GPU, "
-                               f"{args.iters} iterations, "
-                               f"{args.patch}x{args.patch} window, fp32 cost, {'PM_SEM_CPU' if args.semantics == 0 else 'PM_SEM_GPU (5-tap)'}, left+right view + cross-check "
-                               "(BASELINE.json configs[1])",
-                   "pairs_per_gpu_per_step": max(1, args.pairs_per_gpu),
-                   "sharding": "pair index = rank * pairs_per_gpu + i, no collective"},
+        "config": {"workload": f"{nb} synthetic {args.cols}x{args.rows} stereo pair(s) per GPU and step, "
+                               f"{args.iters} iterations, {args.patch}x{args.patch} window, {what}, left+right view + "
+                               "cross-check" + (" (BASELINE.json configs[1])" if not planes and nb == 1 else ""),
+                   "pairs_per_gpu_per_step": nb, "distinct_resident_pairs_rotated": N_ROTATE,
+                   "sharding": "rank r owns pairs r*nb*4 .. (r+1)*nb*4-1, no collective"},
     }
     if args.dry_run:
         # plumbing only: same barrier / reduction path, no engine, no numbers worth reading
         d.barrier()
         t0 = time.perf_counter()
-        for _ in shard(d.rank, d.world, steps):
+        for _ in shard(d.rank, d.world, steps, nb):
             time.sleep(0.001 * (1 + d.rank))
         elapsed = d.max_over_ranks(time.perf_counter() - t0)
         d.barrier()
         if d.rank == 0:
             result.update(value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, dry_run=True)
             print(json.dumps(result), flush=True)
+        d.close()
+        return
+    if args.tiled:
+        run_tiled(args, d)
         d.close()
         return
 
@@ -217,97 +453,61 @@ def main():
 
     torch.cuda.set_device(d.local_rank)
     dev = torch.device(f"cuda:{d.local_rank}")
-    nb = max(1, args.pairs_per_gpu)
-    # rank r owns pairs r*nb .. r*nb+nb-1 (a few distinct pairs are generated and repeated to fill the batch)
-    uniq = [synth.make_pair(d.rank * nb + i, args.rows, args.cols) for i in range(min(nb, 4))]
-    pairs = [uniq[i % len(uniq)] for i in range(nb)]
-    pair = pairs[0]
-    stack = lambda k: torch.from_numpy(np.stack([p[k] for p in pairs])).to(dev).contiguous()
-    L, R, SL, SR = stack("left"), stack("right"), stack("seed_l"), stack("seed_r")
-    DLb = torch.empty((nb, args.rows, args.cols), dtype=torch.float32, device=dev)
-    DRb = torch.empty_like(DLb)
-    DL = DLb[0]
-    params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine,
-                               sparse_init=1 if args.self_seed else 0)
-    eng = pm.Engine(params, device=d.local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=nb)
+    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, args.mode, args.state, args.enhance)
+    eng = w.eng
+    elapsed, prof, n_prof = timed_loop(w, d, steps, warmup, max(1, args.profile_every), args.no_profile)
 
-    def step():
-        eng.match_device(nb, L.data_ptr(), R.data_ptr(), args.rows, args.cols,
-                         None if args.self_seed else SL.data_ptr(), None if args.self_seed else SR.data_ptr(),
-                         DLb.data_ptr(), DRb.data_ptr())
-
-    for _ in range(warmup):
-        step()
+    # determinism: the same resident pair twice
+    w.step(0)
     eng.synchronize()
-    ref = DL.clone()
-    eng.profile_read()
-    every = max(1, args.profile_every)
-    n_prof = 0
-
-    torch.cuda.synchronize()
-    d.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i, _ in enumerate(shard(d.rank, d.world, steps)):
-        timed = (not args.no_profile) and i % every == 0
-        eng.profile_enable(timed)
-        n_prof += 1 if timed else 0
-        step()
+    ref = w.DL[0].clone()
+    counters = None
+    if not planes:
+        # work counters: one extra untimed step (the counting atomics would distort the timed ones)
+        eng.debug_counters_enable(True)
+        eng.debug_counters()
+        w.step(0)
+        counters = eng.debug_counters()
+        eng.debug_counters_enable(False)
+    else:
+        w.step(0)
     eng.synchronize()
-    torch.cuda.synchronize()
-    elapsed_local = time.perf_counter() - t0
-    d.barrier()
-    torch.cuda.synchronize()
-    elapsed = d.max_over_ranks(elapsed_local)
-
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    # work counters: one extra untimed step (the counting atomics would distort the timed ones)
-    eng.debug_counters_enable(True)
-    eng.debug_counters()
-    step()
-    counters = eng.debug_counters()
-    eng.debug_counters_enable(False)
-    deterministic = bool(torch.equal(ref, DL))
-    fg = float((DL > 0).float().mean().item())
-    err = (DL - torch.from_numpy(pair["gt"]).to(dev)).abs()
-    within1 = float((err[DL > 0] < 1.0).float().mean().item()) if fg > 0 else 0.0
+    deterministic = bool(torch.equal(ref, w.DL[0]))
+    check = w.quality()
+    check["deterministic_across_steps"] = deterministic
 
     if d.rank == 0:
-        px_views = args.rows * args.cols * 2 * nb
-        dom = max(("sweep_row", "sweep_col"), key=lambda k: prof[k][1])
-        n_launch, total_ms = prof[dom]
-        avg_ms = total_ms / max(n_launch, 1)
-        # a class runs 2 sweeps per iteration over every pixel of both views; with the views on their own streams
-        # (default) a launch covers one view, and two launches run concurrently on the chip
-        launches_per_step = n_launch / max(n_prof, 1)
-        concurrency = max(1, round(launches_per_step / (2 * args.iters)))
-        bytes_per_launch = SWEEP_BYTES_PER_PX * px_views / concurrency
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
         gpu_ms = sum(v[1] for v in prof.values())
         result.update(
             value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
             ms_per_frame=1e3 * elapsed / steps / nb,
-            roofline={"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
-                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                      "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
-                      "achieved_all_concurrent": achieved * concurrency,
-                      "note": "per-launch figure as specified, HIP events on every --profile-every-th timed step "
-                              "(`profiled_steps` of them); `concurrent_launches` launches of this class (one per view, "
-                              "own streams) share the chip, so the chip-level rate is achieved_all_concurrent"},
-            kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items()},
+            roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state) if n_prof else None,
+            kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
             gpu_busy_ms_per_step=gpu_ms / max(n_prof, 1),
-            run_engine_counters_per_step=counters,
-            check={"deterministic_across_steps": deterministic, "foreground_fraction": fg,
-                   "foreground_within_1px_of_truth": within1},
+            check=check,
         )
-        if d.world == 1 and args.host_pairs > 0:
-            result["host_buffers"] = host_buffer_leg(pm, params, args, pair, d.local_rank)
-        if d.world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(result), flush=True)
+        if counters is not None:
+            result["run_engine_counters_per_step"] = counters
+        if d.world == 1 and not planes and args.host_pairs > 0:
+            result["host_buffers"] = host_buffer_leg(pm, w.params, args, w.pairs[0], d.local_rank)
     eng.close()
+    del w
+    if not planes and not args.no_side_legs and nb == 1:
+        # BASELINE configs[3] beside the headline: one 4096x2160 pair row-tiled over the ranks of this run (every rank
+        # takes part; with one rank it is the untiled large image).  Never `value`.
+        import tiled
+        tl = tiled.bench(args, d, steps=2, quiet=True)
+        if d.rank == 0:
+            result["tiled_4096x2160"] = tl
+    if d.rank == 0:
+        if d.world == 1 and not planes and not args.no_side_legs and nb == 1:
+            result["planes"] = {"f32": side_leg(args, pm, torch, np, synth, dev, d, "f32", False),
+                                "f16_enhanced": side_leg(args, pm, torch, np, synth, dev, d, "f16", True)}
+        if d.world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_planes(args, args.state == "f16") if planes else cpu_baseline(args)
+            if not planes and "planes" in result:
+                result["planes"]["cpu_baseline"] = cpu_baseline_planes(args, False)
+        print(json.dumps(result), flush=True)
     d.close()
 
 

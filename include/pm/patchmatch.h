@@ -259,6 +259,13 @@ int pm_tile_noise(pm_handle* h, int iteration);         /* noise + clamp + cost 
 int pm_tile_sweep(pm_handle* h, int iteration, int k);  /* k: 0 row+, 1 col+, 2 row-, 3 col- (owned rows) */
 int pm_tile_snapshot(pm_handle* h);                     /* save disparity + cost planes                  */
 int pm_tile_restore(pm_handle* h);
+/* Re-sweep after a boundary exchange without leaving the device timeline: d_mask is a DEVICE array of
+ * [n_views][cols] ints (plane columns: view 1 in mirrored coordinates, as pm_tile_get_row delivers its rows);
+ * pm_tile_restore_cols puts the flagged columns back to the snapshot, pm_tile_sweep_masked runs a vertical sweep
+ * (k = 1 or 3) on the flagged columns only.  Columns of a vertical sweep are independent chains, so re-sweeping
+ * the changed ones is exact. */
+int pm_tile_restore_cols(pm_handle* h, const int* d_mask);
+int pm_tile_sweep_masked(pm_handle* h, int iteration, int k, const int* d_mask);
 /* one image row of the disparity planes: [n_views][cols] floats */
 int pm_tile_get_row(pm_handle* h, int image_row, float* d_dst);
 int pm_tile_set_row(pm_handle* h, int image_row, const float* d_src);

@@ -31,6 +31,9 @@ struct PlaneSet {
   float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
   unsigned long long* counters;  // [8] work counters (see pm_debug_counters), one atomic per wavefront
+  // Row-tiled mode: chains a sweep launch works on, [n_views][cols] (chain index = plane column), nullptr = all.
+  // A re-sweep after a boundary exchange only touches the columns whose incoming value changed.
+  const int* chain_mask;
   int rows, cols, pitch;
   int n_views;         // 1 or 2
   int view_fixed;      // -1: slot = pair * n_views + view; 0 / 1: slot = pair, this view only (per-view streams)
@@ -56,6 +59,15 @@ struct View {
   float* disp;
   float* cost;
 };
+
+// view index of a launch slot (the same rule make_view applies)
+__device__ __forceinline__ int slot_view(const PlaneSet& ps, int slot) {
+  return ps.view_fixed >= 0 ? ps.view_fixed : slot - (slot / ps.n_views) * ps.n_views;
+}
+// false: this chain is masked off in this launch (uniform per workgroup for the chain engines)
+__device__ __forceinline__ bool chain_active(const PlaneSet& ps, int slot, int chain) {
+  return !ps.chain_mask || ps.chain_mask[slot_view(ps, slot) * ps.cols + chain] != 0;
+}
 
 __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   const int b = ps.view_fixed >= 0 ? slot : slot / ps.n_views;

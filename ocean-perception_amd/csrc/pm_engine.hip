@@ -180,6 +180,7 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.cost = h->cost;
   ps.noise = h->noise;
   ps.counters = h->counters_on ? h->counters : nullptr;
+  ps.chain_mask = nullptr;
   ps.rows = rows;
   ps.cols = cols;
   ps.pitch = align_up(cols, 64);
@@ -1729,14 +1730,30 @@ int pm_tile_noise(pm_handle* h, int it) {
   return launch_check(h, "noise_cost");
 }
 
-int pm_tile_sweep(pm_handle* h, int it, int k) {
+static int tile_sweep(pm_handle* h, int it, int k, const int* d_mask);
+int pm_tile_sweep(pm_handle* h, int it, int k) { return tile_sweep(h, it, k, nullptr); }
+int pm_tile_sweep_masked(pm_handle* h, int it, int k, const int* d_mask) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!d_mask) {
+    set_err(h, "pm_tile_sweep_masked: null mask");
+    return PM_ERR_INVALID_ARG;
+  }
+  return tile_sweep(h, it, k, d_mask);
+}
+
+static int tile_sweep(pm_handle* h, int it, int k, const int* d_mask) {
   if (int rc = tile_check(h, "pm_tile_sweep")) return rc;
   const pm_params& p = h->params;
   if (it < 0 || it >= p.patchmatch_iters || k < 0 || k > 3) {
     set_err(h, "pm_tile_sweep: iteration %d / sweep %d out of range", it, k);
     return PM_ERR_INVALID_ARG;
   }
-  const PlaneSet ps = tile_plane_set(h);
+  PlaneSet ps = tile_plane_set(h);
+  if (d_mask && (k & 1) == 0) {
+    set_err(h, "pm_tile_sweep_masked: the column mask applies to the vertical sweeps (k = 1, 3)");
+    return PM_ERR_INVALID_ARG;
+  }
+  ps.chain_mask = d_mask;
   const CostParams cp = cost_params(p, p.patch_w[it], p.patch_h[it]);
   // Geometry of the sweep on the WHOLE image (PM_SEM_GPU trims one position at the far end of each sweep,
   // patchmatch_gpu.cu:156,214 -- that end is an end of the image, not of a band), then cut to the owned rows.
@@ -1788,6 +1805,18 @@ int pm_tile_restore(pm_handle* h) {
   PM_HIP(h, hipMemcpyAsync(h->disp, h->snap_disp, bytes, hipMemcpyDeviceToDevice, h->stream));
   PM_HIP(h, hipMemcpyAsync(h->cost, h->snap_cost, bytes, hipMemcpyDeviceToDevice, h->stream));
   return PM_OK;
+}
+
+int pm_tile_restore_cols(pm_handle* h, const int* d_mask) {
+  if (int rc = tile_check(h, "pm_tile_restore_cols")) return rc;
+  if (!h->snap_disp || !d_mask) {
+    set_err(h, "pm_tile_restore_cols: no snapshot or null mask");
+    return PM_ERR_INVALID_ARG;
+  }
+  const PlaneSet ps = tile_plane_set(h);
+  hipLaunchKernelGGL(k_restore_cols, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps,
+                     (const float*)h->snap_disp, (const float*)h->snap_cost, d_mask);
+  return launch_check(h, "restore_cols");
 }
 
 static int tile_row_copy(pm_handle* h, int image_row, float* d_dst, const float* d_src, const char* what) {

@@ -410,7 +410,7 @@ struct SweepGeom {
 __global__ void __launch_bounds__(64) k_sweep_serial(PlaneSet ps, CostParams cp, SweepGeom g) {
   const int chain = g.c_lo + blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = blockIdx.z;
-  if (chain > g.c_hi) return;
+  if (chain > g.c_hi || !chain_active(ps, slot, chain)) return;
   const View v = make_view(ps, slot);
   const int half_w = cp.semantics == 0 ? cp.pw / 2 : 1;
   const int n = (g.s_last - g.s_first) * g.dir + 1;
@@ -571,6 +571,18 @@ __global__ void __launch_bounds__(256) k_mask_occlusions(float* __restrict__ dis
   const int xr = (int)fmaxf((float)x - dl, 0.f);
   const float dr = dispr[(size_t)y * cols + xr];
   if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) displ[(size_t)y * cols + x] = 0.f;
+}
+
+// Row-tiled mode: columns flagged in mask[n_views][cols] get their disparity / cost back from the snapshot taken
+// before the vertical sweep (the re-sweep of those columns then starts from the pre-sweep state).
+__global__ void __launch_bounds__(256) k_restore_cols(PlaneSet ps, const float* __restrict__ snap_disp,
+                                                      const float* __restrict__ snap_cost, const int* __restrict__ mask) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, v = blockIdx.z;
+  if (x >= ps.cols || !mask[v * ps.cols + x]) return;
+  const size_t o = (size_t)v * ps.plane + (size_t)y * ps.pitch + x;
+  ps.disp[o] = snap_disp[o];
+  ps.cost[o] = snap_cost[o];
 }
 
 // Plain copies between caller planes and the pitched disparity plane of view 0.

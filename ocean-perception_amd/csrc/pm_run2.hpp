@@ -358,6 +358,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   int* s_changed = (int*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1);
 
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
+  if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x & 63;
   constexpr int kPerWave = kWave / GS;

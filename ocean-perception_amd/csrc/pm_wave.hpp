@@ -89,6 +89,7 @@ template <int K>
 __global__ void __launch_bounds__(64) k_sweep_wave_cpu(PlaneSet ps, CostParams cp, SweepGeom g) {
   const int chain = g.c_lo + blockIdx.x;
   const int slot = blockIdx.z;
+  if (!chain_active(ps, slot, chain)) return;
   const int lane = threadIdx.x;
   const View v = make_view(ps, slot);
   const int half_w = cp.pw / 2;
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(64) k_sweep_gpu_lanes(PlaneSet ps, CostParams 
   float* s_last = lds + 4 * n1;  // [65]
 
   const int chain = g.c_lo + blockIdx.x;
+  if (!chain_active(ps, blockIdx.z, chain)) return;
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x;
   const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;

@@ -37,7 +37,7 @@ EXPORTS = [
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
-    "pm_tile_set_row", "pm_tile_background", "pm_tile_finish",
+    "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
     "pm_match_view_device", "pm_set_unit_noise",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
 ]
@@ -192,8 +192,11 @@ def load():
     lib.pm_tile_set_row.argtypes = [vp, C.c_int, f32p]
     lib.pm_tile_background.argtypes = [vp]
     lib.pm_tile_finish.argtypes = [vp, f32p, f32p]
+    lib.pm_tile_restore_cols.argtypes = [vp, vp]
+    lib.pm_tile_sweep_masked.argtypes = [vp, C.c_int, C.c_int, vp]
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
-                 "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish"):
+                 "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols",
+                 "pm_tile_sweep_masked"):
         getattr(lib, name).restype = C.c_int
     lib.pm_match_view_device.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_size_t, f32p, C.c_size_t, vp]
     lib.pm_match_view_device.restype = C.c_int
@@ -505,6 +508,12 @@ class Engine:
 
     def tile_restore(self):
         self._check(self.lib.pm_tile_restore(self.h), "pm_tile_restore")
+
+    def tile_restore_cols(self, d_mask):
+        self._check(self.lib.pm_tile_restore_cols(self.h, d_mask), "pm_tile_restore_cols")
+
+    def tile_sweep_masked(self, it, k, d_mask):
+        self._check(self.lib.pm_tile_sweep_masked(self.h, it, k, d_mask), "pm_tile_sweep_masked")
 
     def tile_get_row(self, image_row, d_dst):
         self._check(self.lib.pm_tile_get_row(self.h, image_row, d_dst), "pm_tile_get_row")

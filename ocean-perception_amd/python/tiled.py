@@ -9,13 +9,19 @@ column, the first row of a band continues from the value the last row of the ban
 
 Exact semantics without serialising the GPUs: speculate and fix up at band granularity (the scheme
 the kernels use inside a chain, pm_run.hpp).  Each rank sweeps with the neighbour's OLD boundary row,
-the new boundary rows travel one hop (one row of disparities per view: 16 KB at 4096 columns), and a
-rank whose incoming row differs from the one it used restores its snapshot and sweeps again.  Band k is
-final after round k+1, typically after 2; the fixpoint is the untiled sweep.
+the new boundary rows travel one hop (one row of disparities per view: 16 KB at 4096 columns), and a rank
+re-sweeps exactly the COLUMNS whose incoming value changed (columns of a vertical sweep are independent
+chains) from the snapshot it took before the sweep.  Band k is final after round k+1; the fixpoint is the
+untiled sweep.
 
-Communication = nearest neighbour only: RCCL send/recv (torch.distributed P2P over xGMI) of one row plus
-a 1-word all-reduce per round; no collective on image data.  `LocalComm` runs the same code with the
-ranks as threads of one process (tests on a single GPU).
+Everything stays on the device timeline: the exchange is RCCL send/recv (torch.distributed P2P over xGMI)
+enqueued on the engine's own stream, "which columns changed" is a device mask handed to
+pm_tile_restore_cols / pm_tile_sweep_masked, and the number of rounds per sweep is FIXED (2 by default; a round
+in which nothing changed costs three empty launches), so no rank ever waits on the host inside a Match().
+Whether the fixed rounds sufficed is one device flag per rank -- "my boundary row still changed after the
+last round" -- reduced over the ranks ONCE, after the Match; only if it is set (a value crossed more than
+`rounds` band boundaries in one sweep) is the Match repeated with world - 1 rounds, which always suffices.
+`LocalComm` runs the same protocol with the ranks as threads of one process (tests on a single GPU).
 """
 import threading
 
@@ -23,6 +29,8 @@ import numpy as np
 import torch
 
 import pm_ctypes as pm
+
+DEFAULT_ROUNDS = 2
 
 
 def band_of(rank, world, global_rows, halo):
@@ -43,12 +51,14 @@ def halo_rows(params):
 
 
 class DistComm:
-    """Neighbour exchange over torch.distributed (backend "nccl" = RCCL on ROCm)."""
+    """Neighbour exchange over torch.distributed (backend "nccl" = RCCL on ROCm), ordered on the CURRENT torch
+    stream -- the caller makes the engine's stream current -- so no host synchronisation is involved."""
 
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.exchanges = 0
 
     def shift(self, row, down):
         """Send `row` to the next rank in sweep direction, return the row of the previous one (or None)."""
@@ -63,20 +73,20 @@ class DistComm:
             ops.append(dist.P2POp(dist.irecv, recv, src))
         if ops:
             for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if row.is_cuda:
-            torch.cuda.synchronize()
-        self._dev = row.device
+                req.wait()  # NCCL backend: makes the current stream wait for the transfer, the host does not block
+            self.exchanges += 1
         return recv
 
-    def any(self, flag):
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=getattr(self, "_dev", "cpu"))
+    def any(self, flag_tensor):
+        """Logical OR of a one-element device flag over the ranks -> python bool (the one host read per Match)."""
+        t = flag_tensor.clone()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return bool(t.item())
 
 
 class LocalComm:
-    """The same protocol between threads of one process (one thread per band)."""
+    """The same protocol between threads of one process (one thread, one engine handle, one stream per band).
+    The hand-over between two bands' streams is an event: the receiver's stream waits for the sender's row copy."""
 
     class Shared:
         def __init__(self, world):
@@ -87,19 +97,30 @@ class LocalComm:
 
     def __init__(self, shared, rank):
         self.s, self.rank, self.world = shared, rank, shared.world
+        self.exchanges = 0
 
     def shift(self, row, down):
         s = self.s
-        s.slots[self.rank][0 if down else 1] = row
+        ev = None
+        if row.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        s.slots[self.rank][0 if down else 1] = (row, ev)
         s.barrier.wait()
         src = self.rank - 1 if down else self.rank + 1
-        got = s.slots[src][0 if down else 1].clone() if 0 <= src < self.world else None
+        got = None
+        if 0 <= src < self.world:
+            src_row, src_ev = s.slots[src][0 if down else 1]
+            if src_ev is not None:
+                torch.cuda.current_stream().wait_event(src_ev)
+            got = src_row.clone()
+            self.exchanges += 1
         s.barrier.wait()
         return got
 
-    def any(self, flag):
+    def any(self, flag_tensor):
         s = self.s
-        s.flags[self.rank] = bool(flag)
+        s.flags[self.rank] = bool(flag_tensor.item())
         s.barrier.wait()
         res = any(s.flags)
         s.barrier.wait()
@@ -107,58 +128,74 @@ class LocalComm:
 
 
 def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_band, global_rows, own_row0, own_rows,
-               band_row0):
-    """Runs this rank's part of Match() on device tensors of its band; returns (disp_l, disp_r) of the owned rows
-    and the number of extra sweep rounds that were needed."""
+               band_row0, rounds=DEFAULT_ROUNDS):
+    """Enqueues this rank's part of Match() for device tensors of its band on the engine's stream and returns
+    (disp_l, disp_r, flag): the maps of the owned rows and a one-element device tensor that is non-zero if this rank's
+    boundary row still changed after the last exchange round of some sweep (then `rounds` was too small).
+    Nothing in here waits on the host."""
     band_rows, cols = left_band.shape
     n_views = 2 if params.left_right_check else 1
     dev = left_band.device
     tile = pm.PmTile(global_rows, band_row0, own_row0, own_rows)
     ptr = lambda t: t.data_ptr() if t is not None else None
-    engine.tile_begin(tile, ptr(left_band), ptr(right_band), band_rows, cols, ptr(seed_l_band), ptr(seed_r_band))
-    own_end = own_row0 + own_rows
-    redo_rounds = 0
+    ext = torch.cuda.ExternalStream(engine.stream(), device=dev)
+    ext.wait_stream(torch.cuda.current_stream(dev))  # the inputs were produced on the caller's stream
+    with torch.cuda.stream(ext):
+        engine.tile_begin(tile, ptr(left_band), ptr(right_band), band_rows, cols, ptr(seed_l_band), ptr(seed_r_band))
+        own_end = own_row0 + own_rows
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def get_row(r):
-        t = torch.empty((n_views, cols), dtype=torch.float32, device=dev)
-        engine.tile_get_row(r, t.data_ptr())
-        engine.synchronize()
-        return t
+        def get_row(r):
+            t = torch.empty((n_views, cols), dtype=torch.float32, device=dev)
+            engine.tile_get_row(r, t.data_ptr())
+            return t
 
-    for it in range(params.patchmatch_iters):
-        engine.tile_noise(it)
-        for k in range(4):
-            if k in (0, 2):  # horizontal sweeps never leave the band
-                engine.tile_sweep(it, k)
-                continue
-            down = k == 1
-            out_row = own_end - 1 if down else own_row0
-            pred_row = own_row0 - 1 if down else own_end
-            used = comm.shift(get_row(out_row), down)  # the neighbour's value before the sweep: the guess
-            if used is not None:
-                engine.tile_set_row(pred_row, used.data_ptr())
-            engine.tile_snapshot()
-            engine.tile_sweep(it, k)
-            while True:
-                new_in = comm.shift(get_row(out_row), down)
-                changed = new_in is not None and not torch.equal(new_in, used)
-                if not comm.any(changed):
-                    break
-                redo_rounds += 1
-                if changed:
-                    engine.tile_restore()
-                    engine.tile_set_row(pred_row, new_in.data_ptr())
-                    used = new_in
+        for it in range(params.patchmatch_iters):
+            engine.tile_noise(it)
+            for k in range(4):
+                if k in (0, 2):  # horizontal sweeps never leave the band
                     engine.tile_sweep(it, k)
-    engine.tile_background()
-    out_l = torch.empty((own_rows, cols), dtype=torch.float32, device=dev)
-    out_r = torch.empty_like(out_l) if n_views > 1 else None
-    engine.tile_finish(out_l.data_ptr(), ptr(out_r))
-    engine.synchronize()
-    return out_l, out_r, redo_rounds
+                    continue
+                down = k == 1
+                out_row = own_end - 1 if down else own_row0
+                pred_row = own_row0 - 1 if down else own_end
+                sent = get_row(out_row)
+                used = comm.shift(sent, down)  # the neighbour's value before the sweep: the guess
+                if used is not None:
+                    engine.tile_set_row(pred_row, used.data_ptr())
+                engine.tile_snapshot()
+                engine.tile_sweep(it, k)
+                for _ in range(rounds):
+                    sent = get_row(out_row)
+                    new_in = comm.shift(sent, down)
+                    if new_in is not None:
+                        mask = (new_in != used).to(torch.int32).contiguous()  # columns whose incoming value changed
+                        engine.tile_restore_cols(mask.data_ptr())
+                        engine.tile_set_row(pred_row, new_in.data_ptr())
+                        engine.tile_sweep_masked(it, k, mask.data_ptr())
+                        used = new_in
+                # did my boundary row move after the last row I sent?  then my successor is stale
+                flag = torch.maximum(flag, (get_row(out_row) != sent).any().to(torch.int32).reshape(1))
+        engine.tile_background()
+        out_l = torch.empty((own_rows, cols), dtype=torch.float32, device=dev)
+        out_r = torch.empty_like(out_l) if n_views > 1 else None
+        engine.tile_finish(out_l.data_ptr(), ptr(out_r))
+    torch.cuda.current_stream(dev).wait_stream(ext)
+    return out_l, out_r, flag
 
 
-def match_tiled_local(params, left, right, seed_l, seed_r, world, device=0):
+def match_band_exact(engine, comm, params, *band_args, rounds=DEFAULT_ROUNDS):
+    """match_band + the one convergence check per Match: (disp_l, disp_r, rounds_used, repeated)."""
+    rounds = min(rounds, max(comm.world - 1, 0))
+    out_l, out_r, flag = match_band(engine, comm, params, *band_args, rounds=rounds)
+    if comm.world > 1 and comm.any(flag):
+        rounds = comm.world - 1  # band k is final after round k + 1: always enough
+        out_l, out_r, flag = match_band(engine, comm, params, *band_args, rounds=rounds)
+        return out_l, out_r, rounds, True
+    return out_l, out_r, rounds, False
+
+
+def match_tiled_local(params, left, right, seed_l, seed_r, world, device=0, rounds=DEFAULT_ROUNDS):
     """Single-process emulation: `world` bands on one GPU, one thread and one engine handle per band.
     numpy in, numpy out (whole image)."""
     rows, cols = left.shape
@@ -175,8 +212,12 @@ def match_tiled_local(params, left, right, seed_l, seed_r, world, device=0):
             sl = slice(band_row0, band_row0 + band_rows)
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev, dt).contiguous() if a is not None else None
             with pm.Engine(params, device=device, max_rows=band_rows, max_cols=cols) as eng:
-                res = match_band(eng, LocalComm(shared, rank), params, t(left, torch.uint8), t(right, torch.uint8),
-                                 t(seed_l, torch.float32), t(seed_r, torch.float32), rows, own_row0, own_rows, band_row0)
+                comm = LocalComm(shared, rank)
+                ol, orr, used, repeated = match_band_exact(
+                    eng, comm, params, t(left, torch.uint8), t(right, torch.uint8), t(seed_l, torch.float32),
+                    t(seed_r, torch.float32), rows, own_row0, own_rows, band_row0, rounds=rounds)
+                eng.synchronize()
+                res = (ol.cpu(), orr.cpu() if orr is not None else None, (used, repeated, comm.exchanges))
             results[rank] = (own_row0, res)
         except Exception as e:  # keep the other threads from waiting forever
             errors.append(e)
@@ -191,78 +232,85 @@ def match_tiled_local(params, left, right, seed_l, seed_r, world, device=0):
         raise errors[0]
     disp_l = np.zeros((rows, cols), np.float32)
     disp_r = np.zeros((rows, cols), np.float32) if params.left_right_check else None
-    rounds = 0
+    info = None
     for own_row0, (ol, orr, rr) in results:
-        disp_l[own_row0:own_row0 + ol.shape[0]] = ol.cpu().numpy()
+        disp_l[own_row0:own_row0 + ol.shape[0]] = ol.numpy()
         if disp_r is not None:
-            disp_r[own_row0:own_row0 + orr.shape[0]] = orr.cpu().numpy()
-        rounds = max(rounds, rr)
-    return disp_l, disp_r, rounds
+            disp_r[own_row0:own_row0 + orr.shape[0]] = orr.numpy()
+        info = rr
+    return disp_l, disp_r, {"rounds": info[0], "repeated": info[1], "exchanges_per_rank": info[2]}
+
+
+def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
+    """BASELINE configs[3]: one `cols` x `rows` pair row-tiled over the ranks of `d` (bench.py's Dist: one process per
+    GPU).  Every rank builds the same seeded synthetic pair, matches its band `steps` times; rank 0 returns / prints
+    one JSON object: ms/frame (max over ranks), exchange rounds per vertical sweep, exchanges, repeats."""
+    import json
+    import time
+
+    import synth
+    world, rank, local = d.world, d.rank, d.local_rank
+    steps = steps if steps is not None else max(1, args.steps)
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    comm = DistComm() if world > 1 else LocalComm(LocalComm.Shared(1), 0)
+    params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters)
+    pair = synth.make_pair(0, rows, cols, n_points=200 * (rows * cols) // (720 * 1280))
+    own_row0, own_rows, band_row0, band_rows = band_of(rank, world, rows, halo_rows(params))
+    sl = slice(band_row0, band_row0 + band_rows)
+    t = lambda k, dt: torch.from_numpy(np.ascontiguousarray(pair[k][sl])).to(dev, dt).contiguous()
+    L, R, SL, SR = t("left", torch.uint8), t("right", torch.uint8), t("seed_l", torch.float32), t("seed_r", torch.float32)
+    times, used, repeats = [], 0, 0
+    with pm.Engine(params, device=local, max_rows=band_rows, max_cols=cols) as eng:
+        for step in range(steps + 1):
+            d.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out_l, out_r, used, repeated = match_band_exact(eng, comm, params, L, R, SL, SR, rows, own_row0, own_rows,
+                                                            band_row0)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            if step > 0:
+                times.append(time.perf_counter() - t0)
+                repeats += 1 if repeated else 0
+        exchanges = comm.exchanges / float(steps + 1 + repeats)
+    ms = d.max_over_ranks(1e3 * float(np.median(times)))
+    res = None
+    if rank == 0:
+        gt = torch.from_numpy(pair["gt"][own_row0:own_row0 + own_rows]).to(dev)
+        fg = out_l > 0
+        res = {"workload": f"one {cols}x{rows} pair row-tiled over {world} GPU(s) (BASELINE.json configs[3]), "
+                           f"{args.iters} iterations, {args.patch}x{args.patch}, PM_SEM_CPU", "n_gpus": world,
+               "ms_per_frame": ms, "pairs_per_s": 1e3 / ms, "steps": steps,
+               "exchange_rounds_per_vertical_sweep": 1 + used, "boundary_exchanges_per_match_and_rank": exchanges,
+               "matches_repeated_with_more_rounds": repeats, "host_syncs_inside_a_match": 0,
+               "rank0_foreground_within_1px": float(((out_l - gt).abs()[fg] < 1).float().mean().item())}
+        if not quiet:
+            print(json.dumps(res), flush=True)
+    return res
 
 
 def main():
-    """torchrun entry: one rank per GPU, every rank builds the same seeded synthetic pair, matches its band and
-    rank 0 prints one JSON line (ms/frame = max over ranks, exchange rounds).
+    """torchrun entry (same as `bench.py --tiled`): one rank per GPU.
         python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
             ocean-perception_amd/python/tiled.py --rows 2160 --cols 4096"""
     import argparse
-    import json
     import os
-    import time
-
-    import torch.distributed as dist
-
-    import synth
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench as B
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2160)
     ap.add_argument("--cols", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--patch", type=int, default=11)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--dry-run", action="store_true")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        comm = DistComm()
-    else:
-        comm = LocalComm(LocalComm.Shared(1), 0)
-    params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters)
-    pair = synth.make_pair(0, args.rows, args.cols, n_points=200 * (args.rows * args.cols) // (720 * 1280))
-    own_row0, own_rows, band_row0, band_rows = band_of(rank, world, args.rows, halo_rows(params))
-    sl = slice(band_row0, band_row0 + band_rows)
-    t = lambda k, dt: torch.from_numpy(np.ascontiguousarray(pair[k][sl])).to(dev, dt).contiguous()
-    L, R, SL, SR = t("left", torch.uint8), t("right", torch.uint8), t("seed_l", torch.float32), t("seed_r", torch.float32)
-    times, rounds = [], 0
-    with pm.Engine(params, device=local, max_rows=band_rows, max_cols=args.cols) as eng:
-        for step in range(args.steps + 1):
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            out_l, out_r, rounds = match_band(eng, comm, params, L, R, SL, SR, args.rows, own_row0, own_rows, band_row0)
-            torch.cuda.synchronize()
-            if step > 0:
-                times.append(time.perf_counter() - t0)
-    ms = 1e3 * float(np.median(times))
-    if world > 1:
-        tt = torch.tensor([ms, float(rounds)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms, rounds = float(tt[0].item()), int(tt[1].item())
-    if rank == 0:
-        gt = torch.from_numpy(pair["gt"][own_row0:own_row0 + own_rows]).to(dev)
-        fg = out_l > 0
-        print(json.dumps({"workload": f"one {args.cols}x{args.rows} pair row-tiled over {world} GPU(s), {args.iters} it, "
-                                      f"{args.patch}x{args.patch}", "n_gpus": world, "ms_per_frame": ms,
-                          "extra_sweep_rounds": rounds,
-                          "rank0_foreground_within_1px": float(((out_l - gt).abs()[fg] < 1).float().mean().item())}))
-    if world > 1:
-        dist.destroy_process_group()
+    d = B.Dist(args)
+    bench(args, d, rows=args.rows, cols=args.cols)
+    d.close()
 
 
 if __name__ == "__main__":

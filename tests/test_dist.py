@@ -37,4 +37,8 @@ def test_bench_two_ranks_gloo_dry_run():
 def test_shard_is_rank_local():
     sys.path.insert(0, ROOT)
     import bench
-    assert bench.shard(3, 8, 4) == [3, 3, 3, 3]
+    # rank 3 of 8, one pair per step: its four resident pairs 12..15 in rotation, nobody else's
+    assert bench.shard(3, 8, 6, 1) == [[12], [13], [14], [15], [12], [13]]
+    mine = {i for step in bench.shard(3, 8, 8, 2) for i in step}
+    other = {i for r in (2, 4) for step in bench.shard(r, 8, 8, 2) for i in step}
+    assert mine == set(range(24, 32)) and not (mine & other)

@@ -22,13 +22,18 @@ def test_band_partition_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sem,patch,world", [(0, 5, 4), (0, 11, 3), (1, 3, 4), (0, 3, 7)])
-def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world):
+@pytest.mark.parametrize("sem,patch,world,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 2), (0, 3, 7, 0),
+                                                    (0, 5, 4, 1)])
+def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world, rounds):
+    """rounds = fixed exchange rounds per vertical sweep; 0 forces the "a boundary row still moved" flag and with it
+    the repeat with world - 1 rounds (the exactness guarantee), 2 is the default."""
     import tiled
     rows, cols = 150, 200
     l, r, sl, sr, _ = small_pair(synth, 80 + world, rows, cols, n_points=60, dilate_factor=3)
     params = pm.default_params(sem, patch=patch, patchmatch_iters=3)
-    dl, dr, rounds = tiled.match_tiled_local(params, l, r, sl, sr, world)
+    dl, dr, info = tiled.match_tiled_local(params, l, r, sl, sr, world, rounds=rounds)
+    if rounds == 0:
+        assert info["repeated"] and info["rounds"] == world - 1
     with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
         ul, ur = e.match(l, r, sl, sr)
     assert_same(dl, ul, "tiled vs untiled (left)")
@@ -36,7 +41,31 @@ def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world):
     el, er = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8), l, r, sl, sr)
     assert_same(dl, el, "tiled vs oracle (left)")
     assert_same(dr, er, "tiled vs oracle (right)")
-    assert rounds >= 1  # values did cross band boundaries, i.e. the fix-up path was exercised
+    assert info["exchanges_per_rank"] > 0  # boundary rows did travel
+
+
+@pytest.mark.gpu
+def test_tiled_full_size_4096x2160_eight_bands(pm, oracle, synth):
+    """BASELINE configs[3] at full size on one GPU (8 bands as threads): tiled == untiled bit for bit, and a 64-row
+    band ACROSS a band boundary (rows 238..301 around the boundary at 270) against the oracle -- as its own
+    independent problem, matched by the tiled driver with two bands whose boundary cuts it in the middle."""
+    import tiled
+    rows, cols, world = 2160, 4096, 8
+    p = synth.make_pair(0, rows, cols, n_points=200 * (rows * cols) // (720 * 1280))
+    l, r, sl, sr = p["left"], p["right"], p["seed_l"], p["seed_r"]
+    params = pm.default_params(0, patch=11, patchmatch_iters=8)
+    dl, dr, info = tiled.match_tiled_local(params, l, r, sl, sr, world)
+    with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
+        ul, ur = e.match(l, r, sl, sr)
+    assert_same(dl, ul, "4096x2160, 8 bands vs untiled (left)")
+    assert_same(dr, ur, "4096x2160, 8 bands vs untiled (right)")
+    fg = dl > 0
+    assert fg.mean() > 0.15 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.95
+    band = np.s_[238:302, :]
+    bl, br, _ = tiled.match_tiled_local(params, l[band], r[band], sl[band], sr[band], 2)
+    el, er = oracle.match(oracle.default_params(0, patch=11, n_iters=8, nthreads=16), l[band], r[band], sl[band], sr[band])
+    assert_same(bl, el, "64-row band across a tile boundary vs oracle (left)")
+    assert_same(br, er, "64-row band across a tile boundary vs oracle (right)")
 
 
 def _comm_worker(rank, world, port, q):
@@ -54,7 +83,7 @@ def _comm_worker(rank, world, port, q):
     down = comm.shift(row, True)    # from rank-1
     up = comm.shift(row, False)     # from rank+1
     res = (None if down is None else float(down[0, 0]), None if up is None else float(up[0, 0]),
-           comm.any(rank == 1), comm.any(False))
+           comm.any(torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)), comm.any(torch.zeros(1, dtype=torch.int32)))
     q.put((rank, res))
     dist.destroy_process_group()
 
