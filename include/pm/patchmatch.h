@@ -124,6 +124,10 @@ typedef struct pm_params {
   int templ_rows;                 /* 11    (:22)                                                        */
   int max_disp;                   /* 128   (:23)                                                        */
   double max_matching_cost;       /* 0.15  (:24)                                                        */
+  int cpu_initialize_factor;      /* 0: a self-seeded Match() seeds with SparseInit (patchmatch_gpu.cu:414-442);
+                                     1: with Patchmatch::Initialize(il, ir, 1) as the CPU recipe does
+                                        (patchmatch.cpp:52-87 called at patchmatch_test.cpp:149-150): dilation
+                                        2*(2^(f-1)+1)+1 = 5x5 and the seeds divided by 2^f = 2      */
 
   /* --- PM_MODE_PLANES (no reference counterpart; defaults of oracle/pm_planes_oracle.c) ------------------
    * Shared with the scalar mode: patchmatch_iters, patch_w[0] (square window), noise_amp[i] (dz of the first
@@ -235,6 +239,11 @@ int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right
  * GFTT corners, rectified template matching, scatter, (2*(2^f+1)+1)^2 dilation -- all on the device. */
 int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
                    float* seed);
+/* Patchmatch::Initialize(iml, imr, downsample_factor) (stereo_matching/patchmatch.hpp:24, patchmatch.cpp:52-87):
+ * as SparseInit with dilation 2*(2^(f-1)+1)+1, then cv::resize(INTER_NEAREST) to (rows/f) x (cols/f) and division by
+ * 2^f (not f: SURVEY Q1).  `seed` holds (rows/f) * (cols/f) floats. */
+int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
+                  float* seed);
 /* MaskOcclusions (patchmatch_gpu.cu:273-295). */
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols);
 

@@ -327,8 +327,7 @@ int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
   PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
   PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * 4));
   PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
-  PM_HIP(h, hipMalloc((void**)&sc.sparse, sizeof(float) * plane));
-  PM_HIP(h, hipMalloc((void**)&sc.tmp, sizeof(float) * plane));
+  PM_HIP(h, hipMalloc((void**)&sc.kp_d, sizeof(float) * kSeedMaxFeatures));
   sc.sort_tmp = nullptr;
   sc.sort_tmp_bytes = 0;
   PM_HIP(h, hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap,
@@ -344,8 +343,12 @@ int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scrat
   const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
   const uint8_t* tgt = ps.img8 + ((size_t)b * 4 + (view == 0 ? 1 : 2)) * ps.plane;
   float* out = ps.disp + ((size_t)b * 2 + view) * ps.plane;
-  PM_HIP(h, seed_sparse_init(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
-                             h->params.init_dilate_factor, out, ps.pitch, h->stream));
+  if (h->params.cpu_initialize_factor == 1)  // Patchmatch::Initialize(il, ir, 1) (patchmatch_test.cpp:149-150): 5x5, / 2
+    PM_HIP(h, seed_initialize(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch, 1, out, ps.pitch,
+                              h->stream));
+  else
+    PM_HIP(h, seed_sparse_init(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
+                               h->params.init_dilate_factor, out, ps.pitch, h->stream));
   return PM_OK;
 }
 
@@ -637,6 +640,12 @@ int validate_params(pm_handle* h, const pm_params& p) {
       set_err(h, "noise_amp[%d] must be >= 0", i);
       return PM_ERR_INVALID_ARG;
     }
+  if (p.cpu_initialize_factor != 0 && p.cpu_initialize_factor != 1) {
+    // Initialize(f > 1) also shrinks the map; Match() works at the image size, so only f = 1 (the reference's own
+    // call, patchmatch_test.cpp:149) can seed it.  pm_initialize offers every factor as a stage.
+    set_err(h, "cpu_initialize_factor must be 0 (SparseInit seeding) or 1 (Patchmatch::Initialize(il, ir, 1))");
+    return PM_ERR_INVALID_ARG;
+  }
   if (p.mode != PM_MODE_SCALAR && p.mode != PM_MODE_PLANES) {
     set_err(h, "unknown mode %d", p.mode);
     return PM_ERR_INVALID_ARG;
@@ -853,6 +862,7 @@ void pm_params_default(pm_params* p, int semantics) {
   p->templ_rows = 11;                // :22
   p->max_disp = 128;                 // :23
   p->max_matching_cost = 0.15;       // :24
+  p->cpu_initialize_factor = 0;
   p->mode = PM_MODE_SCALAR;
   p->state_dtype = PM_STATE_F32;
   p->plane_refine_steps = 3;         // oracle/pm_planes_oracle.c: pmo_planes_params_default
@@ -899,9 +909,9 @@ void pm_destroy(pm_handle* h) {
   }
   void* dev[] = {h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
-                 h->seed.counters, h->seed.kp_xy, h->seed.sparse, h->seed.tmp, h->seed.sort_tmp, h->seed2.dx, h->seed2.dy,
-                 h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.sparse,
-                 h->seed2.tmp, h->seed2.sort_tmp, h->snap_disp,
+                 h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.dx, h->seed2.dy,
+                 h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
+                 h->seed2.sort_tmp, h->snap_disp,
                  h->snap_cost, h->planes_state};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -1619,6 +1629,25 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
   PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
                              dilate_factor, ps.disp, ps.pitch, h->stream));
   return stage_out(h, ps, seed, 0);
+}
+
+int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
+                  float* seed) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_initialize")) return rc;
+  if (!left || !right || !seed || downsample_factor < 1 || downsample_factor > 8 || rows / downsample_factor < 1 ||
+      cols / downsample_factor < 1) {
+    set_err(h, "pm_initialize: null pointer or downsample_factor outside [1, 8]");
+    return PM_ERR_INVALID_ARG;
+  }
+  PlaneSet ps;
+  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
+  const int orows = rows / downsample_factor, ocols = cols / downsample_factor;
+  PM_HIP(h, seed_initialize(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
+                            downsample_factor, h->st_disp_l, ocols, h->stream));
+  PM_HIP(h, hipMemcpyAsync(seed, h->st_disp_l, sizeof(float) * (size_t)orows * ocols, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
 }
 
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols) {

@@ -15,7 +15,10 @@
 //   k_seed_match   one workgroup per corner: normalised squared difference of the templ_cols x templ_rows
 //                  template against every position of the max_disp x (templ_rows+2) stripe, exact
 //                  integer sums, first minimum
-//   k_seed_scatter + k_seed_dilate_{rows,cols}: sparse map -> (2k+1)^2 max-dilated seed map
+//   k_seed_splat   the (2k+1)^2 max-dilation of the <= 1024 matched corners written straight into the seed map:
+//                  every pixel takes the largest disparity among the corners whose rectangle covers it (what
+//                  cv::dilate of the scattered map gives), optionally nearest-resized and scaled as
+//                  Patchmatch::Initialize does (patchmatch.cpp:75-81)
 // The arithmetic is this build's definition of the seeder (see oracle/pm_oracle.h): OpenCV's float
 // pipelines are not reproducible without OpenCV; parity is against oracle/pm_seed_oracle.c.
 #pragma once
@@ -43,8 +46,7 @@ struct SeedScratch {
   unsigned long long* keys_sorted;
   unsigned* counters;        // [0] = max response bits, [1] = candidate count, [2] = accepted count
   int* kp_xy;                // [kSeedMaxFeatures][2]
-  float* sparse;             // [rows][pitch]
-  float* tmp;                // [rows][pitch]
+  float* kp_d;               // [kSeedMaxFeatures] matched disparity of a corner, < 0 = no match
   void* sort_tmp;
   size_t sort_tmp_bytes;
   int cap;
@@ -189,14 +191,14 @@ __global__ void __launch_bounds__(64) k_seed_select(const unsigned long long* __
   if (lane == 0) counters[2] = (unsigned)count;
 }
 
-// One workgroup per accepted corner (StereoMatcher::MatchRectified).  Writes the disparity into the sparse
-// map at the corner (>= 0) -- corners are at least min_distance apart, so no two write the same pixel.
+// One workgroup per accepted corner (StereoMatcher::MatchRectified).  Writes the corner's disparity (>= 0) or -1.
 __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                     int rows, int cols, int pitch, const int* __restrict__ kp_xy,
                                                     const unsigned* __restrict__ counters, SeedParams sp,
-                                                    float* __restrict__ sparse) {
+                                                    float* __restrict__ kp_d) {
   const int kp = blockIdx.x;
   if (kp >= (int)counters[2]) return;
+  if (threadIdx.x == 0) kp_d[kp] = -1.f;  // every early exit below means "no match"; thread 0 also writes the result
   const int rx = kp_xy[2 * kp], ry = kp_xy[2 * kp + 1];  // integer corners: round() is the identity
   const int tc = sp.templ_cols, tr = sp.templ_rows, md = sp.max_disp;
   const int stripe_rows = tr + 2;
@@ -256,43 +258,50 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
     const int pos = (int)(best & 0xffffffffull);
     const int bx = pos % rw;
     const int mx = bx + sx + (tc - 1) / 2 + offset_x;
-    if ((double)minv < sp.max_matching_cost && rx >= mx) sparse[(size_t)ry * pitch + rx] = (float)(rx - mx);
+    if ((double)minv < sp.max_matching_cost && rx >= mx) kp_d[kp] = (float)(rx - mx);
   }
 }
 
-// Max filter of half-width k along rows / columns, samples outside the image ignored (cv::dilate).
-__global__ void __launch_bounds__(256) k_seed_dilate_rows(const float* __restrict__ src, float* __restrict__ dst,
-                                                          int rows, int cols, int pitch, int k) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= cols) return;
-  const float* r = src + (size_t)y * pitch;
-  const int x0 = max(x - k, 0), x1 = min(x + k, cols - 1);
-  float m = r[x0];
-  for (int i = x0 + 1; i <= x1; ++i) m = fmaxf(m, r[i]);
-  dst[(size_t)y * pitch + x] = m;
-}
-// dst addressing: out_mirror != 0 writes column cols-1-x... (unused: the right view is seeded on the
-// mirrored pair, so its map is already in mirrored coordinates)
-__global__ void __launch_bounds__(256) k_seed_dilate_cols(const float* __restrict__ src, float* __restrict__ dst,
-                                                          int rows, int cols, int pitch, int k, int dst_pitch) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= cols) return;
-  const int y0 = max(y - k, 0), y1 = min(y + k, rows - 1);
-  float m = src[(size_t)y0 * pitch + x];
-  for (int j = y0 + 1; j <= y1; ++j) m = fmaxf(m, src[(size_t)j * pitch + x]);
-  dst[(size_t)y * dst_pitch + x] = m;
+// Seed map from the matched corners.  Output pixel (xo, yo) of an out_rows x out_cols map looks at source pixel
+// (sx, sy) of the rows x cols image -- the identity for SparseInit, cv::resize(INTER_NEAREST)'s
+// min(floor(xo * cols / out_cols), cols - 1) for Initialize's down-sampled map (patchmatch.cpp:79) -- and takes the
+// maximum disparity over the corners whose (2k+1)^2 rectangle covers it: cv::dilate (MORPH_RECT, anchor (k, k),
+// samples outside the image ignored) of the map that holds d at round(kp) and 0 elsewhere
+// (patchmatch.cpp:61-78, patchmatch_gpu.cu:422-439).  `inv_scale` = 1 or 2^-f (patchmatch.cpp:81: exact).
+__global__ void __launch_bounds__(256) k_seed_splat(const int* __restrict__ kp_xy, const float* __restrict__ kp_d,
+                                                    const unsigned* __restrict__ counters, int rows, int cols, int k,
+                                                    int out_rows, int out_cols, float inv_scale, float* __restrict__ out,
+                                                    int out_pitch) {
+  const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
+  if (xo >= out_cols) return;
+  int sx = xo, sy = yo;
+  if (out_cols != cols || out_rows != rows) {
+    const double ifx = 1.0 / ((double)out_cols / (double)cols), ify = 1.0 / ((double)out_rows / (double)rows);
+    sx = min((int)floor((double)xo * ifx), cols - 1);
+    sy = min((int)floor((double)yo * ify), rows - 1);
+  }
+  const int n = (int)counters[2];
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) {  // uniform loop: the corner list is read through the scalar cache
+    const int kx = kp_xy[2 * i], ky = kp_xy[2 * i + 1];
+    const float d = kp_d[i];
+    if (d >= 0.f && abs(sx - kx) <= k && abs(sy - ky) <= k) m = fmaxf(m, d);
+  }
+  out[(size_t)yo * out_pitch + xo] = m * inv_scale;
 }
 
-// SparseInit(left, right, dilate_factor) for one pair of pitched u8 planes; the seed map is written to
-// `out` (row pitch out_pitch elements).  Enqueue-only.
-inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
-                                   const uint8_t* right, int rows, int cols, int pitch, int dilate_factor, float* out,
-                                   int out_pitch, hipStream_t stream) {
+// SparseInit / Initialize for one pair of pitched u8 planes: corners of `left` matched into `right`, dilated with
+// half-width k, written as an out_rows x out_cols map (row pitch out_pitch elements) scaled by inv_scale.
+//   PatchmatchGpu::SparseInit(iml, imr, f)   k = 2^f + 1,     out = image size, inv_scale = 1   (patchmatch_gpu.cu:436)
+//   Patchmatch::Initialize(iml, imr, f)      k = 2^(f-1) + 1, out = size / f,   inv_scale = 2^-f (patchmatch.cpp:75-81)
+// Enqueue-only.
+inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
+                           int rows, int cols, int pitch, int k, int out_rows, int out_cols, float inv_scale, float* out,
+                           int out_pitch, hipStream_t stream) {
   const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
   hipError_t e;
   if ((e = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned), stream)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(sc.sparse, 0, sizeof(float) * (size_t)rows * pitch, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_seed_sobel, grid, block, 0, stream, left, rows, cols, pitch, sc.dx, sc.dy);
   hipLaunchKernelGGL(k_seed_eig, grid, block, 0, stream, sc.dx, sc.dy, rows, cols, pitch, sp.block_size, sc.eig,
                      sc.counters);
@@ -306,11 +315,25 @@ inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, 
   hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(64), 0, stream, sc.keys_sorted, sc.cap, cols, sp.min_distance, maxf,
                      sc.kp_xy, sc.counters);
   hipLaunchKernelGGL(k_seed_match, dim3((unsigned)(maxf > 0 ? maxf : 1)), dim3(256), 0, stream, left, right, rows,
-                     cols, pitch, sc.kp_xy, sc.counters, sp, sc.sparse);
-  const int k = (1 << dilate_factor) + 1;  // (int)pow(2, f) + 1, patchmatch_gpu.cu:436
-  hipLaunchKernelGGL(k_seed_dilate_rows, grid, block, 0, stream, sc.sparse, sc.tmp, rows, cols, pitch, k);
-  hipLaunchKernelGGL(k_seed_dilate_cols, grid, block, 0, stream, sc.tmp, out, rows, cols, pitch, k, out_pitch);
+                     cols, pitch, sc.kp_xy, sc.counters, sp, sc.kp_d);
+  hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block, 0, stream,
+                     (const int*)sc.kp_xy, (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, out_rows,
+                     out_cols, inv_scale, out, out_pitch);
   return hipGetLastError();
+}
+inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
+                                   const uint8_t* right, int rows, int cols, int pitch, int dilate_factor, float* out,
+                                   int out_pitch, hipStream_t stream) {
+  return seed_map(sc, sp, left, right, rows, cols, pitch, (1 << dilate_factor) + 1, rows, cols, 1.0f, out, out_pitch,
+                  stream);
+}
+// downsample_factor >= 1
+inline hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
+                                  const uint8_t* right, int rows, int cols, int pitch, int downsample_factor, float* out,
+                                  int out_pitch, hipStream_t stream) {
+  const float inv = 1.0f / (float)(1 << downsample_factor);
+  return seed_map(sc, sp, left, right, rows, cols, pitch, (1 << (downsample_factor - 1)) + 1, rows / downsample_factor,
+                  cols / downsample_factor, inv, out, out_pitch, stream);
 }
 
 }  // namespace pm

@@ -38,7 +38,7 @@ EXPORTS = [
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
-    "pm_match_view_device", "pm_set_unit_noise",
+    "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
 ]
 
@@ -73,6 +73,7 @@ class PmParams(C.Structure):
         ("templ_rows", C.c_int),
         ("max_disp", C.c_int),
         ("max_matching_cost", C.c_double),
+        ("cpu_initialize_factor", C.c_int),
         ("mode", C.c_int),
         ("state_dtype", C.c_int),
         ("plane_refine_steps", C.c_int),
@@ -183,6 +184,8 @@ def load():
     lib.pm_mask_occlusions.restype = C.c_int
     lib.pm_sparse_init.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
     lib.pm_sparse_init.restype = C.c_int
+    lib.pm_initialize.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
+    lib.pm_initialize.restype = C.c_int
     lib.pm_tile_begin.argtypes = [vp, C.POINTER(PmTile), u8p, u8p, C.c_int, C.c_int, f32p, f32p]
     lib.pm_tile_noise.argtypes = [vp, C.c_int]
     lib.pm_tile_sweep.argtypes = [vp, C.c_int, C.c_int]
@@ -483,6 +486,15 @@ class Engine:
         seed = np.empty(left.shape, np.float32)
         self._check(self.lib.pm_sparse_init(self.h, pl, pr, left.shape[0], left.shape[1], dilate_factor,
                                             seed.ctypes.data_as(C.c_void_p)), "pm_sparse_init")
+        return seed
+
+    def initialize(self, left, right, downsample_factor=1):
+        left, pl = _u8(left)
+        right, pr = _u8(right)
+        f = downsample_factor
+        seed = np.empty((left.shape[0] // f, left.shape[1] // f), np.float32)
+        self._check(self.lib.pm_initialize(self.h, pl, pr, left.shape[0], left.shape[1], f,
+                                           seed.ctypes.data_as(C.c_void_p)), "pm_initialize")
         return seed
 
     def mask_occlusions(self, disp_l, disp_r):

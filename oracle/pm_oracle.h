@@ -176,6 +176,10 @@ double pmo_match_rectified(const uint8_t* left, const uint8_t* right, int rows, 
 void pmo_sparse_init(const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
                      const pmo_seed_params* p, float* seed);
 
+/* Patchmatch::Initialize (stereo_matching/patchmatch.cpp:52-87); out: (rows/f) x (cols/f) floats. */
+void pmo_cpu_initialize(const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
+                        const pmo_seed_params* p, float* out);
+
 #ifdef __cplusplus
 }
 #endif

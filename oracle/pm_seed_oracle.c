@@ -214,3 +214,40 @@ void pmo_sparse_init(const uint8_t* left, const uint8_t* right, int rows, int co
   free(xs);
   free(ys);
 }
+
+/* Patchmatch::Initialize (src/vehicle/stereo_matching/patchmatch.cpp:52-87): the scatter of SparseInit, dilation with
+ * dilate_size = (int)pow(2, f - 1) + 1 (:75), cv::resize(INTER_NEAREST) to size / f (:79; OpenCV 3.4
+ * resizeNN_: sx = min(cvFloor(x * ifx), cols - 1) with ifx = 1 / ((double)dst_cols / src_cols)) and
+ * disps /= pow(2, f) (:81 -- 2^f although the map shrinks by f: quirk Q1, reproduced).  out: (rows/f) x (cols/f). */
+void pmo_cpu_initialize(const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
+                        const pmo_seed_params* p, float* out) {
+  const size_t n = (size_t)rows * cols;
+  const int f = downsample_factor;
+  int* xs = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  int* ys = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  const int cnt = pmo_gftt_detect(left, rows, cols, p, xs, ys, p->max_features);
+  float* sparse = (float*)calloc(n, sizeof(float));
+  float* dil = (float*)malloc(sizeof(float) * n);
+  for (int i = 0; i < cnt; ++i) {
+    const float d = (float)pmo_match_rectified(left, right, rows, cols, (float)xs[i], (float)ys[i], p);
+    if (d >= 0) sparse[(size_t)ys[i] * cols + xs[i]] = d;
+  }
+  const int k = (int)pow(2.0, (double)(f - 1)) + 1;
+  pmo_dilate_rect(sparse, dil, rows, cols, k);
+  const int orows = rows / f, ocols = cols / f;
+  const double ifx = 1.0 / ((double)ocols / (double)cols), ify = 1.0 / ((double)orows / (double)rows);
+  const double div = pow(2.0, (double)f);
+  for (int y = 0; y < orows; ++y) {
+    int sy = (int)floor((double)y * ify);
+    if (sy > rows - 1) sy = rows - 1;
+    for (int x = 0; x < ocols; ++x) {
+      int sx = (int)floor((double)x * ifx);
+      if (sx > cols - 1) sx = cols - 1;
+      out[(size_t)y * ocols + x] = (float)((double)dil[(size_t)sy * cols + sx] / div);
+    }
+  }
+  free(dil);
+  free(sparse);
+  free(xs);
+  free(ys);
+}

@@ -328,6 +328,21 @@ def sparse_init(left, right, dilate_factor=4, sp=None):
 
 
 # ---- imaging rows: oracle/pm_imaging_oracle.c -------------------------------------------------
+def cpu_initialize(left, right, downsample_factor=1, sp=None):
+    """Patchmatch::Initialize (patchmatch.cpp:52-87)."""
+    lib = load()
+    lib.pmo_cpu_initialize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SeedParams),
+                                       C.c_void_p]
+    lib.pmo_cpu_initialize.restype = None
+    left, right = c_u8(left), c_u8(right)
+    rows, cols = left.shape
+    sp = sp or seed_params()
+    f = downsample_factor
+    out = np.zeros((rows // f, cols // f), np.float32)
+    lib.pmo_cpu_initialize(_p(left), _p(right), rows, cols, f, C.byref(sp), _p(out))
+    return out
+
+
 def _img_lib():
     lib = load()
     if not getattr(lib, "_img_ready", False):

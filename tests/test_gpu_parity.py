@@ -550,6 +550,43 @@ def test_full_size_baseline_config_properties(pm, oracle, synth):
     assert_same(bdr, er, "64-row band at full width, right")
 
 
+def test_full_size_batch_of_32_pairs(pm, oracle, synth):
+    """BASELINE configs[2]'s per-GPU share: 32 slots of 1280x720 (8 iterations, 11x11) in ONE pm_match_device call.
+    Every slot of the default engine must equal the serial anchor's map of its pair, and a 64-row band of one of the
+    pairs must equal the oracle."""
+    torch = pytest.importorskip("torch")
+    rows, cols, patch, iters, nb = 720, 1280, 11, 8, 32
+    dev = torch.device("cuda:0")
+    uniq = [synth.make_pair(10 + i, rows, cols) for i in range(4)]
+    slot_pair = [(3 * i + i // 4) % 4 for i in range(nb)]  # an irregular assignment of the 4 pairs to the 32 slots
+    st = lambda k, idx: torch.from_numpy(np.stack([uniq[j][k] for j in idx])).to(dev).contiguous()
+    L, R, SL, SR = (st(k, slot_pair) for k in ("left", "right", "seed_l", "seed_r"))
+    DL = torch.empty((nb, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    with mk(pm, 0, 0, patch=patch, iters=iters, rows=rows, cols=cols, batch=nb) as e:
+        e.match_device(nb, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
+                       DR.data_ptr())
+        e.synchronize()
+    L4, R4, SL4, SR4 = (st(k, range(4)) for k in ("left", "right", "seed_l", "seed_r"))
+    AL = torch.empty((4, rows, cols), dtype=torch.float32, device=dev)
+    AR = torch.empty_like(AL)
+    with mk(pm, 0, 1, patch=patch, iters=iters, rows=rows, cols=cols, batch=4) as e:  # PM_ENGINE_SERIAL
+        e.match_device(4, L4.data_ptr(), R4.data_ptr(), rows, cols, SL4.data_ptr(), SR4.data_ptr(), AL.data_ptr(),
+                       AR.data_ptr())
+        e.synchronize()
+    for i in range(nb):
+        assert torch.equal(DL[i], AL[slot_pair[i]]), f"slot {i} (pair {slot_pair[i]}), left"
+        assert torch.equal(DR[i], AR[slot_pair[i]]), f"slot {i} (pair {slot_pair[i]}), right"
+    p = uniq[1]
+    band = np.s_[200:264, :]
+    with mk(pm, 0, 0, patch=patch, iters=iters, rows=64, cols=cols) as e:
+        bdl, bdr = e.match(p["left"][band], p["right"][band], p["seed_l"][band], p["seed_r"][band])
+    el, er = oracle.match(oparams(oracle, 0, patch, iters), p["left"][band], p["right"][band], p["seed_l"][band],
+                          p["seed_r"][band])
+    assert_same(bdl, el, "64-row band of pair 11, left")
+    assert_same(bdr, er, "64-row band of pair 11, right")
+
+
 @pytest.mark.parametrize("engine", [2, 5])
 def test_full_size_gpu_semantics_engines_agree(pm, oracle, synth, engine):
     rows, cols = 720, 1280

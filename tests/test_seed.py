@@ -113,6 +113,58 @@ def test_self_seeded_match_matches_oracle(pm, oracle, synth, sem):
     assert fg.mean() > 0.5 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.97
 
 
+def test_cpu_initialize_known_answers(oracle, synth):
+    """Patchmatch::Initialize (patchmatch.cpp:52-87).  With f = 1 it is SparseInit's map for dilate_factor 0
+    (2^(1-1)+1 = 2^0+1: the same 5x5 rectangle) divided by 2^1 -- quirk Q1: the seeds are halved although the image
+    keeps its size.  With f = 2: 7x7 dilation, nearest down-sampling by 2 (source pixel (2y, 2x)), division by 4."""
+    p = synth.make_pair(7, rows=120, cols=200)
+    l, r = p["left"], p["right"]
+    a = oracle.cpu_initialize(l, r, 1)
+    assert_same(a, oracle.sparse_init(l, r, 0) / np.float32(2), "Initialize(f=1) == SparseInit(0) / 2")
+    assert a.shape == l.shape and (a > 0).any()
+    b = oracle.cpu_initialize(l, r, 2)
+    assert b.shape == (60, 100)
+    # SparseInit's rectangle for dilate factor f is 2^f+1; Initialize(2) uses 2^1+1 = 3 = SparseInit(1)'s
+    assert_same(b, oracle.sparse_init(l, r, 1)[::2, ::2] / np.float32(4), "Initialize(f=2)")
+    c = oracle.cpu_initialize(l[:119, :197], r[:119, :197], 3)  # sizes that do not divide: 39 x 65
+    assert c.shape == (39, 65)
+    full = oracle.sparse_init(l[:119, :197], r[:119, :197], 2)  # 2^2+1 = 5
+    ys = np.minimum(np.floor(np.arange(39) * (1.0 / (39 / 119))).astype(int), 118)
+    xs = np.minimum(np.floor(np.arange(65) * (1.0 / (65 / 197))).astype(int), 196)
+    assert_same(c, full[ys][:, xs] / np.float32(8), "Initialize(f=3), non-dividing size")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f", [1, 2, 3])
+def test_device_initialize_matches_oracle(pm, oracle, synth, f):
+    p = synth.make_pair(8, rows=119, cols=197)
+    with pm.Engine(pm.default_params(0), max_rows=119, max_cols=197) as e:
+        got = e.initialize(p["left"], p["right"], f)
+    assert_same(got, oracle.cpu_initialize(p["left"], p["right"], f), f"Initialize(f={f})")
+
+
+@pytest.mark.gpu
+def test_reference_cpu_recipe_end_to_end_self_seeded(pm, oracle, synth):
+    """test/stereo_matching/patchmatch_test.cpp:149-183 as written: Initialize(il, ir, 1), then noise 32 / 8 / 2 / 0.5
+    with 5x5, 5x5, 3x3, 3x3 windows, RemoveBackground(3x3, 1.5) -- one view, seeded by the engine itself."""
+    rows, cols = 240, 376  # the reference test's image size (patchmatch_test.cpp:131-133)
+    p = synth.make_pair(9, rows=rows, cols=cols)
+    l, r = p["left"], p["right"]
+    sched = dict(noise_amp=[32.0, 8.0, 2.0, 0.5], patch_w=[5, 5, 3, 3], patch_h=[5, 5, 3, 3])
+    prm = pm.default_params(0, patchmatch_iters=4, bg_patch_w=3, bg_patch_h=3, win_by_factor=1.5, left_right_check=0,
+                            sparse_init=1, cpu_initialize_factor=1, **sched)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        dl, _ = e.match(l, r)
+    seeds = oracle.cpu_initialize(l, r, 1)
+    op = oracle.default_params(0, n_iters=4, bg_patch_w=3, bg_patch_h=3, bg_factor=1.5, left_right_check=0,
+                               nthreads=8, literal=1, **sched)
+    el, _ = oracle.match(op, l, r, seeds, None)
+    assert_same(dl, el, "patchmatch_test.cpp:149-183 end to end")
+    assert (dl > 0).mean() > 0.05
+    with pytest.raises(pm.PmError):
+        pm.Engine(pm.default_params(0, cpu_initialize_factor=2), max_rows=64, max_cols=64)
+
+
 @pytest.mark.gpu
 def test_full_size_seeding(pm, oracle, synth):
     rows, cols = 720, 1280
