@@ -318,7 +318,8 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
         bytes_per_launch = PLANE_STAGE_BYTES[dom] * scale * px_views / launches_per_iter
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (nb == 1 and state == "f32") else None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
                 "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48, view 64, "
                            "refine 48 (halved for fp16 state)",

@@ -516,35 +516,59 @@ void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
 
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
-int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots) {
+// `sets` plane sets are advanced in step, each on its own stream (one set on the handle's stream, or the two
+// views on their view streams): the host enqueues launch k of EVERY set before launch k + 1 of any, so all
+// streams have work from the first microsecond on.  (Enqueuing one view's whole chain of ~45 launches first left
+// the other stream empty for the 0.2-0.4 ms that takes: visible in the rocprofv3 kernel trace.)
+int run_view_sets(pm_handle* h, const PlaneSet* pss, hipStream_t* streams, int sets, int slots) {
   const pm_params& p = h->params;
+  hipStream_t keep = h->stream;
+  struct Restore {
+    pm_handle* h;
+    hipStream_t s;
+    ~Restore() { h->stream = s; }
+  } restore{h, keep};
   CostParams cp{};
   int last_pw = 0, last_ph = 0;
   for (int it = 0; it < p.patchmatch_iters; ++it) {
     const int pw = p.patch_w[it], ph = p.patch_h[it];
     cp = cost_params(p, pw, ph);
-    const Interior in = interior(p, ps.rows, ps.cols, cp.pw, cp.ph);
-    {
-      Launch l(h, PM_K_NOISE);
-      // from the second iteration on the cost plane is valid for this window if the window is unchanged
-      const int keep_zero = (it > 0 && cp.pw == last_pw && cp.ph == last_ph) ? 1 : 0;
-      launch_noise_cost(h, ps, cp, in, p.noise_amp[it], slots, keep_zero);
+    const Interior in = interior(p, pss[0].rows, pss[0].cols, cp.pw, cp.ph);
+    for (int s = 0; s < sets; ++s) {
+      h->stream = streams[s];  // every launch helper enqueues on h->stream
+      {
+        Launch l(h, PM_K_NOISE);
+        // from the second iteration on the cost plane is valid for this window if the window is unchanged
+        const int keep_zero = (it > 0 && cp.pw == last_pw && cp.ph == last_ph) ? 1 : 0;
+        launch_noise_cost(h, pss[s], cp, in, p.noise_amp[it], slots, keep_zero);
+      }
+      if (int rc = launch_check(h, "noise_cost")) return rc;
     }
-    if (int rc = launch_check(h, "noise_cost")) return rc;
     for (int k = 0; k < 4; ++k)
-      if (int rc = run_sweep(h, ps, cp, sweep_geom(p, in, k), slots, p.noise_amp[it])) return rc;
+      for (int s = 0; s < sets; ++s) {
+        h->stream = streams[s];
+        if (int rc = run_sweep(h, pss[s], cp, sweep_geom(p, in, k), slots, p.noise_amp[it])) return rc;
+      }
     last_pw = cp.pw;
     last_ph = cp.ph;
   }
-  {
+  for (int s = 0; s < sets; ++s) {
+    h->stream = streams[s];
     const CostParams bcp = cost_params(p, p.bg_patch_w, p.bg_patch_h);
-    const Interior in = interior(p, ps.rows, ps.cols, bcp.pw, bcp.ph);
+    const Interior in = interior(p, pss[s].rows, pss[s].cols, bcp.pw, bcp.ph);
     const int cached = (p.patchmatch_iters > 0 && bcp.pw == last_pw && bcp.ph == last_ph) ? 1 : 0;
     const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
-    Launch l(h, PM_K_BACKGROUND);
-    launch_background(h, ps, bcp, in, factor, cached, slots);
+    {
+      Launch l(h, PM_K_BACKGROUND);
+      launch_background(h, pss[s], bcp, in, factor, cached, slots);
+    }
+    if (int rc = launch_check(h, "background")) return rc;
   }
-  return launch_check(h, "background");
+  return PM_OK;
+}
+int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots) {
+  hipStream_t s = h->stream;
+  return run_view_sets(h, &ps, &s, 1, slots);
 }
 
 bool view_streams_enabled() {
@@ -579,19 +603,20 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
   hipStream_t main_stream = h->stream;
   PM_HIP(h, hipEventRecord(h->view_fork, main_stream));
   int rc = PM_OK;
+  PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
-    PlaneSet pv = ps;
-    pv.view_fixed = v;
+    pv[v].view_fixed = v;
     if (hipStreamWaitEvent(h->view_stream[v], h->view_fork, 0) != hipSuccess) {
       rc = PM_ERR_HIP;
       break;
     }
-    h->stream = h->view_stream[v];  // every launch helper enqueues on h->stream
+    h->stream = h->view_stream[v];
     rc = seed_views(h, ps, slots / 2, v, v);
-    if (rc == PM_OK) rc = run_one_view_set(h, pv, slots / 2);
     h->stream = main_stream;
-    if (rc == PM_OK && hipEventRecord(h->view_join[v], h->view_stream[v]) != hipSuccess) rc = PM_ERR_HIP;
   }
+  if (rc == PM_OK) rc = run_view_sets(h, pv, h->view_stream, 2, slots / 2);
+  for (int v = 0; v < 2 && rc == PM_OK; ++v)
+    if (hipEventRecord(h->view_join[v], h->view_stream[v]) != hipSuccess) rc = PM_ERR_HIP;
   if (rc != PM_OK) {
     if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
     return rc;

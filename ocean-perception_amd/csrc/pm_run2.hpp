@@ -114,7 +114,9 @@ __device__ __forceinline__ RowBufs make_row_bufs(const View& v, const PlaneSet& 
   return r;
 }
 
-template <int GS, int AXIS, int TPW, int TPH>
+// DIR = +1 / -1 fixes the sweep direction at compile time (no multiplications by the direction, no selects between
+// the "first set bit" forms); 0 = read it from the geometry.
+template <int GS, int AXIS, int TPW, int TPH, int DIR>
 __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps, const CostParams& cp,
                                               const SweepGeom& g, int chain, bool act, int i, int n_end, float cand,
                                               const float* din, const float* cin) {
@@ -127,7 +129,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   const int win = AXIS == 0 ? pw : ph;
   const int half = win / 2;
   const int nd = run2_nd<GS, AXIS, TPW, TPH>(cp);
-  const int dir = g.dir;
+  const int dir = DIR != 0 ? DIR : g.dir;
   const float shift = (float)(pw - 1) * 0.5f;
   const unsigned lanes_nd = (1u << nd) - 1u;
 
@@ -337,13 +339,13 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 // Rounds and fix-up as described in pm_run.hpp, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
 // SEM = 0: PM_SEM_CPU (run_step2 above); SEM = 1: PM_SEM_GPU (run_step2_gpu, pm_run_gpu.hpp).
-template <int SEM, int GS, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin);
 
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
 __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
   const int n = (g.s_last - g.s_first) * g.dir + 1;
@@ -399,7 +401,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     int i = i0;
     while (__any(active && i < i1)) {
       const bool act = active && i < i1;
-      const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
+      const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
 #ifdef PM_RUN2_TIMING
       if constexpr (SEM == 0) {
@@ -434,7 +436,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       bool merged = false;
       while (__any(redo && !merged && i < i1)) {
         const bool act = redo && !merged && i < i1;
-        const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
+        const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
         ++n_fix;
         const bool mine = st.mpos >= 0 && st.mpos < st.advance;
         const float val = st.mpos == st.rej_pos ? st.rej_d0 : c2;
@@ -444,9 +446,9 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
         if (eq) {  // first merged position in sweep order (lane <-> position mapping of the step function)
           const int lo_lane = __ffs((int)eq) - 1, hi_lane = 31 - __clz((int)eq);
           if (SEM == 0)
-            ms = g.dir > 0 ? lo_lane : nd - 1 - hi_lane;
+            ms = (DIR != 0 ? DIR : g.dir) > 0 ? lo_lane : nd - 1 - hi_lane;
           else
-            ms = g.dir > 0 ? lo_lane - 1 : nd - hi_lane;
+            ms = (DIR != 0 ? DIR : g.dir) > 0 ? lo_lane - 1 : nd - hi_lane;
         }
         const int wlim = ms >= 0 ? ms : st.advance;
         if (st.mpos >= 0 && st.mpos < wlim) {
@@ -496,9 +498,9 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   }
 }
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH>
-inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
-                          hipStream_t stream) {
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
+inline void launch_run2_kd(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                           hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
   const int n = (g.s_last - g.s_first) * g.dir + 1;
   int nwv = waves < 1 ? 1 : (waves > kMaxSegWaves ? kMaxSegWaves : waves);
@@ -507,9 +509,21 @@ inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepG
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
   const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
-  allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH>, lds_bytes);
-  hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv),
-                     lds_bytes, stream, ps, cp, g, len);
+  allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR>, lds_bytes);
+  hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR>), dim3((unsigned)chains, 1, (unsigned)slots),
+                     dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
+}
+// The benchmark window (11x11, PM_SEM_CPU) gets direction-specialised kernels; the others read the direction
+// from the geometry (every instantiation costs build time).
+template <int SEM, int GS, int AXIS, int TPW, int TPH>
+inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                          hipStream_t stream) {
+  if constexpr (SEM == 0 && TPW == 11) {
+    if (g.dir > 0) launch_run2_kd<SEM, GS, AXIS, TPW, TPH, 1>(ps, cp, g, slots, waves, stream);
+    else launch_run2_kd<SEM, GS, AXIS, TPW, TPH, -1>(ps, cp, g, slots, waves, stream);
+  } else {
+    launch_run2_kd<SEM, GS, AXIS, TPW, TPH, 0>(ps, cp, g, slots, waves, stream);
+  }
 }
 
 // group: 32 or 16 lanes per segment.  16-lane groups need the window to leave positions in a strip
@@ -536,12 +550,12 @@ inline void launch_run2_axis(const PlaneSet& ps, const CostParams& cp, const Swe
 #include "pm_run_gpu.hpp"
 namespace pm {
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH>
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin) {
   if constexpr (SEM == 0)
-    return run_step2<GS, AXIS, TPW, TPH>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+    return run_step2<GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
   else
     return run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
 }

@@ -7,7 +7,9 @@ import csv, collections, json, re, sys
 
 
 CLASSES = (("sweep_row", r"k_runblk2<\d+, \d+, 0,"), ("sweep_col", r"k_runblk2<\d+, \d+, 1,"),
-           ("noise_cost", r"k_noise_cost_tiled"))
+           ("noise_cost", r"k_noise_cost_tiled"), ("planes_init", r"k_planes<\d+, 0,"),
+           ("planes_spatial", r"k_planes<\d+, 1,"), ("planes_view", r"k_planes<\d+, 2,"),
+           ("planes_refine", r"k_planes<\d+, 3,"))
 
 
 def per_launch(path, counter):
@@ -27,8 +29,14 @@ def per_launch(path, counter):
 def main():
     fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                     "--warmup 1 --no-cpu-baseline --host-pairs 0; per-launch averages, KiB; FETCH_SIZE is uncalibrated "
-                     "for 1-4 B/lane loads (MI355X_MICROARCH.md HBM section)", "kernels": {}}
+                     "--warmup 1 --no-cpu-baseline --no-side-legs --host-pairs 0 [--mode planes]; per-launch averages, "
+                     "KiB; FETCH_SIZE is uncalibrated for 1-4 B/lane loads (MI355X_MICROARCH.md HBM section)",
+           "kernels": {}}
+    if len(sys.argv) > 4:  # merge into an existing file (second mode)
+        try:
+            out["kernels"] = json.load(open(sys.argv[4]))["kernels"]
+        except Exception:
+            pass
     for cls, _ in CLASSES:
         if cls in fetch:
             out["kernels"][cls] = {"kernels": fetch[cls][1], "launches_sampled": fetch[cls][2],
