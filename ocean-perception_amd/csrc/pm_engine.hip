@@ -656,7 +656,10 @@ int validate_params(pm_handle* h, const pm_params& p) {
   if (p.max_features_per_frame < 0 || p.max_features_per_frame > kSeedMaxFeatures || p.gftt_block_size < 1 ||
       (p.gftt_block_size % 2) == 0 || p.gftt_block_size > 15 || p.templ_cols < 1 || p.templ_rows < 1 ||
       ((p.mode != PM_MODE_PLANES || p.sparse_init) && p.max_disp < p.templ_cols) || p.init_dilate_factor < 0 ||
-      p.init_dilate_factor > 8) {
+      p.init_dilate_factor > 8 ||
+      // the template matcher keeps template + stripe in LDS and its sums in 32 bits
+      (long long)p.templ_rows * p.templ_cols > 4096 ||
+      (long long)p.templ_rows * p.templ_cols + (long long)(p.templ_rows + 2) * p.max_disp > 60 * 1024) {
     set_err(h, "seeder parameters out of range");
     return PM_ERR_INVALID_ARG;
   }

@@ -8,16 +8,16 @@
 //   k_seed_eig     block^2 box sums of dx^2, dxdy, dy^2 (exact integers) -> min-eigenvalue response,
 //                  global maximum by atomicMax on the float bit pattern (responses >= 0)
 //   k_seed_nms     quality threshold + 3x3 non-maximum suppression -> candidate keys
-//                  (response bits << 32 | raster index)
+//                  (response bits << 32 | y << 16 | x: raster order)
 //   hipcub radix sort, descending: strongest first, ties by larger index (cv::goodFeaturesToTrack's
 //                  greaterThanPtr order)
 //   k_seed_select  greedy minimum-distance selection, one wavefront (the accepted list lives in LDS)
 //   k_seed_match   one workgroup per corner: normalised squared difference of the templ_cols x templ_rows
 //                  template against every position of the max_disp x (templ_rows+2) stripe, exact
 //                  integer sums, first minimum
-//   k_seed_splat   the (2k+1)^2 max-dilation of the <= 1024 matched corners written straight into the seed map:
-//                  every pixel takes the largest disparity among the corners whose rectangle covers it (what
-//                  cv::dilate of the scattered map gives), optionally nearest-resized and scaled as
+//   k_seed_splat   the (2k+1)^2 max-dilation of the <= 1024 matched corners written straight into the zeroed seed
+//                  map: one workgroup per corner raises its rectangle with atomicMax on the float bits (what
+//                  cv::dilate of the scattered map gives), optionally scaled and nearest-resized as
 //                  Patchmatch::Initialize does (patchmatch.cpp:75-81)
 // The arithmetic is this build's definition of the seeder (see oracle/pm_oracle.h): OpenCV's float
 // pipelines are not reproducible without OpenCV; parity is against oracle/pm_seed_oracle.c.
@@ -142,7 +142,8 @@ __global__ void __launch_bounds__(256) k_seed_nms(const float* __restrict__ eig,
       }
     if (!is_max) continue;
     const unsigned slot = atomicAdd(&s_count, 1u);
-    s_keys[slot] = ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (unsigned)(y * cols + x);
+    // low word = y << 16 | x: the same order as the raster index y * cols + x (x < cols <= 65535), no division to decode
+    s_keys[slot] = ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | ((unsigned)y << 16) | (unsigned)x;
   }
   __syncthreads();
   const unsigned n = s_count;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(64) k_seed_select(const unsigned long long* __
     const int nk = min(64, ncand - base);
     for (int k = 0; k < nk && count < max_features; ++k) {
       const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine & 0xffffffffull), k);
-      const int y = (int)(idx / (unsigned)cols), x = (int)(idx - (unsigned)y * (unsigned)cols);
+      const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
       bool bad = false;
       if (min_distance >= 1)
         for (int j = lane; j < count; j += 64) {
@@ -187,6 +188,74 @@ __global__ void __launch_bounds__(64) k_seed_select(const unsigned long long* __
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the list entry is visible to the next check
       }
     }
+  }
+  if (lane == 0) counters[2] = (unsigned)count;
+}
+
+// The same greedy selection with the accepted corners kept in a uniform GRID in LDS (cells of min_distance pixels,
+// cv::goodFeaturesToTrack's own data structure): a candidate only meets the corners of its 3x3 cell neighbourhood,
+// and 64 candidates are examined per step -- every lane checks its own candidate against the grid, then the
+// survivors of the batch are taken in sorted order, each one knocking out the later lanes within min_distance.
+// Same result as the sequential loop: a candidate is accepted iff no earlier accepted one is closer than
+// min_distance.  Two corners at least min_distance apart cannot share more than a cell diagonal: <= 2 per cell;
+// four slots are kept and counters[3] flags an overflow (never observed; the caller may assert on it).
+// grid = 1 workgroup of 64, dynamic LDS = gx * gy * 4 ints.  Requires min_distance >= 1.
+__global__ void __launch_bounds__(64) k_seed_select_grid(const unsigned long long* __restrict__ keys, int cap, int cols,
+                                                         int min_distance, int max_features, int gx, int gy,
+                                                         int* __restrict__ kp_xy, unsigned* __restrict__ counters) {
+  extern __shared__ int s_cell[];  // [gy][gx][4] packed x | y << 16, -1 = free
+  const int lane = threadIdx.x;
+  for (int e = lane; e < gx * gy * 4; e += 64) s_cell[e] = -1;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const int ncand = min((int)counters[1], cap);
+  const int md2 = min_distance * min_distance;
+  // cell of a coordinate: floor(v / min_distance) up to float rounding -- any monotone map whose cells are at
+  // least min_distance - 1 wide keeps two points closer than min_distance in adjacent cells, which is all the
+  // 3x3 lookup needs (insertion and lookup use the same map)
+  const float inv_md = 1.0f / (float)min_distance;
+  int count = 0;
+  unsigned long long next_key = lane < ncand ? keys[lane] : 0ull;  // one batch ahead: hides the load latency
+  for (int base = 0; base < ncand && count < max_features; base += 64) {
+    const bool valid = base + lane < ncand;
+    const unsigned idx = (unsigned)(next_key & 0xffffffffull);
+    next_key = base + 64 + lane < ncand ? keys[base + 64 + lane] : 0ull;
+    const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
+    const int cx = min((int)((float)x * inv_md), gx - 1), cy = min((int)((float)y * inv_md), gy - 1);
+    bool bad = !valid;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ccx = cx + dx, ccy = cy + dy;
+        if (ccx < 0 || ccy < 0 || ccx >= gx || ccy >= gy) continue;
+        const int* c = s_cell + (ccy * gx + ccx) * 4;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          const int e = c[sl];
+          if (e >= 0) {
+            const int ddx = x - (e & 0xffff), ddy = y - (e >> 16);
+            bad = bad || (ddx * ddx + ddy * ddy < md2);
+          }
+        }
+      }
+    unsigned long long alive = __ballot(!bad);
+    while (alive != 0ull && count < max_features) {
+      const int w = __ffsll((long long)alive) - 1;
+      const int wx = __builtin_amdgcn_readlane(x, w), wy = __builtin_amdgcn_readlane(y, w);
+      if (lane == 0) {
+        kp_xy[2 * count] = wx;
+        kp_xy[2 * count + 1] = wy;
+        const int wcx = min((int)((float)wx * inv_md), gx - 1), wcy = min((int)((float)wy * inv_md), gy - 1);
+        int* c = s_cell + (wcy * gx + wcx) * 4;
+        int sl = 0;
+        while (sl < 4 && c[sl] >= 0) ++sl;
+        if (sl < 4) c[sl] = wx | (wy << 16);
+        else counters[3] = 1u;
+      }
+      ++count;
+      const int ddx = x - wx, ddy = y - wy;
+      if (ddx * ddx + ddy * ddy < md2) bad = true;  // includes lane w itself
+      alive = __ballot(!bad) & ~((2ull << w) - 1ull);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the grid entries are visible to the next batch
   }
   if (lane == 0) counters[2] = (unsigned)count;
 }
@@ -224,21 +293,47 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
   const int rw = md - tc + 1, rh = stripe_rows - tr + 1;
 
   __shared__ unsigned long long s_best[4];
+  // Template and search stripe staged in LDS once, rows padded to whole dwords (template padding = 0).
+  // num = sum (t - q)^2 = sum t^2 - 2 sum t*q + sum q^2, every sum an exact integer: four taps per v_dot4_u32_u8.
+  extern __shared__ unsigned s_seed_w[];
+  const int tcw = (tc + 3) >> 2;            // template row, dwords
+  const int mdw = ((md + 3) >> 2) + 1;      // stripe row, dwords (+1: the last window may read one dword past)
+  unsigned* s_t = s_seed_w;                 // [tr][tcw]
+  unsigned* s_i = s_seed_w + tr * tcw;      // [stripe_rows][mdw]
+  for (int e = threadIdx.x; e < tr * tcw + stripe_rows * mdw; e += blockDim.x) s_seed_w[e] = 0u;
+  __syncthreads();
+  for (int e = threadIdx.x; e < tr * tc; e += blockDim.x) {
+    const int j = e / tc, i = e - j * tc;
+    ((uint8_t*)(s_t + j * tcw))[i] = left[(size_t)(ty + j) * pitch + tx + i];
+  }
+  for (int e = threadIdx.x; e < stripe_rows * md; e += blockDim.x) {
+    const int j = e / md, i = e - j * md;
+    ((uint8_t*)(s_i + j * mdw))[i] = right[(size_t)(sy + j) * pitch + sx + i];
+  }
+  __syncthreads();
+  unsigned t2 = 0;  // the template's own sum of squares does not depend on the position
+  for (int e = 0; e < tr * tcw; ++e) t2 = __builtin_amdgcn_udot4(s_t[e], s_t[e], t2, false);
+  const int rem = tc - 4 * (tcw - 1);  // taps in the last dword of a row (1..4)
+  const unsigned last_mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
   unsigned long long best = ~0ull;
   for (int pos = threadIdx.x; pos < rw * rh; pos += blockDim.x) {
     const int v = pos / rw, u = pos - v * rw;
-    long long num = 0, i2 = 0, t2 = 0;
+    unsigned tq = 0, i2 = 0;
+    const unsigned sh = (unsigned)u & 3u;
     for (int j = 0; j < tr; ++j) {
-      const uint8_t* T = left + (size_t)(ty + j) * pitch + tx;
-      const uint8_t* I = right + (size_t)(sy + v + j) * pitch + sx + u;
-      for (int i = 0; i < tc; ++i) {
-        const int t = T[i], q = I[i];
-        const int d = t - q;
-        num += d * d;
-        i2 += q * q;
-        t2 += t * t;
+      const unsigned* T = s_t + j * tcw;
+      const unsigned* I = s_i + (v + j) * mdw + (u >> 2);
+      unsigned w0 = I[0];
+      for (int g = 0; g < tcw; ++g) {
+        const unsigned w1 = I[g + 1];
+        unsigned q = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        if (g == tcw - 1) q &= last_mask;  // stripe bytes beyond the template's width do not belong to the window
+        tq = __builtin_amdgcn_udot4(T[g], q, tq, false);
+        i2 = __builtin_amdgcn_udot4(q, q, i2, false);
+        w0 = w1;
       }
     }
+    const unsigned num = t2 + i2 - 2u * tq;  // = sum (t - q)^2 >= 0
     const double den = sqrt((double)t2 * (double)i2);
     const float r = den > 0.0 ? (float)((double)num / den) : 1.f;
     // first minimum in row-major order = minimum of (value bits, position) as one 64-bit key (r >= 0)
@@ -262,32 +357,40 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
   }
 }
 
-// Seed map from the matched corners.  Output pixel (xo, yo) of an out_rows x out_cols map looks at source pixel
-// (sx, sy) of the rows x cols image -- the identity for SparseInit, cv::resize(INTER_NEAREST)'s
-// min(floor(xo * cols / out_cols), cols - 1) for Initialize's down-sampled map (patchmatch.cpp:79) -- and takes the
-// maximum disparity over the corners whose (2k+1)^2 rectangle covers it: cv::dilate (MORPH_RECT, anchor (k, k),
-// samples outside the image ignored) of the map that holds d at round(kp) and 0 elsewhere
-// (patchmatch.cpp:61-78, patchmatch_gpu.cu:422-439).  `inv_scale` = 1 or 2^-f (patchmatch.cpp:81: exact).
+// Seed map from the matched corners = cv::dilate (MORPH_RECT (2k+1)^2, anchor (k, k), samples outside the image
+// ignored) of the map that holds d at round(kp) and 0 elsewhere (patchmatch.cpp:61-78, patchmatch_gpu.cu:422-439):
+// every pixel takes the largest disparity among the corners whose rectangle covers it.  One workgroup per corner
+// writes its rectangle with atomicMax on the float bit patterns (disparities are >= 0, so unsigned order = float
+// order; a maximum does not depend on the order of the updates: deterministic) into a zeroed map.  `inv_scale`
+// (1, or 2^-f for Initialize, patchmatch.cpp:81) is applied to the corner value first: scaling by a power of two
+// is exact and monotone, so it commutes with the maximum.
 __global__ void __launch_bounds__(256) k_seed_splat(const int* __restrict__ kp_xy, const float* __restrict__ kp_d,
                                                     const unsigned* __restrict__ counters, int rows, int cols, int k,
-                                                    int out_rows, int out_cols, float inv_scale, float* __restrict__ out,
-                                                    int out_pitch) {
+                                                    float inv_scale, float* __restrict__ out, int out_pitch) {
+  const int kp = blockIdx.x;
+  if (kp >= (int)counters[2]) return;
+  const float d = kp_d[kp];
+  if (!(d > 0.f)) return;  // no match (-1) or disparity 0: nothing to raise above the zero background
+  const unsigned bits = __builtin_bit_cast(unsigned, d * inv_scale);
+  const int kx = kp_xy[2 * kp], ky = kp_xy[2 * kp + 1];
+  const int x0 = max(kx - k, 0), x1 = min(kx + k, cols - 1), y0 = max(ky - k, 0), y1 = min(ky + k, rows - 1);
+  const int w = x1 - x0 + 1, n = w * (y1 - y0 + 1);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const int yy = e / w, xx = e - yy * w;
+    atomicMax((unsigned*)out + (size_t)(y0 + yy) * out_pitch + x0 + xx, bits);
+  }
+}
+// Initialize's down-sampled map: cv::resize(INTER_NEAREST) of the dilated full-size map (patchmatch.cpp:79):
+// dst(y, x) = src(min(floor(y * rows / out_rows), rows - 1), min(floor(x * cols / out_cols), cols - 1)).
+__global__ void __launch_bounds__(256) k_seed_resize_nearest(const float* __restrict__ src, int rows, int cols,
+                                                             int src_pitch, float* __restrict__ dst, int out_rows,
+                                                             int out_cols, int dst_pitch) {
   const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
   if (xo >= out_cols) return;
-  int sx = xo, sy = yo;
-  if (out_cols != cols || out_rows != rows) {
-    const double ifx = 1.0 / ((double)out_cols / (double)cols), ify = 1.0 / ((double)out_rows / (double)rows);
-    sx = min((int)floor((double)xo * ifx), cols - 1);
-    sy = min((int)floor((double)yo * ify), rows - 1);
-  }
-  const int n = (int)counters[2];
-  float m = 0.f;
-  for (int i = 0; i < n; ++i) {  // uniform loop: the corner list is read through the scalar cache
-    const int kx = kp_xy[2 * i], ky = kp_xy[2 * i + 1];
-    const float d = kp_d[i];
-    if (d >= 0.f && abs(sx - kx) <= k && abs(sy - ky) <= k) m = fmaxf(m, d);
-  }
-  out[(size_t)yo * out_pitch + xo] = m * inv_scale;
+  const double ifx = 1.0 / ((double)out_cols / (double)cols), ify = 1.0 / ((double)out_rows / (double)rows);
+  const int sx = min((int)floor((double)xo * ifx), cols - 1);
+  const int sy = min((int)floor((double)yo * ify), rows - 1);
+  dst[(size_t)yo * dst_pitch + xo] = src[(size_t)sy * src_pitch + sx];
 }
 
 // SparseInit / Initialize for one pair of pitched u8 planes: corners of `left` matched into `right`, dilated with
@@ -312,13 +415,37 @@ inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                                                        stream)) != hipSuccess)
     return e;
   const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
-  hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(64), 0, stream, sc.keys_sorted, sc.cap, cols, sp.min_distance, maxf,
-                     sc.kp_xy, sc.counters);
-  hipLaunchKernelGGL(k_seed_match, dim3((unsigned)(maxf > 0 ? maxf : 1)), dim3(256), 0, stream, left, right, rows,
-                     cols, pitch, sc.kp_xy, sc.counters, sp, sc.kp_d);
-  hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block, 0, stream,
-                     (const int*)sc.kp_xy, (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, out_rows,
-                     out_cols, inv_scale, out, out_pitch);
+  {
+    const int md = sp.min_distance;
+    const int gx = md >= 1 ? (cols + md - 1) / md : 0, gy = md >= 1 ? (rows + md - 1) / md : 0;
+    const size_t grid_bytes = (size_t)gx * gy * 4 * sizeof(int);
+    if (md >= 1 && cols < 65536 && rows < 32768 && grid_bytes <= 150 * 1024) {  // x | y << 16 packing, LDS capacity
+      if (grid_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_seed_select_grid, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)grid_bytes);
+      hipLaunchKernelGGL(k_seed_select_grid, dim3(1), dim3(64), grid_bytes, stream, sc.keys_sorted, sc.cap, cols, md,
+                         maxf, gx, gy, sc.kp_xy, sc.counters);
+    } else {
+      hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(64), 0, stream, sc.keys_sorted, sc.cap, cols, sp.min_distance,
+                         maxf, sc.kp_xy, sc.counters);
+    }
+  }
+  {
+    const size_t px_bytes = 4 * ((size_t)sp.templ_rows * ((sp.templ_cols + 3) / 4) +
+                                 (size_t)(sp.templ_rows + 2) * ((sp.max_disp + 3) / 4 + 1));
+    hipLaunchKernelGGL(k_seed_match, dim3((unsigned)(maxf > 0 ? maxf : 1)), dim3(256), px_bytes, stream, left, right,
+                       rows, cols, pitch, sc.kp_xy, sc.counters, sp, sc.kp_d);
+  }
+  const bool resized = out_rows != rows || out_cols != cols;
+  // full-size splat target: the output itself, or the (idle by now) response plane when a resize follows
+  float* full = resized ? sc.eig : out;
+  const int full_pitch = resized ? pitch : out_pitch;
+  if ((e = hipMemsetAsync(full, 0, sizeof(float) * (size_t)rows * full_pitch, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)(maxf > 0 ? maxf : 1)), block, 0, stream, (const int*)sc.kp_xy,
+                     (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, inv_scale, full, full_pitch);
+  if (resized)
+    hipLaunchKernelGGL(k_seed_resize_nearest, dim3((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block, 0,
+                       stream, (const float*)full, rows, cols, full_pitch, out, out_rows, out_cols, out_pitch);
   return hipGetLastError();
 }
 inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
