@@ -56,6 +56,10 @@ struct View {
   const float* trefg;      // transposed refg (PM_SEM_GPU column sweeps)
   const uint16_t* refpk;   // ref8 | refg8 << 8
   const uint16_t* trefpk;  // transposed
+  // column sweeps with the reference window lines of the chain staged in LDS (pm_run2.hpp, LREF):
+  // element (window column t, image row Y) at lds_ref[t * lds_ref_pitch + Y]
+  const uint16_t* lds_ref;
+  int lds_ref_pitch;
   float* disp;
   float* cost;
 };
@@ -87,6 +91,8 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.trefg = ps.tg32 + (base4 + iref) * ps.plane_t;
   w.refpk = ps.pk16 + (base4 + iref) * ps.plane;
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
+  w.lds_ref = nullptr;
+  w.lds_ref_pitch = 0;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;

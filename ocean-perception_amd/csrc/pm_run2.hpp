@@ -116,7 +116,7 @@ __device__ __forceinline__ RowBufs make_row_bufs(const View& v, const PlaneSet& 
 
 // DIR = +1 / -1 fixes the sweep direction at compile time (no multiplications by the direction, no selects between
 // the "first set bit" forms); 0 = read it from the geometry.
-template <int GS, int AXIS, int TPW, int TPH, int DIR>
+template <int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
 __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps, const CostParams& cp,
                                               const SweepGeom& g, int chain, bool act, int i, int n_end, float cand,
                                               const float* din, const float* cin) {
@@ -204,7 +204,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         for (int t = 0; t < TPH; ++t) {
           const int so = org + t * pitch;
 #if PM_RUN2_REF_PK16
-          const int pk = ld_u16(v.refpk, (unsigned)((X + so) * 2));
+          const int pk = LREF ? (int)v.lds_ref[t * v.lds_ref_pitch + X] : ld_u16(v.refpk, (unsigned)((X + so) * 2));
           const int l8 = pk & 0xff;
           lgv[t] = pk >> 8;
 #else
@@ -259,7 +259,9 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           const int lso = lorg + t * pt;
           const int rso = (t + 1) * pt;
 #if PM_RUN2_REF_PK16
-          const int pk = ld_u16(v.trefpk, (unsigned)((Y + lso) * 2));
+          // the reference line of window column t: from the chain's LDS copy when the kernel staged it (LREF),
+          // else one u16 load from the transposed packed plane
+          const int pk = LREF ? (int)v.lds_ref[t * v.lds_ref_pitch + Y] : ld_u16(v.trefpk, (unsigned)((Y + lso) * 2));
           const int l8 = pk & 0xff;
           lgv[t] = pk >> 8;
 #else
@@ -339,13 +341,16 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 // Rounds and fix-up as described in pm_run.hpp, per group.
 // grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + 2 * kMaxSegWaves + 3 words.
 // SEM = 0: PM_SEM_CPU (run_step2 above); SEM = 1: PM_SEM_GPU (run_step2_gpu, pm_run_gpu.hpp).
-template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin);
 
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
+// LREF (column sweeps, PM_SEM_CPU): the packed reference lines of the chain -- window columns chain - pw/2 .. + pw/2,
+// all image rows -- are staged in LDS once per workgroup; a step then reads its 11 reference values per lane from
+// LDS instead of issuing 11 of its 33 global loads (the steps of a segment re-read almost the same lines).
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
 __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
   const int n = (g.s_last - g.s_first) * g.dir + 1;
@@ -361,7 +366,21 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
 
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
-  const View v = make_view(ps, blockIdx.z);
+  View v = make_view(ps, blockIdx.z);
+  if constexpr (LREF) {
+    // behind the chain arrays and the flags: [win][len] u16 (len = rows for a column sweep on the transposed
+    // plane, cols for a row sweep), row pitch = len rounded up to even
+    const int len = AXIS == 1 ? ps.rows : ps.cols;
+    const int rp = (len + 1) & ~1;
+    uint16_t* sref = (uint16_t*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1 + 2);
+    const uint16_t* src = AXIS == 1 ? v.trefpk + (size_t)(chain - TPW / 2) * ps.pitch_t
+                                    : v.refpk + (size_t)(chain - TPH / 2) * ps.pitch;
+    const int sp = AXIS == 1 ? ps.pitch_t : ps.pitch;
+    for (int t = 0; t < (AXIS == 1 ? TPW : TPH); ++t)
+      for (int e = threadIdx.x; e < rp; e += blockDim.x) sref[t * rp + e] = e < len ? src[(size_t)t * sp + e] : (uint16_t)0;
+    v.lds_ref = sref;
+    v.lds_ref_pitch = rp;
+  }
   const int lane = threadIdx.x & 63;
   constexpr int kPerWave = kWave / GS;
   const int gl = lane & (GS - 1);
@@ -401,7 +420,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     int i = i0;
     while (__any(active && i < i1)) {
       const bool act = active && i < i1;
-      const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
+      const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
 #ifdef PM_RUN2_TIMING
       if constexpr (SEM == 0) {
@@ -436,7 +455,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       bool merged = false;
       while (__any(redo && !merged && i < i1)) {
         const bool act = redo && !merged && i < i1;
-        const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
+        const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
         ++n_fix;
         const bool mine = st.mpos >= 0 && st.mpos < st.advance;
         const float val = st.mpos == st.rej_pos ? st.rej_d0 : c2;
@@ -498,9 +517,9 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   }
 }
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
-inline void launch_run2_kd(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
-                           hipStream_t stream) {
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
+inline void launch_run2_kdl(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                            hipStream_t stream) {
   const int chains = g.c_hi - g.c_lo + 1;
   const int n = (g.s_last - g.s_first) * g.dir + 1;
   int nwv = waves < 1 ? 1 : (waves > kMaxSegWaves ? kMaxSegWaves : waves);
@@ -508,10 +527,42 @@ inline void launch_run2_kd(const PlaneSet& ps, const CostParams& cp, const Sweep
   int len = (n + per_block - 1) / per_block;
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
-  const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
-  allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR>, lds_bytes);
-  hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR>), dim3((unsigned)chains, 1, (unsigned)slots),
+  size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
+  if (LREF) lds_bytes += sizeof(uint16_t) * (size_t)TPW * (((AXIS == 1 ? ps.rows : ps.cols) + 1) & ~1);
+  allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR, LREF>, lds_bytes);
+  hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
+}
+// Column sweeps of the benchmark window stage their reference lines in LDS while that leaves at least four
+// workgroups per CU (720 rows: 27 KB per workgroup); PM_RUN2_LREF=0 turns it off (A/B knob).
+// PM_RUN2_LREF: bit 0 = row sweeps, bit 1 = column sweeps (default 2); PM_RUN2_LREF_KB: LDS budget per workgroup
+inline bool run2_lref_enabled(int axis) {
+  static const int v = [] {
+    const char* e = getenv("PM_RUN2_LREF");
+    return e ? atoi(e) : 2;
+  }();
+  return (v >> axis) & 1;
+}
+inline size_t run2_lref_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("PM_RUN2_LREF_KB");
+    return (size_t)(e ? atoi(e) : 40) * 1024;
+  }();
+  return v;
+}
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
+inline void launch_run2_kd(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                           hipStream_t stream) {
+  if constexpr (SEM == 0 && TPW == 11) {
+    const int n = (g.s_last - g.s_first) * g.dir + 1;
+    const size_t total = sizeof(float) * 4 * (size_t)(n + 4) +
+                         sizeof(uint16_t) * (size_t)TPW * ((AXIS == 1 ? ps.rows : ps.cols) + 1) + 256;
+    if (run2_lref_enabled(AXIS) && total <= run2_lref_limit()) {
+      launch_run2_kdl<SEM, GS, AXIS, TPW, TPH, DIR, true>(ps, cp, g, slots, waves, stream);
+      return;
+    }
+  }
+  launch_run2_kdl<SEM, GS, AXIS, TPW, TPH, DIR, false>(ps, cp, g, slots, waves, stream);
 }
 // The benchmark window (11x11, PM_SEM_CPU) gets direction-specialised kernels; the others read the direction
 // from the geometry (every instantiation costs build time).
@@ -550,12 +601,12 @@ inline void launch_run2_axis(const PlaneSet& ps, const CostParams& cp, const Swe
 #include "pm_run_gpu.hpp"
 namespace pm {
 
-template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
+template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
 __device__ __forceinline__ RunStep2 run_step2_any(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
                                                   float cand, const float* din, const float* cin) {
   if constexpr (SEM == 0)
-    return run_step2<GS, AXIS, TPW, TPH, DIR>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
+    return run_step2<GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
   else
     return run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, n_end, cand, din, cin);
 }
