@@ -284,15 +284,17 @@ int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own);
 
 /* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------
  * pm_match_u8 / pm_match_batch_u8 / pm_submit_u8 / pm_match_device run the whole schedule
- *   begin; for it < patchmatch_iters: {red, black} per view, view 0, view 1, refine per view; finish
+ *   begin; for it < patchmatch_iters: red, black (both views), then per view v = 0, 1: view propagation into v
+ *   followed by v's refinement (one fused launch); finish
  * when params.mode == PM_MODE_PLANES.  These entry points run one stage each (tests, tools). */
-enum { PM_PL_SPATIAL = 1, PM_PL_VIEW = 2, PM_PL_REFINE = 3 };
+enum { PM_PL_SPATIAL = 1, PM_PL_VIEW = 2, PM_PL_REFINE = 3, PM_PL_VIEW_REFINE = 4 };
 /* prep + random plane initialisation (+ its cost) of n pairs; seeds as in pm_match_device */
 int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                     const float* d_seed_l, const float* d_seed_r);
 /* stage = PM_PL_SPATIAL: arg = colour (0 red: x + y even, 1 black), both views;
  *         PM_PL_VIEW:    arg = the view that receives candidates from the other one;
- *         PM_PL_REFINE:  arg = iteration (selects noise_amp[arg] and the random numbers), both views */
+ *         PM_PL_REFINE:  arg = iteration (selects noise_amp[arg] and the random numbers), both views;
+ *         PM_PL_VIEW_REFINE: arg = iteration * 2 + view: PM_PL_VIEW for that view, then its PM_PL_REFINE, fused */
 int pm_planes_step(pm_handle* h, int stage, int arg);
 /* planes of (pair, view) as four tightly packed rows x cols float maps a, b, z, cost: HOST buffer of
  * 4 * rows * cols floats (view 1 is in mirrored coordinates, as the engine holds it) */

@@ -756,6 +756,15 @@ int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
     case PM_PL_REFINE:
       ar.refine_amp = h->params.noise_amp[arg];
       return planes_stage<PL_REFINE>(h, ps, ar, n * nv, PM_K_PL_REFINE, "refinement");
+    case PM_PL_VIEW_REFINE: {  // arg = iteration * 2 + view: view propagation into `view`, then its refinement
+      const int view = arg & 1, it = arg >> 1;
+      if (view >= nv) return PM_OK;
+      ar.arg = it;
+      ar.view_fixed = view;
+      ar.refine_amp = h->params.noise_amp[it];
+      if (nv < 2) return planes_stage<PL_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "refinement");
+      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "view propagation + refinement");
+    }
     default:
       set_err(h, "unknown planes stage %d", stage);
       return PM_ERR_INVALID_ARG;
@@ -825,9 +834,9 @@ int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
   for (int it = 0; it < h->params.patchmatch_iters; ++it) {
     if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 0)) return rc;
     if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 1)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_VIEW, 0)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_VIEW, 1)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_REFINE, it)) return rc;
+    // per view: view propagation then refinement, fused in one launch (one tile fill for 1 + R candidates)
+    for (int v = 0; v < nv; ++v)
+      if (int rc = planes_step(h, ps, n, PM_PL_VIEW_REFINE, it * 2 + v)) return rc;
   }
   return planes_finish(h, d_disp_l, d_disp_r);
 }
@@ -1970,7 +1979,8 @@ int pm_planes_step(pm_handle* h, int stage, int arg) {
   const int nv = h->params.left_right_check ? 2 : 1;
   const bool ok = (stage == PM_PL_SPATIAL && (arg == 0 || arg == 1)) ||
                   (stage == PM_PL_VIEW && (arg == 0 || arg == 1)) ||
-                  (stage == PM_PL_REFINE && arg >= 0 && arg < PM_MAX_ITERS);
+                  (stage == PM_PL_REFINE && arg >= 0 && arg < PM_MAX_ITERS) ||
+                  (stage == PM_PL_VIEW_REFINE && arg >= 0 && arg < 2 * PM_MAX_ITERS);
   if (!ok) {
     set_err(h, "pm_planes_step: stage %d / argument %d out of range", stage, arg);
     return PM_ERR_INVALID_ARG;

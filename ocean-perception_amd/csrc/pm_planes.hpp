@@ -27,7 +27,7 @@
 
 namespace pm {
 
-enum { PL_INIT = 0, PL_SPATIAL = 1, PL_VIEW = 2, PL_REFINE = 3 };
+enum { PL_INIT = 0, PL_SPATIAL = 1, PL_VIEW = 2, PL_REFINE = 3, PL_VIEW_REFINE = 4 };  // 4 = 2 then 3, one tile fill
 enum { PL_RAND_INIT = 0, PL_RAND_REFINE = 1 };  // `stage` of the random key (oracle: ST_INIT / ST_REFINE)
 
 constexpr int kPlTileH = 8;
@@ -89,9 +89,12 @@ typedef __attribute__((address_space(3))) pl_u2 pl_lds_u2;
 struct PlTile {
   int tgt_entry0;       // ABSOLUTE LDS address / 8 of the target tile: [TR][rw] 8-byte entries
                         // {P(c), P(c + 1)}, P = colour | gradient << 16, c = xs_lo + index
-  const unsigned* rc;   // reference colour bytes, flat [(TR) * lw] as dwords
-  const unsigned* rg;   // reference gradient bytes
-  int rw, lw;
+  // Reference window bytes: FOUR copies of the tile per channel, copy s shifted left by s bytes
+  // (copy_s[k] = tile[k + s]), rows padded to whole dwords: a lane whose window starts at byte offset f of a row reads
+  // ALIGNED dwords (f >> 2) of copy (f & 3) and gets its window bytes in place -- no v_alignbyte per dword.
+  const unsigned* rc;   // [4][TR][lww] dwords, colour
+  const unsigned* rg;   // gradient
+  int rw, lww, copy_w;  // target row entries; reference row dwords; dwords per copy
 };
 
 // Window cost of plane (a, b, z) for the pixel at tile position (lx, ty); xrel = its column - h - xs_lo.
@@ -114,7 +117,10 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
   for (int j = 0; j < P; ++j) xoff[j] = j * stepj;
   const int rowstep = (t.rw << 16) - B;
   unsigned sc = 0, sg = 0;
-  int fl = ty * t.lw + lx;
+  // reference side: the lane's copy and dword column are fixed for the whole window (rows are whole dwords)
+  const int ref0 = (lx & 3) * t.copy_w + ty * t.lww + (lx >> 2);
+  const unsigned* pl = t.rc + ref0;
+  const unsigned* pg = t.rg + ref0;
 #pragma unroll 1
   for (int i = 0; i < P; ++i) {
     // all LDS reads of the window row first (target pairs, then reference bytes), arithmetic afterwards: the
@@ -128,19 +134,10 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
       wq[j] = ((unsigned)X >> 8) & 255u;
     }
     unsigned lw[NG], lgw[NG];
-    {
-      const unsigned* pl = t.rc + (fl >> 2);
-      const unsigned* pg = t.rg + (fl >> 2);
-      const unsigned sh = (unsigned)fl & 3u;
-      unsigned a0 = pl[0], b0 = pg[0];
 #pragma unroll
-      for (int q = 0; q < NG; ++q) {
-        const unsigned a1 = pl[q + 1], b1 = pg[q + 1];
-        lw[q] = __builtin_amdgcn_alignbyte(a1, a0, sh);
-        lgw[q] = __builtin_amdgcn_alignbyte(b1, b0, sh);
-        a0 = a1;
-        b0 = b1;
-      }
+    for (int q = 0; q < NG; ++q) {
+      lw[q] = pl[q];
+      lgw[q] = pg[q];
     }
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -165,7 +162,8 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
       sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg, sg);
     }
     xrow += rowstep;
-    fl += t.lw;
+    pl += t.lww;
+    pg += t.lww;
   }
   const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
   const float t0 = pp.alpha * fminf(mc, pp.tau_color);
@@ -198,7 +196,7 @@ __device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xr
 
 struct PlArgs {
   int stage;
-  int arg;         // SPATIAL: parity; VIEW: the view; REFINE: iteration
+  int arg;         // SPATIAL: parity; VIEW: the view; REFINE / VIEW_REFINE: iteration
   int view_fixed;  // >= 0: blockIdx.z = pair, this view; -1: blockIdx.z = pair * n_views + view
   float refine_amp;
   const float* seed_l;  // INIT: tightly packed [n][rows][cols] seed maps in left / right image coordinates, or null
@@ -216,7 +214,9 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   constexpr int TW = STAGE == PL_SPATIAL ? 128 : 64;  // 64 lanes per tile row either way
   constexpr int TR = kPlTileH + P - 1;
   constexpr int LW = TW + P - 1;
-  constexpr int NREF = ((TR * LW + 3) / 4 + 4 + 1) & ~1;
+  constexpr int LWW = (LW + 3) / 4 + 1;          // dwords per reference row (+1: a shifted copy reads 3 bytes further)
+  constexpr int COPYW = TR * LWW;                // dwords per shifted copy
+  constexpr int NREF = (4 * COPYW + 1) & ~1;     // per channel, even
   extern __shared__ __attribute__((aligned(16))) unsigned pl_lds[];
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
   unsigned* s_rc = pl_lds;
@@ -251,8 +251,14 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
       const uint16_t* trw = tgtpk + (size_t)gy * pitch;
       for (int cc = tx; cc < LW; cc += 64) {
         const unsigned pk = rrow[min(max(lx0 + cc, 0), cols - 1)];
-        rc8[rr * LW + cc] = (uint8_t)(pk & 0xffu);
-        rg8[rr * LW + cc] = (uint8_t)(pk >> 8);
+        // byte cc of the row goes to byte cc - s of copy s (s = 0..3)
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)
+          if (cc >= sft) {
+            const int o = 4 * (sft * COPYW + rr * LWW) + cc - sft;
+            rc8[o] = (uint8_t)(pk & 0xffu);
+            rg8[o] = (uint8_t)(pk >> 8);
+          }
       }
       pl_u2* trow = s_tgt + rr * rw;
       for (int cc = tx; cc < rw; cc += 64) {
@@ -288,7 +294,8 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   t.rc = s_rc;
   t.rg = s_rg;
   t.rw = rw;
-  t.lw = LW;
+  t.lww = LWW;
+  t.copy_w = COPYW;
   const int xrel = lx + pp.max_disp + pp.margin;
   const size_t o = (size_t)y * pitch + x;
   const float smax = pp.slope_max;
@@ -347,7 +354,8 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
         const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
         pl_offer<P, ST>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
       }
-    } else if constexpr (STAGE == PL_VIEW) {
+    }
+    if constexpr (STAGE == PL_VIEW || STAGE == PL_VIEW_REFINE) {
       const ST* oa = st.arr(pair, 1 - view, 0);
       const ST* ob = st.arr(pair, 1 - view, 1);
       const ST* oz = st.arr(pair, 1 - view, 2);
@@ -369,7 +377,8 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
       const float tt = na * dx;
       const float nz = zo + tt;
       pl_offer<P, ST>(t, lx, ty, xrel, x, ok, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
-    } else {  // PL_REFINE
+    }
+    if constexpr (STAGE == PL_REFINE || STAGE == PL_VIEW_REFINE) {
       float dz = ar.refine_amp;
       for (int k = 0; k < pp.refine_steps; ++k) {
         const float ds = dz * pp.slope_per_disp;
@@ -396,7 +405,7 @@ inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
   const int h = P / 2;
   const int TW = STAGE == PL_SPATIAL ? 128 : 64;
   const int TR = kPlTileH + P - 1, LW = TW + P - 1;
-  const int nref = ((TR * LW + 3) / 4 + 4 + 1) & ~1;
+  const int nref = (4 * TR * ((LW + 3) / 4 + 1) + 1) & ~1;
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
   size_t words = 2 * (size_t)nref + 2 * (size_t)TR * rw + 4;
   if (STAGE == PL_SPATIAL) words += 3 * (size_t)(kPlTileH + 2) * (TW + 2);

@@ -19,7 +19,7 @@ PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_
 PM_K_COUNT = 11
 PM_MODE_SCALAR, PM_MODE_PLANES = 0, 1
 PM_STATE_F32, PM_STATE_F16 = 0, 1
-PM_PL_SPATIAL, PM_PL_VIEW, PM_PL_REFINE = 1, 2, 3
+PM_PL_SPATIAL, PM_PL_VIEW, PM_PL_REFINE, PM_PL_VIEW_REFINE = 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB: experiment knob to load another build of the same library (e.g. a different unroll factor)

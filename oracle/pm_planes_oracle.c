@@ -317,11 +317,11 @@ void pmo_planes_match(const pmo_planes_params* p, const uint8_t* left, const uin
   for (int it = 0; it < p->n_iters; ++it) {
     for (int par = 0; par < 2; ++par)
       for (int v = 0; v < nv; ++v) pmo_planes_spatial(p, &im[v], &st[v], par);
-    if (nv == 2) {
-      pmo_planes_view_prop(p, &im[0], &st[0], &st[1]);
-      pmo_planes_view_prop(p, &im[1], &st[1], &st[0]);
+    /* per view: candidates from the other view, then the view's own random refinement */
+    for (int v = 0; v < nv; ++v) {
+      if (nv == 2) pmo_planes_view_prop(p, &im[v], &st[v], &st[1 - v]);
+      pmo_planes_refine(p, &im[v], v, it, &st[v]);
     }
-    for (int v = 0; v < nv; ++v) pmo_planes_refine(p, &im[v], v, it, &st[v]);
   }
   /* disparity maps; consistency mask on the left map only, as MaskOcclusions does (patchmatch_gpu.cu:273-295) */
   for (int y = 0; y < rows; ++y)

@@ -170,14 +170,21 @@ def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded):
                 for v in range(2):
                     ov.spatial(op, v, par)
                 check(e, f"spatial it {it} colour {par}")
-            for v in range(2):
-                e.planes_step(pm.PM_PL_VIEW, v)
-                ov.view_prop(op, v)
-                check(e, f"view propagation it {it} into view {v}")
-            e.planes_step(pm.PM_PL_REFINE, it)
-            for v in range(2):
-                ov.refine(op, v, it)
-            check(e, f"refine it {it}")
+            if it == 0:  # the two stages on their own ...
+                for v in range(2):
+                    e.planes_step(pm.PM_PL_VIEW, v)
+                    ov.view_prop(op, v)
+                    check(e, f"view propagation it {it} into view {v}")
+                e.planes_step(pm.PM_PL_REFINE, it)
+                for v in range(2):
+                    ov.refine(op, v, it)
+                check(e, f"refine it {it}")
+            else:        # ... and fused as Match() runs them: per view, propagation then refinement in one launch
+                for v in range(2):
+                    e.planes_step(pm.PM_PL_VIEW_REFINE, 2 * it + v)
+                    ov.view_prop(op, v)
+                    ov.refine(op, v, it)
+                    check(e, f"fused view propagation + refinement it {it} view {v}")
 
 
 @gpu
