@@ -9,7 +9,7 @@ import csv, collections, json, re, sys
 CLASSES = (("sweep_row", r"k_runblk2<\d+, \d+, 0,"), ("sweep_col", r"k_runblk2<\d+, \d+, 1,"),
            ("noise_cost", r"k_noise_cost_tiled"), ("planes_init", r"k_planes<\d+, 0,"),
            ("planes_spatial", r"k_planes<\d+, 1,"), ("planes_view", r"k_planes<\d+, 2,"),
-           ("planes_refine", r"k_planes<\d+, 3,"))
+           ("planes_refine", r"k_planes<\d+, [34],"))
 
 
 def per_launch(path, counter):
