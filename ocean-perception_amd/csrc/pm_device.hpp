@@ -27,6 +27,18 @@ struct PlaneSet {
   size_t plane_t;      // cols * pitch_t
   uint16_t* pk16;      // [B][4][rows][pitch]   img8 | g8 << 8: what a window reads of its own image
   uint16_t* tpk16;     // [B][4][cols][pitch_t] transposed copy of pk16
+  // Row-PAIR planes of the run engine (pm_run2.hpp): one element holds the same column of TWO consecutive window
+  // lines, so a step fetches two window lines per load instruction (the sweeps are bound by the NUMBER of memory
+  // instructions).  Two alignments o = 0 / 1: pair k of alignment o covers lines 2k+o and 2k+o+1, so any window
+  // start finds its lines as whole pairs.  "Lines" are image rows for the row sweeps (rp*) and image columns, on
+  // the transposed planes, for the column sweeps (cp*).  Per pair b and view v (target image of the view for
+  // *8 / *g, reference image for rppk):
+  uint16_t* rp8;       // [B][2][2][npr][pitch]     target colour   lo byte = line 2k+o, hi byte = line 2k+o+1
+  float* rpg;          // [B][2][2][npr][pitch][2]  target gradient
+  uint32_t* rppk;      // [B][2][2][npr][pitch]     reference packed (colour | gradient << 8), lo half = line 2k+o
+  uint16_t* cp8;       // [B][2][2][npc][pitch_t]   transposed target colour
+  float* cpg;          // [B][2][2][npc][pitch_t][2]
+  int npr, npc;        // pairs per alignment: (rows + 1) / 2 + 1, (cols + kTransPad + 1) / 2 + 1
   float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
   float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
@@ -60,6 +72,13 @@ struct View {
   // element (window column t, image row Y) at lds_ref[t * lds_ref_pitch + Y]
   const uint16_t* lds_ref;
   int lds_ref_pitch;
+  // pair planes of this view, alignment 0; alignment 1 follows at + rp_stride / cp_stride elements
+  const uint16_t* rp8;
+  const float* rpg;
+  const uint32_t* rppk;
+  const uint16_t* cp8;
+  const float* cpg;
+  unsigned rp_stride, cp_stride;  // npr * pitch, npc * pitch_t
   float* disp;
   float* cost;
 };
@@ -93,6 +112,14 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
   w.lds_ref = nullptr;
   w.lds_ref_pitch = 0;
+  w.rp_stride = (unsigned)ps.npr * (unsigned)ps.pitch;
+  w.cp_stride = (unsigned)ps.npc * (unsigned)ps.pitch_t;
+  const size_t pv = ((size_t)b * 2 + v) * 2;
+  w.rp8 = ps.rp8 + pv * w.rp_stride;
+  w.rpg = ps.rpg + pv * w.rp_stride * 2;
+  w.rppk = ps.rppk + pv * w.rp_stride;
+  w.cp8 = ps.cp8 + pv * w.cp_stride;
+  w.cpg = ps.cpg + pv * w.cp_stride * 2;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;

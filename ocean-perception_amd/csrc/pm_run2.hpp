@@ -79,6 +79,17 @@ struct RowBufs {
 #ifndef PM_RUN2_GLOBAL_LOADS
 #define PM_RUN2_GLOBAL_LOADS 1
 #endif
+// 1: two window lines per load from the pair planes (PlaneSet::rp8 ...): 18 instead of 33 loads per row-sweep
+// step, 12 instead of 24 per column-sweep step.  The sweeps are bound by the number of memory instructions: one
+// extra byte load per window line costs 28 % of the frame (A/B in DESIGN.md).
+#ifndef PM_RUN2_PAIRS
+#define PM_RUN2_PAIRS 1
+#endif
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ unsigned ld_u32(const uint32_t* base, unsigned elem) { return base[(size_t)elem]; }
+__device__ __forceinline__ f32x2 ld_f32x2(const float* base, unsigned pair_elem) {
+  return *(const f32x2*)(base + 2 * (size_t)pair_elem);
+}
 __device__ __forceinline__ int win_ld8(__amdgpu_buffer_rsrc_t rs, const uint8_t* base, int voff, int soff) {
 #if PM_RUN2_GLOBAL_LOADS
   return ld_u8(base, (unsigned)(voff + soff));
@@ -194,7 +205,46 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       const int R0x4 = R0 * 4;
       const RowBufs rb = make_row_bufs(v, ps);
       const int org = (chain - half_h) * pitch;  // wave-uniform: scalar offsets below
-      if constexpr (TPH > 0 && PM_RUN2_PK_GRAD) {
+      if constexpr (TPH > 0 && PM_RUN2_PK_GRAD && PM_RUN2_PAIRS) {
+        // Two window lines per load: pair m of the alignment of this chain holds image rows y0 + 2m, y0 + 2m + 1
+        // (y0 = first window row).  The colour bytes stay packed -- the multiplies select their byte (SDWA) and ONE
+        // DPP move brings the neighbour lane's pair, i.e. the second bilinear tap of both rows.
+        constexpr int NPR = (TPH + 1) / 2;
+        const int y0 = chain - half_h;                                   // wave-uniform
+        const unsigned eo = (unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch;
+        int lgv[2 * NPR];
+        float gv[2 * NPR + 1];
+#pragma unroll
+        for (int m = 0; m < NPR; ++m) {
+          const unsigned em = eo + (unsigned)(m * pitch);
+          unsigned pp;  // reference: colour | gradient << 8 of row 2m in the low half, of row 2m + 1 in the high half
+          if constexpr (LREF) {
+            pp = (unsigned)v.lds_ref[(2 * m) * v.lds_ref_pitch + X];
+            if (2 * m + 1 < TPH) pp |= (unsigned)v.lds_ref[(2 * m + 1) * v.lds_ref_pitch + X] << 16;
+          } else {
+            pp = ld_u32(v.rppk, em + (unsigned)X);
+          }
+          const unsigned pr = (unsigned)ld_u16(v.rp8, (em + (unsigned)R0) * 2u);
+          const f32x2 pg = ld_f32x2(v.rpg, em + (unsigned)R0);
+          const unsigned prn = (unsigned)wave_shl1((int)pr);
+          gv[2 * m] = pg.x;
+          gv[2 * m + 1] = pg.y;
+          lgv[2 * m] = (int)((pp >> 8) & 0xffu);
+          lgv[2 * m + 1] = (int)(pp >> 24);
+          sc = cpu_acc_color(sc, (int)(pp & 0xffu), (int)(pr & 0xffu), (int)(prn & 0xffu), l);
+          if (2 * m + 1 < TPH)
+            sc = cpu_acc_color(sc, (int)((pp >> 16) & 0xffu), (int)((pr >> 8) & 0xffu), (int)((prn >> 8) & 0xffu), l);
+        }
+        gv[2 * NPR] = 0.f;
+        const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
+#pragma unroll
+        for (int t = 0; t < TPH; t += 2) {
+          const f32x2 gg = {gv[t], gv[t + 1]};
+          const f32x2 pa = gg * ia2, pb = gg * a2;
+          sg = cpu_acc_grad_sum(sg, lgv[t], pa.x + wave_shl1f(pb.x));
+          if (t + 1 < TPH) sg = cpu_acc_grad_sum(sg, lgv[t + 1], pa.y + wave_shl1f(pb.y));
+        }
+      } else if constexpr (TPH > 0 && PM_RUN2_PK_GRAD) {
         // gradient lerp g0 * (1 - a) + g1 * a with g1 = the neighbour lane's g0: both products of a lane's
         // own sample for two rows per packed-f32 multiply, the neighbour's product arrives by DPP inside
         // the add -- every product and sum is the same single IEEE operation as in cpu_acc_grad
@@ -248,8 +298,51 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
       const int vb4 = vb * 4;
       const RowBufs cb = make_col_bufs(v, ps);
       const int lorg = (chain - half_w) * pt;  // wave-uniform: scalar offsets below
-      int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
-      if constexpr (TPW > 0 && PM_RUN2_PK_GRAD) {
+      if constexpr (TPW > 0 && PM_RUN2_PK_GRAD && PM_RUN2_PAIRS) {
+        // samples 0 .. TPW of the lane's row = TPW + 1 consecutive image columns from ipx_r: whole pairs of the
+        // alignment ipx_r & 1 (group-uniform, may differ between the groups of a wavefront)
+        constexpr int NPC = (TPW + 2) / 2;
+        const unsigned e0 = (unsigned)(ipx_r & 1) * v.cp_stride + (unsigned)(ipx_r >> 1) * (unsigned)pt + (unsigned)Y;
+        unsigned prv[NPC];
+        float gv[2 * NPC + 1];
+#pragma unroll
+        for (int m = 0; m < NPC; ++m) {
+          const unsigned em = e0 + (unsigned)(m * pt);
+          prv[m] = (unsigned)ld_u16(v.cp8, em * 2u);
+          const f32x2 pg = ld_f32x2(v.cpg, em);
+          gv[2 * m] = pg.x;
+          gv[2 * m + 1] = pg.y;
+        }
+        gv[2 * NPC] = 0.f;
+        int lgv[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int lso = lorg + t * pt;
+#if PM_RUN2_REF_PK16
+          const int pk = LREF ? (int)v.lds_ref[t * v.lds_ref_pitch + Y] : ld_u16(v.trefpk, (unsigned)((Y + lso) * 2));
+          const int l8 = pk & 0xff;
+          lgv[t] = pk >> 8;
+#else
+          const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
+          lgv[t] = win_ld8(cb.refg8, v.trefg8, Y, lso);
+#endif
+          const int r0 = (int)((prv[t / 2] >> (8 * (t % 2))) & 0xffu);
+          const int r1 = (int)((prv[(t + 1) / 2] >> (8 * ((t + 1) % 2))) & 0xffu);
+          sc = cpu_acc_color(sc, l8, r0, r1, l);
+        }
+        const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
+        f32x2 pa[(TPW + 2) / 2], pb[(TPW + 2) / 2];
+#pragma unroll
+        for (int k = 0; k < (TPW + 2) / 2; ++k) {
+          const f32x2 gg = {gv[2 * k], gv[2 * k + 1]};
+          pa[k] = gg * ia2;
+          pb[k] = gg * a2;
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          sg = cpu_acc_grad_sum(sg, lgv[t], pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2]);
+      } else if constexpr (TPW > 0 && PM_RUN2_PK_GRAD) {
+        int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
         // samples g[0 .. PW] of the lane's row; both products per sample with packed-f32 multiplies
         int lgv[TPW];
         float gv[TPW + 2];
@@ -286,6 +379,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         for (int t = 0; t < TPW; ++t)
           sg = cpu_acc_grad_sum(sg, lgv[t], pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2]);
       } else {
+        int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
         float g0 = win_ldf(cb.tgtg, v.ttgtg, vb4, 0);
 #pragma unroll
         for (int t = 0; t < pw; ++t) {
