@@ -314,17 +314,24 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     // ---- fill: rows y0-PH/2 .. y0+kTileH-1+PH/2, clamped (clamped rows/columns are only ever read by
     // pixels that are not interior, or carry weight 0) -----------------------------------------------
     const int ry0 = y0 - PH / 2, lx0 = x0 - PW / 2;
-    for (int e = tid; e < TR * LW; e += 256) {
-      const int rr = e / LW, cc = e - rr * LW;
-      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
-      s_l8[e] = v.ref8[(size_t)gy * pitch + gx];
-      s_lg[e] = v.refg8[(size_t)gy * pitch + gx];
-    }
-    for (int e = tid; e < TR * rw; e += 256) {
-      const int rr = e / rw, cc = e - rr * rw;
-      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lo + cc, 0), cols - 1);
-      s_r8[rr * kTileRW + cc] = v.tgt8[(size_t)gy * pitch + gx];
-      s_rg[rr * kTileRW + cc] = v.tgtg[(size_t)gy * pitch + gx];
+    // wavefront w fills tile rows w, w + 4, ...; its lanes walk along the row: no division per element, coalesced
+    // reads (the packed reference plane gives colour and gradient byte with one u16 load)
+    const int fw = tid >> 6, fl = tid & 63;
+    for (int rr = fw; rr < TR; rr += 4) {
+      const int gy = min(max(ry0 + rr, 0), rows - 1);
+      const uint16_t* prow = v.refpk + (size_t)gy * pitch;
+      const uint8_t* trow = v.tgt8 + (size_t)gy * pitch;
+      const float* grow = v.tgtg + (size_t)gy * pitch;
+      for (int cc = fl; cc < LW; cc += 64) {
+        const unsigned pk = prow[min(max(lx0 + cc, 0), cols - 1)];
+        s_l8[rr * LW + cc] = (uint8_t)(pk & 0xffu);
+        s_lg[rr * LW + cc] = (uint8_t)(pk >> 8);
+      }
+      for (int cc = fl; cc < rw; cc += 64) {
+        const int gx = min(max(lo + cc, 0), cols - 1);
+        s_r8[rr * kTileRW + cc] = trow[gx];
+        s_rg[rr * kTileRW + cc] = grow[gx];
+      }
     }
     __syncthreads();
     if (interior) {
