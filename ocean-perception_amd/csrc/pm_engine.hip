@@ -739,6 +739,16 @@ PlanesParams planes_params(const pm_params& p) {
 
 int planes_alloc(pm_handle* h) {
   if (h->planes_state) return PM_OK;
+  {  // the tile of the widest stage must fit the CU's LDS: (128 + P-1 + max_disp + slope margin) x (8 + P-1) entries
+    const PlanesParams pp = planes_params(h->params);
+    const size_t need = pl_lds_bytes<PL_SPATIAL>(pp.patch, pp);
+    if (need > kChainLdsMax) {
+      set_err(h, "PM_MODE_PLANES: window %d, max_disp %d and slope_max %.2f need %zu KB of LDS per tile (limit %zu KB): "
+                 "lower max_disp or the window", pp.patch, pp.max_disp, (double)pp.slope_max, need / 1024,
+              kChainLdsMax / 1024);
+      return PM_ERR_INVALID_ARG;
+    }
+  }
   const size_t plane = (size_t)h->max_rows * h->max_pitch;
   const size_t bytes = sizeof(float) * ((size_t)h->max_batch * 2 * 4 * plane + 64);
   PM_HIP(h, hipMalloc(&h->planes_state, bytes));

@@ -234,7 +234,7 @@ def test_stages_on_injected_adversarial_planes(pm, oracle, synth):
 
 @gpu
 @pytest.mark.parametrize("f16", [0, 1])
-@pytest.mark.parametrize("patch,max_disp", [(11, 64), (7, 32), (5, 128), (3, 16), (15, 40)])
+@pytest.mark.parametrize("patch,max_disp", [(11, 64), (7, 32), (5, 128), (3, 16), (15, 40), (11, 300)])  # 300: > 64 KB of LDS
 def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp):
     p = synth.make_pair(20 + patch, ROWS, COLS)
     prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp)
@@ -320,7 +320,7 @@ def test_golden_planes_fixture_on_device(pm):
 @gpu
 def test_parameter_errors(pm):
     for kw in (dict(patch=4), dict(plane_slope_max=0.0), dict(state_dtype=2), dict(max_disp=0), dict(mode=2),
-               dict(plane_refine_steps=-1)):
+               dict(plane_refine_steps=-1), dict(patch=15, max_disp=1024)):  # the last one: the tile exceeds the LDS
         with pytest.raises(pm.PmError) as ei:
             pm.Engine(pparams(pm, **kw), max_rows=64, max_cols=64)
         assert ei.value.status == pm.PM_ERR_INVALID_ARG
