@@ -343,7 +343,7 @@ int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
   PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
   PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
   PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
-  PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * 4));
+  PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * kSeedCounters));
   PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
   PM_HIP(h, hipMalloc((void**)&sc.kp_d, sizeof(float) * kSeedMaxFeatures));
   sc.sort_tmp = nullptr;

@@ -44,7 +44,8 @@ struct SeedScratch {
   float* eig;                // [rows][pitch]
   unsigned long long* keys;  // [cap] candidates, then sorted
   unsigned long long* keys_sorted;
-  unsigned* counters;        // [0] = max response bits, [1] = candidate count, [2] = accepted count
+  unsigned* counters;        // [kSeedCounters]: [0] = max response bits, [1] = candidate count, [2] = accepted
+                             // count, [3] = grid overflow flag
   int* kp_xy;                // [kSeedMaxFeatures][2]
   float* kp_d;               // [kSeedMaxFeatures] matched disparity of a corner, < 0 = no match
   void* sort_tmp;
@@ -111,6 +112,22 @@ __global__ void __launch_bounds__(256) k_seed_eig(const short* __restrict__ dx, 
     if (m > __builtin_bit_cast(float, *(volatile unsigned*)&counters[0]))
       atomicMax(&counters[0], __builtin_bit_cast(unsigned, m));
   }
+}
+
+// ---- constants shared by k_seed_nms and k_seed_select_fused (see the latter)
+constexpr int kSelChunk = 2048;
+constexpr int kSelBins = 2048, kSelDigit = 11, kSelUnroll = 16;
+constexpr int kSelHist = kSelBins + kSelBins / 32;  // bin b lives at b + (b >> 5): 32-bin runs fall on distinct banks
+constexpr int kSeedCounters = 8;                     // SeedScratch::counters
+__host__ __device__ inline size_t seed_select_lds_bytes(int gx, int gy) {
+  return sizeof(unsigned long long) * 2 * kSelChunk + sizeof(unsigned) * (kSelHist + 8) +
+         sizeof(int) * 4 * (size_t)(gx + 2) * (gy + 2);
+}
+// shift of the first digit: the kSelDigit bits ending at the highest bit in which max and threshold differ
+__device__ inline int seed_first_shift(unsigned maxbits, unsigned thrbits) {
+  const unsigned diff = maxbits ^ thrbits;
+  const int ptop = diff != 0u ? 31 - __clz((int)diff) : 0;
+  return max(32 + ptop - (kSelDigit - 1), 0);
 }
 
 // A block covers 256 columns x kNmsRows rows, collects its candidates in LDS and appends them with ONE
@@ -260,6 +277,266 @@ __global__ void __launch_bounds__(64) k_seed_select_grid(const unsigned long lon
   if (lane == 0) counters[2] = (unsigned)count;
 }
 
+// Sort + selection in ONE workgroup, without sorting what the greedy loop never looks at.  The loop stops after
+// max_features corners (200), which it finds among the strongest few hundred candidates of tens of thousands;
+// sorting all `cap` slots (hipcub radix sort, ~100 us at 720p) was the seeder's largest item.  Here the candidates
+// are consumed in CHUNKS of at most kSelChunk keys in descending order:
+//   1. a radix descent (11-bit digits) finds a threshold tau such that between want / 2 and want of the keys not
+//      yet consumed are >= tau (keys are unique: value bits | y << 16 | x; want ~ 4 max_features), histograms in
+//      LDS (counting the first digit in k_seed_nms with global atomics instead cost that kernel 40 us);
+//   2. those keys are gathered into LDS and sorted: counting sort on the 11 bits below the highest bit in which
+//      the chunk's bounds differ (descending bin offsets), then every key is ranked inside its
+//      bin (bins hold a handful of keys);
+//   3. wavefront 0 runs the batch-greedy loop of k_seed_select_grid over the sorted chunk (grid of accepted
+//      corners in LDS, kept across chunks) -- the accept loop works on registers only, the accepted lanes then write
+//      their corners and grid entries in parallel;
+// until max_features corners are accepted or no candidate is left.  The chunks partition the keys by value and are
+// visited from the top, so the sequence of candidates the greedy loop sees is exactly the fully sorted order.
+// All candidate values lie in (thr, max]: the first digit starts at the highest bit in which the two differ.
+// grid = 1 workgroup of 1024; dynamic LDS = seed_select_lds_bytes(gx, gy).
+// Descending exclusive offsets of a histogram, by one wavefront: on return hist[b] = number of keys in bins > b.
+// Optionally finds the bin in which the running count from the top reaches `want` (-> *bin, *above).
+__device__ inline void seed_hist_scan_desc(unsigned* hist, int lane, bool write_offsets, unsigned want, unsigned* bin,
+                                           unsigned* above) {
+  const int btop = kSelBins - 1 - 32 * lane;  // lane l owns bins btop ... btop - 31 (descending)
+  unsigned mine = 0u;
+  for (int q = 0; q < 32; ++q) {
+    const int b = btop - q;
+    mine += hist[b + (b >> 5)];
+  }
+  unsigned incl = mine;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const unsigned o = __shfl_up(incl, ofs, 64);
+    if (lane >= ofs) incl += o;
+  }
+  if (bin) {
+    const unsigned long long cross = __ballot(incl >= want);
+    const int cl = cross != 0ull ? __ffsll((long long)cross) - 1 : 63;
+    if (lane == cl) {
+      unsigned acc = incl - mine;
+      int b = btop;
+      for (int q = 0; q < 32; ++q, --b) {
+        const unsigned hb = hist[b + (b >> 5)];
+        if (acc + hb >= want || q == 31) break;
+        acc += hb;
+      }
+      *bin = (unsigned)b;
+      *above = acc;
+    }
+  }
+  if (write_offsets) {
+    unsigned acc = incl - mine;
+    for (int q = 0; q < 32; ++q) {
+      const int b = btop - q;
+      const unsigned hb = hist[b + (b >> 5)];
+      hist[b + (b >> 5)] = acc;
+      acc += hb;
+    }
+  }
+}
+__global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long long* __restrict__ keys, int cap,
+                                                            int min_distance, int max_features, double quality,
+                                                            int gx, int gy, int* __restrict__ kp_xy,
+                                                            unsigned* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_sel[];
+  unsigned long long* s_keys = s_sel;                 // [kSelChunk] the chunk grouped by bin
+  unsigned long long* s_tmp = s_sel + kSelChunk;      // [kSelChunk] the chunk as gathered, then sorted
+  unsigned* s_hist = (unsigned*)(s_sel + 2 * kSelChunk);  // [kSelHist]
+  unsigned* s_misc = s_hist + kSelHist;               // 0 fill, 1 bin, 2 above, 3 count
+  int* s_cell = (int*)(s_misc + 8);                   // [gy + 2][gx + 2][4] packed x | y << 16, -1 = free
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int pgx = gx + 2;  // padded grid: one ring of cells that stay empty
+  for (int e = tid; e < pgx * (gy + 2) * 4; e += 1024) s_cell[e] = -1;
+  const int ncand = min((int)counters[1], cap);
+  const int md2 = min_distance * min_distance;
+  const float inv_md = 1.0f / (float)min_distance;
+  const unsigned maxbits = counters[0];
+  const unsigned thrbits = __builtin_bit_cast(unsigned, (float)((double)__builtin_bit_cast(float, maxbits) * quality));
+  const int sh_top = seed_first_shift(maxbits, thrbits);
+  const int want0 = min(kSelChunk, max(512, 4 * max_features));
+  int count = 0, remaining = ncand;
+  unsigned long long upper = ~0ull;  // keys >= upper are consumed
+  __syncthreads();
+  while (remaining > 0 && count < max_features) {
+    // ---- 1. threshold
+    unsigned long long tau = 0ull;
+    if (remaining > want0) {
+      unsigned long long prefix = ((unsigned long long)maxbits << 32) >> (sh_top + kSelDigit) << (sh_top + kSelDigit);
+      int want = want0, taken = 0;
+      int sh = sh_top, width = kSelDigit;
+      for (;;) {
+        {
+          for (int e = tid; e < kSelHist; e += 1024) s_hist[e] = 0u;
+          __syncthreads();
+          const unsigned dmask = (1u << width) - 1u;
+          const int shp = sh + width;  // <= 63
+          for (int i0 = tid; i0 < ncand; i0 += 1024 * kSelUnroll) {
+            unsigned long long kk[kSelUnroll];  // independent loads first: one memory latency per kSelUnroll keys
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) kk[u] = keys[min(i0 + 1024 * u, ncand - 1)];  // unconditional loads
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) kk[u] = i0 + 1024 * u < ncand ? kk[u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < kSelUnroll; ++u) {
+              const unsigned long long k = kk[u];
+              if (k < upper && (k >> shp) == (prefix >> shp)) {
+                const unsigned b = (unsigned)(k >> sh) & dmask;
+                atomicAdd(&s_hist[b + (b >> 5)], 1u);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (tid < 64) seed_hist_scan_desc(s_hist, lane, false, (unsigned)want, &s_misc[1], &s_misc[2]);
+        __syncthreads();
+        const unsigned b = s_misc[1], acc = s_misc[2];
+        __syncthreads();
+        if (sh == 0) {  // single keys: the crossing key is the want-th itself
+          tau = prefix | b;
+          break;
+        }
+        if (taken + (int)acc >= want0 / 2) {  // enough above the crossing bin: leave that bin to the next chunk
+          tau = prefix + ((unsigned long long)(b + 1u) << sh);
+          break;
+        }
+        prefix |= (unsigned long long)b << sh;
+        taken += (int)acc;
+        want -= (int)acc;
+        const int nsh = max(sh - kSelDigit, 0);
+        width = sh - nsh;
+        sh = nsh;
+      }
+    }
+    // ---- 2. gather [tau, upper) ...
+    if (tid == 0) s_misc[0] = 0u;
+    for (int e = tid; e < kSelHist; e += 1024) s_hist[e] = 0u;
+    __syncthreads();
+    for (int i0 = tid; i0 < ncand + tid; i0 += 1024 * kSelUnroll) {  // whole wavefronts iterate together (ballot)
+      unsigned long long kk[kSelUnroll];
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) kk[u] = keys[min(i0 + 1024 * u, ncand - 1)];  // unconditional loads
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) kk[u] = i0 + 1024 * u < ncand ? kk[u] : ~0ull;
+#pragma unroll
+      for (int u = 0; u < kSelUnroll; ++u) {
+        const unsigned long long k = kk[u];
+        const bool in = k >= tau && k < upper;  // the filler ~0 is never below `upper`
+        const unsigned long long m = __ballot(in);
+        if (m != 0ull) {
+          const int leader = __ffsll((long long)m) - 1;
+          unsigned base = 0u;
+          if (lane == leader) base = atomicAdd(&s_misc[0], (unsigned)__popcll(m));
+          base = (unsigned)__shfl((int)base, leader, 64);
+          if (in) {
+            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < (unsigned)kSelChunk) s_tmp[pos] = k;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int n = min((int)s_misc[0], kSelChunk);
+    if (n == 0) break;  // cannot happen (every threshold keeps at least one key); uniform
+    // ... and sort it: bins of the 11 bits below the highest bit in which the bounds of the chunk differ (every key
+    // lies in [max(tau, threshold), min(upper - 1, maximum)], so the bits above that one are common to all)
+    const unsigned long long klo = max(tau, (unsigned long long)thrbits << 32);
+    const unsigned long long khi = min(upper - 1ull, ((unsigned long long)maxbits << 32) | 0xffffffffull);
+    const unsigned long long kdiff = klo ^ khi;
+    const int csh = kdiff != 0ull ? max(63 - __clzll((long long)kdiff) - (kSelDigit - 1), 0) : 0;
+    unsigned long long mykey[2];
+    unsigned mybin[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 1024 * u;
+      mykey[u] = e < n ? s_tmp[e] : 0ull;
+      mybin[u] = (unsigned)(mykey[u] >> csh) & (unsigned)(kSelBins - 1);
+      if (e < n) atomicAdd(&s_hist[mybin[u] + (mybin[u] >> 5)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) seed_hist_scan_desc(s_hist, lane, true, 0u, nullptr, nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)  // slot inside the bin: any order; s_hist[b] ends as the END of bin b
+      if (tid + 1024 * u < n) s_keys[atomicAdd(&s_hist[mybin[u] + (mybin[u] >> 5)], 1u)] = mykey[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // rank inside the bin (the bins above it end where it starts)
+      const int e = tid + 1024 * u;
+      if (e < n) {
+        const unsigned long long k = s_keys[e];
+        const unsigned bn = (unsigned)(k >> csh) & (unsigned)(kSelBins - 1);
+        const unsigned end = s_hist[bn + (bn >> 5)];
+        const unsigned start = bn == (unsigned)(kSelBins - 1) ? 0u : s_hist[bn + 1 + ((bn + 1) >> 5)];
+        unsigned r = start;
+        for (unsigned q = start; q < end; ++q) r += s_keys[q] > k ? 1u : 0u;
+        mykey[u] = k;
+        mybin[u] = r;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (tid + 1024 * u < n) s_tmp[mybin[u]] = mykey[u];
+    __syncthreads();
+    // ---- 3. greedy selection over the sorted chunk (wavefront 0; see k_seed_select_grid).  The grid carries a
+    // border of cells that stay empty, so the 3x3 lookup needs no bounds tests: nine 16-byte reads, no branches.
+    if (tid < 64) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int base = 0; base < n && count < max_features; base += 64) {
+        const bool valid = base + lane < n;
+        const unsigned idx = valid ? (unsigned)(s_tmp[base + lane] & 0xffffffffull) : 0u;
+        const int y = (int)(idx >> 16), x = (int)(idx & 0xffffu);
+        const int cx = min((int)((float)x * inv_md), gx - 1), cy = min((int)((float)y * inv_md), gy - 1);
+        const int4* c3 = (const int4*)s_cell + (cy * pgx + cx);  // cell (cx - 1, cy - 1) of the padded grid
+        int4 cell[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cell[q] = c3[(q / 3) * pgx + (q % 3)];
+        bool bad = !valid;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int e4[4] = {cell[q].x, cell[q].y, cell[q].z, cell[q].w};
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) {
+            const int ddx = x - (e4[sl] & 0xffff), ddy = y - (e4[sl] >> 16);
+            bad = bad | ((e4[sl] >= 0) & (__mul24(ddx, ddx) + __mul24(ddy, ddy) < md2));
+          }
+        }
+        // the survivors in sorted order, each one knocking out the later lanes within min_distance: wavefront
+        // masks only (the lanes below the winner have already left `alive`, the winner is within distance 0)
+        unsigned long long alive = __ballot(!bad), accepted = 0ull;
+        int room = max_features - count;
+        while (alive != 0ull && room > 0) {
+          const int w = __ffsll((long long)alive) - 1;
+          const int wx = __builtin_amdgcn_readlane(x, w), wy = __builtin_amdgcn_readlane(y, w);
+          accepted |= 1ull << w;
+          --room;
+          const int ddx = x - wx, ddy = y - wy;
+          alive &= ~__ballot(__mul24(ddx, ddx) + __mul24(ddy, ddy) < md2);
+        }
+        if ((accepted >> lane) & 1ull) {
+          const int slot = count + __popcll(accepted & below);
+          kp_xy[2 * slot] = x;
+          kp_xy[2 * slot + 1] = y;
+          int* c = s_cell + ((cy + 1) * pgx + cx + 1) * 4;
+          int sl = 0;
+          while (sl < 4 && atomicCAS(&c[sl], -1, x | (y << 16)) != -1) ++sl;
+          if (sl == 4) counters[3] = 1u;
+        }
+        count += __popcll(accepted);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the grid entries are visible to the next batch
+      }
+      if (tid == 0) s_misc[3] = (unsigned)count;
+    }
+    __syncthreads();
+    count = (int)s_misc[3];
+    remaining -= n;
+    upper = tau;
+    __syncthreads();
+  }
+  if (tid == 0) counters[2] = (unsigned)count;
+}
+
 // One workgroup per accepted corner (StereoMatcher::MatchRectified).  Writes the corner's disparity (>= 0) or -1.
 __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                     int rows, int cols, int pitch, const int* __restrict__ kp_xy,
@@ -393,6 +670,15 @@ __global__ void __launch_bounds__(256) k_seed_resize_nearest(const float* __rest
   dst[(size_t)yo * dst_pitch + xo] = src[(size_t)sy * src_pitch + sx];
 }
 
+// PM_SEED_FUSED=0 keeps the radix sort + separate selection (A/B and the fallback's own test); read once.
+inline bool seed_fused_enabled() {
+  static const bool on = [] {
+    const char* v = getenv("PM_SEED_FUSED");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 // SparseInit / Initialize for one pair of pitched u8 planes: corners of `left` matched into `right`, dilated with
 // half-width k, written as an out_rows x out_cols map (row pitch out_pitch elements) scaled by inv_scale.
 //   PatchmatchGpu::SparseInit(iml, imr, f)   k = 2^f + 1,     out = image size, inv_scale = 1   (patchmatch_gpu.cu:436)
@@ -403,23 +689,33 @@ inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                            int out_pitch, hipStream_t stream) {
   const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
   hipError_t e;
-  if ((e = hipMemsetAsync(sc.counters, 0, 4 * sizeof(unsigned), stream)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(sc.counters, 0, kSeedCounters * sizeof(unsigned), stream)) != hipSuccess) return e;
+  const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
+  const int md = sp.min_distance;
+  const int gx = md >= 1 ? (cols + md - 1) / md : 0, gy = md >= 1 ? (rows + md - 1) / md : 0;
+  // x | y << 16 packing, and squared distances (any two candidates of a batch) that fit an int
+  const bool packed_ok = md >= 1 && cols <= 32768 && rows <= 32768;
+  const bool fused = packed_ok && seed_select_lds_bytes(gx, gy) <= 150 * 1024 && seed_fused_enabled();
+  // the sort treats 0 as "unused slot"; the fused selection only reads the first counters[1] keys
+  if (!fused && (e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_seed_sobel, grid, block, 0, stream, left, rows, cols, pitch, sc.dx, sc.dy);
   hipLaunchKernelGGL(k_seed_eig, grid, block, 0, stream, sc.dx, sc.dy, rows, cols, pitch, sp.block_size, sc.eig,
                      sc.counters);
   hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
                      rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);
-  size_t tmp_bytes = sc.sort_tmp_bytes;
-  if ((e = hipcub::DeviceRadixSort::SortKeysDescending(sc.sort_tmp, tmp_bytes, sc.keys, sc.keys_sorted, sc.cap, 0, 64,
-                                                       stream)) != hipSuccess)
-    return e;
-  const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
-  {
-    const int md = sp.min_distance;
-    const int gx = md >= 1 ? (cols + md - 1) / md : 0, gy = md >= 1 ? (rows + md - 1) / md : 0;
+  if (fused) {
+    const size_t lds = seed_select_lds_bytes(gx, gy);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_seed_select_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_seed_select_fused, dim3(1), dim3(1024), lds, stream, (const unsigned long long*)sc.keys,
+                       sc.cap, md, maxf, sp.quality_level, gx, gy, sc.kp_xy, sc.counters);
+  } else {
+    size_t tmp_bytes = sc.sort_tmp_bytes;
+    if ((e = hipcub::DeviceRadixSort::SortKeysDescending(sc.sort_tmp, tmp_bytes, sc.keys, sc.keys_sorted, sc.cap, 0, 64,
+                                                         stream)) != hipSuccess)
+      return e;
     const size_t grid_bytes = (size_t)gx * gy * 4 * sizeof(int);
-    if (md >= 1 && cols < 65536 && rows < 32768 && grid_bytes <= 150 * 1024) {  // x | y << 16 packing, LDS capacity
+    if (packed_ok && grid_bytes <= 150 * 1024) {  // LDS capacity
       if (grid_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_seed_select_grid, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)grid_bytes);

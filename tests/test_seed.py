@@ -172,3 +172,44 @@ def test_full_size_seeding(pm, oracle, synth):
     with pm.Engine(pm.default_params(1), max_rows=rows, max_cols=cols) as e:
         got = e.sparse_init(p["left"], p["right"], 4)
     assert_same(got, oracle.sparse_init(p["left"], p["right"], 4), "1280x720 SparseInit")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_features,min_distance", [(1000, 3), (1024, 1), (300, 40)])
+def test_selection_across_many_chunks(pm, oracle, max_features, min_distance):
+    """The fused sort + selection consumes the candidates in chunks of 2048: white noise gives tens of thousands of
+    candidates, many of them with equal responses, and small min_distance / many features walks several chunks."""
+    rows, cols = 480, 752
+    rng = np.random.default_rng(99)
+    left = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    left[100:200, 300:500] //= 8          # a weak region: candidates spread over several octaves
+    right = np.roll(left, -9, axis=1)
+    prm = pm.default_params(1, max_features_per_frame=max_features, min_distance_btw_features=min_distance)
+    sp = oracle.seed_params(max_features=max_features, min_distance=min_distance)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(left, right, 2)
+    assert_same(got, oracle.sparse_init(left, right, 2, sp), "noise image SparseInit")
+    assert (got > 0).any()
+
+
+@pytest.mark.gpu
+def test_sorted_fallback_selection(pm, oracle, synth):
+    """PM_SEED_FUSED=0 (read once per process: run in a child) keeps the full radix sort; same seeds."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import oracle_lib as oracle, synth, pm_ctypes as pm
+        oracle.load(); pm.load()
+        p = synth.make_pair(0, 720, 1280)
+        with pm.Engine(pm.default_params(1), max_rows=720, max_cols=1280) as e:
+            got = e.sparse_init(p["left"], p["right"], 4)
+        assert np.array_equal(got, oracle.sparse_init(p["left"], p["right"], 4))
+        print("ok")
+    """)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PM_SEED_FUSED="0")
+    pydir = os.path.join(os.path.dirname(here), "ocean-perception_amd", "python")
+    r = subprocess.run([sys.executable, "-c", code % (here, pydir)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
