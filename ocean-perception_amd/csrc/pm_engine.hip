@@ -338,8 +338,6 @@ SeedParams seed_params(const pm_params& p) {
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
   const size_t plane = (size_t)h->max_rows * h->max_pitch;
   sc.cap = (int)(plane / 4 + 64);
-  PM_HIP(h, hipMalloc((void**)&sc.dx, sizeof(short) * plane));
-  PM_HIP(h, hipMalloc((void**)&sc.dy, sizeof(short) * plane));
   PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
   PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
   PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
@@ -355,7 +353,7 @@ int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
 }
 
 int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0) {
-  if (scratch == 1 && !h->seed2.dx)
+  if (scratch == 1 && !h->seed2.eig)
     if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
   SeedScratch& sc = scratch == 1 ? h->seed2 : h->seed;
   const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
@@ -973,9 +971,8 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.stop);
   }
   void* dev[] = {h->rp8, h->rpg, h->rppk, h->cp8, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
-                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.dx, h->seed.dy, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
-                 h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.dx, h->seed2.dy,
-                 h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
+                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
+                 h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
                  h->seed2.sort_tmp, h->snap_disp,
                  h->snap_cost, h->planes_state};
   for (void* p : dev)
@@ -1130,7 +1127,7 @@ int pm_capture_begin(pm_handle* h) {
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   // lazily created resources must exist before the capture starts (creating them is not capturable)
-  if (h->params.sparse_init && !h->seed2.dx)
+  if (h->params.sparse_init && !h->seed2.eig)
     if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
   PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   h->capturing = true;

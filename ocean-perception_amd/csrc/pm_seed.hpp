@@ -39,8 +39,6 @@ constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list
 
 // Scratch owned by the handle (sized for max_rows x max_cols).
 struct SeedScratch {
-  short* dx;                 // [rows][pitch]
-  short* dy;
   float* eig;                // [rows][pitch]
   unsigned long long* keys;  // [cap] candidates, then sorted
   unsigned long long* keys_sorted;
@@ -53,20 +51,6 @@ struct SeedScratch {
   int cap;
 };
 
-__global__ void __launch_bounds__(256) k_seed_sobel(const uint8_t* __restrict__ im, int rows, int cols, int pitch,
-                                                    short* __restrict__ dx, short* __restrict__ dy) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= cols) return;
-  const uint8_t* r0 = im + (size_t)reflect101(y - 1, rows) * pitch;
-  const uint8_t* r1 = im + (size_t)y * pitch;
-  const uint8_t* r2 = im + (size_t)reflect101(y + 1, rows) * pitch;
-  const int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
-  dx[(size_t)y * pitch + x] =
-      (short)(((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]));
-  dy[(size_t)y * pitch + x] =
-      (short)(((int)r2[xm] - (int)r0[xm]) + 2 * ((int)r2[x] - (int)r0[x]) + ((int)r2[xp] - (int)r0[xp]));
-}
-
 // General reflect-101 (the box window may reach further out than one pixel).
 __device__ __forceinline__ int reflect101n(int p, int len) {
   if (len == 1) return 0;
@@ -74,35 +58,102 @@ __device__ __forceinline__ int reflect101n(int p, int len) {
   return p;
 }
 
-__global__ void __launch_bounds__(256) k_seed_eig(const short* __restrict__ dx, const short* __restrict__ dy, int rows,
-                                                  int cols, int pitch, int block, float* __restrict__ eig,
-                                                  unsigned* __restrict__ counters) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  float e = 0.f;
-  if (x < cols) {
-    const int h = block / 2;
-    long long sxx = 0, sxy = 0, syy = 0;
-    for (int j = -h; j <= h; ++j) {
-      const size_t ro = (size_t)reflect101n(y + j, rows) * pitch;
-      for (int i = -h; i <= h; ++i) {
-        const size_t o = ro + reflect101n(x + i, cols);
-        const int gx = dx[o], gy = dy[o];
+// cv::cornerMinEigenVal (OpenCV 3.4 imgproc/corner.cpp) in one kernel: 3x3 Sobel derivatives (scale 1, image
+// border reflect-101), the block x block box sums of dx^2, dx dy, dy^2 (border reflect-101 ON THE DERIVATIVE
+// PLANES: outside sample p = D(reflect(p))), and the smaller eigenvalue.  A workgroup produces a 64 x 32 tile:
+// the derivatives of the tile plus its halo are computed once into LDS (dx | dy << 16 per pixel), each thread then
+// sums its windows from LDS.  All sums are exact integers (|d| <= 1020, block <= 15: < 2^28).  Also folds the
+// block maximum of the positive responses into counters[0] with ONE atomic per block, and only if it can raise
+// the maximum (14 400 per-wave atomics on one address serialised: 172 us for a 720p image).
+// This replaced a Sobel kernel + a 25-tap gather from global memory (6 + 40 us at 720p).
+// BLOCK = 3, 5, 7: compile-time window, every thread owns 8 consecutive rows of its column and forms the
+// horizontal sums of the 8 + BLOCK - 1 rows it touches once (7.5 taps per output instead of 25 for BLOCK = 5);
+// BLOCK = 0: any odd `block` <= 15, plain double loop.
+constexpr int kEigTileW = 64, kEigTileH = 32, kEigRowsPerThread = kEigTileH / 4;
+template <int BLOCK>
+__global__ void __launch_bounds__(256) k_seed_response(const uint8_t* __restrict__ im, int rows, int cols, int pitch,
+                                                       int block_rt, float* __restrict__ eig,
+                                                       unsigned* __restrict__ counters) {
+  extern __shared__ unsigned s_d[];  // [kEigTileH + 2h][kEigTileW + 2h]
+  const int block = BLOCK ? BLOCK : block_rt;
+  const int h = block / 2;
+  const int W = kEigTileW + 2 * h, H = kEigTileH + 2 * h;
+  const int x0 = blockIdx.x * kEigTileW, y0 = blockIdx.y * kEigTileH;
+  for (int e = threadIdx.x; e < W * H; e += 256) {
+    const int py = e / W, px = e - py * W;
+    const int X = reflect101n(x0 - h + px, cols), Y = reflect101n(y0 - h + py, rows);
+    const uint8_t* r0 = im + (size_t)reflect101(Y - 1, rows) * pitch;
+    const uint8_t* r1 = im + (size_t)Y * pitch;
+    const uint8_t* r2 = im + (size_t)reflect101(Y + 1, rows) * pitch;
+    const int xm = reflect101(X - 1, cols), xp = reflect101(X + 1, cols);
+    const int a = r0[xm], b = r0[X], c = r0[xp], d = r1[xm], f = r1[xp], g = r2[xm], hh = r2[X], k = r2[xp];
+    const int gx = (c - a) + 2 * (f - d) + (k - g);
+    const int gy = (g - a) + 2 * (hh - b) + (k - c);
+    s_d[e] = (unsigned)(gx & 0xffff) | ((unsigned)gy << 16);
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int x = x0 + tx;
+  float m = 0.f;
+  auto finish = [&](int y, int sxx, int sxy, int syy) {
+    if (x < cols && y < rows) {
+      const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+      const float t = a - c;
+      const float tt = t * t, bb = b * b;
+      const float s = a + c;
+      const float e = s - sqrtf(tt + bb);
+      eig[(size_t)y * pitch + x] = e;
+      m = fmaxf(m, e);  // m starts at 0: only positive responses count
+    }
+  };
+  if constexpr (BLOCK != 0) {
+    constexpr int NR = kEigRowsPerThread + BLOCK - 1;
+    int hxx[NR], hxy[NR], hyy[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const unsigned* row = s_d + (ty * kEigRowsPerThread + j) * W + tx;
+      int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+      for (int i = 0; i < BLOCK; ++i) {
+        const unsigned v = row[i];
+        const int gx = (int)(short)(v & 0xffffu), gy = (int)v >> 16;
         sxx += gx * gx;
         sxy += gx * gy;
         syy += gy * gy;
       }
+      hxx[j] = sxx;
+      hxy[j] = sxy;
+      hyy[j] = syy;
     }
-    const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-    const float t = a - c;
-    const float tt = t * t, bb = b * b;
-    const float s = a + c;
-    e = s - sqrtf(tt + bb);
-    eig[(size_t)y * pitch + x] = e;
+#pragma unroll
+    for (int r = 0; r < kEigRowsPerThread; ++r) {
+      int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+      for (int j = 0; j < BLOCK; ++j) {
+        sxx += hxx[r + j];
+        sxy += hxy[r + j];
+        syy += hyy[r + j];
+      }
+      finish(y0 + ty * kEigRowsPerThread + r, sxx, sxy, syy);
+    }
+  } else {
+    for (int r = 0; r < kEigRowsPerThread; ++r) {
+      const int yy = ty * kEigRowsPerThread + r;
+      int sxx = 0, sxy = 0, syy = 0;
+      for (int j = 0; j < block; ++j) {
+        const unsigned* row = s_d + (yy + j) * W + tx;
+        for (int i = 0; i < block; ++i) {
+          const unsigned v = row[i];
+          const int gx = (int)(short)(v & 0xffffu), gy = (int)v >> 16;
+          sxx += gx * gx;
+          sxy += gx * gy;
+          syy += gy * gy;
+        }
+      }
+      finish(y0 + yy, sxx, sxy, syy);
+    }
   }
-  // block maximum of the positive responses; ONE atomic per block and only if it can raise the maximum
-  // (14 400 per-wave atomics on one address serialised: 172 us for a 720p image)
   __shared__ float s_m[4];
-  float m = e > 0.f ? e : 0.f;
 #pragma unroll
   for (int ofs = 32; ofs > 0; ofs >>= 1) m = fmaxf(m, __shfl_xor(m, ofs, 64));
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
@@ -698,9 +749,16 @@ inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   const bool fused = packed_ok && seed_select_lds_bytes(gx, gy) <= 150 * 1024 && seed_fused_enabled();
   // the sort treats 0 as "unused slot"; the fused selection only reads the first counters[1] keys
   if (!fused && (e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_seed_sobel, grid, block, 0, stream, left, rows, cols, pitch, sc.dx, sc.dy);
-  hipLaunchKernelGGL(k_seed_eig, grid, block, 0, stream, sc.dx, sc.dy, rows, cols, pitch, sp.block_size, sc.eig,
-                     sc.counters);
+  {
+    const int hb = sp.block_size / 2;
+    const size_t lds = sizeof(unsigned) * (size_t)(kEigTileW + 2 * hb) * (kEigTileH + 2 * hb);
+    const dim3 tiles((unsigned)((cols + kEigTileW - 1) / kEigTileW), (unsigned)((rows + kEigTileH - 1) / kEigTileH));
+    auto kern = sp.block_size == 3   ? k_seed_response<3>
+                : sp.block_size == 5 ? k_seed_response<5>
+                : sp.block_size == 7 ? k_seed_response<7>
+                                     : k_seed_response<0>;
+    hipLaunchKernelGGL(kern, tiles, block, lds, stream, left, rows, cols, pitch, sp.block_size, sc.eig, sc.counters);
+  }
   hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
                      rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);
   if (fused) {

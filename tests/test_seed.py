@@ -213,3 +213,18 @@ def test_sorted_fallback_selection(pm, oracle, synth):
     r = subprocess.run([sys.executable, "-c", code % (here, pydir)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", [3, 7, 9])
+def test_response_window_sizes(pm, oracle, synth, block):
+    """cornerMinEigenVal's box window: 3, 5, 7 are compiled-in (sliding row sums), the rest take the generic loop;
+    133 x 259 leaves partial tiles on both axes and reflects the window at every border."""
+    rows, cols = 133, 259
+    p = synth.make_pair(3, rows=rows, cols=cols)
+    prm = pm.default_params(1, gftt_block_size=block)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(p["left"], p["right"], 4)
+    assert_same(got, oracle.sparse_init(p["left"], p["right"], 4, oracle.seed_params(block_size=block)),
+                f"SparseInit block {block}")
+    assert (got > 0).any()
