@@ -39,6 +39,9 @@ struct RunStep2 {
 #ifdef PM_RUN2_TIMING
   long long t[5];  // s_memtime at: entry, after the need ballot, after the line sums, after the cost, at return
 #endif
+#ifdef PM_RUN2_STATS
+  bool evald, g_need;
+#endif
 };
 #ifdef PM_RUN2_TIMING
 #define PM_T(k) st.t[k] = clock64()
@@ -187,6 +190,10 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   const int delta_r = (px0 - half_w) - (int)fl0;
   const bool same = valid && (a == a_r) && (delta == delta_r);
 
+#ifdef PM_RUN2_STATS
+  st.evald = __any(valid_r);
+  st.g_need = valid_r;
+#endif
   st.cost = 0.f;
   if (__any(valid_r)) {  // at least one group evaluates; the other computes along and ignores the result
     const float ia_r = 1.f - a_r;
@@ -503,6 +510,9 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   const int i1 = min(n, i0 + seg_len);
   const bool active = i0 < n;
   unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
+#ifdef PM_RUN2_STATS
+  unsigned n_eval = 0, n_gsteps = 0, n_geval = 0, adv_sum = 0;
+#endif
 #ifdef PM_RUN2_TIMING
   long long tph[5] = {0, 0, 0, 0, 0}, t_prev_end = 0;
 #endif
@@ -516,6 +526,14 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       const bool act = active && i < i1;
       const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
+#ifdef PM_RUN2_STATS
+      if constexpr (SEM == 0) {
+        n_eval += st.evald;
+        n_gsteps += act;
+        n_geval += act && st.g_need;
+        adv_sum += st.advance;
+      }
+#endif
 #ifdef PM_RUN2_TIMING
       if constexpr (SEM == 0) {
         for (int k = 0; k < 4; ++k) tph[k] += st.t[k + 1] - st.t[k];
@@ -593,6 +611,20 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     atomicAdd(&ps.counters[13], (unsigned long long)n_steps);
   }
 #endif
+#ifdef PM_RUN2_STATS
+  if (ps.counters) {
+    if (lane == 0) {
+      atomicAdd(&ps.counters[0], (unsigned long long)n_steps);
+      atomicAdd(&ps.counters[1], (unsigned long long)n_fix);
+      atomicAdd(&ps.counters[2], (unsigned long long)n_eval);
+    }
+    if (gl == 0) {
+      atomicAdd(&ps.counters[3], (unsigned long long)n_gsteps);
+      atomicAdd(&ps.counters[4], (unsigned long long)n_geval);
+      atomicAdd(&ps.counters[5], (unsigned long long)adv_sum);
+    }
+  }
+#else
   if (ps.counters && lane == 0) {
     const int base = AXIS * 4;
     atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);
@@ -600,6 +632,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
     if (w == 0) atomicAdd(&ps.counters[base + 2], (unsigned long long)n_rounds);
     if (w == 0) atomicAdd(&ps.counters[base + 3], (unsigned long long)n);
   }
+#endif
 
   for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) {
     const float d = dout[k];

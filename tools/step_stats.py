@@ -1,0 +1,25 @@
+"""Run-step statistics of the sweep engine (needs a build with -DPM_RUN2_STATS, loaded through PM_LIB).
+
+    PM_LIB=ocean-perception_amd/lib/ab_stats.so python tools/step_stats.py
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import pm_ctypes as pm
+import synth
+
+pm.load()
+rows, cols = 720, 1280
+p = synth.make_pair(0, rows, cols)
+for iters in (1, 2, 4, 8):
+    prm = pm.default_params(0, patchmatch_iters=iters)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        e.debug_counters_enable(True)
+        e.match(p["left"], p["right"], p["seed_l"], p["seed_r"])
+        d = e.debug_counters()
+        c = list(d["row"].values()) + list(d["col"].values())
+    ws, fix, wev, gs, gev, adv = c[:6]
+    print(f"iters {iters}: wave-steps {ws} (+{fix} fix-up), evaluating {wev} ({100*wev/max(ws,1):.1f} %); "
+          f"group-steps {gs}, evaluating {gev} ({100*gev/max(gs,1):.1f} %); positions/group-step {adv/max(gs,1):.2f}")
