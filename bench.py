@@ -79,6 +79,11 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="skip the plane-mode side legs of the default run")
     ap.add_argument("--tiled", action="store_true",
                     help="BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks (see python/tiled.py)")
+    ap.add_argument("--tiled-timeout", type=int, default=150,
+                    help="deadline (s) of the crash-isolated configs[3] leg of a multi-rank run")
+    ap.add_argument("--rehearse-tiled-leg", action="store_true",
+                    help="with --dry-run: start the tiled children anyway (without a GPU they fail) -- tests that a "
+                         "failing leg ends up as an error entry and the line is still printed")
     return ap.parse_args()
 
 
@@ -406,12 +411,53 @@ def run_tiled(args, d):
     tiled.bench(args, d)
 
 
+def tiled_children(args):
+    """The configs[3] leg of a multi-rank run, crash-isolated: every rank starts `python/tiled.py` as a CHILD process
+    (its own rendezvous on another port, same RANK / LOCAL_RANK) BEFORE this process touches the GPU or joins its
+    process group, waits for it with a deadline, and rank 0 keeps the child's JSON line.  The RCCL neighbour exchange
+    of that leg cannot be exercised on a one-GPU box; whatever it does on an 8-GPU node -- exception, hang, abort --
+    ends in an {"error": ...} entry here and never costs the headline."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 4099) % 60000 + 1024)
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+        env.pop(k, None)  # the child rendezvous is a plain env:// TCP store of its own
+    cmd = [sys.executable, os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py"), "--rows", "2160", "--cols",
+           "4096", "--iters", str(args.iters), "--patch", str(args.patch), "--steps", "2", "--backend", args.backend]
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return {"error": "could not start the tiled leg: %r" % (e,)}
+    try:
+        out, err = p.communicate(timeout=args.tiled_timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return {"error": "tiled leg did not finish within %d s (killed)" % args.tiled_timeout}
+    if rank != 0:
+        return None
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": err[-400:]}
+
+
 def main():
     args = parse()
+    planes = args.mode == "planes"
+    tiled_result = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and not planes and not args.no_side_legs and not args.tiled
+            and max(1, args.pairs_per_gpu) == 1 and (not args.dry_run or args.rehearse_tiled_leg)):
+        import torch  # noqa: F401 -- pages the libraries in before the children import them
+        tiled_result = tiled_children(args)
     d = Dist(args)
     steps, warmup = args.steps, args.warmup
     nb = max(1, args.pairs_per_gpu)
-    planes = args.mode == "planes"
     sem_name = "PM_SEM_CPU" if args.semantics == 0 else "PM_SEM_GPU (5-tap)"
     if planes:
         what = (f"PM_MODE_PLANES (random plane init, red-black / view propagation, refinement), {args.state} state"
@@ -439,6 +485,8 @@ def main():
         d.barrier()
         if d.rank == 0:
             result.update(value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, dry_run=True)
+            if tiled_result is not None:
+                result["tiled_4096x2160"] = tiled_result
             print(json.dumps(result), flush=True)
         d.close()
         return
@@ -494,35 +542,17 @@ def main():
     eng.close()
     del w
     if not planes and not args.no_side_legs and nb == 1:
-        # BASELINE configs[3] beside the headline: one 4096x2160 pair row-tiled over the ranks of this run (every rank
-        # takes part; with one rank it is the untiled large image).  Never `value`.
-        # The multi-rank exchange (RCCL send/recv on the engine's stream) cannot be exercised on a one-GPU box, so this
-        # leg must never cost the headline: a watchdog on every rank prints the line without it and leaves if the leg
-        # has not finished in time, and an exception in it is reported inside the line.
-        import threading
-        import tiled
-
-        def bail(reason):
-            if d.rank == 0:
-                result["tiled_4096x2160"] = {"error": reason}
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-
-        watchdog = None
-        if d.world > 1:
-            watchdog = threading.Timer(180.0, bail, args=("tiled leg did not finish within 180 s (watchdog)",))
-            watchdog.daemon = True
-            watchdog.start()
-        try:
-            tl = tiled.bench(args, d, steps=2, quiet=True)
-        except Exception as e:  # noqa: BLE001 -- report, never lose the headline
-            if d.world > 1:
-                bail("tiled leg failed: %r" % (e,))  # the other ranks leave through their watchdogs
-            tl = {"error": repr(e)}
-        if watchdog is not None:
-            watchdog.cancel()
-        if d.rank == 0:
-            result["tiled_4096x2160"] = tl
+        # BASELINE configs[3] beside the headline, never `value`: one 4096x2160 pair row-tiled over the ranks of this
+        # run.  One rank: the untiled large image, in this process.  Several ranks: measured by tiled_children()
+        # before this process touched the GPU.
+        if d.world == 1:
+            import tiled
+            try:
+                tiled_result = tiled.bench(args, d, steps=2, quiet=True)
+            except Exception as e:  # noqa: BLE001 -- report, never lose the headline
+                tiled_result = {"error": repr(e)}
+        if d.rank == 0 and tiled_result is not None:
+            result["tiled_4096x2160"] = tiled_result
     if d.rank == 0:
         if d.world == 1 and not planes and not args.no_side_legs and nb == 1:
             result["planes"] = {"f32": side_leg(args, pm, torch, np, synth, dev, d, "f32", False),

@@ -59,6 +59,8 @@ class DistComm:
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.exchanges = 0
+        self.timed = False   # bench: bracket every exchange with events on the current (= the engine's) stream
+        self._events = []
 
     def shift(self, row, down):
         """Send `row` to the next rank in sweep direction, return the row of the previous one (or None)."""
@@ -72,10 +74,24 @@ class DistComm:
             recv = torch.empty_like(row)
             ops.append(dist.P2POp(dist.irecv, recv, src))
         if ops:
+            ev = None
+            if self.timed and row.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(torch.cuda.current_stream())
             for req in dist.batch_isend_irecv(ops):
                 req.wait()  # NCCL backend: makes the current stream wait for the transfer, the host does not block
+            if ev is not None:
+                ev[1].record(torch.cuda.current_stream())
+                self._events.append(ev)
             self.exchanges += 1
         return recv
+
+    def exchange_ms(self):
+        """Stream time between the start and the end of every timed exchange since the last call (the transfer
+        itself plus waiting for the neighbour to reach its side of it).  Call after synchronising the stream."""
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        self._events = []
+        return ms
 
     def any(self, flag_tensor):
         """Logical OR of a one-element device flag over the ranks -> python bool (the one host read per Match)."""
@@ -260,8 +276,10 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
     sl = slice(band_row0, band_row0 + band_rows)
     t = lambda k, dt: torch.from_numpy(np.ascontiguousarray(pair[k][sl])).to(dev, dt).contiguous()
     L, R, SL, SR = t("left", torch.uint8), t("right", torch.uint8), t("seed_l", torch.float32), t("seed_r", torch.float32)
-    times, used, repeats = [], 0, 0
+    times, ex_ms, used, repeats = [], [], 0, 0
     with pm.Engine(params, device=local, max_rows=band_rows, max_cols=cols) as eng:
+        if isinstance(comm, DistComm):
+            comm.timed = True
         for step in range(steps + 1):
             d.barrier()
             torch.cuda.synchronize()
@@ -270,11 +288,14 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
                                                             band_row0)
             eng.synchronize()
             torch.cuda.synchronize()
+            ex = comm.exchange_ms() if isinstance(comm, DistComm) else 0.0
             if step > 0:
                 times.append(time.perf_counter() - t0)
+                ex_ms.append(ex)
                 repeats += 1 if repeated else 0
         exchanges = comm.exchanges / float(steps + 1 + repeats)
     ms = d.max_over_ranks(1e3 * float(np.median(times)))
+    ex_max = d.max_over_ranks(float(np.median(ex_ms)))
     res = None
     if rank == 0:
         gt = torch.from_numpy(pair["gt"][own_row0:own_row0 + own_rows]).to(dev)
@@ -284,6 +305,9 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
                "ms_per_frame": ms, "pairs_per_s": 1e3 / ms, "steps": steps,
                "exchange_rounds_per_vertical_sweep": 1 + used, "boundary_exchanges_per_match_and_rank": exchanges,
                "matches_repeated_with_more_rounds": repeats, "host_syncs_inside_a_match": 0,
+               # engine-stream time inside the neighbour exchanges of one Match (transfer + waiting for the neighbour),
+               # max over ranks; 0 with one rank
+               "exchange_ms_per_match": ex_max,
                "rank0_foreground_within_1px": float(((out_l - gt).abs()[fg] < 1).float().mean().item())}
         if not quiet:
             print(json.dumps(res), flush=True)

@@ -34,6 +34,23 @@ def test_bench_two_ranks_gloo_dry_run():
     assert abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5 / 1e3)) < 1e-6 * out["value"]
 
 
+def test_failing_tiled_leg_does_not_cost_the_line():
+    """A multi-rank default run measures configs[3] in child processes started before the ranks touch the GPU
+    (bench.tiled_children).  Here there is no GPU, so the children fail: the run must still exit 0 with ONE line
+    that carries the headline fields and an error entry for the leg."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+           "3", "--warmup", "1", "--backend", "gloo", "--dry-run", "--rehearse-tiled-leg", "--tiled-timeout", "120"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "error" in out["tiled_4096x2160"], out["tiled_4096x2160"]
+
+
 def test_shard_is_rank_local():
     sys.path.insert(0, ROOT)
     import bench
