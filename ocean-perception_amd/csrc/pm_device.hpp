@@ -186,6 +186,11 @@ __device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, con
 // Accumulate forms for the VALU-bound kernels: acc + |left - sample| as ONE v_sad_u8 each.
 // v_sad_u8 adds the absolute differences of all four bytes of its operands; `left` and the colour
 // sample are < 256, so only byte 0 contributes.
+// The colour lerp sum alone: r0 * a11 + r1 * a12 + 2^15 < 2^24, the sample is its byte 2.
+__device__ __forceinline__ unsigned cpu_color_sum(int r0, int r1, const CpuLerp& l) {
+  const unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
+  return __umul24((unsigned)r0, (unsigned)l.a11) + t;
+}
 __device__ __forceinline__ unsigned cpu_acc_color(unsigned acc, int left, int r0, int r1, const CpuLerp& l) {
   unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
   t = __umul24((unsigned)r0, (unsigned)l.a11) + t;

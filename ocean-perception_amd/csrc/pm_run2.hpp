@@ -219,7 +219,8 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         constexpr int NPR = (TPH + 1) / 2;
         const int y0 = chain - half_h;                                   // wave-uniform
         const unsigned eo = (unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch;
-        int lgv[2 * NPR];
+        unsigned ppv[NPR + 1];     // reference pairs
+        unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2 (< 2^24)
         float gv[2 * NPR + 1];
 #pragma unroll
         for (int m = 0; m < NPR; ++m) {
@@ -236,20 +237,51 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           const unsigned prn = (unsigned)wave_shl1((int)pr);
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
-          lgv[2 * m] = (int)((pp >> 8) & 0xffu);
-          lgv[2 * m + 1] = (int)(pp >> 24);
-          sc = cpu_acc_color(sc, (int)(pp & 0xffu), (int)(pr & 0xffu), (int)(prn & 0xffu), l);
-          if (2 * m + 1 < TPH)
-            sc = cpu_acc_color(sc, (int)((pp >> 16) & 0xffu), (int)((pr >> 8) & 0xffu), (int)((prn >> 8) & 0xffu), l);
+          ppv[m] = pp;
+          tcol[2 * m] = cpu_color_sum((int)(pr & 0xffu), (int)(prn & 0xffu), l);
+          tcol[2 * m + 1] = cpu_color_sum((int)((pr >> 8) & 0xffu), (int)((prn >> 8) & 0xffu), l);
         }
+        ppv[NPR] = 0u;
+        tcol[2 * NPR] = tcol[2 * NPR + 1] = 0u;
         gv[2 * NPR] = 0.f;
+        // gradient lerp sums, one per row (packed-f32 products, the neighbour's product arrives by DPP)
+        float sgr[2 * NPR];
         const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
 #pragma unroll
         for (int t = 0; t < TPH; t += 2) {
           const f32x2 gg = {gv[t], gv[t + 1]};
           const f32x2 pa = gg * ia2, pb = gg * a2;
-          sg = cpu_acc_grad_sum(sg, lgv[t], pa.x + wave_shl1f(pb.x));
-          if (t + 1 < TPH) sg = cpu_acc_grad_sum(sg, lgv[t + 1], pa.y + wave_shl1f(pb.y));
+          sgr[t] = pa.x + wave_shl1f(pb.x);
+          if (t + 1 < TPH) sgr[t + 1] = pa.y + wave_shl1f(pb.y);
+        }
+        // FOUR rows per v_sad_u8: the four colour samples (byte 2 of their sums) and the four saturated gradient
+        // samples (v_cvt_pk_u8_f32 drops each into its byte) are gathered into one dword each and meet the four
+        // reference bytes gathered from two reference pairs -- instead of a shift, a byte extract and a v_sad_u8
+        // per row and channel.  Rows the window does not have select the constant 0 on both sides.
+#pragma unroll
+        for (int q = 0; 4 * q < TPH; ++q) {
+          const int r0 = 4 * q;
+          const bool h1 = r0 + 1 < TPH, h2 = r0 + 2 < TPH, h3 = r0 + 3 < TPH;
+          // samples: bytes 0..3 = rows r0..r0+3
+          const unsigned u = __builtin_amdgcn_perm(tcol[r0 + 1], tcol[r0], h1 ? 0x0c0c0602u : 0x0c0c0c02u);
+          unsigned s4 = u;
+          if (h2) {
+            const unsigned w = __builtin_amdgcn_perm(tcol[r0 + 3], tcol[r0 + 2], h3 ? 0x0c0c0602u : 0x0c0c0c02u);
+            s4 = (w << 16) | u;
+          }
+          unsigned g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0], 0, 0u);
+          if (h1) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 1], 1, g4);
+          if (h2) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 2], 2, g4);
+          if (h3) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 3], 3, g4);
+          // references: pair 2q = rows r0, r0 + 1 (bytes c, g, c, g), pair 2q + 1 = rows r0 + 2, r0 + 3
+          const unsigned selc = (h3 ? 0x06000000u : 0x0c000000u) | (h2 ? 0x00040000u : 0x000c0000u) |
+                                (h1 ? 0x00000200u : 0x00000c00u) | 0x00u;
+          const unsigned selg = (h3 ? 0x07000000u : 0x0c000000u) | (h2 ? 0x00050000u : 0x000c0000u) |
+                                (h1 ? 0x00000300u : 0x00000c00u) | 0x01u;
+          const unsigned rc4 = __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selc);
+          const unsigned rg4 = __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selg);
+          sc = __builtin_amdgcn_sad_u8(rc4, s4, sc);
+          sg = __builtin_amdgcn_sad_u8(rg4, g4, sg);
         }
       } else if constexpr (TPH > 0 && PM_RUN2_PK_GRAD) {
         // gradient lerp g0 * (1 - a) + g1 * a with g1 = the neighbour lane's g0: both products of a lane's
