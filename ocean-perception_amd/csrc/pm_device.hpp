@@ -72,6 +72,8 @@ struct View {
   // element (window column t, image row Y) at lds_ref[t * lds_ref_pitch + Y]
   const uint16_t* lds_ref;
   int lds_ref_pitch;
+  // column sweeps: [image row][kLref4Stride] dwords, four window columns per dword (pm_run2.hpp)
+  const unsigned* lds_ref4;
   // pair planes of this view, alignment 0; alignment 1 follows at + rp_stride / cp_stride elements
   const uint16_t* rp8;
   const float* rpg;
@@ -112,6 +114,7 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
   w.lds_ref = nullptr;
   w.lds_ref_pitch = 0;
+  w.lds_ref4 = nullptr;
   w.rp_stride = (unsigned)ps.npr * (unsigned)ps.pitch;
   w.cp_stride = (unsigned)ps.npc * (unsigned)ps.pitch_t;
   const size_t pv = ((size_t)b * 2 + v) * 2;

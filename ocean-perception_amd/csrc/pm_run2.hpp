@@ -19,6 +19,7 @@
 namespace pm {
 
 constexpr int kGroup = 32;   // default group width; 16 (four segments per wavefront) is the other choice
+constexpr int kLref4Stride = 7;  // dwords per image row of the column sweeps' staged reference bytes (odd)
 
 // Occupancy experiment knob: -DPM_RUNBLK2_MIN_WAVES=8 caps the kernel at 64 VGPRs (8 waves per SIMD).
 #ifdef PM_RUNBLK2_MIN_WAVES
@@ -353,21 +354,40 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           gv[2 * m + 1] = pg.y;
         }
         gv[2 * NPC] = 0.f;
-        int lgv[TPW];
+        // reference bytes of the lane's row, four window columns per dword: colour dwords, then gradient dwords.
+        // LREF: staged in exactly that form (k_runblk2), six dwords per row; else gathered from TPW packed loads.
+        constexpr int NQ = (TPW + 3) / 4;
+        unsigned rc4[NQ], rg4[NQ];
+        if constexpr (LREF) {
+          const unsigned* rr = v.lds_ref4 + Y * kLref4Stride;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const int lso = lorg + t * pt;
-#if PM_RUN2_REF_PK16
-          const int pk = LREF ? (int)v.lds_ref[t * v.lds_ref_pitch + Y] : ld_u16(v.trefpk, (unsigned)((Y + lso) * 2));
-          const int l8 = pk & 0xff;
-          lgv[t] = pk >> 8;
-#else
-          const int l8 = win_ld8(cb.ref8, v.tref8, Y, lso);
-          lgv[t] = win_ld8(cb.refg8, v.trefg8, Y, lso);
-#endif
-          const int r0 = (int)((prv[t / 2] >> (8 * (t % 2))) & 0xffu);
-          const int r1 = (int)((prv[(t + 1) / 2] >> (8 * ((t + 1) % 2))) & 0xffu);
-          sc = cpu_acc_color(sc, l8, r0, r1, l);
+          for (int q = 0; q < NQ; ++q) {
+            rc4[q] = rr[q];
+            rg4[q] = rr[NQ + q];
+          }
+        } else {
+          unsigned pkv[4 * NQ];
+#pragma unroll
+          for (int t = 0; t < 4 * NQ; ++t)
+            pkv[t] = t < TPW ? (unsigned)ld_u16(v.trefpk, (unsigned)((Y + lorg + t * pt) * 2)) : 0u;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const unsigned lo = __builtin_amdgcn_perm(pkv[4 * q + 1], pkv[4 * q], 0x05010400u);      // c0 c1 g0 g1
+            const unsigned hi = __builtin_amdgcn_perm(pkv[4 * q + 3], pkv[4 * q + 2], 0x05010400u);  // c2 c3 g2 g3
+            rc4[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            rg4[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+          }
+        }
+        unsigned tcol[4 * NQ];
+#pragma unroll
+        for (int t = 0; t < 4 * NQ; ++t) {
+          if (t < TPW) {
+            const int r0 = (int)((prv[t / 2] >> (8 * (t % 2))) & 0xffu);
+            const int r1 = (int)((prv[(t + 1) / 2] >> (8 * ((t + 1) % 2))) & 0xffu);
+            tcol[t] = cpu_color_sum(r0, r1, l);
+          } else {
+            tcol[t] = 0u;
+          }
         }
         const f32x2 ia2 = {l.ia, l.ia}, a2 = {l.a, l.a};
         f32x2 pa[(TPW + 2) / 2], pb[(TPW + 2) / 2];
@@ -377,9 +397,26 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           pa[k] = gg * ia2;
           pb[k] = gg * a2;
         }
+        // four window columns per v_sad_u8 (see the row sweeps above)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          sg = cpu_acc_grad_sum(sg, lgv[t], pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2]);
+        for (int q = 0; q < NQ; ++q) {
+          const int t0 = 4 * q;
+          const bool h1 = t0 + 1 < TPW, h2 = t0 + 2 < TPW, h3 = t0 + 3 < TPW;
+          const unsigned u = __builtin_amdgcn_perm(tcol[t0 + 1], tcol[t0], h1 ? 0x0c0c0602u : 0x0c0c0c02u);
+          unsigned s4 = u;
+          if (h2) {
+            const unsigned w = __builtin_amdgcn_perm(tcol[t0 + 3], tcol[t0 + 2], h3 ? 0x0c0c0602u : 0x0c0c0c02u);
+            s4 = (w << 16) | u;
+          }
+          unsigned g4 = 0u;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k;
+            if (t < TPW) g4 = __builtin_amdgcn_cvt_pk_u8_f32(pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2], k, g4);
+          }
+          sc = __builtin_amdgcn_sad_u8(rc4[q], s4, sc);
+          sg = __builtin_amdgcn_sad_u8(rg4[q], g4, sg);
+        }
       } else if constexpr (TPW > 0 && PM_RUN2_PK_GRAD) {
         int r0 = win_ld8(cb.tgt8, v.ttgt8, vb, 0);
         // samples g[0 .. PW] of the lane's row; both products per sample with packed-f32 multiplies
@@ -500,17 +537,39 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
   View v = make_view(ps, blockIdx.z);
-  if constexpr (LREF) {
-    // behind the chain arrays and the flags: [win][len] u16 (len = rows for a column sweep on the transposed
-    // plane, cols for a row sweep), row pitch = len rounded up to even
-    const int len = AXIS == 1 ? ps.rows : ps.cols;
+  if constexpr (LREF && AXIS == 1) {
+    // behind the chain arrays and the flags: per image row (a position of the transposed chain) the TPW packed
+    // reference values of window columns chain - pw/2 .. + pw/2 as bytes, four columns per dword: NQ colour dwords,
+    // NQ gradient dwords, row stride kLref4Stride dwords (odd: lane = row reads without bank conflicts)
+    constexpr int NQ = (TPW + 3) / 4;
+    static_assert(2 * NQ <= kLref4Stride, "reference row does not fit its LDS stride");
+    const int len = ps.rows;
+    unsigned* sref4 = (unsigned*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1 + 2);
+    const uint16_t* src = v.trefpk + (size_t)(chain - TPW / 2) * ps.pitch_t;
+    for (int e = threadIdx.x; e < NQ * len; e += blockDim.x) {
+      const int q = e / len, row = e - q * len;
+      unsigned cw = 0u, gw = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = 4 * q + k;
+        if (t < TPW) {
+          const unsigned pk = src[(size_t)t * ps.pitch_t + row];
+          cw |= (pk & 0xffu) << (8 * k);
+          gw |= (pk >> 8) << (8 * k);
+        }
+      }
+      sref4[row * kLref4Stride + q] = cw;
+      sref4[row * kLref4Stride + NQ + q] = gw;
+    }
+    v.lds_ref4 = sref4;
+  } else if constexpr (LREF) {
+    // row sweeps (off by default): [win][cols] u16 behind the chain arrays, row pitch = cols rounded up to even
+    const int len = ps.cols;
     const int rp = (len + 1) & ~1;
     uint16_t* sref = (uint16_t*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1 + 2);
-    const uint16_t* src = AXIS == 1 ? v.trefpk + (size_t)(chain - TPW / 2) * ps.pitch_t
-                                    : v.refpk + (size_t)(chain - TPH / 2) * ps.pitch;
-    const int sp = AXIS == 1 ? ps.pitch_t : ps.pitch;
-    for (int t = 0; t < (AXIS == 1 ? TPW : TPH); ++t)
-      for (int e = threadIdx.x; e < rp; e += blockDim.x) sref[t * rp + e] = e < len ? src[(size_t)t * sp + e] : (uint16_t)0;
+    const uint16_t* src = v.refpk + (size_t)(chain - TPH / 2) * ps.pitch;
+    for (int t = 0; t < TPH; ++t)
+      for (int e = threadIdx.x; e < rp; e += blockDim.x) sref[t * rp + e] = e < len ? src[(size_t)t * ps.pitch + e] : (uint16_t)0;
     v.lds_ref = sref;
     v.lds_ref_pitch = rp;
   }
@@ -676,6 +735,13 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   }
 }
 
+// LDS bytes of the staged reference lines (LREF): column sweeps keep kLref4Stride dwords per image row, row sweeps
+// TPW lines of u16.
+template <int AXIS, int TPW>
+inline size_t run2_lref_bytes(const PlaneSet& ps) {
+  if (AXIS == 1) return sizeof(unsigned) * (size_t)kLref4Stride * ps.rows;
+  return sizeof(uint16_t) * (size_t)TPW * ((ps.cols + 1) & ~1);
+}
 template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR, bool LREF>
 inline void launch_run2_kdl(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                             hipStream_t stream) {
@@ -687,7 +753,7 @@ inline void launch_run2_kdl(const PlaneSet& ps, const CostParams& cp, const Swee
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
   size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
-  if (LREF) lds_bytes += sizeof(uint16_t) * (size_t)TPW * (((AXIS == 1 ? ps.rows : ps.cols) + 1) & ~1);
+  if (LREF) lds_bytes += run2_lref_bytes<AXIS, TPW>(ps);
   allow_big_lds(k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR, LREF>, lds_bytes);
   hipLaunchKernelGGL((k_runblk2<SEM, GS, AXIS, TPW, TPH, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
@@ -712,10 +778,10 @@ inline size_t run2_lref_limit() {
 template <int SEM, int GS, int AXIS, int TPW, int TPH, int DIR>
 inline void launch_run2_kd(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
                            hipStream_t stream) {
-  if constexpr (SEM == 0 && TPW == 11) {
+  // (the column sweeps' staged form is read by the pair-plane path only)
+  if constexpr (SEM == 0 && TPW == 11 && (AXIS == 0 || (PM_RUN2_PAIRS && PM_RUN2_PK_GRAD))) {
     const int n = (g.s_last - g.s_first) * g.dir + 1;
-    const size_t total = sizeof(float) * 4 * (size_t)(n + 4) +
-                         sizeof(uint16_t) * (size_t)TPW * ((AXIS == 1 ? ps.rows : ps.cols) + 1) + 256;
+    const size_t total = sizeof(float) * 4 * (size_t)(n + 4) + run2_lref_bytes<AXIS, TPW>(ps) + 256;
     if (run2_lref_enabled(AXIS) && total <= run2_lref_limit()) {
       launch_run2_kdl<SEM, GS, AXIS, TPW, TPH, DIR, true>(ps, cp, g, slots, waves, stream);
       return;
