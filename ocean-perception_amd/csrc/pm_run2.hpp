@@ -90,9 +90,13 @@ struct RowBufs {
 #define PM_RUN2_PAIRS 1
 #endif
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-__device__ __forceinline__ unsigned ld_u32(const uint32_t* base, unsigned elem) { return base[(size_t)elem]; }
+// 32-bit byte offsets (a view's pair planes are far below 4 GiB): (wave-uniform base) + (VGPR offset) is the
+// global_load ... v_off, s[base:base+1] form -- one v_add_lshl_u32 per load instead of a 64-bit address pair
+__device__ __forceinline__ unsigned ld_u32(const uint32_t* base, unsigned elem) {
+  return *(const uint32_t*)((const char*)base + (size_t)(elem << 2));
+}
 __device__ __forceinline__ f32x2 ld_f32x2(const float* base, unsigned pair_elem) {
-  return *(const f32x2*)(base + 2 * (size_t)pair_elem);
+  return *(const f32x2*)((const char*)base + (size_t)(pair_elem << 3));
 }
 __device__ __forceinline__ int win_ld8(__amdgpu_buffer_rsrc_t rs, const uint8_t* base, int voff, int soff) {
 #if PM_RUN2_GLOBAL_LOADS
