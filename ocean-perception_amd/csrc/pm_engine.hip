@@ -1010,6 +1010,11 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   h->device = device;
   h->no_tiled = getenv("PM_NO_TILED") != nullptr;
   if (int rc = validate_params(h, *params)) return rc;
+  // the sweep kernels address a view's planes with 32-bit byte offsets (8 bytes per pixel at most)
+  if ((size_t)(max_rows + 64) * (size_t)(max_cols + 128) >= ((size_t)1 << 28)) {
+    set_err(h, "plan of %dx%d exceeds the 2^28 pixels per view the kernels address", max_cols, max_rows);
+    return PM_ERR_SIZE;
+  }
 
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);

@@ -250,6 +250,10 @@ def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
                                  out_r.ctypes.data, 0) == pm.PM_ERR_INVALID_ARG
         with pytest.raises(pm.PmError):
             e.match(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.uint8))
+    # a plan beyond the 2^28 pixels per view the kernels' 32-bit offsets reach is refused before any allocation
+    with pytest.raises(pm.PmError) as ex:
+        pm.Engine(pm.default_params(0), max_rows=16384, max_cols=16384)
+    assert ex.value.status == pm.PM_ERR_SIZE
         with pytest.raises(pm.PmError):
             e.propagate(l, r, sl, 4, 3)
         # smallest supported image, and the engine still works after the errors
