@@ -58,7 +58,7 @@ __device__ __forceinline__ int run2_nd(const CostParams& cp) {
 // Ballot of this lane's group (GS = 32, 16 or 8 lanes), in the low GS bits.
 template <int GS>
 __device__ __forceinline__ unsigned gballot(bool p, int gbase) {
-  const unsigned long long b = __ballot(p);
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(p);  // (the int form costs a v_cndmask + v_cmp per ballot)
   if (GS == 32) return gbase ? (unsigned)(b >> 32) : (unsigned)b;
   return (unsigned)(b >> gbase) & ((1u << GS) - 1u);
 }
@@ -200,7 +200,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   st.g_need = valid_r;
 #endif
   st.cost = 0.f;
-  if (__any(valid_r)) {  // at least one group evaluates; the other computes along and ignores the result
+  if (__builtin_amdgcn_ballot_w64(valid_r) != 0ull) {  // at least one group evaluates; the other computes along and ignores the result
     const float ia_r = 1.f - a_r;
     CpuLerp l;
     l.a = a_r;
@@ -617,7 +617,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   float cand = in_used;
   {
     int i = i0;
-    while (__any(active && i < i1)) {
+    while (__builtin_amdgcn_ballot_w64(active && i < i1) != 0ull) {
       const bool act = active && i < i1;
       const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
       ++n_steps;
@@ -660,7 +660,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       float c2 = in;
       int i = i0;
       bool merged = false;
-      while (__any(redo && !merged && i < i1)) {
+      while (__builtin_amdgcn_ballot_w64(redo && !merged && i < i1) != 0ull) {
         const bool act = redo && !merged && i < i1;
         const RunStep2 st = run_step2_any<SEM, GS, AXIS, TPW, TPH, DIR, LREF>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
         ++n_fix;

@@ -250,10 +250,6 @@ def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
                                  out_r.ctypes.data, 0) == pm.PM_ERR_INVALID_ARG
         with pytest.raises(pm.PmError):
             e.match(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.uint8))
-    # a plan beyond the 2^28 pixels per view the kernels' 32-bit offsets reach is refused before any allocation
-    with pytest.raises(pm.PmError) as ex:
-        pm.Engine(pm.default_params(0), max_rows=16384, max_cols=16384)
-    assert ex.value.status == pm.PM_ERR_SIZE
         with pytest.raises(pm.PmError):
             e.propagate(l, r, sl, 4, 3)
         # smallest supported image, and the engine still works after the errors
@@ -600,3 +596,12 @@ def test_full_size_gpu_semantics_engines_agree(pm, oracle, synth, engine):
     el, er = oracle.match(oparams(oracle, 1, 3, 3), p["left"], p["right"], p["seed_l"], p["seed_r"])
     assert_same(dl, el, "1280x720 PM_SEM_GPU left vs oracle")
     assert_same(dr, er, "1280x720 PM_SEM_GPU right vs oracle")
+
+
+@pytest.mark.gpu
+def test_plan_beyond_the_32_bit_plane_offsets_is_refused(pm):
+    """The sweep kernels address a view's planes with 32-bit byte offsets: pm_create refuses such a plan before any
+    allocation."""
+    with pytest.raises(pm.PmError) as ex:
+        pm.Engine(pm.default_params(0), max_rows=16384, max_cols=16384)
+    assert ex.value.status == pm.PM_ERR_SIZE
