@@ -51,7 +51,8 @@ __device__ __forceinline__ int xcd_band_index(int b, int nb) {
 // lane l <- lane l+1 across the whole wavefront (DPP wave_shl:1, gfx9 incl. gfx950); lane 63 has no
 // source and receives 0.
 __device__ __forceinline__ int wave_shl1(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, false);
+  // bound_ctrl: the lane without a source reads 0 and the old value is dead -- no zero-initialising v_mov per use
+  return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true);
 }
 __device__ __forceinline__ float wave_shl1f(float v) {
   return __builtin_bit_cast(float, wave_shl1(__builtin_bit_cast(int, v)));
