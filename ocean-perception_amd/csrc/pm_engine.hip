@@ -435,8 +435,12 @@ int runblk_waves(int chain_len, int axis) {
 // A tuning choice only (results do not depend on it).  Runs of adopted values get shorter as the noise
 // amplitude decays, and short runs waste most of a 32-lane strip: measured at 720p / 11x11 / amp 32/2^i
 // (tools/sweep_g16_iter.sh) column sweeps win with 16-lane groups from amplitude 4 on, row sweeps (one
-// position fewer per strip: the DPP spare lane) only from 0.5 on.
-int runblk_group(int semantics, int axis, float amp, int win) {
+// position fewer per strip: the DPP spare lane) only from 0.5 on.  That holds for the FORWARD sweeps, which come
+// first after the noise and carry a good value a long way; the BACKWARD sweeps of the same iteration meet what the
+// forward ones left -- short runs, 58 % more steps per launch (profiles/r02d_pmc_insts.txt) -- and win with 16-lane
+// groups from amplitude 8 (rows) / 16 (columns) on: 294 -> 307 pairs/s (tools/sweep_neg.sh,
+// profiles/r02f_sweep_group_thresholds.txt).
+int runblk_group(int semantics, int axis, float amp, int win, int dir = 1) {
   static int v = [] {
     const char* e = getenv("PM_RUNBLK_GROUP");
     const int g = e ? atoi(e) : 0;
@@ -446,16 +450,20 @@ int runblk_group(int semantics, int axis, float amp, int win) {
   if (semantics != PM_SEM_CPU) return 16;
   if (win <= 5) return 16;  // small windows leave 11+ positions in a 16-lane strip: 16 wins at every amplitude
   struct Thr {
-    float t[2];
+    float t[2], tn[2];  // forward sweeps, backward sweeps (PM_G16_*_AMP_NEG)
     Thr() {
       const char* er = getenv("PM_G16_ROW_AMP");
       const char* ec = getenv("PM_G16_COL_AMP");
+      const char* ern = getenv("PM_G16_ROW_AMP_NEG");
+      const char* ecn = getenv("PM_G16_COL_AMP_NEG");
       t[0] = er ? (float)atof(er) : 0.5f;
       t[1] = ec ? (float)atof(ec) : 4.0f;
+      tn[0] = ern ? (float)atof(ern) : 8.0f;
+      tn[1] = ecn ? (float)atof(ecn) : 16.0f;
     }
   };
   static const Thr thr_knobs;
-  const float* thr = thr_knobs.t;
+  const float* thr = dir < 0 ? thr_knobs.tn : thr_knobs.t;
   return amp <= thr[axis] ? 16 : 32;
 }
 
@@ -479,7 +487,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else {
     launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis),
-                      runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph), h->stream);
+                      runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir), h->stream);
   }
   return launch_check(h, "sweep");
 }
