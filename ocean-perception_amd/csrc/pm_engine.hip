@@ -409,22 +409,26 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
 
 // Wavefronts per chain in PM_ENGINE_RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
 // 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
-int runblk_waves(int chain_len, int axis) {
+int runblk_waves(int chain_len, int axis, int group = 32) {
   struct Knobs {
-    int v[2];
+    int v[2][2];  // [axis][group == 16]
     Knobs() {
-      const char* names[2] = {"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_COL"};
+      const char* names[2][2] = {{"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_ROW16"},
+                                 {"PM_RUNBLK_WAVES_COL", "PM_RUNBLK_WAVES_COL16"}};
       const char* both = getenv("PM_RUNBLK_WAVES");
-      for (int a = 0; a < 2; ++a) {
-        const char* e = getenv(names[a]);
-        if (!e) e = both;
-        const int x = e ? atoi(e) : 0;
-        v[a] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
-      }
+      for (int a = 0; a < 2; ++a)
+        for (int g = 0; g < 2; ++g) {
+          const char* e = getenv(names[a][g]);
+          if (!e && g == 1) e = getenv(names[a][0]);
+          if (!e) e = both;
+          const int x = e ? atoi(e) : 0;
+          v[a][g] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
+        }
     }
   };
   static const Knobs k;  // initialised once, thread-safe
-  if (k.v[axis]) return k.v[axis];
+  const int g16 = group <= 16 ? 1 : 0;
+  if (k.v[axis][g16]) return k.v[axis][g16];
   return chain_len > 1600 ? 8 : 4;
 }
 
@@ -486,8 +490,8 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
   } else if (engine == PM_ENGINE_WAVE) {
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else {
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis),
-                      runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir), h->stream);
+    const int group = runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir);
+    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
   }
   return launch_check(h, "sweep");
 }
