@@ -189,6 +189,17 @@ __device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, con
 // Accumulate forms for the VALU-bound kernels: acc + |left - sample| as ONE v_sad_u8 each.
 // v_sad_u8 adds the absolute differences of all four bytes of its operands; `left` and the colour
 // sample are < 256, so only byte 0 contributes.
+// The colour lerp sum as ONE v_dot2_u32_u16: r01 = r0 | r1 << 16, w = cpu_color_weights().  Both weights are
+// clamped to 65535 so that they fit 16 bits: a weight of 65536 happens only when the other one is 0 (a <= 2^-17 or
+// 1 - a <= 2^-17: the other product rounds to 0), and then r * 65535 + 2^15 = r * 65536 + (2^15 - r) has the same
+// byte 2 (= r) as r * 65536 + 2^15.  Only byte 2 of the result -- the sample -- may be used.
+typedef unsigned short pm_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cpu_color_weights(const CpuLerp& l) {
+  return (unsigned)min(l.a11, 65535) | ((unsigned)min(l.a12, 65535) << 16);
+}
+__device__ __forceinline__ unsigned cpu_color_sum_pk(unsigned r01, unsigned w) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(pm_u16x2, r01), __builtin_bit_cast(pm_u16x2, w), 1u << 15, false);
+}
 // The colour lerp sum alone: r0 * a11 + r1 * a12 + 2^15 < 2^24, the sample is its byte 2.
 __device__ __forceinline__ unsigned cpu_color_sum(int r0, int r1, const CpuLerp& l) {
   const unsigned t = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);

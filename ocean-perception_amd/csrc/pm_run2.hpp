@@ -224,6 +224,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         constexpr int NPR = (TPH + 1) / 2;
         const int y0 = chain - half_h;                                   // wave-uniform
         const unsigned eo = (unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch;
+        const unsigned cw = cpu_color_weights(l);
         unsigned ppv[NPR + 1];     // reference pairs
         unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2 (< 2^24)
         float gv[2 * NPR + 1];
@@ -243,8 +244,9 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
           ppv[m] = pp;
-          tcol[2 * m] = cpu_color_sum((int)(pr & 0xffu), (int)(prn & 0xffu), l);
-          tcol[2 * m + 1] = cpu_color_sum((int)((pr >> 8) & 0xffu), (int)((prn >> 8) & 0xffu), l);
+          // (own byte | neighbour's byte << 16) of row 2m, of row 2m + 1: one v_perm each, then one v_dot2_u32_u16
+          tcol[2 * m] = cpu_color_sum_pk(__builtin_amdgcn_perm(prn, pr, 0x0c040c00u), cw);
+          tcol[2 * m + 1] = cpu_color_sum_pk(__builtin_amdgcn_perm(prn, pr, 0x0c050c01u), cw);
         }
         ppv[NPR] = 0u;
         tcol[2 * NPR] = tcol[2 * NPR + 1] = 0u;
@@ -382,13 +384,15 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
             rg4[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
           }
         }
+        const unsigned cw = cpu_color_weights(l);
         unsigned tcol[4 * NQ];
 #pragma unroll
         for (int t = 0; t < 4 * NQ; ++t) {
           if (t < TPW) {
-            const int r0 = (int)((prv[t / 2] >> (8 * (t % 2))) & 0xffu);
-            const int r1 = (int)((prv[(t + 1) / 2] >> (8 * ((t + 1) % 2))) & 0xffu);
-            tcol[t] = cpu_color_sum(r0, r1, l);
+            // samples t, t + 1 as halfwords: both in pair t / 2 (t even) or one in each of two pairs (t odd)
+            const unsigned r01 = (t % 2 == 0) ? __builtin_amdgcn_perm(0u, prv[t / 2], 0x0c010c00u)
+                                              : __builtin_amdgcn_perm(prv[t / 2 + 1], prv[t / 2], 0x0c040c01u);
+            tcol[t] = cpu_color_sum_pk(r01, cw);
           } else {
             tcol[t] = 0u;
           }
