@@ -110,6 +110,31 @@ def test_gpu_propagate_adversarial_fields(pm, oracle, synth, engine, kind):
                         f"{kind} sweep mask {mask}")
 
 
+@pytest.mark.parametrize("engine", [1, 5])
+@pytest.mark.parametrize("pw", [5, 11])
+def test_cpu_propagate_lerp_weight_extremes(pm, oracle, synth, engine, pw):
+    """PM_SEM_CPU sweeps with sample positions within a few ulps of an integer column: the fixed-point lerp weights
+    reach 0 and 65536 (the run engine packs them into 16 bits for v_dot2_u32_u16 and relies on the other weight
+    being 0 then), on both sides of the integer, next to ordinary fractions and long runs."""
+    rows, cols = 40, 200
+    l, r, _, _, _ = small_pair(synth, 23, rows, cols, n_points=20, dilate_factor=2)
+    ims = oracle.ImageSet(l, r)
+    rng = np.random.default_rng(17)
+    xs = np.arange(cols, dtype=np.float32)[None, :].repeat(rows, 0)
+    shift = np.float32((pw - 1) * 0.5)
+    # x - d - shift = k + eps  with  eps in {0, +-1 ulp ... +-2^-16, +-2^-17, +-2^-18}
+    k = rng.integers(0, 60, (rows, cols)).astype(np.float32)
+    eps = rng.choice(np.array([0.0, 2.0 ** -16, -2.0 ** -16, 2.0 ** -17, -2.0 ** -17, 2.0 ** -18, -2.0 ** -18, 7.6e-6,
+                               -7.6e-6, 7.7e-6, -7.7e-6, 0.25, 0.5], np.float32), (rows, cols))
+    d = np.maximum(xs - shift - k - eps, 0).astype(np.float32)
+    d = np.repeat(d[:, ::3], 3, axis=1)[:, :cols]        # runs of three equal values
+    d[rng.random((rows, cols)) < 0.3] = np.float32(13.99999)
+    with mk(pm, 0, engine, rows=rows, cols=cols) as e:
+        for mask in (1, 2, 4, 8, 15):
+            assert_same(e.propagate(l, r, d, pw, pw, mask), oracle.cpu_propagate(ims, d, pw, pw, pass_mask=mask, nthreads=8),
+                        f"weight extremes, pass mask {mask}")
+
+
 def test_remove_background_and_mask_occlusions(pm, oracle, synth):
     rows, cols = 50, 90
     l, r, sl, sr, _ = small_pair(synth, 13, rows, cols, n_points=30, dilate_factor=2)
