@@ -33,11 +33,10 @@ struct PlaneSet {
   // start finds its lines as whole pairs.  "Lines" are image rows for the row sweeps (rp*) and image columns, on
   // the transposed planes, for the column sweeps (cp*).  Per pair b and view v (target image of the view for
   // *8 / *g, reference image for rppk):
-  uint16_t* rp8;       // [B][2][2][npr][pitch]     target colour   lo byte = line 2k+o, hi byte = line 2k+o+1
-  float* rpg;          // [B][2][2][npr][pitch][2]  target gradient
+  float* rpg;          // [B][2][2][npr][pitch][3]  target records {gradient of line 2k+o, of line 2k+o+1,
+                       //                           u32 colour byte of line 2k+o | of line 2k+o+1 << 8}
   uint32_t* rppk;      // [B][2][2][npr][pitch]     reference packed (colour | gradient << 8), lo half = line 2k+o
-  uint16_t* cp8;       // [B][2][2][npc][pitch_t]   transposed target colour
-  float* cpg;          // [B][2][2][npc][pitch_t][2]
+  float* cpg;          // [B][2][2][npc][pitch_t][3] the same records on the transposed target planes
   int npr, npc;        // pairs per alignment: (rows + 1) / 2 + 1, (cols + kTransPad + 1) / 2 + 1
   float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
   float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
@@ -75,10 +74,8 @@ struct View {
   // column sweeps: [image row][kLref4Stride] dwords, four window columns per dword (pm_run2.hpp)
   const unsigned* lds_ref4;
   // pair planes of this view, alignment 0; alignment 1 follows at + rp_stride / cp_stride elements
-  const uint16_t* rp8;
   const float* rpg;
   const uint32_t* rppk;
-  const uint16_t* cp8;
   const float* cpg;
   unsigned rp_stride, cp_stride;  // npr * pitch, npc * pitch_t
   float* disp;
@@ -118,11 +115,9 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.rp_stride = (unsigned)ps.npr * (unsigned)ps.pitch;
   w.cp_stride = (unsigned)ps.npc * (unsigned)ps.pitch_t;
   const size_t pv = ((size_t)b * 2 + v) * 2;
-  w.rp8 = ps.rp8 + pv * w.rp_stride;
-  w.rpg = ps.rpg + pv * w.rp_stride * 2;
+  w.rpg = ps.rpg + pv * w.rp_stride * 3;
   w.rppk = ps.rppk + pv * w.rp_stride;
-  w.cp8 = ps.cp8 + pv * w.cp_stride;
-  w.cpg = ps.cpg + pv * w.cp_stride * 2;
+  w.cpg = ps.cpg + pv * w.cp_stride * 3;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;

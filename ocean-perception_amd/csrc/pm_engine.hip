@@ -51,10 +51,8 @@ struct pm_handle {
   uint8_t* tg8 = nullptr;
   uint16_t* pk16 = nullptr;
   uint16_t* tpk16 = nullptr;
-  uint16_t* rp8 = nullptr;   // row / column PAIR planes of the run engine (pm::PlaneSet)
-  float* rpg = nullptr;
+  float* rpg = nullptr;      // row / column PAIR planes of the run engine (pm::PlaneSet)
   uint32_t* rppk = nullptr;
-  uint16_t* cp8 = nullptr;
   float* cpg = nullptr;
   float* disp = nullptr;
   float* cost = nullptr;
@@ -181,10 +179,8 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.plane_t = (size_t)(cols + kTransPad) * ps.pitch_t;
   ps.pk16 = h->pk16;
   ps.tpk16 = h->tpk16;
-  ps.rp8 = h->rp8;
   ps.rpg = h->rpg;
   ps.rppk = h->rppk;
-  ps.cp8 = h->cp8;
   ps.cpg = h->cpg;
   ps.npr = (rows + 1) / 2 + 1;
   ps.npc = (cols + kTransPad + 1) / 2 + 1;
@@ -982,7 +978,7 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  void* dev[] = {h->rp8, h->rpg, h->rppk, h->cp8, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
+  void* dev[] = {h->rpg, h->rppk, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
                  h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
                  h->seed2.sort_tmp, h->snap_disp,
@@ -1022,7 +1018,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   h->device = device;
   h->no_tiled = getenv("PM_NO_TILED") != nullptr;
   if (int rc = validate_params(h, *params)) return rc;
-  // the sweep kernels address a view's planes with 32-bit byte offsets (8 bytes per pixel at most)
+  // the sweep kernels address a view's planes with 32-bit byte offsets (12 bytes per pair element at most)
   if ((size_t)(max_rows + 64) * (size_t)(max_cols + 128) >= ((size_t)1 << 28)) {
     set_err(h, "plan of %dx%d exceeds the 2^28 pixels per view the kernels address", max_cols, max_rows);
     return PM_ERR_SIZE;
@@ -1072,17 +1068,13 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
     const size_t rp_stride = (size_t)((max_rows + 1) / 2 + 1) * h->max_pitch;
     const size_t cp_stride = (size_t)((max_cols + kTransPad + 1) / 2 + 1) * align_up(max_rows, 64);
     const size_t nrp = B * 4 * rp_stride + 64, ncp = B * 4 * cp_stride + 64;
-    PM_HIP(h, hipMalloc((void**)&h->rp8, sizeof(uint16_t) * nrp));
-    PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 2 * nrp));
+    PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 3 * nrp));
     PM_HIP(h, hipMalloc((void**)&h->rppk, sizeof(uint32_t) * nrp));
-    PM_HIP(h, hipMalloc((void**)&h->cp8, sizeof(uint16_t) * ncp));
-    PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 2 * ncp));
+    PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 3 * ncp));
     // row padding behind `cols` / `rows` is read (with weight 0 or by lanes out of reach) and must be finite
-    PM_HIP(h, hipMemsetAsync(h->rp8, 0, sizeof(uint16_t) * nrp, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 2 * nrp, h->stream));
+    PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 3 * nrp, h->stream));
     PM_HIP(h, hipMemsetAsync(h->rppk, 0, sizeof(uint32_t) * nrp, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->cp8, 0, sizeof(uint16_t) * ncp, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 2 * ncp, h->stream));
+    PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 3 * ncp, h->stream));
   }
   PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T*
   }
 }
 
-// Pair planes of the run engine (PlaneSet::rp8 ...): built from the plain and the transposed planes once per Match.
+// Pair planes of the run engine (PlaneSet::rpg ...): built from the plain and the transposed planes once per Match.
 // grid = (ceil(len / 256), pairs, B * 4) with z = ((b * 2 + view) * 2 + alignment); `rows_mode` != 0: row pairs
 // (len = cols, line = image row, source planes img8 / g32 / pk16 with pitch), else column pairs on the transposed
 // planes (len = rows, line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
@@ -137,9 +137,10 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
     const size_t src0 = (size_t)l0 * ps.pitch + e, src1 = (size_t)l1 * ps.pitch + e;
     const size_t tp = ((size_t)b * 4 + itgt) * ps.plane, rp = ((size_t)b * 4 + iref) * ps.plane;
     const size_t dst = ((size_t)z * ps.npr + k) * ps.pitch + e;
-    ps.rp8[dst] = (uint16_t)(ps.img8[tp + src0] | ((unsigned)ps.img8[tp + src1] << 8));
-    ps.rpg[2 * dst] = ps.g32[tp + src0];
-    ps.rpg[2 * dst + 1] = ps.g32[tp + src1];
+    // one 12-byte record per pair element: the two gradients and the two colour bytes -- ONE load in the sweeps
+    ps.rpg[3 * dst] = ps.g32[tp + src0];
+    ps.rpg[3 * dst + 1] = ps.g32[tp + src1];
+    ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8);
     ps.rppk[dst] = (uint32_t)ps.pk16[rp + src0] | ((uint32_t)ps.pk16[rp + src1] << 16);
   } else {
     if (e >= ps.rows || k >= ps.npc) return;
@@ -148,9 +149,9 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
     const size_t src0 = (size_t)l0 * ps.pitch_t + e, src1 = (size_t)l1 * ps.pitch_t + e;
     const size_t tp = ((size_t)b * 4 + itgt) * ps.plane_t;
     const size_t dst = ((size_t)z * ps.npc + k) * ps.pitch_t + e;
-    ps.cp8[dst] = (uint16_t)(ps.timg8[tp + src0] | ((unsigned)ps.timg8[tp + src1] << 8));
-    ps.cpg[2 * dst] = ps.tg32[tp + src0];
-    ps.cpg[2 * dst + 1] = ps.tg32[tp + src1];
+    ps.cpg[3 * dst] = ps.tg32[tp + src0];
+    ps.cpg[3 * dst + 1] = ps.tg32[tp + src1];
+    ((uint32_t*)ps.cpg)[3 * dst + 2] = (uint32_t)ps.timg8[tp + src0] | ((uint32_t)ps.timg8[tp + src1] << 8);
   }
 }
 

@@ -83,8 +83,8 @@ struct RowBufs {
 #ifndef PM_RUN2_GLOBAL_LOADS
 #define PM_RUN2_GLOBAL_LOADS 1
 #endif
-// 1: two window lines per load from the pair planes (PlaneSet::rp8 ...): 18 instead of 33 loads per row-sweep
-// step, 12 instead of 24 per column-sweep step.  The sweeps are bound by the number of memory instructions: one
+// 1: two window lines per load from the pair planes (PlaneSet::rpg ...), colour bytes and gradients of the target in
+// one 12-byte record: 12 instead of 33 loads per row-sweep step, 6 instead of 24 per column-sweep step.  The sweeps are bound by the number of memory instructions: one
 // extra byte load per window line costs 28 % of the frame (A/B in DESIGN.md).
 #ifndef PM_RUN2_PAIRS
 #define PM_RUN2_PAIRS 1
@@ -95,8 +95,13 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ unsigned ld_u32(const uint32_t* base, unsigned elem) {
   return *(const uint32_t*)((const char*)base + (size_t)(elem << 2));
 }
-__device__ __forceinline__ f32x2 ld_f32x2(const float* base, unsigned pair_elem) {
-  return *(const f32x2*)((const char*)base + (size_t)(pair_elem << 3));
+// one target record: .x / .y = the gradients of the pair's two lines, .c = their colour bytes (line 0 | line 1 << 8)
+struct PairRec {
+  float x, y;
+  unsigned c;
+};
+__device__ __forceinline__ PairRec ld_rec(const float* base, unsigned pair_elem) {
+  return *(const PairRec*)((const char*)base + (size_t)(pair_elem * 12u));
 }
 __device__ __forceinline__ int win_ld8(__amdgpu_buffer_rsrc_t rs, const uint8_t* base, int voff, int soff) {
 #if PM_RUN2_GLOBAL_LOADS
@@ -238,8 +243,8 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
           } else {
             pp = ld_u32(v.rppk, em + (unsigned)X);
           }
-          const unsigned pr = (unsigned)ld_u16(v.rp8, (em + (unsigned)R0) * 2u);
-          const f32x2 pg = ld_f32x2(v.rpg, em + (unsigned)R0);
+          const PairRec pg = ld_rec(v.rpg, em + (unsigned)R0);
+          const unsigned pr = pg.c;
           const unsigned prn = (unsigned)wave_shl1((int)pr);
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
@@ -354,8 +359,8 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 #pragma unroll
         for (int m = 0; m < NPC; ++m) {
           const unsigned em = e0 + (unsigned)(m * pt);
-          prv[m] = (unsigned)ld_u16(v.cp8, em * 2u);
-          const f32x2 pg = ld_f32x2(v.cpg, em);
+          const PairRec pg = ld_rec(v.cpg, em);
+          prv[m] = pg.c;
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
         }
