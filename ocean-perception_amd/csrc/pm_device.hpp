@@ -32,10 +32,13 @@ struct PlaneSet {
   // instructions).  Two alignments o = 0 / 1: pair k of alignment o covers lines 2k+o and 2k+o+1, so any window
   // start finds its lines as whole pairs.  "Lines" are image rows for the row sweeps (rp*) and image columns, on
   // the transposed planes, for the column sweeps (cp*).  Per pair b and view v (target image of the view for
-  // *8 / *g, reference image for rppk):
+  // the records, reference image for the quads):
   float* rpg;          // [B][2][2][npr][pitch][3]  target records {gradient of line 2k+o, of line 2k+o+1,
                        //                           u32 colour byte of line 2k+o | of line 2k+o+1 << 8}
-  uint32_t* rppk;      // [B][2][2][npr][pitch]     reference packed (colour | gradient << 8), lo half = line 2k+o
+  // reference QUADS (row sweeps): four alignments o = 0..3, quad k of alignment o covers image rows 4k+o .. 4k+o+3;
+  // element = {colour bytes of the four rows, gradient bytes of the four rows}: the form the sweeps' v_sad_u8 takes
+  uint32_t* rqk;       // [B][2][4][nq][pitch][2]
+  int nq;              // quads per alignment: (rows + 3) / 4 + 1
   float* cpg;          // [B][2][2][npc][pitch_t][3] the same records on the transposed target planes
   int npr, npc;        // pairs per alignment: (rows + 1) / 2 + 1, (cols + kTransPad + 1) / 2 + 1
   float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
@@ -75,7 +78,8 @@ struct View {
   const unsigned* lds_ref4;
   // pair planes of this view, alignment 0; alignment 1 follows at + rp_stride / cp_stride elements
   const float* rpg;
-  const uint32_t* rppk;
+  const uint32_t* rqk;
+  unsigned rq_stride;  // elements (8 bytes) per alignment of rqk
   const float* cpg;
   unsigned rp_stride, cp_stride;  // npr * pitch, npc * pitch_t
   float* disp;
@@ -116,7 +120,8 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.cp_stride = (unsigned)ps.npc * (unsigned)ps.pitch_t;
   const size_t pv = ((size_t)b * 2 + v) * 2;
   w.rpg = ps.rpg + pv * w.rp_stride * 3;
-  w.rppk = ps.rppk + pv * w.rp_stride;
+  w.rq_stride = (unsigned)ps.nq * (unsigned)ps.pitch;
+  w.rqk = ps.rqk + pv * 2 * (size_t)w.rq_stride * 2;
   w.cpg = ps.cpg + pv * w.cp_stride * 3;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;

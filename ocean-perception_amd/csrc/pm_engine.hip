@@ -52,7 +52,7 @@ struct pm_handle {
   uint16_t* pk16 = nullptr;
   uint16_t* tpk16 = nullptr;
   float* rpg = nullptr;      // row / column PAIR planes of the run engine (pm::PlaneSet)
-  uint32_t* rppk = nullptr;
+  uint32_t* rqk = nullptr;
   float* cpg = nullptr;
   float* disp = nullptr;
   float* cost = nullptr;
@@ -180,7 +180,8 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.pk16 = h->pk16;
   ps.tpk16 = h->tpk16;
   ps.rpg = h->rpg;
-  ps.rppk = h->rppk;
+  ps.rqk = h->rqk;
+  ps.nq = (rows + 3) / 4 + 1;
   ps.cpg = h->cpg;
   ps.npr = (rows + 1) / 2 + 1;
   ps.npc = (cols + kTransPad + 1) / 2 + 1;
@@ -312,6 +313,8 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
                        h->stream, ps, 1);
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.npc, (unsigned)(n * 4)), block, 0,
                        h->stream, ps, 0);
+    hipLaunchKernelGGL(k_quads, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nq, (unsigned)(n * 8)), block, 0,
+                       h->stream, ps);
   }
   return launch_check(h, "transpose");
 }
@@ -978,7 +981,7 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  void* dev[] = {h->rpg, h->rppk, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
+  void* dev[] = {h->rpg, h->rqk, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
                  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
                  h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
                  h->seed2.sort_tmp, h->snap_disp,
@@ -1069,11 +1072,12 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
     const size_t cp_stride = (size_t)((max_cols + kTransPad + 1) / 2 + 1) * align_up(max_rows, 64);
     const size_t nrp = B * 4 * rp_stride + 64, ncp = B * 4 * cp_stride + 64;
     PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 3 * nrp));
-    PM_HIP(h, hipMalloc((void**)&h->rppk, sizeof(uint32_t) * nrp));
+    const size_t nrq = B * 8 * (size_t)((max_rows + 3) / 4 + 1) * h->max_pitch * 2 + 64;
+    PM_HIP(h, hipMalloc((void**)&h->rqk, sizeof(uint32_t) * nrq));
     PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 3 * ncp));
     // row padding behind `cols` / `rows` is read (with weight 0 or by lanes out of reach) and must be finite
     PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 3 * nrp, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->rppk, 0, sizeof(uint32_t) * nrp, h->stream));
+    PM_HIP(h, hipMemsetAsync(h->rqk, 0, sizeof(uint32_t) * nrq, h->stream));
     PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 3 * ncp, h->stream));
   }
   PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));

@@ -130,18 +130,17 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   const int z = blockIdx.z, o = z & 1, view = (z >> 1) & 1, b = z >> 2;
-  const int itgt = view == 0 ? 1 : 2, iref = view == 0 ? 0 : 3;
+  const int itgt = view == 0 ? 1 : 2;
   if (rows_mode) {
     if (e >= ps.cols || k >= ps.npr) return;
     const int l0 = min(2 * k + o, ps.rows - 1), l1 = min(2 * k + o + 1, ps.rows - 1);
     const size_t src0 = (size_t)l0 * ps.pitch + e, src1 = (size_t)l1 * ps.pitch + e;
-    const size_t tp = ((size_t)b * 4 + itgt) * ps.plane, rp = ((size_t)b * 4 + iref) * ps.plane;
+    const size_t tp = ((size_t)b * 4 + itgt) * ps.plane;
     const size_t dst = ((size_t)z * ps.npr + k) * ps.pitch + e;
     // one 12-byte record per pair element: the two gradients and the two colour bytes -- ONE load in the sweeps
     ps.rpg[3 * dst] = ps.g32[tp + src0];
     ps.rpg[3 * dst + 1] = ps.g32[tp + src1];
     ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8);
-    ps.rppk[dst] = (uint32_t)ps.pk16[rp + src0] | ((uint32_t)ps.pk16[rp + src1] << 16);
   } else {
     if (e >= ps.rows || k >= ps.npc) return;
     const int lmax = ps.cols + kTransPad - 1;
@@ -153,6 +152,28 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
     ps.cpg[3 * dst + 1] = ps.tg32[tp + src1];
     ((uint32_t*)ps.cpg)[3 * dst + 2] = (uint32_t)ps.timg8[tp + src0] | ((uint32_t)ps.timg8[tp + src1] << 8);
   }
+}
+
+// Reference quads of the row sweeps (PlaneSet::rqk).  grid = (ceil(cols / 256), nq, B * 8) with
+// z = ((b * 2 + view) * 4 + alignment).  Rows beyond the last one repeat it (only ever the unused twelfth row).
+__global__ void __launch_bounds__(256) k_quads(PlaneSet ps) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  const int z = blockIdx.z, o = z & 3, view = (z >> 2) & 1, b = z >> 3;
+  if (e >= ps.cols || k >= ps.nq) return;
+  const int iref = view == 0 ? 0 : 3;
+  const size_t rp = ((size_t)b * 4 + iref) * ps.plane;
+  uint32_t cw = 0u, gw = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = min(4 * k + o + j, ps.rows - 1);
+    const uint32_t pk = ps.pk16[rp + (size_t)row * ps.pitch + e];
+    cw |= (pk & 0xffu) << (8 * j);
+    gw |= (pk >> 8) << (8 * j);
+  }
+  const size_t dst = (((size_t)z * ps.nq + k) * ps.pitch + e) * 2;
+  ps.rqk[dst] = cw;
+  ps.rqk[dst + 1] = gw;
 }
 
 // seed maps -> disparity planes; the right-view seed is mirrored like the images

@@ -236,12 +236,10 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
 #pragma unroll
         for (int m = 0; m < NPR; ++m) {
           const unsigned em = eo + (unsigned)(m * pitch);
-          unsigned pp;  // reference: colour | gradient << 8 of row 2m in the low half, of row 2m + 1 in the high half
+          unsigned pp = 0u;  // LREF only: colour | gradient << 8 of row 2m in the low half, of row 2m + 1 in the high half
           if constexpr (LREF) {
             pp = (unsigned)v.lds_ref[(2 * m) * v.lds_ref_pitch + X];
             if (2 * m + 1 < TPH) pp |= (unsigned)v.lds_ref[(2 * m + 1) * v.lds_ref_pitch + X] << 16;
-          } else {
-            pp = ld_u32(v.rppk, em + (unsigned)X);
           }
           const PairRec pg = ld_rec(v.rpg, em + (unsigned)R0);
           const unsigned pr = pg.c;
@@ -270,6 +268,21 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         // samples (v_cvt_pk_u8_f32 drops each into its byte) are gathered into one dword each and meet the four
         // reference bytes gathered from two reference pairs -- instead of a shift, a byte extract and a v_sad_u8
         // per row and channel.  Rows the window does not have select the constant 0 on both sides.
+        // reference bytes of four rows per dword: one 8-byte load per quad from the quad plane of this chain's
+        // alignment (rows the window does not have are masked), or gathered from the staged lines (LREF)
+        constexpr int NQR = (TPH + 3) / 4;
+        unsigned rq_c[NQR], rq_g[NQR];
+        if constexpr (!LREF) {
+          const unsigned eq = (unsigned)(y0 & 3) * v.rq_stride + (unsigned)(y0 >> 2) * (unsigned)pitch + (unsigned)X;
+#pragma unroll
+          for (int q = 0; q < NQR; ++q) {
+            const uint2 rr = *(const uint2*)((const char*)v.rqk + (size_t)((eq + (unsigned)(q * pitch)) << 3));
+            const int rem = TPH - 4 * q;
+            const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+            rq_c[q] = rr.x & mask;
+            rq_g[q] = rr.y & mask;
+          }
+        }
 #pragma unroll
         for (int q = 0; 4 * q < TPH; ++q) {
           const int r0 = 4 * q;
@@ -290,8 +303,8 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
                                 (h1 ? 0x00000200u : 0x00000c00u) | 0x00u;
           const unsigned selg = (h3 ? 0x07000000u : 0x0c000000u) | (h2 ? 0x00050000u : 0x000c0000u) |
                                 (h1 ? 0x00000300u : 0x00000c00u) | 0x01u;
-          const unsigned rc4 = __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selc);
-          const unsigned rg4 = __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selg);
+          const unsigned rc4 = LREF ? __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selc) : rq_c[q];
+          const unsigned rg4 = LREF ? __builtin_amdgcn_perm(ppv[2 * q + 1], ppv[2 * q], selg) : rq_g[q];
           sc = __builtin_amdgcn_sad_u8(rc4, s4, sc);
           sg = __builtin_amdgcn_sad_u8(rg4, g4, sg);
         }
