@@ -390,8 +390,13 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
             c0 = c1;
           }
         }
-        auto rbyte = [&](int j) -> int { return (int)((rw[j / 4] >> (8 * (j % 4))) & 0xffu); };
-        int r0 = rbyte(0);
+        // target bytes j and j + 1 as the two halfwords of a dword (they may straddle two dwords of rw[]): the
+        // operand of the one-instruction colour lerp (cpu_color_sum_pk)
+        auto rpair = [&](int j) -> unsigned {
+          const unsigned sel = 0x0c000c00u | (unsigned)(j % 4) | ((unsigned)(j % 4 + 1) << 16);
+          return __builtin_amdgcn_perm(rw[min(j / 4 + 1, NR - 1)], rw[j / 4], sel);
+        };
+        const unsigned cw = cpu_color_weights(l);
         // gradient lerp g[j] * (1 - a) + g[j + 1] * a: both products of every sample with packed-f32
         // multiplies (two samples per instruction), one add per tap; each product and each sum is a single
         // IEEE operation exactly as in the scalar form
@@ -412,12 +417,9 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
           for (int k = 0; k < 4; ++k) {
             const int j = 4 * q + k;
             if (j < PW) {
-              const int r1 = rbyte(j + 1);
-              unsigned tt = __umul24((unsigned)r1, (unsigned)l.a12) + (1u << 15);
-              t[k] = __umul24((unsigned)r0, (unsigned)l.a11) + tt;
+              t[k] = cpu_color_sum_pk(rpair(j), cw);
               const float sgr = ga[j / 2][j % 2] + gb[(j + 1) / 2][(j + 1) % 2];
               pg = __builtin_amdgcn_cvt_pk_u8_f32(sgr, k, pg);  // saturate_cast<uchar> into byte k
-              r0 = r1;
             }
           }
           // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
