@@ -41,7 +41,7 @@ struct RunStep2 {
   long long t[5];  // s_memtime at: entry, after the need ballot, after the line sums, after the cost, at return
 #endif
 #ifdef PM_RUN2_STATS
-  bool evald, g_need;
+  bool evald, g_need, pred_ok;  // pred_ok: the step ended in a reject at its first evaluated position
 #endif
 };
 #ifdef PM_RUN2_TIMING
@@ -529,6 +529,9 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
   st.rej_pos = act ? rej_pos : -1;
   st.advance = act ? advance : 0;
   st.adopt = adopt && st.mpos < q;
+#ifdef PM_RUN2_STATS
+  st.pred_ok = act && has_need && q_real && q == r;
+#endif
   PM_T(4);
   return st;
 }
@@ -628,7 +631,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
   const bool active = i0 < n;
   unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
 #ifdef PM_RUN2_STATS
-  unsigned n_eval = 0, n_gsteps = 0, n_geval = 0, adv_sum = 0;
+  unsigned n_eval = 0, n_gsteps = 0, n_geval = 0, adv_sum = 0, n_pred = 0;
 #endif
 #ifdef PM_RUN2_TIMING
   long long tph[5] = {0, 0, 0, 0, 0}, t_prev_end = 0;
@@ -648,6 +651,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
         n_eval += st.evald;
         n_gsteps += act;
         n_geval += act && st.g_need;
+        n_pred += st.pred_ok;
         adv_sum += st.advance;
       }
 #endif
@@ -739,6 +743,7 @@ __global__ void PM_RUNBLK2_BOUNDS k_runblk2(PlaneSet ps, CostParams cp, SweepGeo
       atomicAdd(&ps.counters[3], (unsigned long long)n_gsteps);
       atomicAdd(&ps.counters[4], (unsigned long long)n_geval);
       atomicAdd(&ps.counters[5], (unsigned long long)adv_sum);
+      atomicAdd(&ps.counters[6], (unsigned long long)n_pred);
     }
   }
 #else
