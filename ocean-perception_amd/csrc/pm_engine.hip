@@ -437,7 +437,7 @@ int runblk_waves(int chain_len, int axis, int group = 32) {
 // frame), PM_SEM_CPU's 11-lane window with 32 (a 16-lane strip leaves it only 5-6 positions per step).
 // A tuning choice only (results do not depend on it).  Runs of adopted values get shorter as the noise
 // amplitude decays, and short runs waste most of a 32-lane strip: measured at 720p / 11x11 / amp 32/2^i
-// (tools/sweep_g16_iter.sh) column sweeps win with 16-lane groups from amplitude 4 on, row sweeps (one
+// (tools/sweep_waves.sh) column sweeps win with 16-lane groups from amplitude 4 on, row sweeps (one
 // position fewer per strip: the DPP spare lane) only from 0.5 on.  That holds for the FORWARD sweeps, which come
 // first after the noise and carry a good value a long way; the BACKWARD sweeps of the same iteration meet what the
 // forward ones left -- short runs, 58 % more steps per launch (profiles/r02d_pmc_insts.txt) -- and win with 16-lane
