@@ -100,8 +100,15 @@ struct PairRec {
   float x, y;
   unsigned c;
 };
-__device__ __forceinline__ PairRec ld_rec(const float* base, unsigned pair_elem) {
-  return *(const PairRec*)((const char*)base + (size_t)(pair_elem * 12u));
+// `byte_off` = 12 * element: the callers form it as 12 * (first element) -- one shift-add and one shift, no 32-bit
+// multiply (quarter rate) -- plus a wave-uniform 12 * pitch per line pair
+__device__ __forceinline__ PairRec ld_rec(const float* base, unsigned byte_off) {
+  return *(const PairRec*)((const char*)base + (size_t)byte_off);
+}
+__device__ __forceinline__ unsigned rec_offset(unsigned elem) {
+  unsigned t = (elem << 1) + elem;
+  asm volatile("" : "+v"(t));  // opaque: otherwise the optimiser folds this back into a v_mul_lo_u32 by 12 per load
+  return t << 2;
 }
 __device__ __forceinline__ int win_ld8(__amdgpu_buffer_rsrc_t rs, const uint8_t* base, int voff, int soff) {
 #if PM_RUN2_GLOBAL_LOADS
@@ -230,6 +237,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         const int y0 = chain - half_h;                                   // wave-uniform
         const unsigned eo = (unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch;
         const unsigned cw = cpu_color_weights(l);
+        const unsigned rb0 = rec_offset(eo + (unsigned)R0), rpitch12 = (unsigned)pitch * 12u;  // rpitch12: scalar
         unsigned ppv[NPR + 1];     // reference pairs
         unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2 (< 2^24)
         float gv[2 * NPR + 1];
@@ -241,7 +249,7 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
             pp = (unsigned)v.lds_ref[(2 * m) * v.lds_ref_pitch + X];
             if (2 * m + 1 < TPH) pp |= (unsigned)v.lds_ref[(2 * m + 1) * v.lds_ref_pitch + X] << 16;
           }
-          const PairRec pg = ld_rec(v.rpg, em + (unsigned)R0);
+          const PairRec pg = ld_rec(v.rpg, rb0 + (unsigned)m * rpitch12);
           const unsigned pr = pg.c;
           const unsigned prn = (unsigned)wave_shl1((int)pr);
           gv[2 * m] = pg.x;
@@ -366,13 +374,15 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         // samples 0 .. TPW of the lane's row = TPW + 1 consecutive image columns from ipx_r: whole pairs of the
         // alignment ipx_r & 1 (group-uniform, may differ between the groups of a wavefront)
         constexpr int NPC = (TPW + 2) / 2;
-        const unsigned e0 = (unsigned)(ipx_r & 1) * v.cp_stride + (unsigned)(ipx_r >> 1) * (unsigned)pt + (unsigned)Y;
+        // (both factors < 2^16: the 24-bit multiply is exact and full rate)
+        const unsigned e0 = ((ipx_r & 1) ? v.cp_stride : 0u) + __umul24((unsigned)(ipx_r >> 1), (unsigned)pt) + (unsigned)Y;
+        const unsigned cb0 = rec_offset(e0), cpitch12 = (unsigned)pt * 12u;  // cpitch12: scalar
         unsigned prv[NPC];
         float gv[2 * NPC + 1];
 #pragma unroll
         for (int m = 0; m < NPC; ++m) {
           const unsigned em = e0 + (unsigned)(m * pt);
-          const PairRec pg = ld_rec(v.cpg, em);
+          const PairRec pg = ld_rec(v.cpg, cb0 + (unsigned)m * cpitch12);
           prv[m] = pg.c;
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
@@ -383,7 +393,12 @@ __device__ __forceinline__ RunStep2 run_step2(const View& v, const PlaneSet& ps,
         constexpr int NQ = (TPW + 3) / 4;
         unsigned rc4[NQ], rg4[NQ];
         if constexpr (LREF) {
-          const unsigned* rr = v.lds_ref4 + Y * kLref4Stride;
+          unsigned y8 = (unsigned)Y << 3;     // Y * kLref4Stride (7) as a shift and a subtraction; opaque, or the
+          asm volatile("" : "+v"(y8));       // optimiser turns it back into a (quarter-rate, 64-bit) multiply-add
+          unsigned y7 = y8 - (unsigned)Y;
+          asm volatile("" : "+v"(y7));
+          const unsigned* rr = v.lds_ref4 + y7;
+          static_assert(kLref4Stride == 7, "row stride of the staged reference bytes");
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
             rc4[q] = rr[q];
