@@ -190,9 +190,11 @@ __device__ __forceinline__ int cpu_tap_grad(int left_g8, float g0, float g1, con
 // v_sad_u8 adds the absolute differences of all four bytes of its operands; `left` and the colour
 // sample are < 256, so only byte 0 contributes.
 // The colour lerp sum as ONE v_dot2_u32_u16: r01 = r0 | r1 << 16, w = cpu_color_weights().  Both weights are
-// clamped to 65535 so that they fit 16 bits: a weight of 65536 happens only when the other one is 0 (a <= 2^-17 or
-// 1 - a <= 2^-17: the other product rounds to 0), and then r * 65535 + 2^15 = r * 65536 + (2^15 - r) has the same
-// byte 2 (= r) as r * 65536 + 2^15.  Only byte 2 of the result -- the sample -- may be used.
+// clamped to 65535 so that they fit 16 bits: a weight of 65536 happens only next to a = 0 or a = 1, where the other
+// weight is 0 or 1, and then r * 65535 + r' * k + 2^15 = r * 65536 + (2^15 + r' * k - r) has the same byte 2 (= r)
+// as r * 65536 + r' * k + 2^15 (the low part stays within [0, 2^16)): checked for every pair that occurs by
+// tests/test_oracle_primitives.py::test_lerp_weights_fit_16_bits_when_clamped.  Only byte 2 of the result -- the
+// sample -- may be used.
 typedef unsigned short pm_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cpu_color_weights(const CpuLerp& l) {
   return (unsigned)min(l.a11, 65535) | ((unsigned)min(l.a12, 65535) << 16);

@@ -131,3 +131,51 @@ def test_mean_from_sum_is_exact():
             e2 = (sf * lo).astype(np.float32)
             got = (p + (e1 + e2).astype(np.float32)).astype(np.float32)
             assert np.array_equal(got, want), (pw, ph)
+
+
+def test_lerp_weights_fit_16_bits_when_clamped():
+    """The sweep kernels pack the fixed-point lerp weights a11 = rint((1 - a) * 65536), a12 = rint(a * 65536) into
+    16 bits each (v_dot2_u32_u16) by clamping them to 65535 (pm_device.hpp::cpu_color_weights).  A weight of 65536
+    only ever meets a weight of 0 or 1 (a within one ulp-of-1 of 2^-17), and for every such pair the clamped sum
+    r0 * min(a11, 65535) + r1 * min(a12, 65535) + 2^15 has the same byte 2 -- the sample -- as the unclamped one, for
+    all bytes r0, r1.  Pairs collected from every a = i / 2^24, the floats next to 0, 1 and the ties, random floats."""
+    def weights(a):
+        a = a.astype(np.float32)
+        ia = (np.float32(1.0) - a).astype(np.float32)
+        a11 = np.rint((ia * np.float32(65536.0)).astype(np.float32)).astype(np.int64)
+        a12 = np.rint((a * np.float32(65536.0)).astype(np.float32)).astype(np.int64)
+        return a11, a12
+
+    chunks = [np.arange(0, 1 << 24, dtype=np.float64) / float(1 << 24)]
+    near = [np.float32(0.0)]
+    x = np.float32(0.0)
+    for _ in range(64):
+        x = np.nextafter(x, np.float32(1.0))
+        near.append(x)
+    x = np.float32(1.0)
+    for _ in range(64):
+        x = np.nextafter(x, np.float32(0.0))
+        near.append(x)
+    for e in (2.0 ** -17, 2.0 ** -16, 1 - 2.0 ** -17, 1 - 2.0 ** -16):
+        c = np.float32(e)
+        lo = hi = c
+        near.append(c)
+        for _ in range(64):
+            lo, hi = np.nextafter(lo, np.float32(0.0)), np.nextafter(hi, np.float32(1.0))
+            near += [lo, hi]
+    chunks.append(np.array(near, np.float64))
+    chunks.append(np.random.default_rng(3).random(1 << 20))
+    extreme = set()
+    for ch in chunks:
+        a = ch[ch < 1.0]
+        a11, a12 = weights(a)
+        assert a11.min() >= 0 and a12.min() >= 0 and a11.max() <= 65536 and a12.max() <= 65536
+        m = (a11 == 65536) | (a12 == 65536)
+        extreme |= set(zip(a11[m].tolist(), a12[m].tolist()))
+    assert (65536, 0) in extreme and (0, 65536) in extreme and len(extreme) <= 6, extreme
+    r0, r1 = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+    for a11, a12 in extreme:
+        assert min(a11, a12) <= 1, (a11, a12)
+        full = (r0 * a11 + r1 * a12 + (1 << 15)) >> 16
+        clamped = (r0 * min(a11, 65535) + r1 * min(a12, 65535) + (1 << 15)) >> 16
+        assert full.max() <= 255 and np.array_equal(full & 0xff, clamped & 0xff), (a11, a12)
