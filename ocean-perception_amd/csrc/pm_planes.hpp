@@ -118,9 +118,16 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
   int stepj = 65536 - A;
   // opaque to the optimiser: otherwise it splits j * stepj into j * 65536 - j * A and spends three adds per tap
   asm volatile("" : "+v"(stepj));
+  // column offsets j * stepj by running additions, each made opaque: written as products they compile to one
+  // 64-bit v_mad_u64_u32 (quarter rate) per odd multiple and candidate
   int xoff[P];
+  xoff[0] = 0;
 #pragma unroll
-  for (int j = 0; j < P; ++j) xoff[j] = j * stepj;
+  for (int j = 1; j < P; ++j) {
+    int t = xoff[j - 1] + stepj;
+    asm volatile("" : "+v"(t));
+    xoff[j] = t;
+  }
   const int rowstep = (t.rw << 16) - B;
   unsigned sc = 0, sg = 0;
   // reference side: the lane's copy and dword column are fixed for the whole window (rows are whole dwords)
