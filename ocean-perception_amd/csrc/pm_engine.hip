@@ -104,6 +104,7 @@ struct pm_handle {
   bool capturing = false;
   bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
   hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
+  hipEvent_t left_out = nullptr;  // pm_match_u8: the left map has arrived in the pinned buffer
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -976,6 +977,7 @@ void pm_destroy(pm_handle* h) {
   pm_internal::release_imaging(h);
   if (h->ext_fork) (void)hipEventDestroy(h->ext_fork);
   if (h->ext_join) (void)hipEventDestroy(h->ext_join);
+  if (h->left_out) (void)hipEventDestroy(h->left_out);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->ev_pool) {
     (void)hipEventDestroy(r.start);
@@ -1417,26 +1419,48 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
   float* pdr = pdl + px;
   uint8_t* pl = (uint8_t*)(pdr + px);
   uint8_t* pr = pl + px;
-  for (int y = 0; y < rows; ++y) {
-    std::memcpy(pl + (size_t)y * cols, left + (size_t)y * image_step, (size_t)cols);
-    std::memcpy(pr + (size_t)y * cols, right + (size_t)y * image_step, (size_t)cols);
-    if (seed_l) std::memcpy(psl + (size_t)y * cols, (const char*)seed_l + (size_t)y * seed_step, sizeof(float) * cols);
-    if (seed_r) std::memcpy(psr + (size_t)y * cols, (const char*)seed_r + (size_t)y * seed_step, sizeof(float) * cols);
-  }
+  // every plane is packed into the pinned buffer and its upload enqueued at once: the DMA of one plane runs while
+  // the host packs the next
+  auto pack = [&](void* dst, const void* src, size_t step, size_t row_bytes) {
+    if (step == row_bytes) {
+      std::memcpy(dst, src, row_bytes * (size_t)rows);
+    } else {
+      for (int y = 0; y < rows; ++y)
+        std::memcpy((char*)dst + (size_t)y * row_bytes, (const char*)src + (size_t)y * step, row_bytes);
+    }
+  };
+  pack(pl, left, image_step, (size_t)cols);
   PM_HIP(h, hipMemcpyAsync(h->st_left, pl, px, hipMemcpyHostToDevice, h->stream));
+  pack(pr, right, image_step, (size_t)cols);
   PM_HIP(h, hipMemcpyAsync(h->st_right, pr, px, hipMemcpyHostToDevice, h->stream));
-  if (seed_l) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  if (seed_r) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  if (seed_l) {
+    pack(psl, seed_l, seed_step, sizeof(float) * (size_t)cols);
+    PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  }
+  if (seed_r) {
+    pack(psr, seed_r, seed_step, sizeof(float) * (size_t)cols);
+    PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
+  }
   if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
                                seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
+  // the left map is unpacked into the caller's buffer while the right one is still on the bus
+  if (!h->left_out) PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
   PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipEventRecord(h->left_out, h->stream));
   if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  auto unpack = [&](void* dst, const float* src) {
+    if (disp_step == sizeof(float) * (size_t)cols) {
+      std::memcpy(dst, src, sizeof(float) * px);
+    } else {
+      for (int y = 0; y < rows; ++y)
+        std::memcpy((char*)dst + (size_t)y * disp_step, src + (size_t)y * cols, sizeof(float) * cols);
+    }
+  };
+  PM_HIP(h, hipEventSynchronize(h->left_out));
+  unpack(disp_l, pdl);
   PM_HIP(h, hipStreamSynchronize(h->stream));
-  for (int y = 0; y < rows; ++y) {
-    std::memcpy((char*)disp_l + (size_t)y * disp_step, pdl + (size_t)y * cols, sizeof(float) * cols);
-    if (lr) std::memcpy((char*)disp_r + (size_t)y * disp_step, pdr + (size_t)y * cols, sizeof(float) * cols);
-  }
+  if (lr) unpack(disp_r, pdr);
   return PM_OK;
 }
 
