@@ -630,3 +630,15 @@ def test_plan_beyond_the_32_bit_plane_offsets_is_refused(pm):
     with pytest.raises(pm.PmError) as ex:
         pm.Engine(pm.default_params(0), max_rows=16384, max_cols=16384)
     assert ex.value.status == pm.PM_ERR_SIZE
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_product_engine_vs_serial_anchor():
+    """tools/fuzz_engines.py: random sizes / windows / iteration counts / noise schedules / seed fields (incl. sample
+    positions at the lerp-weight extremes), whole Match() of the product engine == the serial anchor, bit for bit.
+    (4500 cases were run when the packed-SAD / dot2 / record-plane kernels went in; 60 here.)"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "--cases", "60", "--seed", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
