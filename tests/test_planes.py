@@ -382,3 +382,15 @@ def test_full_size_properties(pm, oracle, synth, f16):
     drs = np.take_along_axis(dr, xt, axis=1)
     keep = np.abs(z0 - drs) <= 1.0
     assert_same(dl, np.where(keep, z0, 0).astype(np.float32), "consistency mask")
+
+
+@gpu
+def test_differential_fuzz_against_the_definition():
+    """tools/fuzz_planes.py: random sizes / windows 3..15 / iteration counts / disparity ranges / slope and schedule
+    constants / seeds / f32 and f16 state, whole Match() == oracle/pm_planes_oracle.c bit for bit (4000 cases were run
+    after the last kernel change; 40 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_planes.py"), "--cases", "40", "--seed", "9"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
