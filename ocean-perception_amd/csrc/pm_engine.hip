@@ -337,7 +337,9 @@ SeedParams seed_params(const pm_params& p) {
 // mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
   const size_t plane = (size_t)h->max_rows * h->max_pitch;
-  sc.cap = (int)(plane / 4 + 64);
+  // every pixel can be a candidate: the 3x3 test is not strict, so plateaus of EQUAL responses (periodic images) pass
+  // whole; a capacity of a quarter of the pixels dropped candidates there in whatever order the atomics fell
+  sc.cap = (int)(plane + 64);
   PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
   PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
   PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));

@@ -228,3 +228,33 @@ def test_response_window_sizes(pm, oracle, synth, block):
     assert_same(got, oracle.sparse_init(p["left"], p["right"], 4, oracle.seed_params(block_size=block)),
                 f"SparseInit block {block}")
     assert (got > 0).any()
+
+
+@pytest.mark.gpu
+def test_periodic_image_with_plateaus_of_equal_responses(pm, oracle):
+    """A periodic image gives thousands of IDENTICAL corner responses, whole plateaus of which pass the (non-strict)
+    3x3 test: more candidates than a quarter of the pixels.  The candidate list must hold them all (round 2: it did
+    not, and dropped some in atomic order) and ties are ordered by position like cv::goodFeaturesToTrack's sort."""
+    rows, cols = 390, 310
+    rng = np.random.default_rng(35)
+    tile = rng.integers(0, 256, (5, 7), dtype=np.uint8)
+    left = np.tile(tile, (rows // 5 + 1, cols // 7 + 1))[:rows, :cols].copy()
+    right = np.roll(left, -6, axis=1)
+    prm = pm.default_params(1, max_features_per_frame=600, min_distance_btw_features=5, gftt_quality_level=0.01,
+                            gftt_block_size=9, templ_cols=11, templ_rows=5, max_disp=100)
+    sp = oracle.seed_params(max_features=600, min_distance=5, quality_level=0.01, block_size=9, templ_cols=11,
+                            templ_rows=5, max_disp=100)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(left, right, 4)
+    assert_same(got, oracle.sparse_init(left, right, 4, sp), "periodic image SparseInit")
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_of_the_seeder():
+    """tools/fuzz_seed.py: random sizes, image kinds (scenes, noise, periodic, flat + blobs) and detector / matcher
+    parameters, device SparseInit == oracle bit for bit (2700 cases were run after the capacity fix; 50 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_seed.py"), "--cases", "50", "--seed", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
