@@ -110,3 +110,14 @@ def test_dist_comm_protocol_gloo():
     assert out[0] == (None, 1.0, True, False)
     assert out[1] == (0.0, 2.0, True, False)
     assert out[2] == (1.0, None, True, False)
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_tiled_vs_untiled():
+    """tools/fuzz_tiled.py: random sizes, band counts 2..6, windows, iteration counts, exchange rounds 0..3 (0 and 1
+    mostly end in the repeat path), both semantics: tiled == untiled bit for bit (2500 cases were run; 40 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_tiled.py"), "--cases", "40", "--seed", "8"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
