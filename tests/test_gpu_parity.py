@@ -642,3 +642,15 @@ def test_differential_fuzz_product_engine_vs_serial_anchor():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_engines.py"), "--cases", "60", "--seed", "5"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_of_the_entry_points():
+    """tools/fuzz_api.py: batches, the submit / collect queue at random depths, device-resident batches, strided host
+    buffers, sizes below the plan, captured graphs replayed on new data -- every entry point == pm_match_u8 of the
+    same parameters, both scalar semantics and the plane mode (4000 cases were run; 60 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "--cases", "60", "--seed", "6"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

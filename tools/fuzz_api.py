@@ -1,0 +1,135 @@
+"""Differential fuzz of the C-ABI entry points against the plain pm_match_u8 of the same handle parameters: batches
+(with and without per-slot seeds), the pipelined submit / collect queue at random depths, device-resident batches
+(pm_match_device on torch tensors), strided host buffers, image sizes below the plan, captured graphs replayed on new
+data, and one handle reused across sizes.  Bit-exact or it prints the case and exits 1.
+
+    python tools/fuzz_api.py [--cases 40] [--seed 1]
+"""
+import argparse, ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import pm_ctypes as pm
+import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=40)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+pm.load()
+rng = np.random.default_rng(a.seed)
+dev = torch.device("cuda:0")
+t0 = time.time()
+
+
+def same(x, y):
+    return all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+for case in range(a.cases):
+    sem = 0 if rng.random() < 0.7 else 1
+    patch = int(rng.choice([3, 5, 11])) if sem == 0 else 3
+    iters = int(rng.integers(1, 4))
+    mode_planes = sem == 0 and rng.random() < 0.25
+    max_rows, max_cols = int(rng.integers(60, 200)), int(rng.integers(100, 400))
+    rows = int(rng.integers(max(2 * patch + 8, max_rows // 2), max_rows + 1))
+    cols = int(rng.integers(max(2 * patch + 40, max_cols // 2), max_cols + 1))
+    n = int(rng.integers(1, 5))
+    kw = dict(mode=pm.PM_MODE_PLANES, max_disp=int(rng.choice([32, 64]))) if mode_planes else {}
+    params = pm.default_params(sem, patch=patch, patchmatch_iters=iters, **kw)
+    pairs = [synth.make_pair(int(rng.integers(0, 1000)), rows=rows, cols=cols, n_points=int(rng.integers(5, 50)),
+                             dilate_factor=int(rng.integers(1, 4))) for _ in range(n)]
+    seeded = [bool(rng.random() < 0.7) for _ in range(n)]
+    L = [p["left"] for p in pairs]
+    R = [p["right"] for p in pairs]
+    SL = [p["seed_l"] if s else None for p, s in zip(pairs, seeded)]
+    SR = [p["seed_r"] if s else None for p, s in zip(pairs, seeded)]
+    what = int(rng.integers(0, 5))
+    with pm.Engine(params, max_rows=max_rows, max_cols=max_cols, max_batch=n) as e:
+        want = [e.match(L[i], R[i], SL[i], SR[i]) for i in range(n)]
+        if what == 0:    # batch
+            dls, drs = e.match_batch(L, R, SL, SR)
+            got = list(zip(dls, drs))
+            name = "batch"
+        elif what == 1:  # pipelined queue
+            got, depth = [], int(rng.integers(1, 4))
+            for i in range(n):
+                if e.in_flight() >= depth:
+                    dl, dr, tag = e.collect()
+                    got.append((dl, dr))
+                e.submit(L[i], R[i], SL[i], SR[i], tag=i)
+            while e.in_flight():
+                dl, dr, tag = e.collect()
+                got.append((dl, dr))
+            name = f"submit/collect depth {depth}"
+        elif what == 2:  # device-resident batch
+            tl = torch.from_numpy(np.stack(L)).to(dev)
+            tr = torch.from_numpy(np.stack(R)).to(dev)
+            zero = np.zeros((rows, cols), np.float32)
+            any_seed = any(seeded)
+            tsl = torch.from_numpy(np.stack([s if s is not None else zero for s in SL])).to(dev) if any_seed else None
+            tsr = torch.from_numpy(np.stack([s if s is not None else zero for s in SR])).to(dev) if any_seed else None
+            if any_seed and not all(seeded):   # an all-zero map is "no seeds" for the scalar mode, not for the planes
+                want = [e.match(L[i], R[i], SL[i] if SL[i] is not None else zero, SR[i] if SR[i] is not None else zero)
+                        for i in range(n)]
+            dl = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
+            dr = torch.empty_like(dl)
+            torch.cuda.synchronize()
+            e.match_device(n, tl.data_ptr(), tr.data_ptr(), rows, cols, tsl.data_ptr() if any_seed else None,
+                           tsr.data_ptr() if any_seed else None, dl.data_ptr(), dr.data_ptr())
+            e.synchronize()
+            got = [(dl[i].cpu().numpy(), dr[i].cpu().numpy()) for i in range(n)]
+            name = "match_device"
+        elif what == 3:  # strided host buffers
+            got = []
+            for i in range(n):
+                pad_i, pad_s, pad_d = int(rng.integers(0, 40)), int(rng.integers(0, 9)), int(rng.integers(0, 9))
+                lw = np.zeros((rows, cols + pad_i), np.uint8); lw[:, :cols] = L[i]
+                rw = np.zeros((rows, cols + pad_i), np.uint8); rw[:, :cols] = R[i]
+                ol = np.full((rows, cols + pad_d), -7, np.float32)
+                orr = np.full((rows, cols + pad_d), -7, np.float32)
+                sl = sr = None
+                if SL[i] is not None:
+                    sl = np.zeros((rows, cols + pad_s), np.float32); sl[:, :cols] = SL[i]
+                    sr = np.zeros((rows, cols + pad_s), np.float32); sr[:, :cols] = SR[i]
+                rc = e.lib.pm_match_u8(e.h, lw.ctypes.data, rw.ctypes.data, rows, cols, cols + pad_i,
+                                       sl.ctypes.data if sl is not None else None, sr.ctypes.data if sr is not None else None,
+                                       4 * (cols + pad_s), ol.ctypes.data, orr.ctypes.data, 4 * (cols + pad_d))
+                assert rc == 0, rc
+                assert np.all(ol[:, cols:] == -7) and np.all(orr[:, cols:] == -7)
+                got.append((ol[:, :cols].copy(), orr[:, :cols].copy()))
+            name = "strided host buffers"
+        else:            # capture once, replay on every pair's data
+            if mode_planes:
+                got, name = want, "capture (skipped for the plane mode)"
+            else:
+                tl = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+                tr = torch.empty_like(tl)
+                tsl = torch.zeros((rows, cols), dtype=torch.float32, device=dev)
+                tsr = torch.zeros_like(tsl)
+                dl = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+                dr = torch.empty_like(dl)
+                torch.cuda.synchronize()
+                e.capture_begin()
+                e.match_device(1, tl.data_ptr(), tr.data_ptr(), rows, cols, tsl.data_ptr(), tsr.data_ptr(),
+                               dl.data_ptr(), dr.data_ptr())
+                e.capture_end()
+                got = []
+                zero = np.zeros((rows, cols), np.float32)
+                for i in range(n):
+                    tl.copy_(torch.from_numpy(L[i])); tr.copy_(torch.from_numpy(R[i]))
+                    tsl.copy_(torch.from_numpy(SL[i] if SL[i] is not None else zero))
+                    tsr.copy_(torch.from_numpy(SR[i] if SR[i] is not None else zero))
+                    torch.cuda.synchronize()
+                    e.replay()
+                    e.synchronize()
+                    got.append((dl.cpu().numpy(), dr.cpu().numpy()))
+                name = "capture + replay"
+    ok = all(same(g, w) for g, w in zip(got, want)) and len(got) == len(want)
+    print(f"case {case:3d}: {'planes' if mode_planes else 'sem %d' % sem} {cols}x{rows} (plan {max_cols}x{max_rows}) patch {patch} "
+          f"iters {iters} n {n} {name}: {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
+    if not ok:
+        sys.exit(1)
+print("all", a.cases, "cases bit-identical")
