@@ -258,3 +258,15 @@ def test_differential_fuzz_of_the_seeder():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_seed.py"), "--cases", "50", "--seed", "4"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_of_the_self_seeded_match():
+    """tools/fuzz_selfseed.py: Match() with sparse_init on (device SparseInit on both views, then the iterations) ==
+    the same composition of the oracles, both scalar semantics and the plane mode, random parameters (3000 cases were
+    run; 40 here)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_selfseed.py"), "--cases", "40", "--seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
