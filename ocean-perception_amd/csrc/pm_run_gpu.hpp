@@ -146,8 +146,9 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
         const unsigned col0 = (unsigned)(int)f0, col1 = (unsigned)(int)ceilf(s3[k]);
         const float tcol = s3[k] - f0;
         const unsigned lcol = (unsigned)min(max(chain - 1 + k, 0), cols - 1);
-        t[k] = gpu_tap_at(v.tref8, v.trefg, v.ttgt8, v.ttgtg, lcol * (unsigned)pt + Y, col0 * (unsigned)pt + Y,
-                          col1 * (unsigned)pt + Y, tcol, cp);
+        // column * pitch: both factors below 2^24, the 24-bit multiply is exact and full rate (v_mul_lo_u32 is not)
+        t[k] = gpu_tap_at(v.tref8, v.trefg, v.ttgt8, v.ttgtg, __umul24(lcol, (unsigned)pt) + Y,
+                          __umul24(col0, (unsigned)pt) + Y, __umul24(col1, (unsigned)pt) + Y, tcol, cp);
       }
       // rows y-1 / y+1 are the neighbour lanes; left / centre / right columns are t[0] / t[1] / t[2]
       float c = wave_shr1f(t[0]) + wave_shr1f(t[2]);
@@ -173,12 +174,9 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
       const float f0 = floorf(xs);
       const int col0 = (int)f0, col1 = (int)ceilf(xs);
       const float tcol = xs - f0;
-      const size_t lrow = (size_t)(y_r + dy) * pitch;
-      const float il = (float)v.ref8[lrow + x_r + dx];
-      const float gg = v.refg[lrow + x_r + dx];
-      const float r0 = (float)v.tgt8[lrow + col0], r1 = (float)v.tgt8[lrow + col1];
-      const float g0 = v.tgtg[lrow + col0], g1 = v.tgtg[lrow + col1];
-      s = gpu_tap(il, gg, r0, r1, g0, g1, tcol, cp);
+      const unsigned lrow = __umul24((unsigned)(y_r + dy), (unsigned)pitch);  // 32-bit offsets: no 64-bit multiply-adds
+      s = gpu_tap_at(v.ref8, v.refg, v.tgt8, v.tgtg, lrow + (unsigned)(x_r + dx), lrow + (unsigned)col0,
+                     lrow + (unsigned)col1, tcol, cp);
     }
     float c = 0.f + __shfl(s, gbase + 0, kWave);
     c = c + __shfl(s, gbase + 1, kWave);
