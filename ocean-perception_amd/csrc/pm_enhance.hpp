@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __res
 // the kernel writes orig / (2 * s) (0 where the divisor is 0), orig being the 8-bit (cast) or float source image.
 // A thread owns TWO adjacent columns (packed-f32 adds and multiplies: the same IEEE operations, two per
 // instruction) and walks its share of the tile's T output rows.
-// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = ((T + 2c) * W + c + 1) floats, W even.
+// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = ((T + 2c + 3) * W + c + 1) floats, W even.
 template <bool DIVIDE, bool ORIG_U8>
 __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp, int rows, int width, int ksize,
                                                    const float* __restrict__ taps, int W, int T,
@@ -132,11 +132,17 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
   const int c = ksize / 2;
   const int x0 = blockIdx.x * W, y0 = blockIdx.y * T;
   const int span = T + 2 * c;
-  float* s_k = lds + span * W;  // taps[c .. ksize-1]
-  for (int e = threadIdx.x; e < span * W; e += 256) {
-    const int r = e / W, w = e - r * W;
-    const int sy = clampi_d(y0 - c + r, 0, rows - 1), sx = min(x0 + w, width - 1);
-    lds[e] = tmp[(size_t)sy * width + sx];
+  float* s_k = lds + (span + 3) * W;  // taps[c .. ksize-1], behind three spare rows (the four-row windows of the last
+                                      // row group read up to three rows past the tile; those outputs are not stored)
+  {
+    // W is a power of two (8, 16 or 32): every thread keeps its column and walks down the rows -- no division per
+    // element (with a run-time W the fill cost more vector instructions than the taps)
+    const int fw = threadIdx.x & (W - 1), fr = threadIdx.x / W, fstep = 256 / W;
+    const int sx = min(x0 + fw, width - 1);
+    for (int r = fr; r < span; r += fstep) {
+      const int sy = clampi_d(y0 - c + r, 0, rows - 1);
+      lds[r * W + fw] = tmp[(size_t)sy * width + sx];
+    }
   }
   for (int e = threadIdx.x; e <= c; e += 256) s_k[e] = taps[c + e];
   __syncthreads();
@@ -145,16 +151,7 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
   const int x = x0 + w;
   if (x >= width) return;
   const float cast = (float)(1.0 / 255.0);
-  for (int yy = g; yy < T && y0 + yy < rows; yy += G) {
-    const float* col = lds + (yy + c) * W + w;
-    const float kc = s_k[0];
-    f2 s = *(const f2*)col * (f2){kc, kc};
-#pragma unroll 4
-    for (int j = 1; j <= c; ++j) {
-      const float kj = s_k[j];
-      const f2 pair = *(const f2*)(col + j * W) + *(const f2*)(col - j * W);
-      s = s + pair * (f2){kj, kj};
-    }
+  auto finish = [&](int yy, f2 s) {
     const size_t o = (size_t)(y0 + yy) * width + x;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -168,6 +165,50 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
         dst[o + u] = sv;
       }
     }
+  };
+  // FOUR consecutive output rows per thread: the samples S[y + r + j] and S[y + r - j] of the four rows r at tap j
+  // are two sliding windows of four values each, so a tap costs TWO new LDS reads for four outputs instead of eight
+  // (the one-row form spent 2 LDS reads per 3 vector instructions and was LDS-bound).  The windows live in
+  // registers as circular buffers indexed by (row offset & 3); the tap loop is unrolled by four so that every index
+  // is a compile-time constant.  Each output still adds its taps in the same order: bit-identical.
+  constexpr int RB = 4;
+  for (int yb = g * RB; yb < T && y0 + yb < rows; yb += G * RB) {
+    const float* col = lds + (yb + c) * W + w;  // S[y0 + yb] of this column pair
+    const float kc = s_k[0];
+    f2 acc[RB], up[RB], dn[RB];  // up[k & 3] = S[yb + k], k = j .. j + 3;  dn[k & 3] = S[yb + k], k = -j .. 3 - j
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const f2 v = *(const f2*)(col + r * W);
+      acc[r] = v * (f2){kc, kc};
+      up[r] = v;
+      dn[r] = v;
+    }
+    // before tap j: up holds S[yb + j - 1 .. yb + j + 2], dn holds S[yb - j + 1 .. yb - j + 4]
+    auto tap = [&](int j, int jm) {  // jm = j & 3 as a compile-time constant at every call site
+      // slide: up gains S[yb + j + 3] in place of S[yb + j - 1]; dn gains S[yb - j] in place of S[yb - j + 4]
+      up[(jm + 3) & 3] = *(const f2*)(col + (j + 3) * W);
+      dn[(4 - jm) & 3] = *(const f2*)(col - j * W);
+      const float kj = s_k[j];
+      const f2 kk = {kj, kj};
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const f2 pair = up[(r + jm) & 3] + dn[(r + 4 - jm) & 3];
+        acc[r] = acc[r] + pair * kk;
+      }
+    };
+    int j = 1;
+    for (; j + 3 <= c; j += 4) {  // j = 1 (mod 4) at the top
+      tap(j, 1);
+      tap(j + 1, 2);
+      tap(j + 2, 3);
+      tap(j + 3, 0);
+    }
+    if (j <= c) tap(j, 1);
+    if (j + 1 <= c) tap(j + 1, 2);
+    if (j + 2 <= c) tap(j + 2, 3);
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (yb + r < T && y0 + yb + r < rows) finish(yb + r, acc[r]);
   }
 }
 

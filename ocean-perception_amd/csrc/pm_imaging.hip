@@ -314,7 +314,7 @@ int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, in
   const int c = ksize / 2;
   int W = 0, T = 0;
   for (size_t kb : {32, 64}) {
-    const size_t budget = kb * 1024 - sizeof(float) * (size_t)(c + 1);
+    const size_t budget = kb * 1024 - sizeof(float) * (size_t)(c + 1 + 3 * 32);  // taps + three spare rows
     W = 32;
     while (W > 8 && (size_t)(32 + 2 * c) * W * sizeof(float) > budget) W /= 2;
     T = (int)(budget / (sizeof(float) * W)) - 2 * c;
@@ -326,7 +326,7 @@ int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, in
     return PM_ERR_SIZE;
   }
   const int width = cols * ch;
-  const size_t col_lds = sizeof(float) * ((size_t)(T + 2 * c) * W + c + 1);
+  const size_t col_lds = sizeof(float) * ((size_t)(T + 2 * c + 3) * W + c + 1);
   const dim3 cgrid((unsigned)((width + W - 1) / W), (unsigned)((rows + T - 1) / T));
   if (divide)
     hipLaunchKernelGGL((k_blur_cols<true, SRC_U8>), cgrid, dim3(256), col_lds, pm_internal::stream(h), (const float*)state_of(h)->enh_tmp, rows,
