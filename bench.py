@@ -61,7 +61,7 @@ def parse():
                     help="pairs matched per step and GPU (1 = BASELINE configs[1]; 32 = configs[2]'s per-GPU share)")
     ap.add_argument("--self-seed", action="store_true",
                     help="let Match() compute its seeds with the device SparseInit (side measurement)")
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=8,
                     help="per-kernel HIP events are recorded on every n-th timed step (the ~180 event records of a "
                          "fully timed step cost 6 %% of the step; 1 = every step)")
     ap.add_argument("--no-profile", action="store_true",
