@@ -15,6 +15,8 @@ import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--big", action="store_true", help="sizes up to 2600 x 1800: chains beyond 1600 positions (8 wavefronts per chain),\n"
+                "column sweeps whose reference lines no longer fit the LDS budget")
 a = ap.parse_args()
 pm.load()
 rng = np.random.default_rng(a.seed)
@@ -24,6 +26,8 @@ for case in range(a.cases):
     patch = int(rng.choice([3, 5, 7, 9, 11])) if sem == 0 else 3
     rows = int(rng.integers(2 * patch + 8, 260))
     cols = int(rng.integers(2 * patch + 40, 700))
+    if a.big:
+        rows, cols = int(rng.integers(300, 1800)), int(rng.integers(500, 2600))
     iters = int(rng.integers(1, 9))
     amp0 = float(rng.choice([32.0, 8.0, 2.0, 0.75]))
     noise = [amp0 / (2 ** i) for i in range(iters)]
