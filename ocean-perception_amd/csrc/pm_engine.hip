@@ -18,6 +18,7 @@
 #include "pm_kernels.hpp"
 #include "pm_wave.hpp"
 #include "pm_run2.hpp"
+#include "pm_run3.hpp"
 #include "pm_internal.hpp"
 #include "pm_seed.hpp"
 #include "pm_planes.hpp"
@@ -493,7 +494,14 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else {
     const int group = runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir);
-    launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
+    static const bool run3 = [] {
+      const char* e = getenv("PM_RUN3");
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (cp.semantics == PM_SEM_CPU && run3)
+      launch_sweep_run3(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
+    else
+      launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
   }
   return launch_check(h, "sweep");
 }

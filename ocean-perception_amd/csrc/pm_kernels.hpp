@@ -140,7 +140,11 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
     // one 12-byte record per pair element: the two gradients and the two colour bytes -- ONE load in the sweeps
     ps.rpg[3 * dst] = ps.g32[tp + src0];
     ps.rpg[3 * dst + 1] = ps.g32[tp + src1];
-    ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8);
+    // colours: byte 0 / 1 = the two lines at column e, byte 2 / 3 = the same lines at column e + 1 (replicated at the
+    // border like cv::getRectSubPix): both bilinear taps of both lines without a cross-lane move
+    const int e1 = min(e + 1, ps.cols - 1) - e;
+    ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8) |
+                                       ((uint32_t)ps.img8[tp + src0 + e1] << 16) | ((uint32_t)ps.img8[tp + src1 + e1] << 24);
   } else {
     if (e >= ps.rows || k >= ps.npc) return;
     const int lmax = ps.cols + kTransPad - 1;

@@ -1,0 +1,597 @@
+// pm_run3.hpp -- PM_ENGINE_RUNBLK2 for PM_SEM_CPU: the run step with its decisions on the scalar unit.
+//
+// The run step itself (one candidate value tested at up to GS - win consecutive positions of a chain segment, lane =
+// window LINE, window sums as a sliding sum across lanes, segments + fix-up rounds) is described in pm_run2.hpp.
+// Round-2 counters showed the sweeps bound by vector-instruction issue, with ~70 of a step's 168 vector instructions
+// spent on DECISIONS, not on taps: every ballot was shifted into the lane's group by a 64-bit vector shift, turned
+// into "first position" indices by vector ffs / min / select chains, and broadcast back by ds_bpermute.  Here
+//   * every predicate is ONE v_cmp into a 64-bit scalar mask and all logic on the masks runs on the scalar unit, for
+//     the two or four groups of the wavefront at once (fields of 32 / 16 bits, SWAR):  a sentinel bit behind the
+//     last position of every field makes "x - 1 per field" borrow-free, so `x & ~(x - F)` is the first stopping
+//     position of every group and `that - F0` the positions the run passed;
+//   * lanes always sit in SWEEP order: a backward sweep mirrors the lane -> line mapping (the loads stay coalesced,
+//     the neighbour tap comes from lane - 1 instead of lane + 1), so no mask is ever bit-reversed;
+//   * "same bilinear parameters as the step's first position" is an exponent compare: within one binade of
+//     fl(x - d) the float grid is invariant under integer shifts of x, so fl((x + k) - d) = fl(x - d) + k exactly
+//     and fraction and column offset agree; positions in another binade wait for the next step (as before);
+//   * the candidate of a group lives in an LDS slot: the rejecting lane stores its value, everybody reads it back
+//     (no ds_bpermute address arithmetic); a lane's chain index advances by a popcount of its group's field;
+//   * chain state is one float2 array per direction (one ds_read_b64 / ds_write_b64 per step);
+//   * 16-lane groups add up their window lines with row_shl DPP in log steps (5 adds for 11 lines instead of 10).
+// Results are bit-identical to the serial engine, the wave engine and the oracle (tests/test_gpu_parity.py,
+// tools/fuzz_engines.py).
+#pragma once
+
+#include "pm_run2.hpp"
+
+namespace pm {
+
+template <int GS> struct Fields;
+template <> struct Fields<16> { static constexpr unsigned long long lsb = 0x0001000100010001ull; };
+template <> struct Fields<32> { static constexpr unsigned long long lsb = 0x0000000100000001ull; };
+
+__device__ __forceinline__ unsigned long long mask_of(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// lane predicate from a wave-uniform mask: the mask is used as it is (exec / vcc), no vector instruction
+__device__ __forceinline__ bool in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// lane l <- lane l + N of its 16-lane row (DPP row_shl:N); lanes without a source read 0
+template <int N>
+__device__ __forceinline__ int row_shl(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true);
+}
+// the lane holding the next line in increasing image coordinate: lane + 1 in a forward sweep, lane - 1 in a backward
+// one (wave_shl:1 / wave_shr:1; the lane without a source reads 0: it is the group's spare line)
+template <int DIR>
+__device__ __forceinline__ int next_line_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, DIR > 0 ? 0x130 : 0x138, 0xF, 0xF, true);
+}
+template <int DIR>
+__device__ __forceinline__ float next_line_f(float v) {
+  return __builtin_bit_cast(float, next_line_i<DIR>(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int clamp_med3(int x, int hi) {  // min(max(x, 0), hi) as one v_med3_i32
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
+}
+
+// sum of the `win` lines l .. l + win - 1 (packed colour | gradient << 16 sums) in every lane l that is a position
+template <int GS, int WIN>
+__device__ __forceinline__ int window_sum(int line, int win) {
+  if constexpr (GS == 16 && WIN >= 3 && WIN <= 11) {
+    const int s2 = line + row_shl<1>(line);
+    if constexpr (WIN == 3) return s2 + row_shl<2>(line);
+    const int s4 = s2 + row_shl<2>(s2);
+    if constexpr (WIN == 5) return s4 + row_shl<4>(line);
+    if constexpr (WIN == 7) return (s4 + row_shl<4>(s2)) + row_shl<6>(line);
+    const int s8 = s4 + row_shl<4>(s4);
+    if constexpr (WIN == 9) return s8 + row_shl<8>(line);
+    return (s8 + row_shl<8>(s2)) + row_shl<10>(line);
+  } else {
+    int w = line;
+    if constexpr (WIN > 0) {
+#pragma unroll
+      for (int t = 1; t < WIN; ++t) w = line + wave_shl1(w);
+    } else {
+      for (int t = 1; t < win; ++t) w = line + wave_shl1(w);
+    }
+    return w;
+  }
+}
+
+// The LDS word that carries a group's candidate from the rejecting lane to the others: volatile keeps the accesses in
+// program order, the explicit address space keeps them ds_read / ds_write (a volatile generic pointer is a flat access).
+typedef __attribute__((address_space(3))) volatile float* LdsSlot;
+
+// per-lane constants of the kernel
+struct Run3Lane {
+  int gl, gbase;
+  int mpos;          // position of the lane inside a step (lane - POS0); < 0 or >= nd: a line-only lane
+  float dmposf;      // (float)(DIR * mpos)
+  int rofs;          // row sweeps: target column of the lane's line minus the first target column of the step
+  int lim;           // segment end for position lanes of an active segment, INT_MIN otherwise
+};
+
+// TP = square window 3 .. 11, or 0: any window from cp (GS = 32).  One step of every group of the wavefront.
+// inr_m: lanes whose position exists (inside their segment, group still running).
+template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX>
+__device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g,
+                                          int chain, const Run3Lane& k, unsigned long long inr_m, int& ipm,
+                                          const float2* din2, float2* dout2, LdsSlot cand_slot,
+                                          unsigned long long& merged_fill) {
+  const int pitch = ps.pitch, cols = ps.cols, rows = ps.rows;
+  const int pw = TP > 0 ? TP : cp.pw, ph = TP > 0 ? TP : cp.ph;
+  const int half_w = pw / 2, half_h = ph / 2;
+  const int win = AXIS == 0 ? pw : ph;
+  const int half = win / 2;
+  const int nd = AXIS == 0 ? GS - pw : GS - ph + 1;
+  constexpr int POS0 = (AXIS == 0 && DIR < 0) ? 1 : 0;
+  constexpr unsigned long long F = Fields<GS>::lsb;
+  constexpr unsigned long long F0 = F << POS0;
+  const unsigned long long S = F << (POS0 + nd);
+  const unsigned long long POSM = S - F0;
+  const float shift = (float)(pw - 1) * 0.5f;
+
+  // ---- state of the lane's position and the group's candidate -------------------------------------------------------
+  float d0 = 0.f, c0 = 0.f;
+  if (in_mask(inr_m)) {
+    const float2 t = din2[ipm + 1];
+    d0 = t.x;
+    c0 = t.y;
+  }
+  const float cand = *cand_slot;
+  const unsigned long long neutral_m = mask_of(d0 == cand) & inr_m;
+  const unsigned long long need_m = inr_m & ~neutral_m;
+
+  const int pos = g.s_first + DIR * ipm;  // image column (row sweep) / row (column sweep) of the lane's position
+  float cx, cx0;                          // x - d of the lane's position and of the step's first position
+  if (AXIS == 0) {
+    const float posf = (float)pos;
+    cx = posf - cand;
+    cx0 = (posf - k.dmposf) - cand;
+  } else {
+    cx = cx0 = (float)chain - cand;
+  }
+  const unsigned long long valid_m = mask_of(cx >= (float)half_w);  // patchmatch.cpp:186
+  // same sign and exponent as the first position's x - d: same bilinear fraction and column offset (header)
+  const unsigned long long same_m =
+      AXIS == 0 ? mask_of((__builtin_bit_cast(unsigned, cx) ^ __builtin_bit_cast(unsigned, cx0)) < 0x00800000u) : ~0ull;
+  const float t0 = cx0 - shift;
+  const float fl0 = floorf(t0);
+  const float a_r = t0 - fl0;
+  const int ipx_r = (int)fl0;  // first target column of the first position's window
+
+  float cost = 0.f;
+  if ((need_m & valid_m) != 0ull) {  // some lane may adopt: the wavefront evaluates (groups without need compute along)
+    const float ia_r = 1.f - a_r;
+    unsigned sc = 0, sg = 0;
+    if constexpr (TP > 0) {
+      // colour weights cvRound(w * 2^16), clamped to 16 bits (pm_device.hpp::cpu_color_weights): w * 2^16 is exact, so
+      // adding 2^23 rounds it to the nearest-even integer, which then sits in the low mantissa bits
+      const float m_a = __builtin_fmaf(a_r, 65536.f, 8388608.f), m_ia = __builtin_fmaf(ia_r, 65536.f, 8388608.f);
+      const float cap = __builtin_bit_cast(float, 0x4b00ffffu);  // 2^23 + 65535
+      const unsigned cw = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, fminf(m_a, cap)),
+                                                __builtin_bit_cast(unsigned, fminf(m_ia, cap)), 0x05040100u);
+      const f32x2 ia2 = {ia_r, ia_r}, a2 = {a_r, a_r};
+      if constexpr (AXIS == 0) {
+        // lane = image column X (its own position's column -+ half), window rows in the lane, two per load
+        constexpr int NPR = (TP + 1) / 2, NQR = (TP + 3) / 4;
+        const int y0 = chain - half_h;  // wave-uniform
+        const unsigned eo12 = ((unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch) * 12u;
+        const unsigned rpitch12 = (unsigned)pitch * 12u;
+        const int X = clamp_med3(pos - DIR * half, cols - 1);
+        const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
+        unsigned r3 = ((unsigned)R0 << 1) + (unsigned)R0;
+        asm volatile("" : "+v"(r3));  // opaque: keeps 12 * R0 a shift-add (no quarter-rate v_mul_lo_u32)
+        const unsigned rb0 = (r3 << 2) + eo12;
+        unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
+        float gv[2 * NPR + 1];
+#pragma unroll
+        for (int m = 0; m < NPR; ++m) {
+          const PairRec pg = ld_rec(v.rpg, rb0 + (unsigned)m * rpitch12);
+          gv[2 * m] = pg.x;
+          gv[2 * m + 1] = pg.y;
+          // record colours: byte 0 / 1 = rows 2m / 2m + 1 at column R0, byte 2 / 3 = the same rows at R0 + 1
+          tcol[2 * m] = cpu_color_sum_pk(__builtin_amdgcn_perm(pg.c, pg.c, 0x0c020c00u), cw);
+          tcol[2 * m + 1] = cpu_color_sum_pk(__builtin_amdgcn_perm(pg.c, pg.c, 0x0c030c01u), cw);
+        }
+        tcol[2 * NPR] = tcol[2 * NPR + 1] = 0u;
+        gv[2 * NPR] = 0.f;
+        float sgr[2 * NPR];  // gradient lerp sums g0 * (1 - a) + g1 * a, g1 = the next line's g0
+#pragma unroll
+        for (int t = 0; t < TP; t += 2) {
+          const f32x2 gg = {gv[t], gv[t + 1]};
+          const f32x2 pa = gg * ia2, pb = gg * a2;
+          sgr[t] = pa.x + next_line_f<DIR>(pb.x);
+          if (t + 1 < TP) sgr[t + 1] = pa.y + next_line_f<DIR>(pb.y);
+        }
+        unsigned rq_c[NQR], rq_g[NQR];  // reference bytes of four window rows per dword (quad plane of this alignment)
+        {
+          const unsigned eq8 = ((unsigned)(y0 & 3) * v.rq_stride + (unsigned)(y0 >> 2) * (unsigned)pitch) << 3;
+          const unsigned qb0 = ((unsigned)X << 3) + eq8, qpitch8 = (unsigned)pitch << 3;
+#pragma unroll
+          for (int q = 0; q < NQR; ++q) {
+            const uint2 rr = *(const uint2*)((const char*)v.rqk + (size_t)(qb0 + (unsigned)q * qpitch8));
+            const int rem = TP - 4 * q;
+            const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+            rq_c[q] = rr.x & mask;
+            rq_g[q] = rr.y & mask;
+          }
+        }
+#pragma unroll
+        for (int q = 0; 4 * q < TP; ++q) {  // four rows per v_sad_u8
+          const int r0 = 4 * q;
+          const bool h1 = r0 + 1 < TP, h2 = r0 + 2 < TP, h3 = r0 + 3 < TP;
+          const unsigned u = __builtin_amdgcn_perm(tcol[r0 + 1], tcol[r0], h1 ? 0x0c0c0602u : 0x0c0c0c02u);
+          unsigned s4 = u;
+          if (h2) {
+            const unsigned w = __builtin_amdgcn_perm(tcol[r0 + 3], tcol[r0 + 2], h3 ? 0x0c0c0602u : 0x0c0c0c02u);
+            s4 = (w << 16) | u;
+          }
+          unsigned g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0], 0, 0u);
+          if (h1) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 1], 1, g4);
+          if (h2) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 2], 2, g4);
+          if (h3) g4 = __builtin_amdgcn_cvt_pk_u8_f32(sgr[r0 + 3], 3, g4);
+          sc = __builtin_amdgcn_sad_u8(rq_c[q], s4, sc);
+          sg = __builtin_amdgcn_sad_u8(rq_g[q], g4, sg);
+        }
+      } else {
+        // lane = image row Y (transposed planes), window columns in the lane: samples 0 .. TP of the lane's row are
+        // TP + 1 consecutive image columns from ipx_r, whole pairs of the alignment ipx_r & 1
+        constexpr int NPC = (TP + 2) / 2, NQ = (TP + 3) / 4;
+        const int pt = ps.pitch_t;
+        const int Y = clamp_med3(pos - DIR * half, rows - 1);
+        const int ipx_c = clamp_med3(ipx_r, cols - 1);  // (a group that cannot adopt may carry any ipx_r)
+        const unsigned e0 =
+            ((ipx_c & 1) ? v.cp_stride : 0u) + __umul24((unsigned)(ipx_c >> 1), (unsigned)pt) + (unsigned)Y;
+        const unsigned cb0 = rec_offset(e0), cpitch12 = (unsigned)pt * 12u;
+        unsigned prv[NPC];
+        float gv[2 * NPC + 1];
+#pragma unroll
+        for (int m = 0; m < NPC; ++m) {
+          const PairRec pg = ld_rec(v.cpg, cb0 + (unsigned)m * cpitch12);
+          prv[m] = pg.c;
+          gv[2 * m] = pg.x;
+          gv[2 * m + 1] = pg.y;
+        }
+        gv[2 * NPC] = 0.f;
+        unsigned rc4[NQ], rg4[NQ];  // reference bytes of the lane's row, four window columns per dword
+        if constexpr (LREF) {
+          unsigned y8 = (unsigned)Y << 3;  // Y * kLref4Stride (7) as a shift and a subtraction, opaque (no multiply)
+          asm volatile("" : "+v"(y8));
+          unsigned y7 = y8 - (unsigned)Y;
+          asm volatile("" : "+v"(y7));
+          const unsigned* rr = v.lds_ref4 + y7;
+          static_assert(kLref4Stride == 7, "row stride of the staged reference bytes");
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            rc4[q] = rr[q];
+            rg4[q] = rr[NQ + q];
+          }
+        } else {
+          const int lorg = (chain - half_w) * pt;
+          unsigned pkv[4 * NQ];
+#pragma unroll
+          for (int t = 0; t < 4 * NQ; ++t)
+            pkv[t] = t < TP ? (unsigned)ld_u16(v.trefpk, (unsigned)((Y + lorg + t * pt) * 2)) : 0u;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const unsigned lo = __builtin_amdgcn_perm(pkv[4 * q + 1], pkv[4 * q], 0x05010400u);      // c0 c1 g0 g1
+            const unsigned hi = __builtin_amdgcn_perm(pkv[4 * q + 3], pkv[4 * q + 2], 0x05010400u);  // c2 c3 g2 g3
+            rc4[q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            rg4[q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+          }
+        }
+        unsigned tcol[4 * NQ];
+#pragma unroll
+        for (int t = 0; t < 4 * NQ; ++t) {
+          if (t < TP) {
+            // samples t, t + 1 as halfwords: both in pair t / 2 (t even) or one in each of two pairs (t odd)
+            const unsigned r01 = (t % 2 == 0) ? __builtin_amdgcn_perm(0u, prv[t / 2], 0x0c010c00u)
+                                              : __builtin_amdgcn_perm(prv[t / 2 + 1], prv[t / 2], 0x0c040c01u);
+            tcol[t] = cpu_color_sum_pk(r01, cw);
+          } else {
+            tcol[t] = 0u;
+          }
+        }
+        f32x2 pa[NPC], pb[NPC];
+#pragma unroll
+        for (int m = 0; m < NPC; ++m) {
+          const f32x2 gg = {gv[2 * m], gv[2 * m + 1]};
+          pa[m] = gg * ia2;
+          pb[m] = gg * a2;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {  // four window columns per v_sad_u8
+          const int t0q = 4 * q;
+          const bool h1 = t0q + 1 < TP, h2 = t0q + 2 < TP, h3 = t0q + 3 < TP;
+          const unsigned u = __builtin_amdgcn_perm(tcol[t0q + 1], tcol[t0q], h1 ? 0x0c0c0602u : 0x0c0c0c02u);
+          unsigned s4 = u;
+          if (h2) {
+            const unsigned w = __builtin_amdgcn_perm(tcol[t0q + 3], tcol[t0q + 2], h3 ? 0x0c0c0602u : 0x0c0c0c02u);
+            s4 = (w << 16) | u;
+          }
+          unsigned g4 = 0u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int t = t0q + j;
+            if (t < TP) g4 = __builtin_amdgcn_cvt_pk_u8_f32(pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2], j, g4);
+          }
+          sc = __builtin_amdgcn_sad_u8(rc4[q], s4, sc);
+          sg = __builtin_amdgcn_sad_u8(rg4[q], g4, sg);
+        }
+      }
+    } else {
+      // any window: one load per tap and plane (the form of pm_device.hpp::cpu_cost_lane, one line per lane)
+      CpuLerp l;
+      l.a = a_r;
+      l.ia = ia_r;
+      l.a11 = __float2int_rn(ia_r * 65536.f);
+      l.a12 = __float2int_rn(a_r * 65536.f);
+      l.ipx = 0;
+      if constexpr (AXIS == 0) {
+        const int X = clamp_med3(pos - DIR * half, cols - 1);
+        const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
+        const int org = (chain - half_h) * pitch;
+        for (int t = 0; t < ph; ++t) {
+          const int so = org + t * pitch;
+          const int l8 = ld_u8(v.ref8, (unsigned)(X + so));
+          const int lg = ld_u8(v.refg8, (unsigned)(X + so));
+          const int r0 = ld_u8(v.tgt8, (unsigned)(R0 + so));
+          const float g0 = ld_f32(v.tgtg, (unsigned)(R0 + so) * 4u);
+          sc = cpu_acc_color(sc, l8, r0, next_line_i<DIR>(r0), l);
+          sg = cpu_acc_grad(sg, lg, g0, next_line_f<DIR>(g0), l);
+        }
+      } else {
+        const int pt = ps.pitch_t;
+        const int Y = clamp_med3(pos - DIR * half, rows - 1);
+        const int ipx_c = clamp_med3(ipx_r, cols - 1);
+        const int vb = ipx_c * pt + Y;
+        const int lorg = (chain - half_w) * pt;
+        int r0 = ld_u8(v.ttgt8, (unsigned)vb);
+        float g0 = ld_f32(v.ttgtg, (unsigned)vb * 4u);
+        for (int t = 0; t < pw; ++t) {
+          const int lso = lorg + t * pt, rso = (t + 1) * pt;
+          const int l8 = ld_u8(v.tref8, (unsigned)(Y + lso));
+          const int lg = ld_u8(v.trefg8, (unsigned)(Y + lso));
+          const int r1 = ld_u8(v.ttgt8, (unsigned)(vb + rso));
+          const float g1 = ld_f32(v.ttgtg, (unsigned)(vb + rso) * 4u);
+          sc = cpu_acc_color(sc, l8, r0, r1, l);
+          sg = cpu_acc_grad(sg, lg, g0, g1, l);
+          r0 = r1;
+          g0 = g1;
+        }
+      }
+    }
+    const int wsum = window_sum<GS, TP>((int)(sc | (sg << 16)), win);
+    cost = cpu_cost_from_sums(wsum & 0xffff, (int)((unsigned)wsum >> 16), cp);
+  }
+
+  // ---- decisions: scalar unit, all groups at once -----------------------------------------------------------------
+  // The run passes a position iff it ends up holding `cand`: already equal (neutral) or adopted (needs an allowed
+  // candidate, the step's bilinear parameters and a strictly smaller cost).  The first position that does not pass
+  // is decided in this step if its candidate is not allowed at all or was evaluated with its own parameters; then
+  // it keeps its value, which becomes the next candidate.  Otherwise the next step starts there.
+  const unsigned long long lt_m = mask_of(cost < c0);
+  const unsigned long long adopt_m = need_m & valid_m & same_m & lt_m;
+  const unsigned long long stop_m = (POSM & ~(neutral_m | adopt_m)) | S;
+  const unsigned long long q_m = stop_m & ~(stop_m - F);   // one bit per group: its first stop (or the sentinel)
+  const unsigned long long passed_m = q_m - F0;            // positions before it
+  const unsigned long long real_m = q_m & inr_m & (~valid_m | same_m);  // the stop is a decided position
+  const unsigned long long done_m = passed_m | real_m;     // positions resolved by this step
+  const float dval = in_mask(real_m) ? d0 : cand;
+  const float cval = in_mask(adopt_m & passed_m) ? cost : c0;
+  unsigned long long write_m = done_m;
+  if constexpr (FIX) {
+    // a re-run merges with the stored trajectory at the first position where both hold the same value
+    float spec = 0.f;
+    if (in_mask(done_m)) spec = dout2[ipm + 1].x;
+    const unsigned long long eq_m = (mask_of(dval == spec) & done_m) | S;
+    const unsigned long long m_m = eq_m & ~(eq_m - F);
+    write_m = done_m & (m_m - F0);
+    // groups that merged stop: fill their fields
+    constexpr unsigned long long H = F << (GS - 1);
+    const unsigned long long merged1 = m_m & ~S;  // at most one bit per field, below the field's top bit
+    const unsigned long long nz = F & ~((H - merged1) >> (GS - 1));
+    merged_fill |= (nz << GS) - nz;
+  }
+  if (in_mask(write_m)) dout2[ipm + 1] = make_float2(dval, cval);
+  if (in_mask(real_m)) *cand_slot = d0;
+  const unsigned field = GS == 16 ? ((unsigned)(done_m >> k.gbase) & 0xffffu)
+                                  : (k.gbase ? (unsigned)(done_m >> 32) : (unsigned)done_m);
+  ipm += __builtin_popcount(field);
+}
+
+// One workgroup per chain; a wavefront carries 64 / GS segments.  grid = (chains, 1, slots), block = 64 * nw,
+// dynamic LDS = run3_lds_bytes().
+template <int GS, int AXIS, int TP, int DIR, bool LREF>
+__global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
+  extern __shared__ float lds[];
+  const int n = (g.s_last - g.s_first) * DIR + 1;
+  const int n1 = n + 1;
+  constexpr int kPerWave = kWave / GS;
+  const int nw = blockDim.x >> 6;
+  const int nseg = kPerWave * nw;
+  float2* din2 = (float2*)lds;      // [k] = (disparity, cost) of chain position k - 1; [0] = the pixel before the chain
+  float2* dout2 = din2 + n1;
+  float* s_last = lds + 4 * n1;     // [nseg + 1] last value of every segment
+  float* s_cand = s_last + nseg + 1;  // [nseg] current candidate of every segment
+  int* s_changed = (int*)(s_cand + nseg);  // [2]
+
+  const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
+  if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
+  View v = make_view(ps, blockIdx.z);
+  if constexpr (LREF) {
+    static_assert(AXIS == 1 && TP > 0, "staged reference lines: column sweeps with a fixed window");
+    // per image row the TP packed reference values of window columns chain - TP/2 .. + TP/2 as bytes, four columns
+    // per dword: NQ colour dwords, NQ gradient dwords, row stride kLref4Stride dwords (odd: no bank conflicts)
+    constexpr int NQ = (TP + 3) / 4;
+    static_assert(2 * NQ <= kLref4Stride, "reference row does not fit its LDS stride");
+    const int len = ps.rows;
+    unsigned* sref4 = (unsigned*)(s_changed + 2);
+    const uint16_t* src = v.trefpk + (size_t)(chain - TP / 2) * ps.pitch_t;
+    for (int e = threadIdx.x; e < NQ * len; e += blockDim.x) {
+      const int q = e / len, row = e - q * len;
+      unsigned cw = 0u, gw = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * q + j;
+        if (t < TP) {
+          const unsigned pk = src[(size_t)t * ps.pitch_t + row];
+          cw |= (pk & 0xffu) << (8 * j);
+          gw |= (pk >> 8) << (8 * j);
+        }
+      }
+      sref4[row * kLref4Stride + q] = cw;
+      sref4[row * kLref4Stride + NQ + q] = gw;
+    }
+    v.lds_ref4 = sref4;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int pw = TP > 0 ? TP : cp.pw, ph = TP > 0 ? TP : cp.ph;
+  const int nd = AXIS == 0 ? GS - pw : GS - ph + 1;
+  constexpr int POS0 = (AXIS == 0 && DIR < 0) ? 1 : 0;
+  Run3Lane k;
+  k.gl = lane & (GS - 1);
+  k.gbase = lane & ~(GS - 1);
+  k.mpos = k.gl - POS0;
+  k.dmposf = (float)(DIR * k.mpos);
+  k.rofs = DIR > 0 ? k.gl : pw - k.gl;
+  const int sidx = kPerWave * w + lane / GS;
+  const int stride = AXIS == 0 ? DIR : DIR * ps.pitch;
+  const ptrdiff_t first =
+      AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
+
+  for (int j = threadIdx.x; j <= n; j += blockDim.x) {
+    const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
+    const float2 t = make_float2(v.disp[o], j > 0 ? v.cost[o] : 0.f);
+    din2[j] = t;
+    dout2[j] = t;
+  }
+  __syncthreads();
+
+  const int i0 = sidx * seg_len;
+  const int i1 = min(n, i0 + seg_len);
+  const bool active = i0 < n;
+  k.lim = (active && k.mpos >= 0 && k.mpos < nd) ? i1 : (int)0x80000000;
+  LdsSlot cand_slot = (LdsSlot)(s_cand + sidx);
+  unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
+  unsigned long long no_merge = 0ull;
+
+  // ---- round 1: every segment speculatively from the OLD value of the pixel before it -----------------------------
+  float in_used = active ? din2[i0].x : 0.f;
+  if (k.gl == 0) *cand_slot = in_used;
+  int ipm = i0 + k.mpos;
+  for (;;) {
+    const unsigned long long inr_m = mask_of(ipm < k.lim);
+    if (inr_m == 0ull) break;
+    run3_step<GS, AXIS, TP, DIR, LREF, false>(v, ps, cp, g, chain, k, inr_m, ipm, din2, dout2, cand_slot, no_merge);
+    ++n_steps;
+  }
+  float lastv = *cand_slot;
+  if (active && k.gl == 0) s_last[sidx + 1] = lastv;
+  if (threadIdx.x == 0) s_last[0] = in_used;
+
+  // ---- fix-up rounds: a segment whose predecessor ended on another value re-runs until it merges ------------------
+  for (int round = 1; round < nseg; ++round) {
+    if (threadIdx.x == 0) s_changed[round & 1] = 0;
+    __syncthreads();
+    const float in = (active && sidx > 0) ? s_last[sidx] : in_used;
+    const bool redo = active && sidx > 0 && (in != in_used);
+    const unsigned long long redo_m = mask_of(redo);
+    bool new_last = false;
+    if (redo_m != 0ull) {
+      if (redo) {
+        in_used = in;
+        ipm = i0 + k.mpos;
+        if (k.gl == 0) *cand_slot = in;
+      }
+      unsigned long long merged_fill = 0ull;
+      for (;;) {
+        const unsigned long long inr_m = mask_of(ipm < k.lim) & redo_m & ~merged_fill;
+        if (inr_m == 0ull) break;
+        run3_step<GS, AXIS, TP, DIR, LREF, true>(v, ps, cp, g, chain, k, inr_m, ipm, din2, dout2, cand_slot, merged_fill);
+        ++n_fix;
+      }
+      const float c2 = *cand_slot;
+      if (redo && !in_mask(merged_fill) && c2 != lastv) {
+        lastv = c2;
+        new_last = true;
+      }
+    }
+    __syncthreads();
+    if (new_last && k.gl == 0) {
+      s_last[sidx + 1] = lastv;
+      s_changed[round & 1] = 1;
+    }
+    __syncthreads();
+    ++n_rounds;
+    if (!s_changed[round & 1]) break;
+  }
+  __syncthreads();
+  if (ps.counters && lane == 0) {
+    const int base = AXIS * 4;
+    atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);
+    atomicAdd(&ps.counters[base + 1], (unsigned long long)n_fix);
+    if (w == 0) atomicAdd(&ps.counters[base + 2], (unsigned long long)n_rounds);
+    if (w == 0) atomicAdd(&ps.counters[base + 3], (unsigned long long)n);
+  }
+
+  for (int j = threadIdx.x + 1; j <= n; j += blockDim.x) {
+    const float2 t = dout2[j];
+    if (t.x != din2[j].x) {
+      const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
+      v.disp[o] = t.x;
+      v.cost[o] = t.y;
+    }
+  }
+}
+
+inline size_t run3_lds_bytes(int n, int nseg) { return sizeof(float) * (4 * (size_t)(n + 1) + 2 * (size_t)nseg + 3); }
+
+template <int GS, int AXIS, int TP, int DIR, bool LREF>
+inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                          hipStream_t stream) {
+  const int chains = g.c_hi - g.c_lo + 1;
+  const int n = (g.s_last - g.s_first) * g.dir + 1;
+  const int nwv = waves < 1 ? 1 : (waves > kMaxSegWaves ? kMaxSegWaves : waves);
+  const int nseg = (kWave / GS) * nwv;
+  int len = (n + nseg - 1) / nseg;
+  if (len < 8) len = 8;
+  size_t lds_bytes = run3_lds_bytes(n, nseg);
+  if (LREF) lds_bytes += run2_lref_bytes<AXIS, TP>(ps);
+  allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
+  hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
+                     dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
+}
+template <int GS, int AXIS, int TP>
+inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                          hipStream_t stream) {
+  // column sweeps of the benchmark window stage their reference lines in LDS while that leaves room for at least
+  // four workgroups per CU (PM_RUN2_LREF / PM_RUN2_LREF_KB: A/B knobs)
+  if constexpr (AXIS == 1 && TP == 11) {
+    const int n = (g.s_last - g.s_first) * g.dir + 1;
+    const size_t total = run3_lds_bytes(n, 64) + run2_lref_bytes<AXIS, TP>(ps);
+    if (run2_lref_enabled(AXIS) && total <= run2_lref_limit()) {
+      if (g.dir > 0) launch_run3_l<GS, AXIS, TP, 1, true>(ps, cp, g, slots, waves, stream);
+      else launch_run3_l<GS, AXIS, TP, -1, true>(ps, cp, g, slots, waves, stream);
+      return;
+    }
+  }
+  if (g.dir > 0) launch_run3_l<GS, AXIS, TP, 1, false>(ps, cp, g, slots, waves, stream);
+  else launch_run3_l<GS, AXIS, TP, -1, false>(ps, cp, g, slots, waves, stream);
+}
+
+// group = lanes per chain segment (32 or 16); windows of 3 and 5 always take 16, windows the fixed-size kernels do
+// not cover (not square, or wider than 11) take the general kernel with 32.
+template <int AXIS>
+inline void launch_run3_axis(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                             int group, hipStream_t stream) {
+  const int sq = (cp.pw == cp.ph && cp.pw <= 11) ? cp.pw : 0;
+  const bool g16 = group <= 16;
+  switch (sq) {
+    case 3: launch_run3_d<16, AXIS, 3>(ps, cp, g, slots, waves, stream); break;
+    case 5: launch_run3_d<16, AXIS, 5>(ps, cp, g, slots, waves, stream); break;
+    case 7:
+      if (g16) launch_run3_d<16, AXIS, 7>(ps, cp, g, slots, waves, stream);
+      else launch_run3_d<32, AXIS, 7>(ps, cp, g, slots, waves, stream);
+      break;
+    case 9:
+      if (g16) launch_run3_d<16, AXIS, 9>(ps, cp, g, slots, waves, stream);
+      else launch_run3_d<32, AXIS, 9>(ps, cp, g, slots, waves, stream);
+      break;
+    case 11:
+      if (g16) launch_run3_d<16, AXIS, 11>(ps, cp, g, slots, waves, stream);
+      else launch_run3_d<32, AXIS, 11>(ps, cp, g, slots, waves, stream);
+      break;
+    default: launch_run3_d<32, AXIS, 0>(ps, cp, g, slots, waves, stream); break;
+  }
+}
+inline void launch_sweep_run3(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
+                              int group, hipStream_t stream) {
+  if (g.axis == 0) launch_run3_axis<0>(ps, cp, g, slots, waves, group, stream);
+  else launch_run3_axis<1>(ps, cp, g, slots, waves, group, stream);
+}
+
+}  // namespace pm
