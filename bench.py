@@ -110,6 +110,9 @@ class Dist:
         if self.dist:
             self.dist.barrier()
 
+    def ranks_seen(self):
+        return self.dist.get_world_size() if self.dist else 1
+
     def max_over_ranks(self, value):
         if not self.dist:
             return value
@@ -447,14 +450,87 @@ def tiled_children(args):
     return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": err[-400:]}
 
 
+def device_count():
+    """GPUs visible to this job, read in a CHILD process: the parent must not touch the GPU before it starts its
+    ranks (a forked / spawned rank of a process that has initialised HIP is not safe)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), wait for all of them, relay rank 0's JSON
+    line and fail if any rank failed.  The parent never imports torch or touches a GPU."""
+    import subprocess
+    want = args.gpus
+    n = want
+    note = None
+    if not args.dry_run:
+        have = device_count()
+        if have < 1:
+            print(json.dumps({"error": "no GPU visible", "n_gpus_requested": want}), flush=True)
+            return 3
+        if have < want:
+            n, note = have, f"--gpus {want} requested, {have} GPU(s) visible: ran {have}; the {want}-GPU point is UNRUN"
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               PM_BENCH_GPUS_REQUESTED=str(want))
+    if note:
+        env["PM_BENCH_LAUNCH_NOTE"] = note
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting at a barrier for ever: end them
+        codes = [None] * n
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.kill()
+                        codes[r] = p.wait()
+            time.sleep(0.2)
+        out0.seek(0)
+        for line in out0.read().splitlines():  # the JSON line to stdout, library chatter (e.g. "[Gloo] Rank 0 ...") to stderr
+            print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("bench.py: rank(s) failed (rank, exit code): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     planes = args.mode == "planes"
     tiled_result = None
     if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and not planes and not args.no_side_legs and not args.tiled
             and max(1, args.pairs_per_gpu) == 1 and (not args.dry_run or args.rehearse_tiled_leg)):
         import torch  # noqa: F401 -- pages the libraries in before the children import them
         tiled_result = tiled_children(args)
+    if os.environ.get("PM_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # fault injection of tests/test_dist.py
+        sys.exit(7)
     d = Dist(args)
     steps, warmup = args.steps, args.warmup
     nb = max(1, args.pairs_per_gpu)
@@ -469,12 +545,17 @@ def main():
         "warmup": warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("u8 window cost, " + args.state + " state") if planes else "f32",
         "data": "synthetic",
+        # the world size the timed barrier saw (torch.distributed; backend nccl = RCCL); 1 = no process group
+        "rccl_ranks": d.ranks_seen(), "backend": args.backend if d.world > 1 else None,
         "config": {"workload": f"{nb} synthetic {args.cols}x{args.rows} stereo pair(s) per GPU and step, "
                                f"{args.iters} iterations, {args.patch}x{args.patch} window, {what}, left+right view + "
                                "cross-check" + (" (BASELINE.json configs[1])" if not planes and nb == 1 else ""),
                    "pairs_per_gpu_per_step": nb, "distinct_resident_pairs_rotated": N_ROTATE,
                    "sharding": "rank r owns pairs r*nb*4 .. (r+1)*nb*4-1, no collective"},
     }
+    if os.environ.get("PM_BENCH_LAUNCH_NOTE"):
+        result["n_gpus_requested"] = int(os.environ.get("PM_BENCH_GPUS_REQUESTED", d.world))
+        result["launch_note"] = os.environ["PM_BENCH_LAUNCH_NOTE"]
     if args.dry_run:
         # plumbing only: same barrier / reduction path, no engine, no numbers worth reading
         d.barrier()

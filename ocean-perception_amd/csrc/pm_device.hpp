@@ -27,20 +27,18 @@ struct PlaneSet {
   size_t plane_t;      // cols * pitch_t
   uint16_t* pk16;      // [B][4][rows][pitch]   img8 | g8 << 8: what a window reads of its own image
   uint16_t* tpk16;     // [B][4][cols][pitch_t] transposed copy of pk16
-  // Row-PAIR planes of the run engine (pm_run2.hpp): one element holds the same column of TWO consecutive window
-  // lines, so a step fetches two window lines per load instruction (the sweeps are bound by the NUMBER of memory
-  // instructions).  Two alignments o = 0 / 1: pair k of alignment o covers lines 2k+o and 2k+o+1, so any window
-  // start finds its lines as whole pairs.  "Lines" are image rows for the row sweeps (rp*) and image columns, on
-  // the transposed planes, for the column sweeps (cp*).  Per pair b and view v (target image of the view for
-  // the records, reference image for the quads):
-  float* rpg;          // [B][2][2][npr][pitch][3]  target records {gradient of line 2k+o, of line 2k+o+1,
-                       //                           u32 colour byte of line 2k+o | of line 2k+o+1 << 8}
-  // reference QUADS (row sweeps): four alignments o = 0..3, quad k of alignment o covers image rows 4k+o .. 4k+o+3;
-  // element = {colour bytes of the four rows, gradient bytes of the four rows}: the form the sweeps' v_sad_u8 takes
-  uint32_t* rqk;       // [B][2][4][nq][pitch][2]
-  int nq;              // quads per alignment: (rows + 3) / 4 + 1
-  float* cpg;          // [B][2][2][npc][pitch_t][3] the same records on the transposed target planes
-  int npr, npc;        // pairs per alignment: (rows + 1) / 2 + 1, (cols + kTransPad + 1) / 2 + 1
+  // Line-PAIR planes of the run engine (pm_run3.hpp): element (l, e) holds position e of the two consecutive lines
+  // l and l + 1, so a step fetches two window lines per load instruction (the sweeps are bound by the NUMBER of
+  // memory instructions) and a window starting at any line finds its lines as whole pairs l, l + 2, l + 4 ...
+  // "Lines" are image rows for the row sweeps (rpg) and image columns, on the transposed planes, for the column
+  // sweeps (cpg).  Per pair b and view v (target image of the view for the records, reference image for the quads):
+  float* rpg;          // [B][2][nrl][pitch][3]    target records {gradient of line l, of line l + 1, u32 colours:
+                       //                          byte 0 / 1 = lines l / l + 1 at column e, byte 2 / 3 = at column e + 1}
+  // reference QUADS (row sweeps): element (l, e) = image rows l .. l + 3 at column e as {four colour bytes, four
+  // gradient bytes}: the form the sweeps' v_sad_u8 takes
+  uint32_t* rqk;       // [B][2][nrl][pitch][2]
+  float* cpg;          // [B][2][ncl][pitch_t][3]  the same records on the transposed target planes (colours: bytes 0 / 1)
+  int nrl, ncl;        // lines per view: rows + 2, cols + kTransPad + 2 (lines beyond the last repeat it)
   float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
   float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
@@ -70,18 +68,13 @@ struct View {
   const float* trefg;      // transposed refg (PM_SEM_GPU column sweeps)
   const uint16_t* refpk;   // ref8 | refg8 << 8
   const uint16_t* trefpk;  // transposed
-  // column sweeps with the reference window lines of the chain staged in LDS (pm_run2.hpp, LREF):
-  // element (window column t, image row Y) at lds_ref[t * lds_ref_pitch + Y]
-  const uint16_t* lds_ref;
-  int lds_ref_pitch;
-  // column sweeps: [image row][kLref4Stride] dwords, four window columns per dword (pm_run2.hpp)
+  // column sweeps: the reference window lines of the chain staged in LDS, [image row][kLref4Stride] dwords, four
+  // window columns per dword (pm_run3.hpp, LREF)
   const unsigned* lds_ref4;
-  // pair planes of this view, alignment 0; alignment 1 follows at + rp_stride / cp_stride elements
+  // line-pair / quad planes of this view (first line)
   const float* rpg;
   const uint32_t* rqk;
-  unsigned rq_stride;  // elements (8 bytes) per alignment of rqk
   const float* cpg;
-  unsigned rp_stride, cp_stride;  // npr * pitch, npc * pitch_t
   float* disp;
   float* cost;
 };
@@ -113,16 +106,11 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.trefg = ps.tg32 + (base4 + iref) * ps.plane_t;
   w.refpk = ps.pk16 + (base4 + iref) * ps.plane;
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
-  w.lds_ref = nullptr;
-  w.lds_ref_pitch = 0;
   w.lds_ref4 = nullptr;
-  w.rp_stride = (unsigned)ps.npr * (unsigned)ps.pitch;
-  w.cp_stride = (unsigned)ps.npc * (unsigned)ps.pitch_t;
-  const size_t pv = ((size_t)b * 2 + v) * 2;
-  w.rpg = ps.rpg + pv * w.rp_stride * 3;
-  w.rq_stride = (unsigned)ps.nq * (unsigned)ps.pitch;
-  w.rqk = ps.rqk + pv * 2 * (size_t)w.rq_stride * 2;
-  w.cpg = ps.cpg + pv * w.cp_stride * 3;
+  const size_t pv = (size_t)b * 2 + v;
+  w.rpg = ps.rpg + pv * (size_t)ps.nrl * ps.pitch * 3;
+  w.rqk = ps.rqk + pv * (size_t)ps.nrl * ps.pitch * 2;
+  w.cpg = ps.cpg + pv * (size_t)ps.ncl * ps.pitch_t * 3;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;

@@ -183,10 +183,9 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.tpk16 = h->tpk16;
   ps.rpg = h->rpg;
   ps.rqk = h->rqk;
-  ps.nq = (rows + 3) / 4 + 1;
   ps.cpg = h->cpg;
-  ps.npr = (rows + 1) / 2 + 1;
-  ps.npc = (cols + kTransPad + 1) / 2 + 1;
+  ps.nrl = rows + 2;
+  ps.ncl = cols + kTransPad + 2;
   ps.disp = h->disp;
   ps.cost = h->cost;
   ps.noise = h->noise;
@@ -299,6 +298,31 @@ int launch_check(pm_handle* h, const char* what) {
 
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
 
+// The line-pair planes (about 60 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
+// scalar mode, the run engine.  Other handles (PM_SEM_GPU, PM_MODE_PLANES, the serial / wave anchors) neither
+// allocate nor build them; allocation happens on the first call that builds them.
+bool pair_planes_wanted(const pm_handle* h) {
+  const pm_params& p = h->params;
+  if (p.semantics != PM_SEM_CPU || p.mode != PM_MODE_SCALAR) return false;
+  if (p.engine != PM_ENGINE_AUTO && p.engine != PM_ENGINE_RUNBLK2) return false;
+  return true;
+}
+int pair_planes_alloc(pm_handle* h) {
+  if (h->rpg) return PM_OK;
+  const size_t B = (size_t)h->max_batch;
+  const size_t pitch_t = (size_t)align_up(h->max_rows, 64);
+  const size_t nrp = B * 2 * (size_t)(h->max_rows + 2) * h->max_pitch + 64;
+  const size_t ncp = B * 2 * (size_t)(h->max_cols + kTransPad + 2) * pitch_t + 64;
+  PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 3 * nrp));
+  PM_HIP(h, hipMalloc((void**)&h->rqk, sizeof(uint32_t) * 2 * nrp));
+  PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 3 * ncp));
+  // row padding behind `cols` / `rows` is read (with weight 0 or by lanes out of reach) and must be finite
+  PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 3 * nrp, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->rqk, 0, sizeof(uint32_t) * 2 * nrp, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 3 * ncp, h->stream));
+  return PM_OK;
+}
+
 // transposed copies of the 12 image-type planes of n pairs (run by every path that ran k_prep)
 int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
   const dim3 grid((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 63) / 64), (unsigned)(n * 4)), block(256);
@@ -310,13 +334,18 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
                      ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
   hipLaunchKernelGGL(k_transpose<uint16_t>, grid, block, 0, h->stream, (const uint16_t*)ps.pk16, ps.tpk16, ps.rows,
                      ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  if (h->params.semantics == PM_SEM_CPU) {  // the pair planes of the run engine (PM_SEM_CPU square windows)
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.npr, (unsigned)(n * 4)), block, 0,
-                       h->stream, ps, 1);
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.npc, (unsigned)(n * 4)), block, 0,
-                       h->stream, ps, 0);
-    hipLaunchKernelGGL(k_quads, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nq, (unsigned)(n * 8)), block, 0,
-                       h->stream, ps);
+  if (pair_planes_wanted(h)) {  // the line-pair / quad planes of the run engine (pm_run3.hpp)
+    if (int rc = pair_planes_alloc(h)) return rc;
+    PlaneSet pp = ps;
+    pp.rpg = h->rpg;
+    pp.rqk = h->rqk;
+    pp.cpg = h->cpg;
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
+                       h->stream, pp, 1);
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.ncl, (unsigned)(n * 2)), block, 0,
+                       h->stream, pp, 0);
+    hipLaunchKernelGGL(k_quads, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
+                       h->stream, pp);
   }
   return launch_check(h, "transpose");
 }
@@ -494,11 +523,7 @@ int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Swee
     launch_sweep_wave(ps, cp, g, slots, h->stream);
   } else {
     const int group = runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir);
-    static const bool run3 = [] {
-      const char* e = getenv("PM_RUN3");
-      return e ? atoi(e) != 0 : true;
-    }();
-    if (cp.semantics == PM_SEM_CPU && run3)
+    if (cp.semantics == PM_SEM_CPU)
       launch_sweep_run3(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
     else
       launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, h->stream);
@@ -1079,19 +1104,8 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMalloc((void**)&h->tpk16, sizeof(uint16_t) * (B * 4 * plane_t + 128)));
   PM_HIP(h, hipMemsetAsync(h->pk16, 0, sizeof(uint16_t) * (B * 4 * plane + 128), h->stream));
   PM_HIP(h, hipMemsetAsync(h->tpk16, 0, sizeof(uint16_t) * (B * 4 * plane_t + 128), h->stream));
-  {
-    const size_t rp_stride = (size_t)((max_rows + 1) / 2 + 1) * h->max_pitch;
-    const size_t cp_stride = (size_t)((max_cols + kTransPad + 1) / 2 + 1) * align_up(max_rows, 64);
-    const size_t nrp = B * 4 * rp_stride + 64, ncp = B * 4 * cp_stride + 64;
-    PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 3 * nrp));
-    const size_t nrq = B * 8 * (size_t)((max_rows + 3) / 4 + 1) * h->max_pitch * 2 + 64;
-    PM_HIP(h, hipMalloc((void**)&h->rqk, sizeof(uint32_t) * nrq));
-    PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 3 * ncp));
-    // row padding behind `cols` / `rows` is read (with weight 0 or by lanes out of reach) and must be finite
-    PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 3 * nrp, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->rqk, 0, sizeof(uint32_t) * nrq, h->stream));
-    PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 3 * ncp, h->stream));
-  }
+  if (pair_planes_wanted(h))
+    if (int rc = pair_planes_alloc(h)) return rc;
   PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));

@@ -121,23 +121,23 @@ __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T*
   }
 }
 
-// Pair planes of the run engine (PlaneSet::rpg ...): built from the plain and the transposed planes once per Match.
-// grid = (ceil(len / 256), pairs, B * 4) with z = ((b * 2 + view) * 2 + alignment); `rows_mode` != 0: row pairs
-// (len = cols, line = image row, source planes img8 / g32 / pk16 with pitch), else column pairs on the transposed
-// planes (len = rows, line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
+// Line-pair planes of the run engine (PlaneSet::rpg / cpg): built from the plain and the transposed planes once per
+// Match.  grid = (ceil(len / 256), lines, B * 2) with z = b * 2 + view; `rows_mode` != 0: row pairs (len = cols,
+// line = image row, source planes img8 / g32 with pitch), else column pairs on the transposed planes (len = rows,
+// line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
 // Lines beyond the last one repeat it (they are only ever the unused twelfth line of a window).
 __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const int z = blockIdx.z, o = z & 1, view = (z >> 1) & 1, b = z >> 2;
+  const int l = blockIdx.y;
+  const int z = blockIdx.z, view = z & 1, b = z >> 1;
   const int itgt = view == 0 ? 1 : 2;
   if (rows_mode) {
-    if (e >= ps.cols || k >= ps.npr) return;
-    const int l0 = min(2 * k + o, ps.rows - 1), l1 = min(2 * k + o + 1, ps.rows - 1);
+    if (e >= ps.cols || l >= ps.nrl) return;
+    const int l0 = min(l, ps.rows - 1), l1 = min(l + 1, ps.rows - 1);
     const size_t src0 = (size_t)l0 * ps.pitch + e, src1 = (size_t)l1 * ps.pitch + e;
     const size_t tp = ((size_t)b * 4 + itgt) * ps.plane;
-    const size_t dst = ((size_t)z * ps.npr + k) * ps.pitch + e;
-    // one 12-byte record per pair element: the two gradients and the two colour bytes -- ONE load in the sweeps
+    const size_t dst = ((size_t)z * ps.nrl + l) * ps.pitch + e;
+    // one 12-byte record per element: the two gradients and the colour bytes -- ONE load in the sweeps
     ps.rpg[3 * dst] = ps.g32[tp + src0];
     ps.rpg[3 * dst + 1] = ps.g32[tp + src1];
     // colours: byte 0 / 1 = the two lines at column e, byte 2 / 3 = the same lines at column e + 1 (replicated at the
@@ -146,36 +146,36 @@ __global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
     ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8) |
                                        ((uint32_t)ps.img8[tp + src0 + e1] << 16) | ((uint32_t)ps.img8[tp + src1 + e1] << 24);
   } else {
-    if (e >= ps.rows || k >= ps.npc) return;
+    if (e >= ps.rows || l >= ps.ncl) return;
     const int lmax = ps.cols + kTransPad - 1;
-    const int l0 = min(2 * k + o, lmax), l1 = min(2 * k + o + 1, lmax);
+    const int l0 = min(l, lmax), l1 = min(l + 1, lmax);
     const size_t src0 = (size_t)l0 * ps.pitch_t + e, src1 = (size_t)l1 * ps.pitch_t + e;
     const size_t tp = ((size_t)b * 4 + itgt) * ps.plane_t;
-    const size_t dst = ((size_t)z * ps.npc + k) * ps.pitch_t + e;
+    const size_t dst = ((size_t)z * ps.ncl + l) * ps.pitch_t + e;
     ps.cpg[3 * dst] = ps.tg32[tp + src0];
     ps.cpg[3 * dst + 1] = ps.tg32[tp + src1];
     ((uint32_t*)ps.cpg)[3 * dst + 2] = (uint32_t)ps.timg8[tp + src0] | ((uint32_t)ps.timg8[tp + src1] << 8);
   }
 }
 
-// Reference quads of the row sweeps (PlaneSet::rqk).  grid = (ceil(cols / 256), nq, B * 8) with
-// z = ((b * 2 + view) * 4 + alignment).  Rows beyond the last one repeat it (only ever the unused twelfth row).
+// Reference quads of the row sweeps (PlaneSet::rqk).  grid = (ceil(cols / 256), nrl, B * 2) with z = b * 2 + view.
+// Rows beyond the last one repeat it (only ever the unused twelfth row).
 __global__ void __launch_bounds__(256) k_quads(PlaneSet ps) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const int z = blockIdx.z, o = z & 3, view = (z >> 2) & 1, b = z >> 3;
-  if (e >= ps.cols || k >= ps.nq) return;
+  const int l = blockIdx.y;
+  const int z = blockIdx.z, view = z & 1, b = z >> 1;
+  if (e >= ps.cols || l >= ps.nrl) return;
   const int iref = view == 0 ? 0 : 3;
   const size_t rp = ((size_t)b * 4 + iref) * ps.plane;
   uint32_t cw = 0u, gw = 0u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int row = min(4 * k + o + j, ps.rows - 1);
+    const int row = min(l + j, ps.rows - 1);
     const uint32_t pk = ps.pk16[rp + (size_t)row * ps.pitch + e];
     cw |= (pk & 0xffu) << (8 * j);
     gw |= (pk >> 8) << (8 * j);
   }
-  const size_t dst = (((size_t)z * ps.nq + k) * ps.pitch + e) * 2;
+  const size_t dst = (((size_t)z * ps.nrl + l) * ps.pitch + e) * 2;
   ps.rqk[dst] = cw;
   ps.rqk[dst + 1] = gw;
 }

@@ -16,7 +16,10 @@
 //     and fraction and column offset agree; positions in another binade wait for the next step (as before);
 //   * the candidate of a group lives in an LDS slot: the rejecting lane stores its value, everybody reads it back
 //     (no ds_bpermute address arithmetic); a lane's chain index advances by a popcount of its group's field;
-//   * chain state is one float2 array per direction (one ds_read_b64 / ds_write_b64 per step);
+//   * chain state is one float4 per position {old value, old cost, new value, new cost}: one ds_read_b64 and one
+//     ds_write_b64 per step at the same address, no conditional read;
+//   * the two / four window lines of a load come from LINE-indexed pair planes (PlaneSet::rpg ...): the line offsets
+//     are wave-uniform base pointers (scalar registers), the lane's column is ONE vector offset shared by all loads;
 //   * 16-lane groups add up their window lines with row_shl DPP in log steps (5 adds for 11 lines instead of 10).
 // Results are bit-identical to the serial engine, the wave engine and the oracle (tests/test_gpu_parity.py,
 // tools/fuzz_engines.py).
@@ -79,6 +82,39 @@ __device__ __forceinline__ int window_sum(int line, int win) {
   }
 }
 
+// cpu_cost_from_sums (pm_device.hpp) on both sums at once with packed-f32 instructions: the same operations in the
+// same order per component (mean_from_sum: p = s * hi, e1 = fma(s, hi, -p), e2 = s * lo, mean = p + (e1 + e2)).
+__device__ __forceinline__ float cost_from_packed_sums(int wsum, const CostParams& cp) {
+  const f32x2 sf = {(float)(wsum & 0xffff), (float)((unsigned)wsum >> 16)};
+  const f32x2 hi = {cp.inv_n_hi, cp.inv_n_hi}, lo = {cp.inv_n_lo, cp.inv_n_lo};
+  const f32x2 p = sf * hi;
+  const f32x2 e1 = __builtin_elementwise_fma(sf, hi, -p);
+  const f32x2 e2 = sf * lo;
+  const f32x2 m = p + (e1 + e2);
+  const f32x2 e = {fminf(m.x, cp.tau_color), fminf(m.y, cp.tau_grad)};
+  const f32x2 wgt = {cp.alpha, cp.one_minus_alpha};
+  const f32x2 t = wgt * e;
+  return t.x + t.y;
+}
+
+// LDS bytes of the column sweeps' staged reference lines (LREF): kLref4Stride dwords per image row.
+inline size_t run3_lref_bytes(const PlaneSet& ps) { return sizeof(unsigned) * (size_t)kLref4Stride * ps.rows; }
+// PM_RUN2_LREF=0 turns the staging off, PM_RUN2_LREF_KB is the LDS budget per workgroup (A/B knobs)
+inline bool run3_lref_enabled() {
+  static const int v = [] {
+    const char* e = getenv("PM_RUN2_LREF");
+    return e ? atoi(e) : 2;
+  }();
+  return (v >> 1) & 1;
+}
+inline size_t run3_lref_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("PM_RUN2_LREF_KB");
+    return (size_t)(e ? atoi(e) : 40) * 1024;
+  }();
+  return v;
+}
+
 // The LDS word that carries a group's candidate from the rejecting lane to the others: volatile keeps the accesses in
 // program order, the explicit address space keeps them ds_read / ds_write (a volatile generic pointer is a flat access).
 typedef __attribute__((address_space(3))) volatile float* LdsSlot;
@@ -92,12 +128,65 @@ struct Run3Lane {
   int lim;           // segment end for position lanes of an active segment, INT_MIN otherwise
 };
 
+// Wave-uniform base pointers of the window's line pairs (and reference quads), fixed for the whole kernel: with them
+// in scalar registers a load is global_load ... v_off, s[base] and ONE vector offset serves all loads of a step.
+typedef __attribute__((address_space(1))) const char* GlobalPtr;  // explicit: a pinned generic pointer loads as flat_load
+struct Run3Bases {
+  GlobalPtr line[6];
+  GlobalPtr quad[3];
+};
+// (member-wise through the qualified pointer: the compiler fuses them into one global_load_dwordx3 / dwordx2.  An
+// `ext_vector_type(3), aligned(4)` load is NOT an alternative: hipcc 7.2 returns element 0 for element 1 of it.)
+struct alignas(8) QuadRec {
+  unsigned c, g;
+};
+__device__ __forceinline__ PairRec ld_rec_g(GlobalPtr base, unsigned byte_off) {
+  const __attribute__((address_space(1))) PairRec* q =
+      (const __attribute__((address_space(1))) PairRec*)(base + (size_t)byte_off);
+  PairRec r;
+  r.x = q->x;
+  r.y = q->y;
+  r.c = q->c;
+  return r;
+}
+__device__ __forceinline__ QuadRec ld_quad_g(GlobalPtr base, unsigned byte_off) {
+  const __attribute__((address_space(1))) QuadRec* q =
+      (const __attribute__((address_space(1))) QuadRec*)(base + (size_t)byte_off);
+  QuadRec r;
+  r.c = q->c;
+  r.g = q->g;
+  return r;
+}
+template <int AXIS, int TP>
+__device__ __forceinline__ Run3Bases run3_bases(const View& v, const PlaneSet& ps, int chain) {
+  Run3Bases b{};
+  if constexpr (TP > 0) {
+    if constexpr (AXIS == 0) {
+      const int y0 = chain - TP / 2;  // first window row
+#pragma unroll
+      for (int m = 0; m < (TP + 1) / 2; ++m)
+        b.line[m] = (GlobalPtr)v.rpg + ((size_t)(y0 + 2 * m) * (size_t)ps.pitch) * 12u;
+#pragma unroll
+      for (int q = 0; q < (TP + 3) / 4; ++q)
+        b.quad[q] = (GlobalPtr)v.rqk + ((size_t)(y0 + 4 * q) * (size_t)ps.pitch) * 8u;
+    } else {
+#pragma unroll
+      for (int m = 0; m < (TP + 2) / 2; ++m) b.line[m] = (GlobalPtr)v.cpg + ((size_t)(2 * m) * (size_t)ps.pitch_t) * 12u;
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) asm volatile("" : "+s"(b.line[m]));  // pinned: not re-derived per step in vector registers
+#pragma unroll
+    for (int q = 0; q < 3; ++q) asm volatile("" : "+s"(b.quad[q]));
+  }
+  return b;
+}
+
 // TP = square window 3 .. 11, or 0: any window from cp (GS = 32).  One step of every group of the wavefront.
 // inr_m: lanes whose position exists (inside their segment, group still running).
 template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX>
 __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g,
-                                          int chain, const Run3Lane& k, unsigned long long inr_m, int& ipm,
-                                          const float2* din2, float2* dout2, LdsSlot cand_slot,
+                                          int chain, const Run3Lane& k, const Run3Bases& bases,
+                                          unsigned long long inr_m, int& ipm, float4* st4, LdsSlot cand_slot,
                                           unsigned long long& merged_fill) {
   const int pitch = ps.pitch, cols = ps.cols, rows = ps.rows;
   const int pw = TP > 0 ? TP : cp.pw, ph = TP > 0 ? TP : cp.ph;
@@ -113,12 +202,10 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
   const float shift = (float)(pw - 1) * 0.5f;
 
   // ---- state of the lane's position and the group's candidate -------------------------------------------------------
-  float d0 = 0.f, c0 = 0.f;
-  if (in_mask(inr_m)) {
-    const float2 t = din2[ipm + 1];
-    d0 = t.x;
-    c0 = t.y;
-  }
+  // (every lane reads: lanes beyond their segment see some other position of the chain, masked off by inr_m)
+  float4* const my = st4 + (ipm + 1);
+  const float2 dc = *(const float2*)my;
+  const float d0 = dc.x, c0 = dc.y;
   const float cand = *cand_slot;
   const unsigned long long neutral_m = mask_of(d0 == cand) & inr_m;
   const unsigned long long need_m = inr_m & ~neutral_m;
@@ -156,19 +243,16 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
       if constexpr (AXIS == 0) {
         // lane = image column X (its own position's column -+ half), window rows in the lane, two per load
         constexpr int NPR = (TP + 1) / 2, NQR = (TP + 3) / 4;
-        const int y0 = chain - half_h;  // wave-uniform
-        const unsigned eo12 = ((unsigned)(y0 & 1) * v.rp_stride + (unsigned)(y0 >> 1) * (unsigned)pitch) * 12u;
-        const unsigned rpitch12 = (unsigned)pitch * 12u;
         const int X = clamp_med3(pos - DIR * half, cols - 1);
         const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
         unsigned r3 = ((unsigned)R0 << 1) + (unsigned)R0;
         asm volatile("" : "+v"(r3));  // opaque: keeps 12 * R0 a shift-add (no quarter-rate v_mul_lo_u32)
-        const unsigned rb0 = (r3 << 2) + eo12;
+        const unsigned rv = r3 << 2;  // the lane's byte offset inside every line
         unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
         float gv[2 * NPR + 1];
 #pragma unroll
         for (int m = 0; m < NPR; ++m) {
-          const PairRec pg = ld_rec(v.rpg, rb0 + (unsigned)m * rpitch12);
+          const PairRec pg = ld_rec_g(bases.line[m], rv);
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
           // record colours: byte 0 / 1 = rows 2m / 2m + 1 at column R0, byte 2 / 3 = the same rows at R0 + 1
@@ -187,15 +271,14 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         }
         unsigned rq_c[NQR], rq_g[NQR];  // reference bytes of four window rows per dword (quad plane of this alignment)
         {
-          const unsigned eq8 = ((unsigned)(y0 & 3) * v.rq_stride + (unsigned)(y0 >> 2) * (unsigned)pitch) << 3;
-          const unsigned qb0 = ((unsigned)X << 3) + eq8, qpitch8 = (unsigned)pitch << 3;
+          const unsigned qv = (unsigned)X << 3;
 #pragma unroll
           for (int q = 0; q < NQR; ++q) {
-            const uint2 rr = *(const uint2*)((const char*)v.rqk + (size_t)(qb0 + (unsigned)q * qpitch8));
+            const QuadRec rr = ld_quad_g(bases.quad[q], qv);
             const int rem = TP - 4 * q;
             const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
-            rq_c[q] = rr.x & mask;
-            rq_g[q] = rr.y & mask;
+            rq_c[q] = rr.c & mask;
+            rq_g[q] = rr.g & mask;
           }
         }
 #pragma unroll
@@ -222,14 +305,14 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         const int pt = ps.pitch_t;
         const int Y = clamp_med3(pos - DIR * half, rows - 1);
         const int ipx_c = clamp_med3(ipx_r, cols - 1);  // (a group that cannot adopt may carry any ipx_r)
-        const unsigned e0 =
-            ((ipx_c & 1) ? v.cp_stride : 0u) + __umul24((unsigned)(ipx_c >> 1), (unsigned)pt) + (unsigned)Y;
-        const unsigned cb0 = rec_offset(e0), cpitch12 = (unsigned)pt * 12u;
+        // element (line ipx_c, row Y); both factors < 2^16: the 24-bit multiply-add is exact and full rate
+        const unsigned e0 = __umul24((unsigned)ipx_c, (unsigned)pt) + (unsigned)Y;
+        const unsigned cv = rec_offset(e0);
         unsigned prv[NPC];
         float gv[2 * NPC + 1];
 #pragma unroll
         for (int m = 0; m < NPC; ++m) {
-          const PairRec pg = ld_rec(v.cpg, cb0 + (unsigned)m * cpitch12);
+          const PairRec pg = ld_rec_g(bases.line[m], cv);
           prv[m] = pg.c;
           gv[2 * m] = pg.x;
           gv[2 * m + 1] = pg.y;
@@ -344,7 +427,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
       }
     }
     const int wsum = window_sum<GS, TP>((int)(sc | (sg << 16)), win);
-    cost = cpu_cost_from_sums(wsum & 0xffff, (int)((unsigned)wsum >> 16), cp);
+    cost = cost_from_packed_sums(wsum, cp);
   }
 
   // ---- decisions: scalar unit, all groups at once -----------------------------------------------------------------
@@ -364,8 +447,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
   unsigned long long write_m = done_m;
   if constexpr (FIX) {
     // a re-run merges with the stored trajectory at the first position where both hold the same value
-    float spec = 0.f;
-    if (in_mask(done_m)) spec = dout2[ipm + 1].x;
+    const float spec = my->z;
     const unsigned long long eq_m = (mask_of(dval == spec) & done_m) | S;
     const unsigned long long m_m = eq_m & ~(eq_m - F);
     write_m = done_m & (m_m - F0);
@@ -375,7 +457,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
     const unsigned long long nz = F & ~((H - merged1) >> (GS - 1));
     merged_fill |= (nz << GS) - nz;
   }
-  if (in_mask(write_m)) dout2[ipm + 1] = make_float2(dval, cval);
+  if (in_mask(write_m)) *(float2*)&my->z = make_float2(dval, cval);
   if (in_mask(real_m)) *cand_slot = d0;
   const unsigned field = GS == 16 ? ((unsigned)(done_m >> k.gbase) & 0xffffu)
                                   : (k.gbase ? (unsigned)(done_m >> 32) : (unsigned)done_m);
@@ -392,8 +474,8 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   constexpr int kPerWave = kWave / GS;
   const int nw = blockDim.x >> 6;
   const int nseg = kPerWave * nw;
-  float2* din2 = (float2*)lds;      // [k] = (disparity, cost) of chain position k - 1; [0] = the pixel before the chain
-  float2* dout2 = din2 + n1;
+  // [k] = {disparity, cost, new disparity, new cost} of chain position k - 1; [0] = the pixel before the chain
+  float4* st4 = (float4*)lds;
   float* s_last = lds + 4 * n1;     // [nseg + 1] last value of every segment
   float* s_cand = s_last + nseg + 1;  // [nseg] current candidate of every segment
   int* s_changed = (int*)(s_cand + nseg);  // [2]
@@ -427,6 +509,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
     }
     v.lds_ref4 = sref4;
   }
+  const Run3Bases bases = run3_bases<AXIS, TP>(v, ps, chain);
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int pw = TP > 0 ? TP : cp.pw, ph = TP > 0 ? TP : cp.ph;
@@ -445,9 +528,8 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
 
   for (int j = threadIdx.x; j <= n; j += blockDim.x) {
     const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
-    const float2 t = make_float2(v.disp[o], j > 0 ? v.cost[o] : 0.f);
-    din2[j] = t;
-    dout2[j] = t;
+    const float d = v.disp[o], c = j > 0 ? v.cost[o] : 0.f;
+    st4[j] = make_float4(d, c, d, c);
   }
   __syncthreads();
 
@@ -460,13 +542,13 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   unsigned long long no_merge = 0ull;
 
   // ---- round 1: every segment speculatively from the OLD value of the pixel before it -----------------------------
-  float in_used = active ? din2[i0].x : 0.f;
+  float in_used = active ? st4[i0].x : 0.f;
   if (k.gl == 0) *cand_slot = in_used;
   int ipm = i0 + k.mpos;
   for (;;) {
     const unsigned long long inr_m = mask_of(ipm < k.lim);
     if (inr_m == 0ull) break;
-    run3_step<GS, AXIS, TP, DIR, LREF, false>(v, ps, cp, g, chain, k, inr_m, ipm, din2, dout2, cand_slot, no_merge);
+    run3_step<GS, AXIS, TP, DIR, LREF, false>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, cand_slot, no_merge);
     ++n_steps;
   }
   float lastv = *cand_slot;
@@ -491,7 +573,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
       for (;;) {
         const unsigned long long inr_m = mask_of(ipm < k.lim) & redo_m & ~merged_fill;
         if (inr_m == 0ull) break;
-        run3_step<GS, AXIS, TP, DIR, LREF, true>(v, ps, cp, g, chain, k, inr_m, ipm, din2, dout2, cand_slot, merged_fill);
+        run3_step<GS, AXIS, TP, DIR, LREF, true>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, cand_slot, merged_fill);
         ++n_fix;
       }
       const float c2 = *cand_slot;
@@ -519,11 +601,11 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   }
 
   for (int j = threadIdx.x + 1; j <= n; j += blockDim.x) {
-    const float2 t = dout2[j];
-    if (t.x != din2[j].x) {
+    const float4 t = st4[j];
+    if (t.z != t.x) {
       const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
-      v.disp[o] = t.x;
-      v.cost[o] = t.y;
+      v.disp[o] = t.z;
+      v.cost[o] = t.w;
     }
   }
 }
@@ -540,7 +622,7 @@ inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepG
   int len = (n + nseg - 1) / nseg;
   if (len < 8) len = 8;
   size_t lds_bytes = run3_lds_bytes(n, nseg);
-  if (LREF) lds_bytes += run2_lref_bytes<AXIS, TP>(ps);
+  if (LREF) lds_bytes += run3_lref_bytes(ps);
   allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
   hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
@@ -552,8 +634,8 @@ inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepG
   // four workgroups per CU (PM_RUN2_LREF / PM_RUN2_LREF_KB: A/B knobs)
   if constexpr (AXIS == 1 && TP == 11) {
     const int n = (g.s_last - g.s_first) * g.dir + 1;
-    const size_t total = run3_lds_bytes(n, 64) + run2_lref_bytes<AXIS, TP>(ps);
-    if (run2_lref_enabled(AXIS) && total <= run2_lref_limit()) {
+    const size_t total = run3_lds_bytes(n, 64) + run3_lref_bytes(ps);
+    if (run3_lref_enabled() && total <= run3_lref_limit()) {
       if (g.dir > 0) launch_run3_l<GS, AXIS, TP, 1, true>(ps, cp, g, slots, waves, stream);
       else launch_run3_l<GS, AXIS, TP, -1, true>(ps, cp, g, slots, waves, stream);
       return;

@@ -59,3 +59,36 @@ def test_shard_is_rank_local():
     mine = {i for step in bench.shard(3, 8, 8, 2) for i in step}
     other = {i for r in (2, 4) for step in bench.shard(r, 8, 8, 2) for i in step}
     assert mine == set(range(24, 32)) and not (mine & other)
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (what the driver's N=1..8 sweep issues when it does not wrap the
+    command in torch.distributed.run): the script starts its two ranks itself, rank 0's line says n_gpus 2 and the
+    process group the timed barrier saw had 2 ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend",
+           "gloo", "--dry-run"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 4
+    assert out["ms_per_step"] >= 2.0  # rank 1's 2 ms per step: the max over ranks
+    # --gpus 1 stays a single process without a process group
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
+                         "--dry-run"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    out1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert out1["n_gpus"] == 1 and out1["rccl_ranks"] == 1
+
+
+def test_bench_gpus_flag_reports_a_failed_rank(tmp_path):
+    """A rank that dies must end the run with a non-zero exit code instead of leaving the others at the barrier."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PM_BENCH_FAIL_RANK"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--backend",
+           "gloo", "--dry-run"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank(s) failed" in r.stderr
