@@ -39,7 +39,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/
 SWEEP_BYTES_PER_PX = 24
 # Plane mode: state = 12 B plane + 4 B cost per pixel and view (8 B with fp16 state); per iteration and view the
 # spatial stage moves 48 B/px (two colour launches of 24), view propagation 64, refinement 48: N * (74 + 320 * I).
-PLANE_STAGE_BYTES = {"planes_spatial": 48, "planes_view": 64, "planes_refine": 48}
+# bytes per px and view of ONE launch of a class: a red or black launch of the spatial stage is half of its 48; the fused
+# view propagation + refinement launch of the default schedule is 64 + 48
+PLANE_LAUNCH_BYTES = {"planes_spatial": 24, "planes_view": 64, "planes_refine": 48, "planes_view_refine": 112}
+# views one launch of the class covers (the spatial stage sweeps both views of a pair in one launch)
+PLANE_LAUNCH_VIEWS = {"planes_spatial": 2, "planes_view": 1, "planes_refine": 2, "planes_view_refine": 1}
 N_ROTATE = 4  # distinct device-resident pairs the timed steps rotate over
 
 
@@ -52,6 +56,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise sharding/barrier/reduction without a GPU (no compute, no engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the single-threaded oracle on the WHOLE frame (about 70 s) instead of scaling a 160-row band")
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--iters", type=int, default=ITERS)
@@ -140,6 +146,22 @@ def pmc_traffic(kernel_class):
         return None
 
 
+def pmc_valu(kernel_class):
+    """The binding roof of the window kernels beside the HBM figure BASELINE.json asks for: vector-instruction issue,
+    from the committed SQ passes of this same command (profiles/valu.json, written by tools/make_valu.py from separate
+    rocprofv3 --pmc runs; rocprofv3 serialises the launches, so `issue_frac` is that of a kernel ALONE on the chip).
+    issue_frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles).  None if the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
+            t = json.load(f)
+        out = dict(t["kernels"][kernel_class])
+        out["insts_per_step"] = t.get("insts_valu_per_step")
+        out["source"] = "profiles/valu.json"
+        return out
+    except Exception:
+        return None
+
+
 def shard(rank, world, steps, nb):
     """Pair indices matched by `rank` at each step: independent pairs, contiguous by rank; the steps rotate over
     N_ROTATE distinct pairs of the rank's share."""
@@ -154,7 +176,8 @@ def cpu_baseline(args):
     import oracle_lib as O
     import synth
     p = synth.make_pair(0, args.rows, args.cols)
-    band_rows = min(160, args.rows)  # ~10-15 s of single-thread CPU work on the GPU node's host
+    # ~10-15 s of single-thread CPU work on the GPU node's host; --cpu-baseline-full: the whole frame, unscaled
+    band_rows = args.rows if args.cpu_baseline_full else min(160, args.rows)
     y0 = (args.rows - band_rows) // 2
     band = slice(y0, y0 + band_rows)
     prm = O.default_params(O.SEM_CPU, patch=args.patch, n_iters=args.iters, nthreads=1, literal=1, left_right_check=1)
@@ -172,6 +195,7 @@ def cpu_baseline(args):
     t_all = time.perf_counter() - t0
     return {
         "value": 1.0 / (t * scale), "unit": "pairs/s", "cores": 1, "kind": "port",
+        "sampled": "whole frame, unscaled" if band_rows == args.rows else "band sample scaled by swept rows (x%.3f)" % scale,
         "sample": f"oracle (literal getRectSubPix+functor port, 1 thread: the reference CPU path has no threading) on a "
                   f"{band_rows}-row full-width band of pair 0, both views, {args.iters} iterations, "
                   f"{args.patch}x{args.patch}: {t:.2f} s; scaled by swept rows {args.rows - 2 * h}/{band_rows - 2 * h}",
@@ -318,19 +342,21 @@ class Workload:
 def roofline_of(args, prof, n_prof, nb, mode, state):
     px_views = args.rows * args.cols * 2 * nb
     if mode == "planes":
-        dom = max(PLANE_STAGE_BYTES, key=lambda k: prof[k][1])
+        dom = max(PLANE_LAUNCH_BYTES, key=lambda k: prof.get(k, (0, 0.0))[1])
         n_launch, total_ms = prof[dom]
         avg_ms = total_ms / max(n_launch, 1)
-        launches_per_iter = {"planes_spatial": 2, "planes_view": 2, "planes_refine": 1}[dom]
         scale = 0.5 if state == "f16" else 1.0  # "with fp16 state replace 16 -> 8 B" 
-        bytes_per_launch = PLANE_STAGE_BYTES[dom] * scale * px_views / launches_per_iter
+        bytes_per_launch = PLANE_LAUNCH_BYTES[dom] * scale * args.rows * args.cols * nb * PLANE_LAUNCH_VIEWS[dom]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (nb == 1 and state == "f32") else None,
+                "traffic_source": "profiles/traffic.json" if (nb == 1 and state == "f32") else None,
+                "valu": pmc_valu(dom) if (nb == 1 and state == "f32") else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
-                "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48, view 64, "
-                           "refine 48 (halved for fp16 state)",
+                "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48 (two "
+                           "launches of 24: red, black), view 64, refine 48, fused view + refine launch 112 (halved "
+                           "for fp16 state)",
                 "note": "the window cost makes these kernels VALU-bound (about 100 vector instructions per window row "
                         "and candidate, DESIGN.md): the HBM fraction is the figure BASELINE.json asks for, not the "
                         "binding roof"}
@@ -345,6 +371,9 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
+            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command, not measured in this run)" if nb == 1 else None,
+            "valu": pmc_valu(dom) if nb == 1 else None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
             "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
             "achieved_all_concurrent": achieved * concurrency,
@@ -355,6 +384,9 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
 
 
 def timed_loop(w, d, steps, warmup, every, no_profile):
+    """W untimed steps, then exactly `steps` timed ones between barrier + synchronize on both sides (wall clock: the
+    contract's figure).  Beside it every step boundary is a HIP event recorded on the ENGINE's stream (torch's own
+    events only see torch's current stream): per-step durations without any host synchronisation, for the median."""
     torch = w.torch
     eng = w.eng
     for s in range(warmup):
@@ -362,15 +394,19 @@ def timed_loop(w, d, steps, warmup, every, no_profile):
     eng.synchronize()
     eng.profile_read()
     n_prof = 0
+    es = torch.cuda.ExternalStream(eng.stream())
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     d.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record(es)
     for s in range(steps):
         timed = (not no_profile) and s % every == 0
         eng.profile_enable(timed)
         n_prof += 1 if timed else 0
         w.step(s)
+        marks[s + 1].record(es)
     eng.synchronize()
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
@@ -379,7 +415,11 @@ def timed_loop(w, d, steps, warmup, every, no_profile):
     elapsed = d.max_over_ranks(elapsed_local)
     prof = eng.profile_read()
     eng.profile_enable(False)
-    return elapsed, prof, n_prof
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    stats = {"median": step_ms[steps // 2] if steps % 2 else 0.5 * (step_ms[steps // 2 - 1] + step_ms[steps // 2]),
+             "min": step_ms[0], "max": step_ms[-1], "mean": sum(step_ms) / steps,
+             "clock": "HIP events on the engine's stream at every step boundary (this rank)"} if steps else None
+    return elapsed, prof, n_prof, stats
 
 
 def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
@@ -392,7 +432,7 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
             return v
     w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance)
     steps = 8
-    elapsed, prof, n_prof = timed_loop(w, NoDist(), steps, 2, 2, False)
+    elapsed, prof, n_prof, step_stats = timed_loop(w, NoDist(), steps, 2, 2, False)
     w.step(0)
     w.eng.synchronize()
     out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
@@ -400,6 +440,7 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
                                                       "front of every Match (BASELINE configs[4] per-GPU shape)" if enhance
                                                       else " (BASELINE configs[1] shape)"),
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
+           "step_ms": step_stats,
            "dtype": "u8 window cost, " + state + " state",
            "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state),
            "kernels_ms_per_step": {k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
@@ -585,7 +626,7 @@ def main():
     dev = torch.device(f"cuda:{d.local_rank}")
     w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, args.mode, args.state, args.enhance)
     eng = w.eng
-    elapsed, prof, n_prof = timed_loop(w, d, steps, warmup, max(1, args.profile_every), args.no_profile)
+    elapsed, prof, n_prof, step_stats = timed_loop(w, d, steps, warmup, max(1, args.profile_every), args.no_profile)
 
     # determinism: the same resident pair twice
     w.step(0)
@@ -611,6 +652,7 @@ def main():
         result.update(
             value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
             ms_per_frame=1e3 * elapsed / steps / nb,
+            step_ms=step_stats,
             roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state) if n_prof else None,
             kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
             gpu_busy_ms_per_step=gpu_ms / max(n_prof, 1),

@@ -317,7 +317,8 @@ enum {
   PM_K_PL_SPATIAL = 8, /* red / black spatial propagation                    */
   PM_K_PL_VIEW = 9,    /* view propagation                                   */
   PM_K_PL_REFINE = 10, /* random plane refinement                            */
-  PM_K_COUNT = 11
+  PM_K_PL_VIEW_REFINE = 11, /* view propagation + refinement of one view in one launch (the default schedule) */
+  PM_K_COUNT = 12
 };
 typedef struct pm_profile {
   uint64_t launches[PM_K_COUNT];

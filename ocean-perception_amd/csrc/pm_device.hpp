@@ -27,17 +27,17 @@ struct PlaneSet {
   size_t plane_t;      // cols * pitch_t
   uint16_t* pk16;      // [B][4][rows][pitch]   img8 | g8 << 8: what a window reads of its own image
   uint16_t* tpk16;     // [B][4][cols][pitch_t] transposed copy of pk16
-  // Line-PAIR planes of the run engine (pm_run3.hpp): element (l, e) holds position e of the two consecutive lines
-  // l and l + 1, so a step fetches two window lines per load instruction (the sweeps are bound by the NUMBER of
-  // memory instructions) and a window starting at any line finds its lines as whole pairs l, l + 2, l + 4 ...
+  // Line-TRIPLE planes of the run engine (pm_run3.hpp): element (l, e) holds position e of the three consecutive
+  // lines l, l + 1, l + 2 as one aligned 16-byte record, so a step fetches three window lines per load instruction
+  // and a window starting at any line finds its lines as whole triples l, l + 3, l + 6 ...  (The sweeps are bound by
+  // the vector memory pipeline, which works per 4 lanes and cache line: fewer, wider loads are what counts.)
   // "Lines" are image rows for the row sweeps (rpg) and image columns, on the transposed planes, for the column
   // sweeps (cpg).  Per pair b and view v (target image of the view for the records, reference image for the quads):
-  float* rpg;          // [B][2][nrl][pitch][3]    target records {gradient of line l, of line l + 1, u32 colours:
-                       //                          byte 0 / 1 = lines l / l + 1 at column e, byte 2 / 3 = at column e + 1}
+  float* rpg;          // [B][2][nrl][pitch][4]    target records {gradient of lines l, l + 1, l + 2, u32 colour bytes}
   // reference QUADS (row sweeps): element (l, e) = image rows l .. l + 3 at column e as {four colour bytes, four
   // gradient bytes}: the form the sweeps' v_sad_u8 takes
   uint32_t* rqk;       // [B][2][nrl][pitch][2]
-  float* cpg;          // [B][2][ncl][pitch_t][3]  the same records on the transposed target planes (colours: bytes 0 / 1)
+  float* cpg;          // [B][2][ncl][pitch_t][4]  the same records on the transposed target planes
   int nrl, ncl;        // lines per view: rows + 2, cols + kTransPad + 2 (lines beyond the last repeat it)
   float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
   float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
@@ -71,7 +71,7 @@ struct View {
   // column sweeps: the reference window lines of the chain staged in LDS, [image row][kLref4Stride] dwords, four
   // window columns per dword (pm_run3.hpp, LREF)
   const unsigned* lds_ref4;
-  // line-pair / quad planes of this view (first line)
+  // line-triple / quad planes of this view (first line)
   const float* rpg;
   const uint32_t* rqk;
   const float* cpg;
@@ -108,9 +108,9 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.trefpk = ps.tpk16 + (base4 + iref) * ps.plane_t;
   w.lds_ref4 = nullptr;
   const size_t pv = (size_t)b * 2 + v;
-  w.rpg = ps.rpg + pv * (size_t)ps.nrl * ps.pitch * 3;
+  w.rpg = ps.rpg + pv * (size_t)ps.nrl * ps.pitch * 4;
   w.rqk = ps.rqk + pv * (size_t)ps.nrl * ps.pitch * 2;
-  w.cpg = ps.cpg + pv * (size_t)ps.ncl * ps.pitch_t * 3;
+  w.cpg = ps.cpg + pv * (size_t)ps.ncl * ps.pitch_t * 4;
   const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;

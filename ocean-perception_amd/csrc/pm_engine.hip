@@ -298,7 +298,7 @@ int launch_check(pm_handle* h, const char* what) {
 
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
 
-// The line-pair planes (about 60 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
+// The line-triple planes (about 80 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
 // scalar mode, the run engine.  Other handles (PM_SEM_GPU, PM_MODE_PLANES, the serial / wave anchors) neither
 // allocate nor build them; allocation happens on the first call that builds them.
 bool pair_planes_wanted(const pm_handle* h) {
@@ -313,13 +313,13 @@ int pair_planes_alloc(pm_handle* h) {
   const size_t pitch_t = (size_t)align_up(h->max_rows, 64);
   const size_t nrp = B * 2 * (size_t)(h->max_rows + 2) * h->max_pitch + 64;
   const size_t ncp = B * 2 * (size_t)(h->max_cols + kTransPad + 2) * pitch_t + 64;
-  PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 3 * nrp));
+  PM_HIP(h, hipMalloc((void**)&h->rpg, sizeof(float) * 4 * nrp));
   PM_HIP(h, hipMalloc((void**)&h->rqk, sizeof(uint32_t) * 2 * nrp));
-  PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 3 * ncp));
+  PM_HIP(h, hipMalloc((void**)&h->cpg, sizeof(float) * 4 * ncp));
   // row padding behind `cols` / `rows` is read (with weight 0 or by lanes out of reach) and must be finite
-  PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 3 * nrp, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->rpg, 0, sizeof(float) * 4 * nrp, h->stream));
   PM_HIP(h, hipMemsetAsync(h->rqk, 0, sizeof(uint32_t) * 2 * nrp, h->stream));
-  PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 3 * ncp, h->stream));
+  PM_HIP(h, hipMemsetAsync(h->cpg, 0, sizeof(float) * 4 * ncp, h->stream));
   return PM_OK;
 }
 
@@ -334,15 +334,15 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
                      ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
   hipLaunchKernelGGL(k_transpose<uint16_t>, grid, block, 0, h->stream, (const uint16_t*)ps.pk16, ps.tpk16, ps.rows,
                      ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  if (pair_planes_wanted(h)) {  // the line-pair / quad planes of the run engine (pm_run3.hpp)
+  if (pair_planes_wanted(h)) {  // the line-triple / quad planes of the run engine (pm_run3.hpp)
     if (int rc = pair_planes_alloc(h)) return rc;
     PlaneSet pp = ps;
     pp.rpg = h->rpg;
     pp.rqk = h->rqk;
     pp.cpg = h->cpg;
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
+    hipLaunchKernelGGL(k_triples, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
                        h->stream, pp, 1);
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.ncl, (unsigned)(n * 2)), block, 0,
+    hipLaunchKernelGGL(k_triples, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.ncl, (unsigned)(n * 2)), block, 0,
                        h->stream, pp, 0);
     hipLaunchKernelGGL(k_quads, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
                        h->stream, pp);
@@ -836,7 +836,7 @@ int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
       ar.view_fixed = view;
       ar.refine_amp = h->params.noise_amp[it];
       if (nv < 2) return planes_stage<PL_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "refinement");
-      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "view propagation + refinement");
+      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_VIEW_REFINE, "view propagation + refinement");
     }
     default:
       set_err(h, "unknown planes stage %d", stage);
@@ -998,7 +998,7 @@ const char* pm_status_string(int status) {
 const char* pm_kernel_name(int k) {
   static const char* names[PM_K_COUNT] = {"prep", "seed", "noise_cost", "sweep_row", "sweep_col", "background",
                                           "finalize", "planes_init", "planes_spatial", "planes_view",
-                                          "planes_refine"};
+                                          "planes_refine", "planes_view_refine"};
   return (k >= 0 && k < PM_K_COUNT) ? names[k] : "?";
 }
 
@@ -2155,15 +2155,18 @@ int pm_debug_counters(pm_handle* h, uint64_t out[8]) {
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   PM_HIP(h, hipMemcpy(out, h->counters, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost));
-#ifdef PM_RUN2_TIMING
+#ifdef PM_RUN3_STATS
   {
     uint64_t t[8];
     PM_HIP(h, hipMemcpy(t, h->counters + 8, sizeof(t), hipMemcpyDeviceToHost));
-    if (t[5])
-      fprintf(stderr, "run2 timing (cycles per sampled round-1 step): lds+ballot %.0f, loads+lines %.0f, window+cost %.0f, "
-                      "decide %.0f, loop %.0f; steps %llu\n",
-              (double)t[0] / t[5], (double)t[1] / t[5], (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5],
-              (unsigned long long)t[5]);
+    if (t[3]) {
+      const double blocks = (double)t[3], waves = blocks * 4.0;  // (4 wavefronts per workgroup: the default)
+      fprintf(stderr, "run3 stats: workgroups %.0f; round-1 steps of the slowest wavefront per workgroup %.1f, of the average "
+                      "wavefront %.1f, of the average group %.1f; fix-up steps of the slowest wavefront %.1f; clock ticks per "
+                      "workgroup: round 1 %.0f, fix-up rounds %.0f\n",
+              blocks, (double)t[0] / blocks, (double)(out[0] + out[4]) / waves, (double)t[2] / (double)t[6],
+              (double)t[1] / blocks, (double)t[4] / blocks, (double)t[5] / blocks);
+    }
   }
 #endif
   PM_HIP(h, hipMemset(h->counters, 0, sizeof(uint64_t) * 16));

@@ -121,41 +121,33 @@ __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T*
   }
 }
 
-// Line-pair planes of the run engine (PlaneSet::rpg / cpg): built from the plain and the transposed planes once per
-// Match.  grid = (ceil(len / 256), lines, B * 2) with z = b * 2 + view; `rows_mode` != 0: row pairs (len = cols,
-// line = image row, source planes img8 / g32 with pitch), else column pairs on the transposed planes (len = rows,
+// Line-triple planes of the run engine (PlaneSet::rpg / cpg): built from the plain and the transposed planes once per
+// Match.  grid = (ceil(len / 256), lines, B * 2) with z = b * 2 + view; `rows_mode` != 0: row triples (len = cols,
+// line = image row, source planes img8 / g32 with pitch), else column triples on the transposed planes (len = rows,
 // line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
 // Lines beyond the last one repeat it (they are only ever the unused twelfth line of a window).
-__global__ void __launch_bounds__(256) k_pairs(PlaneSet ps, int rows_mode) {
+__global__ void __launch_bounds__(256) k_triples(PlaneSet ps, int rows_mode) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = blockIdx.y;
   const int z = blockIdx.z, view = z & 1, b = z >> 1;
   const int itgt = view == 0 ? 1 : 2;
-  if (rows_mode) {
-    if (e >= ps.cols || l >= ps.nrl) return;
-    const int l0 = min(l, ps.rows - 1), l1 = min(l + 1, ps.rows - 1);
-    const size_t src0 = (size_t)l0 * ps.pitch + e, src1 = (size_t)l1 * ps.pitch + e;
-    const size_t tp = ((size_t)b * 4 + itgt) * ps.plane;
-    const size_t dst = ((size_t)z * ps.nrl + l) * ps.pitch + e;
-    // one 12-byte record per element: the two gradients and the colour bytes -- ONE load in the sweeps
-    ps.rpg[3 * dst] = ps.g32[tp + src0];
-    ps.rpg[3 * dst + 1] = ps.g32[tp + src1];
-    // colours: byte 0 / 1 = the two lines at column e, byte 2 / 3 = the same lines at column e + 1 (replicated at the
-    // border like cv::getRectSubPix): both bilinear taps of both lines without a cross-lane move
-    const int e1 = min(e + 1, ps.cols - 1) - e;
-    ((uint32_t*)ps.rpg)[3 * dst + 2] = (uint32_t)ps.img8[tp + src0] | ((uint32_t)ps.img8[tp + src1] << 8) |
-                                       ((uint32_t)ps.img8[tp + src0 + e1] << 16) | ((uint32_t)ps.img8[tp + src1 + e1] << 24);
-  } else {
-    if (e >= ps.rows || l >= ps.ncl) return;
-    const int lmax = ps.cols + kTransPad - 1;
-    const int l0 = min(l, lmax), l1 = min(l + 1, lmax);
-    const size_t src0 = (size_t)l0 * ps.pitch_t + e, src1 = (size_t)l1 * ps.pitch_t + e;
-    const size_t tp = ((size_t)b * 4 + itgt) * ps.plane_t;
-    const size_t dst = ((size_t)z * ps.ncl + l) * ps.pitch_t + e;
-    ps.cpg[3 * dst] = ps.tg32[tp + src0];
-    ps.cpg[3 * dst + 1] = ps.tg32[tp + src1];
-    ((uint32_t*)ps.cpg)[3 * dst + 2] = (uint32_t)ps.timg8[tp + src0] | ((uint32_t)ps.timg8[tp + src1] << 8);
-  }
+  const int len = rows_mode ? ps.cols : ps.rows, nl = rows_mode ? ps.nrl : ps.ncl;
+  if (e >= len || l >= nl) return;
+  const int lmax = rows_mode ? ps.rows - 1 : ps.cols + kTransPad - 1;
+  const size_t sp = rows_mode ? (size_t)ps.pitch : (size_t)ps.pitch_t;
+  const size_t tp = ((size_t)b * 4 + itgt) * (rows_mode ? ps.plane : ps.plane_t);
+  const float* g = (rows_mode ? ps.g32 : ps.tg32) + tp;
+  const uint8_t* c = (rows_mode ? ps.img8 : ps.timg8) + tp;
+  const size_t s0 = (size_t)min(l, lmax) * sp + e, s1 = (size_t)min(l + 1, lmax) * sp + e,
+               s2 = (size_t)min(l + 2, lmax) * sp + e;
+  // one 16-byte record per element: three gradients and three colour bytes -- ONE aligned global_load_dwordx4 in the sweeps
+  float4 rec;
+  rec.x = g[s0];
+  rec.y = g[s1];
+  rec.z = g[s2];
+  rec.w = __builtin_bit_cast(float, (uint32_t)c[s0] | ((uint32_t)c[s1] << 8) | ((uint32_t)c[s2] << 16));
+  float4* dst = (float4*)(rows_mode ? ps.rpg : ps.cpg);
+  dst[((size_t)z * nl + l) * sp + e] = rec;
 }
 
 // Reference quads of the row sweeps (PlaneSet::rqk).  grid = (ceil(cols / 256), nrl, B * 2) with z = b * 2 + view.

@@ -64,22 +64,6 @@ __device__ __forceinline__ float wave_shl1f(float v) {
   return __builtin_bit_cast(float, wave_shl1(__builtin_bit_cast(int, v)));
 }
 
-// One record of the pair planes (PlaneSet::rpg / cpg): .x / .y = the gradients of two consecutive lines, .c = their
-// colour bytes (k_pairs).  `byte_off` = 12 * element, relative to a wave-uniform base: global_load_dwordx3 v_off, s[base].
-struct PairRec {
-  float x, y;
-  unsigned c;
-};
-__device__ __forceinline__ PairRec ld_rec(const void* base, unsigned byte_off) {
-  return *(const PairRec*)((const char*)base + (size_t)byte_off);
-}
-// 12 * elem as two shift-adds; opaque, otherwise the optimiser folds it back into a quarter-rate v_mul_lo_u32
-__device__ __forceinline__ unsigned rec_offset(unsigned elem) {
-  unsigned t = (elem << 1) + elem;
-  asm volatile("" : "+v"(t));
-  return t << 2;
-}
-
 // ---- PM_SEM_GPU --------------------------------------------------------------------------------------------------
 struct RunStep2 {
   // group-uniform

@@ -18,8 +18,12 @@
 //     (no ds_bpermute address arithmetic); a lane's chain index advances by a popcount of its group's field;
 //   * chain state is one float4 per position {old value, old cost, new value, new cost}: one ds_read_b64 and one
 //     ds_write_b64 per step at the same address, no conditional read;
-//   * the two / four window lines of a load come from LINE-indexed pair planes (PlaneSet::rpg ...): the line offsets
-//     are wave-uniform base pointers (scalar registers), the lane's column is ONE vector offset shared by all loads;
+//   * three window lines per load: 16-byte records {three gradients, three colour bytes} from LINE-indexed planes
+//     (PlaneSet::rpg / cpg, k_triples); the line offsets are wave-uniform base pointers (scalar registers), the
+//     lane's column is ONE vector offset shared by all loads of a step.  Round-3 counters (profiles/r03b_*): with the
+//     chip full of sweeps the vector units issue 31-35 % of the time while the texture address / data units are
+//     73-92 % busy -- the memory pipeline works per 4 lanes and cache line (23 accesses per wave-load of 12-byte
+//     records), so the number and width of the loads is what a step costs;
 //   * 16-lane groups add up their window lines with row_shl DPP in log steps (5 adds for 11 lines instead of 10).
 // Results are bit-identical to the serial engine, the wave engine and the oracle (tests/test_gpu_parity.py,
 // tools/fuzz_engines.py).
@@ -132,21 +136,29 @@ struct Run3Lane {
 // in scalar registers a load is global_load ... v_off, s[base] and ONE vector offset serves all loads of a step.
 typedef __attribute__((address_space(1))) const char* GlobalPtr;  // explicit: a pinned generic pointer loads as flat_load
 struct Run3Bases {
-  GlobalPtr line[6];
+  GlobalPtr line[4];
   GlobalPtr quad[3];
 };
-// (member-wise through the qualified pointer: the compiler fuses them into one global_load_dwordx3 / dwordx2.  An
-// `ext_vector_type(3), aligned(4)` load is NOT an alternative: hipcc 7.2 returns element 0 for element 1 of it.)
+// One record of the line-triple planes: the gradients of three consecutive lines and their colour bytes (k_triples).
+struct alignas(16) TripleRec {
+  float g0, g1, g2;
+  unsigned c;
+};
 struct alignas(8) QuadRec {
   unsigned c, g;
 };
-__device__ __forceinline__ PairRec ld_rec_g(GlobalPtr base, unsigned byte_off) {
-  const __attribute__((address_space(1))) PairRec* q =
-      (const __attribute__((address_space(1))) PairRec*)(base + (size_t)byte_off);
-  PairRec r;
-  r.x = q->x;
-  r.y = q->y;
-  r.c = q->c;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ TripleRec ld_rec_g(GlobalPtr base, unsigned byte_off) {
+  // one global_load_dwordx4 (a member-wise struct load is split into dwordx2 + dword when a line is unused: two
+  // trips through the memory pipeline).  The elements go through scalar temporaries: hipcc 7.2 evaluates
+  // __builtin_bit_cast(float, t.y) on a vector element as element 0.
+  const u32x4 t = *(const __attribute__((address_space(1))) u32x4*)(base + (size_t)byte_off);
+  const unsigned t0 = t.x, t1 = t.y, t2 = t.z, t3 = t.w;
+  TripleRec r;
+  r.g0 = __builtin_bit_cast(float, t0);
+  r.g1 = __builtin_bit_cast(float, t1);
+  r.g2 = __builtin_bit_cast(float, t2);
+  r.c = t3;
   return r;
 }
 __device__ __forceinline__ QuadRec ld_quad_g(GlobalPtr base, unsigned byte_off) {
@@ -164,17 +176,17 @@ __device__ __forceinline__ Run3Bases run3_bases(const View& v, const PlaneSet& p
     if constexpr (AXIS == 0) {
       const int y0 = chain - TP / 2;  // first window row
 #pragma unroll
-      for (int m = 0; m < (TP + 1) / 2; ++m)
-        b.line[m] = (GlobalPtr)v.rpg + ((size_t)(y0 + 2 * m) * (size_t)ps.pitch) * 12u;
+      for (int m = 0; m < (TP + 2) / 3; ++m)
+        b.line[m] = (GlobalPtr)v.rpg + ((size_t)(y0 + 3 * m) * (size_t)ps.pitch) * 16u;
 #pragma unroll
       for (int q = 0; q < (TP + 3) / 4; ++q)
         b.quad[q] = (GlobalPtr)v.rqk + ((size_t)(y0 + 4 * q) * (size_t)ps.pitch) * 8u;
     } else {
 #pragma unroll
-      for (int m = 0; m < (TP + 2) / 2; ++m) b.line[m] = (GlobalPtr)v.cpg + ((size_t)(2 * m) * (size_t)ps.pitch_t) * 12u;
+      for (int m = 0; m < (TP + 3) / 3; ++m) b.line[m] = (GlobalPtr)v.cpg + ((size_t)(3 * m) * (size_t)ps.pitch_t) * 16u;
     }
 #pragma unroll
-    for (int m = 0; m < 6; ++m) asm volatile("" : "+s"(b.line[m]));  // pinned: not re-derived per step in vector registers
+    for (int m = 0; m < 4; ++m) asm volatile("" : "+s"(b.line[m]));  // pinned: not re-derived per step in vector registers
 #pragma unroll
     for (int q = 0; q < 3; ++q) asm volatile("" : "+s"(b.quad[q]));
   }
@@ -241,27 +253,30 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
                                                 __builtin_bit_cast(unsigned, fminf(m_ia, cap)), 0x05040100u);
       const f32x2 ia2 = {ia_r, ia_r}, a2 = {a_r, a_r};
       if constexpr (AXIS == 0) {
-        // lane = image column X (its own position's column -+ half), window rows in the lane, two per load
-        constexpr int NPR = (TP + 1) / 2, NQR = (TP + 3) / 4;
+        // lane = image column X (its own position's column -+ half), window rows in the lane, three per load
+        constexpr int NT = (TP + 2) / 3, NQR = (TP + 3) / 4;
         const int X = clamp_med3(pos - DIR * half, cols - 1);
         const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
-        unsigned r3 = ((unsigned)R0 << 1) + (unsigned)R0;
-        asm volatile("" : "+v"(r3));  // opaque: keeps 12 * R0 a shift-add (no quarter-rate v_mul_lo_u32)
-        const unsigned rv = r3 << 2;  // the lane's byte offset inside every line
-        unsigned tcol[2 * NPR + 2];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
-        float gv[2 * NPR + 1];
+        const unsigned rv = (unsigned)R0 << 4;  // the lane's byte offset inside every line
+        unsigned tcol[4 * NQR + 4];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
+        float gv[3 * NT + 1];
 #pragma unroll
-        for (int m = 0; m < NPR; ++m) {
-          const PairRec pg = ld_rec_g(bases.line[m], rv);
-          gv[2 * m] = pg.x;
-          gv[2 * m + 1] = pg.y;
-          // record colours: byte 0 / 1 = rows 2m / 2m + 1 at column R0, byte 2 / 3 = the same rows at R0 + 1
-          tcol[2 * m] = cpu_color_sum_pk(__builtin_amdgcn_perm(pg.c, pg.c, 0x0c020c00u), cw);
-          tcol[2 * m + 1] = cpu_color_sum_pk(__builtin_amdgcn_perm(pg.c, pg.c, 0x0c030c01u), cw);
+        for (int m = 0; m < NT; ++m) {
+          const TripleRec rec = ld_rec_g(bases.line[m], rv);
+          gv[3 * m] = rec.g0;
+          gv[3 * m + 1] = rec.g1;
+          gv[3 * m + 2] = rec.g2;
+          // the second bilinear tap of the three rows is the next line's first one: one DPP move per record, then per
+          // row (own byte | neighbour's byte << 16) by one v_perm and the lerp sum by one v_dot2_u32_u16
+          const unsigned cn = (unsigned)next_line_i<DIR>((int)rec.c);
+          tcol[3 * m] = cpu_color_sum_pk(__builtin_amdgcn_perm(cn, rec.c, 0x0c040c00u), cw);
+          tcol[3 * m + 1] = cpu_color_sum_pk(__builtin_amdgcn_perm(cn, rec.c, 0x0c050c01u), cw);
+          tcol[3 * m + 2] = cpu_color_sum_pk(__builtin_amdgcn_perm(cn, rec.c, 0x0c060c02u), cw);
         }
-        tcol[2 * NPR] = tcol[2 * NPR + 1] = 0u;
-        gv[2 * NPR] = 0.f;
-        float sgr[2 * NPR];  // gradient lerp sums g0 * (1 - a) + g1 * a, g1 = the next line's g0
+#pragma unroll
+        for (int t = 3 * NT; t < 4 * NQR + 4; ++t) tcol[t] = 0u;
+        gv[3 * NT] = 0.f;
+        float sgr[4 * NQR + 4];  // gradient lerp sums g0 * (1 - a) + g1 * a, g1 = the next line's g0
 #pragma unroll
         for (int t = 0; t < TP; t += 2) {
           const f32x2 gg = {gv[t], gv[t + 1]};
@@ -300,24 +315,25 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         }
       } else {
         // lane = image row Y (transposed planes), window columns in the lane: samples 0 .. TP of the lane's row are
-        // TP + 1 consecutive image columns from ipx_r, whole pairs of the alignment ipx_r & 1
-        constexpr int NPC = (TP + 2) / 2, NQ = (TP + 3) / 4;
+        // TP + 1 consecutive image columns from ipx_r: whole triples of the line-indexed plane
+        constexpr int NTC = (TP + 3) / 3, NQ = (TP + 3) / 4;
         const int pt = ps.pitch_t;
         const int Y = clamp_med3(pos - DIR * half, rows - 1);
         const int ipx_c = clamp_med3(ipx_r, cols - 1);  // (a group that cannot adopt may carry any ipx_r)
         // element (line ipx_c, row Y); both factors < 2^16: the 24-bit multiply-add is exact and full rate
-        const unsigned e0 = __umul24((unsigned)ipx_c, (unsigned)pt) + (unsigned)Y;
-        const unsigned cv = rec_offset(e0);
-        unsigned prv[NPC];
-        float gv[2 * NPC + 1];
+        const unsigned cv = (__umul24((unsigned)ipx_c, (unsigned)pt) + (unsigned)Y) << 4;
+        unsigned prv[NTC + 1];
+        float gv[3 * NTC + 1];
 #pragma unroll
-        for (int m = 0; m < NPC; ++m) {
-          const PairRec pg = ld_rec_g(bases.line[m], cv);
-          prv[m] = pg.c;
-          gv[2 * m] = pg.x;
-          gv[2 * m + 1] = pg.y;
+        for (int m = 0; m < NTC; ++m) {
+          const TripleRec rec = ld_rec_g(bases.line[m], cv);
+          prv[m] = rec.c;
+          gv[3 * m] = rec.g0;
+          gv[3 * m + 1] = rec.g1;
+          gv[3 * m + 2] = rec.g2;
         }
-        gv[2 * NPC] = 0.f;
+        prv[NTC] = 0u;
+        gv[3 * NTC] = 0.f;
         unsigned rc4[NQ], rg4[NQ];  // reference bytes of the lane's row, four window columns per dword
         if constexpr (LREF) {
           unsigned y8 = (unsigned)Y << 3;  // Y * kLref4Stride (7) as a shift and a subtraction, opaque (no multiply)
@@ -349,17 +365,19 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
 #pragma unroll
         for (int t = 0; t < 4 * NQ; ++t) {
           if (t < TP) {
-            // samples t, t + 1 as halfwords: both in pair t / 2 (t even) or one in each of two pairs (t odd)
-            const unsigned r01 = (t % 2 == 0) ? __builtin_amdgcn_perm(0u, prv[t / 2], 0x0c010c00u)
-                                              : __builtin_amdgcn_perm(prv[t / 2 + 1], prv[t / 2], 0x0c040c01u);
+            // samples t, t + 1 as halfwords: bytes t % 3 of record t / 3 and (t + 1) % 3 of record (t + 1) / 3
+            const unsigned sel = 0x0c000c00u | (unsigned)(t % 3) |
+                                 ((unsigned)(((t + 1) / 3 != t / 3 ? 4 : 0) + (t + 1) % 3) << 16);
+            const unsigned r01 = __builtin_amdgcn_perm(prv[(t + 1) / 3], prv[t / 3], sel);
             tcol[t] = cpu_color_sum_pk(r01, cw);
           } else {
             tcol[t] = 0u;
           }
         }
-        f32x2 pa[NPC], pb[NPC];
+        constexpr int NP2 = (TP + 2) / 2;  // samples 0 .. TP in pairs
+        f32x2 pa[NP2], pb[NP2];
 #pragma unroll
-        for (int m = 0; m < NPC; ++m) {
+        for (int m = 0; m < NP2; ++m) {
           const f32x2 gg = {gv[2 * m], gv[2 * m + 1]};
           pa[m] = gg * ia2;
           pb[m] = gg * a2;
@@ -545,12 +563,22 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   float in_used = active ? st4[i0].x : 0.f;
   if (k.gl == 0) *cand_slot = in_used;
   int ipm = i0 + k.mpos;
+#ifdef PM_RUN3_STATS
+  const long long t_start = clock64();
+  unsigned n_gsteps = 0;
+#endif
   for (;;) {
     const unsigned long long inr_m = mask_of(ipm < k.lim);
     if (inr_m == 0ull) break;
+#ifdef PM_RUN3_STATS
+    n_gsteps += __builtin_popcountll(inr_m & (Fields<GS>::lsb << POS0));
+#endif
     run3_step<GS, AXIS, TP, DIR, LREF, false>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, cand_slot, no_merge);
     ++n_steps;
   }
+#ifdef PM_RUN3_STATS
+  const long long t_r1 = clock64();
+#endif
   float lastv = *cand_slot;
   if (active && k.gl == 0) s_last[sidx + 1] = lastv;
   if (threadIdx.x == 0) s_last[0] = in_used;
@@ -592,6 +620,28 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
     if (!s_changed[round & 1]) break;
   }
   __syncthreads();
+#ifdef PM_RUN3_STATS
+  if (ps.counters) {  // load balance of a launch: what the slowest wavefront of a workgroup does vs the average one
+    const long long t_end = clock64();
+    __shared__ unsigned s_max_steps, s_max_fix;
+    if (threadIdx.x == 0) s_max_steps = s_max_fix = 0;
+    __syncthreads();
+    if (lane == 0) {
+      atomicMax(&s_max_steps, n_steps);
+      atomicMax(&s_max_fix, n_fix);
+      atomicAdd(&ps.counters[10], (unsigned long long)n_gsteps);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&ps.counters[8], (unsigned long long)s_max_steps);
+      atomicAdd(&ps.counters[9], (unsigned long long)s_max_fix);
+      atomicAdd(&ps.counters[11], 1ull);
+      atomicAdd(&ps.counters[12], (unsigned long long)(t_r1 - t_start));
+      atomicAdd(&ps.counters[13], (unsigned long long)(t_end - t_r1));
+      atomicAdd(&ps.counters[14], (unsigned long long)nseg);
+    }
+  }
+#endif
   if (ps.counters && lane == 0) {
     const int base = AXIS * 4;
     atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);

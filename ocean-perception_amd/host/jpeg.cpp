@@ -83,6 +83,14 @@ const int kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11,
                          30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 inline uint8_t Clamp(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+// coefficient * quantiser in 64 bits, clamped to what the inverse DCT's 32-bit arithmetic takes without overflow: a valid
+// 8-bit baseline stream stays far inside (|coef| <= 2^15, the clamp never acts); a hostile one (16-bit quantiser entries
+// times 15-bit values) would otherwise be signed-overflow UB
+inline int Dequant(int v, int q) {
+  const long long p = (long long)v * (long long)q;
+  const long long lim = 1 << 20;
+  return (int)(p < -lim ? -lim : (p > lim ? lim : p));
+}
 
 // Accurate integer inverse DCT (the "slow-but-accurate" one: CONST_BITS 13, PASS1_BITS 2), coefficients already
 // dequantised, output level-shifted by 128 and clamped.
@@ -380,7 +388,9 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
         if (t > 15) throw std::runtime_error("JPEG: bad DC category");  // 8-bit samples: at most 11 (15 tolerated)
         const int diff = t ? Extend(br.bits(t), t) : 0;
         c.pred += diff;
-        coef[0] = c.pred * qt[c.tq][0];
+        // a baseline DC value fits 12 bits; a stream that drifts beyond 16 is hostile (and c.pred * q would overflow)
+        if (c.pred < -32768 || c.pred > 32767) throw std::runtime_error("JPEG: DC predictor out of range");
+        coef[0] = Dequant(c.pred, qt[c.tq][0]);
         for (int k = 1; k < 64;) {
           const int rs = DecodeSymbol(br, ac);
           const int r = rs >> 4, s = rs & 15;
@@ -390,7 +400,7 @@ int DecodeJpeg(const uint8_t* buf, size_t n, bool want_color, Image1b* gray, Ima
           }
           k += r;
           if (k > 63) throw std::runtime_error("JPEG: coefficient index out of range");
-          coef[kZigzag[k]] = Extend(br.bits(s), s) * qt[c.tq][kZigzag[k]];
+          coef[kZigzag[k]] = Dequant(Extend(br.bits(s), s), qt[c.tq][kZigzag[k]]);
           ++k;
         }
         if (bx < c.blocks_w && by < c.blocks_h)

@@ -16,7 +16,7 @@ PM_SEM_CPU, PM_SEM_GPU = 0, 1
 PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUNBLK2 = 0, 1, 2, 5
 PM_OK = 0
 PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY = -1, -2, -3, -4, -5, -6
-PM_K_COUNT = 11
+PM_K_COUNT = 12
 PM_MODE_SCALAR, PM_MODE_PLANES = 0, 1
 PM_STATE_F32, PM_STATE_F16 = 0, 1
 PM_PL_SPATIAL, PM_PL_VIEW, PM_PL_REFINE, PM_PL_VIEW_REFINE = 1, 2, 3, 4

@@ -108,6 +108,7 @@ class LocalComm:
         def __init__(self, world):
             self.world = world
             self.slots = [[None, None] for _ in range(world)]  # [rank][0 = row for rank+1, 1 = row for rank-1]
+            self.done = [[None, None] for _ in range(world)]   # [rank][dir]: the reader has copied that row (event)
             self.flags = [False] * world
             self.barrier = threading.Barrier(world)
 
@@ -117,19 +118,31 @@ class LocalComm:
 
     def shift(self, row, down):
         s = self.s
+        d = 0 if down else 1
         ev = None
         if row.is_cuda:
+            # the row handed over last time stays referenced by the slot until now; its reader recorded an event after
+            # copying it, and this stream waits for that event before the slot lets go of the tensor -- so whatever
+            # this stream's allocator does with the block next is ordered behind the reader's copy.  (record_stream()
+            # would say the same, but it crashes on a torch.cuda.ExternalStream in this torch build.)
+            if s.done[self.rank][d] is not None:
+                torch.cuda.current_stream().wait_event(s.done[self.rank][d])
+                s.done[self.rank][d] = None
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-        s.slots[self.rank][0 if down else 1] = (row, ev)
+        s.slots[self.rank][d] = (row, ev)
         s.barrier.wait()
         src = self.rank - 1 if down else self.rank + 1
         got = None
         if 0 <= src < self.world:
-            src_row, src_ev = s.slots[src][0 if down else 1]
+            src_row, src_ev = s.slots[src][d]
             if src_ev is not None:
                 torch.cuda.current_stream().wait_event(src_ev)
             got = src_row.clone()
+            if src_ev is not None:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream())
+                s.done[src][d] = done
             self.exchanges += 1
         s.barrier.wait()
         return got
@@ -190,8 +203,12 @@ def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_
                         engine.tile_set_row(pred_row, new_in.data_ptr())
                         engine.tile_sweep_masked(it, k, mask.data_ptr())
                         used = new_in
-                # did my boundary row move after the last row I sent?  then my successor is stale
-                flag = torch.maximum(flag, (get_row(out_row) != sent).any().to(torch.int32).reshape(1))
+                # did my boundary row move after the last row I sent?  then my successor is stale.  Only a rank
+                # that HAS a successor in this sweep's direction asks: the last band's row is an image border
+                # nobody consumes, and a change there must not make every rank repeat the Match.
+                succ = comm.rank + 1 if down else comm.rank - 1
+                if 0 <= succ < comm.world:
+                    flag = torch.maximum(flag, (get_row(out_row) != sent).any().to(torch.int32).reshape(1))
         engine.tile_background()
         out_l = torch.empty((own_rows, cols), dtype=torch.float32, device=dev)
         out_r = torch.empty_like(out_l) if n_views > 1 else None

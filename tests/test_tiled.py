@@ -23,7 +23,7 @@ def test_band_partition_cpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sem,patch,world,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 2), (0, 3, 7, 0),
-                                                    (0, 5, 4, 1)])
+                                                    (0, 5, 4, 1), (0, 5, 2, 2), (1, 3, 2, 2)])
 def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world, rounds):
     """rounds = fixed exchange rounds per vertical sweep; 0 forces the "a boundary row still moved" flag and with it
     the repeat with world - 1 rounds (the exactness guarantee), 2 is the default."""
@@ -34,6 +34,10 @@ def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world, rounds):
     dl, dr, info = tiled.match_tiled_local(params, l, r, sl, sr, world, rounds=rounds)
     if rounds == 0:
         assert info["repeated"] and info["rounds"] == world - 1
+    if world == 2 and rounds >= 1:
+        # two bands are exact after one round; the last band's re-sweep moves its own border row, which nobody consumes
+        # and which therefore must not raise the "repeat the Match" flag (it did before round 3)
+        assert not info["repeated"]
     with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
         ul, ur = e.match(l, r, sl, sr)
     assert_same(dl, ul, "tiled vs untiled (left)")
