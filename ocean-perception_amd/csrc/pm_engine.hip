@@ -325,28 +325,29 @@ int pair_planes_alloc(pm_handle* h) {
 
 // transposed copies of the 12 image-type planes of n pairs (run by every path that ran k_prep)
 int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
-  const dim3 grid((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 63) / 64), (unsigned)(n * 4)), block(256);
-  hipLaunchKernelGGL(k_transpose<uint8_t>, grid, block, 0, h->stream, (const uint8_t*)ps.img8, ps.timg8, ps.rows,
-                     ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  hipLaunchKernelGGL(k_transpose<float>, grid, block, 0, h->stream, (const float*)ps.g32, ps.tg32, ps.rows, ps.cols,
-                     ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  hipLaunchKernelGGL(k_transpose<uint8_t>, grid, block, 0, h->stream, (const uint8_t*)ps.g8, ps.tg8, ps.rows, ps.cols,
-                     ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  hipLaunchKernelGGL(k_transpose<uint16_t>, grid, block, 0, h->stream, (const uint16_t*)ps.pk16, ps.tpk16, ps.rows,
-                     ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t);
-  if (pair_planes_wanted(h)) {  // the line-triple / quad planes of the run engine (pm_run3.hpp)
+  SetupGrid sg{};
+  sg.tx = (unsigned)((ps.cols + 63) / 64);
+  sg.ty = (unsigned)((ps.rows + 63) / 64);
+  sg.tz = (unsigned)(n * 4);
+  sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
+  PlaneSet pp = ps;
+  unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
+  if (sg.with_lines) {
     if (int rc = pair_planes_alloc(h)) return rc;
-    PlaneSet pp = ps;
     pp.rpg = h->rpg;
     pp.rqk = h->rqk;
     pp.cpg = h->cpg;
-    hipLaunchKernelGGL(k_triples, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
-                       h->stream, pp, 1);
-    hipLaunchKernelGGL(k_triples, dim3((unsigned)((ps.rows + 255) / 256), (unsigned)ps.ncl, (unsigned)(n * 2)), block, 0,
-                       h->stream, pp, 0);
-    hipLaunchKernelGGL(k_quads, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.nrl, (unsigned)(n * 2)), block, 0,
-                       h->stream, pp);
+    sg.lx = (unsigned)((ps.cols + 255) / 256);
+    sg.ly = (unsigned)ps.nrl;
+    sg.lz = (unsigned)(n * 2);
+    sg.cx = (unsigned)((ps.rows + 255) / 256);
+    sg.cy = (unsigned)ps.ncl;
+    sg.cz = (unsigned)(n * 2);
+    blocks0 += 2 * sg.lx * sg.ly * sg.lz;
   }
+  hipLaunchKernelGGL(k_setup, dim3(blocks0), dim3(256), 0, h->stream, pp, sg, 0);
+  if (sg.with_lines)
+    hipLaunchKernelGGL(k_setup, dim3(sg.cx * sg.cy * sg.cz), dim3(256), 0, h->stream, pp, sg, 1);
   return launch_check(h, "transpose");
 }
 

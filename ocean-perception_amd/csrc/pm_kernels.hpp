@@ -91,19 +91,20 @@ __global__ void __launch_bounds__(256) k_prep_view(PlaneSet ps, const float* __r
 
 // Transposes `planes` planes of rows x cols (pitch `sp`) into cols x rows (pitch `dp`) through a
 // 64x64 LDS tile (+1 column of padding: conflict-free for 4-byte elements, 2-way for bytes) so that
-// both the reads and the writes are coalesced.  grid = (ceil(cols/64), ceil(rows/64), planes), block = 256.
+// both the reads and the writes are coalesced.  Block (bx, by, bz) of a (ceil(cols/64), ceil(rows/64), planes) grid, 256 threads.
 // The transposed planes carry kTransPad extra rows (= image columns cols .. cols + kTransPad - 1) that
 // replicate the last column: a window that leaves the image on the right reads them instead of clamping
 // its column index (cv::getRectSubPix replicates the border), which keeps the column sweep's target row
 // offsets affine in the window column (pm_run2.hpp).
 constexpr int kTransPad = 16;
 template <typename T>
-__global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
-                                                   int sp, int dp, size_t src_plane, size_t dst_plane) {
-  __shared__ T tile[64][65];
-  const T* s = src + (size_t)blockIdx.z * src_plane;
-  T* d = dst + (size_t)blockIdx.z * dst_plane;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+__device__ __forceinline__ void transpose_block(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols, int sp,
+                                                int dp, size_t src_plane, size_t dst_plane, int bx, int by, int bz,
+                                                void* lds) {
+  T(*tile)[65] = (T(*)[65])lds;
+  const T* s = src + (size_t)bz * src_plane;
+  T* d = dst + (size_t)bz * dst_plane;
+  const int x0 = bx * 64, y0 = by * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
     const int y = y0 + r, x = x0 + tx;
@@ -122,14 +123,13 @@ __global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, T*
 }
 
 // Line-triple planes of the run engine (PlaneSet::rpg / cpg): built from the plain and the transposed planes once per
-// Match.  grid = (ceil(len / 256), lines, B * 2) with z = b * 2 + view; `rows_mode` != 0: row triples (len = cols,
+// Match.  Block (bx, l, z) of a (ceil(len / 256), lines, B * 2) grid with z = b * 2 + view; `rows_mode` != 0: row triples (len = cols,
 // line = image row, source planes img8 / g32 with pitch), else column triples on the transposed planes (len = rows,
 // line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
 // Lines beyond the last one repeat it (they are only ever the unused twelfth line of a window).
-__global__ void __launch_bounds__(256) k_triples(PlaneSet ps, int rows_mode) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int l = blockIdx.y;
-  const int z = blockIdx.z, view = z & 1, b = z >> 1;
+__device__ __forceinline__ void triples_block(const PlaneSet& ps, int rows_mode, int bx, int l, int z) {
+  const int e = bx * blockDim.x + threadIdx.x;
+  const int view = z & 1, b = z >> 1;
   const int itgt = view == 0 ? 1 : 2;
   const int len = rows_mode ? ps.cols : ps.rows, nl = rows_mode ? ps.nrl : ps.ncl;
   if (e >= len || l >= nl) return;
@@ -150,12 +150,11 @@ __global__ void __launch_bounds__(256) k_triples(PlaneSet ps, int rows_mode) {
   dst[((size_t)z * nl + l) * sp + e] = rec;
 }
 
-// Reference quads of the row sweeps (PlaneSet::rqk).  grid = (ceil(cols / 256), nrl, B * 2) with z = b * 2 + view.
+// Reference quads of the row sweeps (PlaneSet::rqk).  Block (bx, l, z) of a (ceil(cols / 256), nrl, B * 2) grid, z = b * 2 + view.
 // Rows beyond the last one repeat it (only ever the unused twelfth row).
-__global__ void __launch_bounds__(256) k_quads(PlaneSet ps) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int l = blockIdx.y;
-  const int z = blockIdx.z, view = z & 1, b = z >> 1;
+__device__ __forceinline__ void quads_block(const PlaneSet& ps, int bx, int l, int z) {
+  const int e = bx * blockDim.x + threadIdx.x;
+  const int view = z & 1, b = z >> 1;
   if (e >= ps.cols || l >= ps.nrl) return;
   const int iref = view == 0 ? 0 : 3;
   const size_t rp = ((size_t)b * 4 + iref) * ps.plane;
@@ -170,6 +169,47 @@ __global__ void __launch_bounds__(256) k_quads(PlaneSet ps) {
   const size_t dst = (((size_t)z * ps.nrl + l) * ps.pitch + e) * 2;
   ps.rqk[dst] = cw;
   ps.rqk[dst + 1] = gw;
+}
+
+// The planes derived from k_prep's output, in TWO launches instead of eight (each of these passes is a few microseconds
+// of work behind ~10 us of launch latency, and a Match starts with all of them in a row):
+//   stage 0: the four transposes (u8 image, f32 gradient, u8 gradient, u16 packed), the row triples and the reference
+//            quads -- all read k_prep's planes only;
+//   stage 1: the column triples, which read the transposed planes.
+// One linear grid per stage; a block finds its section and its (bx, by, bz) there from the section sizes.
+struct SetupGrid {
+  unsigned tx, ty, tz;  // transpose sections: (ceil(cols/64), ceil(rows/64), B * 4) each
+  unsigned lx, ly, lz;  // row triples / quads: (ceil(cols/256), nrl, B * 2) each
+  unsigned cx, cy, cz;  // column triples: (ceil(rows/256), ncl, B * 2)
+  int with_lines;       // 0: transposes only (PM_SEM_GPU, plane mode, anchor engines)
+};
+__global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int stage) {
+  __shared__ float lds[64 * 65];
+  unsigned b = blockIdx.x;
+  if (stage == 1) {
+    triples_block(ps, 0, (int)(b % sg.cx), (int)((b / sg.cx) % sg.cy), (int)(b / (sg.cx * sg.cy)));
+    return;
+  }
+  const unsigned nt = sg.tx * sg.ty * sg.tz;
+  if (b < 4 * nt) {
+    const unsigned kind = b / nt;
+    b -= kind * nt;
+    const int bx = (int)(b % sg.tx), by = (int)((b / sg.tx) % sg.ty), bz = (int)(b / (sg.tx * sg.ty));
+    if (kind == 0)
+      transpose_block<uint8_t>(ps.img8, ps.timg8, ps.rows, ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t, bx, by, bz, lds);
+    else if (kind == 1)
+      transpose_block<float>(ps.g32, ps.tg32, ps.rows, ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t, bx, by, bz, lds);
+    else if (kind == 2)
+      transpose_block<uint8_t>(ps.g8, ps.tg8, ps.rows, ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t, bx, by, bz, lds);
+    else
+      transpose_block<uint16_t>(ps.pk16, ps.tpk16, ps.rows, ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t, bx, by, bz, lds);
+    return;
+  }
+  b -= 4 * nt;
+  const unsigned nl = sg.lx * sg.ly * sg.lz;
+  const int bx = (int)(b % sg.lx), l = (int)((b / sg.lx) % sg.ly), z = (int)((b % nl) / (sg.lx * sg.ly));
+  if (b < nl) triples_block(ps, 1, bx, l, z);
+  else quads_block(ps, bx, l, z);
 }
 
 // seed maps -> disparity planes; the right-view seed is mirrored like the images

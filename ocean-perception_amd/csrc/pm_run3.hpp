@@ -19,7 +19,7 @@
 //   * chain state is one float4 per position {old value, old cost, new value, new cost}: one ds_read_b64 and one
 //     ds_write_b64 per step at the same address, no conditional read;
 //   * three window lines per load: 16-byte records {three gradients, three colour bytes} from LINE-indexed planes
-//     (PlaneSet::rpg / cpg, k_triples); the line offsets are wave-uniform base pointers (scalar registers), the
+//     (PlaneSet::rpg / cpg, pm_kernels.hpp::triples_block); the line offsets are wave-uniform base pointers (scalar registers), the
 //     lane's column is ONE vector offset shared by all loads of a step.  Round-3 counters (profiles/r03b_*): with the
 //     chip full of sweeps the vector units issue 31-35 % of the time while the texture address / data units are
 //     73-92 % busy -- the memory pipeline works per 4 lanes and cache line (23 accesses per wave-load of 12-byte
@@ -102,14 +102,17 @@ __device__ __forceinline__ float cost_from_packed_sums(int wsum, const CostParam
 }
 
 // LDS bytes of the column sweeps' staged reference lines (LREF): kLref4Stride dwords per image row.
-inline size_t run3_lref_bytes(const PlaneSet& ps) { return sizeof(unsigned) * (size_t)kLref4Stride * ps.rows; }
-// PM_RUN2_LREF=0 turns the staging off, PM_RUN2_LREF_KB is the LDS budget per workgroup (A/B knobs)
-inline bool run3_lref_enabled() {
+template <int AXIS>
+inline size_t run3_lref_bytes(const PlaneSet& ps) {
+  return sizeof(unsigned) * (size_t)kLref4Stride * (AXIS == 1 ? ps.rows : ps.cols);
+}
+// PM_RUN2_LREF: bit 0 = row sweeps, bit 1 = column sweeps (default 2); PM_RUN2_LREF_KB: LDS budget per workgroup (A/B knobs)
+inline bool run3_lref_enabled(int axis) {
   static const int v = [] {
     const char* e = getenv("PM_RUN2_LREF");
     return e ? atoi(e) : 2;
   }();
-  return (v >> 1) & 1;
+  return (v >> axis) & 1;
 }
 inline size_t run3_lref_limit() {
   static const size_t v = [] {
@@ -139,7 +142,7 @@ struct Run3Bases {
   GlobalPtr line[4];
   GlobalPtr quad[3];
 };
-// One record of the line-triple planes: the gradients of three consecutive lines and their colour bytes (k_triples).
+// One record of the line-triple planes: the gradients of three consecutive lines and their colour bytes (pm_kernels.hpp::triples_block).
 struct alignas(16) TripleRec {
   float g0, g1, g2;
   unsigned c;
@@ -256,7 +259,11 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         // lane = image column X (its own position's column -+ half), window rows in the lane, three per load
         constexpr int NT = (TP + 2) / 3, NQR = (TP + 3) / 4;
         const int X = clamp_med3(pos - DIR * half, cols - 1);
+#ifdef PM_EXP_ALIGN  // experiment (wrong results): what would 64-byte aligned quads of lanes buy?
+        const int R0 = clamp_med3((ipx_r & ~3) + k.rofs, cols - 1);
+#else
         const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
+#endif
         const unsigned rv = (unsigned)R0 << 4;  // the lane's byte offset inside every line
         unsigned tcol[4 * NQR + 4];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
         float gv[3 * NT + 1];
@@ -284,8 +291,21 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
           sgr[t] = pa.x + next_line_f<DIR>(pb.x);
           if (t + 1 < TP) sgr[t + 1] = pa.y + next_line_f<DIR>(pb.y);
         }
-        unsigned rq_c[NQR], rq_g[NQR];  // reference bytes of four window rows per dword (quad plane of this alignment)
-        {
+        unsigned rq_c[NQR], rq_g[NQR];  // reference bytes of four window rows per dword
+        if constexpr (LREF) {  // staged by the kernel: [image column][kLref4Stride] dwords
+          unsigned x8 = (unsigned)X << 3;
+          asm volatile("" : "+v"(x8));
+          unsigned x7 = x8 - (unsigned)X;
+          asm volatile("" : "+v"(x7));
+          const unsigned* rr = v.lds_ref4 + x7;
+#pragma unroll
+          for (int q = 0; q < NQR; ++q) {
+            const int rem = TP - 4 * q;
+            const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+            rq_c[q] = rr[q] & mask;
+            rq_g[q] = rr[NQR + q] & mask;
+          }
+        } else {
           const unsigned qv = (unsigned)X << 3;
 #pragma unroll
           for (int q = 0; q < NQR; ++q) {
@@ -318,7 +338,11 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         // TP + 1 consecutive image columns from ipx_r: whole triples of the line-indexed plane
         constexpr int NTC = (TP + 3) / 3, NQ = (TP + 3) / 4;
         const int pt = ps.pitch_t;
+#ifdef PM_EXP_ALIGN
+        const int Y = clamp_med3(((g.s_first + DIR * (ipm - k.mpos) - DIR * half) & ~3) + (DIR > 0 ? k.gl : 3 - k.gl), rows - 1);
+#else
         const int Y = clamp_med3(pos - DIR * half, rows - 1);
+#endif
         const int ipx_c = clamp_med3(ipx_r, cols - 1);  // (a group that cannot adopt may carry any ipx_r)
         // element (line ipx_c, row Y); both factors < 2^16: the 24-bit multiply-add is exact and full rate
         const unsigned cv = (__umul24((unsigned)ipx_c, (unsigned)pt) + (unsigned)Y) << 4;
@@ -501,8 +525,23 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
   View v = make_view(ps, blockIdx.z);
-  if constexpr (LREF) {
-    static_assert(AXIS == 1 && TP > 0, "staged reference lines: column sweeps with a fixed window");
+  if constexpr (LREF && AXIS == 0) {
+    // row sweeps: the reference quads of the chain's window rows (quads_block lines y0, y0 + 4, y0 + 8), per image column
+    // NQ colour dwords and NQ gradient dwords at stride kLref4Stride
+    static_assert(TP > 0, "staged reference lines need a fixed window");
+    constexpr int NQ = (TP + 3) / 4;
+    static_assert(2 * NQ <= kLref4Stride, "reference column does not fit its LDS stride");
+    unsigned* sref4 = (unsigned*)(s_changed + 2);
+    const int y0 = chain - TP / 2;
+    for (int e = threadIdx.x; e < NQ * ps.cols; e += blockDim.x) {
+      const int q = e / ps.cols, x = e - q * ps.cols;
+      const uint32_t* src = v.rqk + ((size_t)(y0 + 4 * q) * ps.pitch + x) * 2;
+      sref4[x * kLref4Stride + q] = src[0];
+      sref4[x * kLref4Stride + NQ + q] = src[1];
+    }
+    v.lds_ref4 = sref4;
+  } else if constexpr (LREF) {
+    static_assert(TP > 0, "staged reference lines need a fixed window");
     // per image row the TP packed reference values of window columns chain - TP/2 .. + TP/2 as bytes, four columns
     // per dword: NQ colour dwords, NQ gradient dwords, row stride kLref4Stride dwords (odd: no bank conflicts)
     constexpr int NQ = (TP + 3) / 4;
@@ -672,7 +711,7 @@ inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepG
   int len = (n + nseg - 1) / nseg;
   if (len < 8) len = 8;
   size_t lds_bytes = run3_lds_bytes(n, nseg);
-  if (LREF) lds_bytes += run3_lref_bytes(ps);
+  if (LREF) lds_bytes += run3_lref_bytes<AXIS>(ps);
   allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
   hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
@@ -682,10 +721,10 @@ inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepG
                           hipStream_t stream) {
   // column sweeps of the benchmark window stage their reference lines in LDS while that leaves room for at least
   // four workgroups per CU (PM_RUN2_LREF / PM_RUN2_LREF_KB: A/B knobs)
-  if constexpr (AXIS == 1 && TP == 11) {
+  if constexpr (TP == 11) {
     const int n = (g.s_last - g.s_first) * g.dir + 1;
-    const size_t total = run3_lds_bytes(n, 64) + run3_lref_bytes(ps);
-    if (run3_lref_enabled() && total <= run3_lref_limit()) {
+    const size_t total = run3_lds_bytes(n, 64) + run3_lref_bytes<AXIS>(ps);
+    if (run3_lref_enabled(AXIS) && total <= run3_lref_limit()) {
       if (g.dir > 0) launch_run3_l<GS, AXIS, TP, 1, true>(ps, cp, g, slots, waves, stream);
       else launch_run3_l<GS, AXIS, TP, -1, true>(ps, cp, g, slots, waves, stream);
       return;
