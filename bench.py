@@ -263,20 +263,6 @@ def host_buffer_leg(pm, params, args, pair, device):
     return out
 
 
-def to_bgr(gray, seed):
-    """A synthetic underwater-looking BGR image whose stereo-ready enhancement is well defined: the gray pattern
-    under a smooth coloured illuminant (blue-green cast, vignette)."""
-    import numpy as np
-    rows, cols = gray.shape
-    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
-    vig = 0.55 + 0.45 * np.exp(-(((xx - cols / 2) / (0.6 * cols)) ** 2 + ((yy - rows / 2) / (0.6 * rows)) ** 2))
-    g = gray.astype(np.float32)
-    rng = np.random.default_rng(seed)
-    gains = (1.0, 0.85, 0.55)  # B, G, R
-    bgr = np.stack([np.clip(g * gains[c] * vig + rng.normal(0, 0.6, g.shape), 0, 255) for c in range(3)], -1)
-    return np.rint(bgr).astype(np.uint8)
-
-
 class Workload:
     """Device-resident inputs/outputs of one rank and the step function of the selected mode."""
 
@@ -308,8 +294,8 @@ class Workload:
         if enhance:
             # BGR inputs; the enhanced gray images are produced on the device, on the engine's stream, in front of
             # every Match (no host round trip): pm_stereo_ready (imaging::Normalize(NormalizeColorIlluminant(.)) -> gray)
-            self.BL = [torch.from_numpy(np.stack([to_bgr(p["left"], 1) for p in g])).to(dev).contiguous() for g in groups]
-            self.BR = [torch.from_numpy(np.stack([to_bgr(p["right"], 2) for p in g])).to(dev).contiguous() for g in groups]
+            self.BL = [torch.from_numpy(np.stack([synth.to_bgr(p["left"], 1) for p in g])).to(dev).contiguous() for g in groups]
+            self.BR = [torch.from_numpy(np.stack([synth.to_bgr(p["right"], 2) for p in g])).to(dev).contiguous() for g in groups]
             self.J = torch.empty((args.rows, args.cols, 3), dtype=torch.float32, device=dev)
             self.GL = torch.empty((nb, args.rows, args.cols), dtype=torch.uint8, device=dev)
             self.GR = torch.empty_like(self.GL)

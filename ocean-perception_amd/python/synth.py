@@ -110,3 +110,16 @@ def make_pair(index, rows=720, cols=1280, d_max=96.0, n_points=200, dilate_facto
     right = np.clip(np.rint(right_f + rng.normal(0.0, 1.0, right_f.shape)), 0, 255).astype(np.uint8)
     seed_l, seed_r = seed_maps(rng, gt, n_points, dilate_factor)
     return {"left": left, "right": right, "gt": gt, "seed_l": seed_l, "seed_r": seed_r}
+
+
+def to_bgr(gray, seed):
+    """A synthetic underwater-looking BGR image whose stereo-ready enhancement is well defined: the gray pattern
+    under a smooth coloured illuminant (blue-green cast, vignette).  BASELINE configs[4]'s input shape."""
+    rows, cols = gray.shape
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    vig = 0.55 + 0.45 * np.exp(-(((xx - cols / 2) / (0.6 * cols)) ** 2 + ((yy - rows / 2) / (0.6 * rows)) ** 2))
+    g = gray.astype(np.float32)
+    rng = np.random.default_rng(seed)
+    gains = (1.0, 0.85, 0.55)  # B, G, R
+    bgr = np.stack([np.clip(g * gains[c] * vig + rng.normal(0, 0.6, g.shape), 0, 255) for c in range(3)], -1)
+    return np.rint(bgr).astype(np.uint8)

@@ -123,6 +123,60 @@ void pmo_dilate_rect(const float* src, float* dst, int rows, int cols, int k) {
   free(tmp);
 }
 
+/* cv::resize INTER_LINEAR, CV_8UC1 (pm_oracle.h).  OpenCV 3.4 modules/imgproc/src/resize.cpp: resize() -> the
+ * is_area_fast shortcut for an exact 2x2 shrink (ResizeAreaFast_Invoker / ResizeAreaFastVec for uchar), else
+ * resizeGeneric_ with HResizeLinear<uchar, int, short, INTER_RESIZE_COEF_SCALE> and the uchar VResizeLinear. */
+void pmo_resize_linear_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols) {
+  if (drows * 2 == rows && dcols * 2 == cols) { /* inv_scale == 2 exactly in both axes */
+    for (int y = 0; y < drows; ++y) {
+      const uint8_t* s0 = src + (size_t)(2 * y) * cols;
+      const uint8_t* s1 = s0 + cols;
+      for (int x = 0; x < dcols; ++x)
+        dst[(size_t)y * dcols + x] = (uint8_t)((s0[2 * x] + s0[2 * x + 1] + s1[2 * x] + s1[2 * x + 1] + 2) >> 2);
+    }
+    return;
+  }
+  const double scale_x = (double)cols / dcols, scale_y = (double)rows / drows;
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dcols);
+  short* alpha = (short*)malloc(sizeof(short) * 2 * (size_t)dcols);
+  int* hbuf[2];
+  hbuf[0] = (int*)malloc(sizeof(int) * (size_t)dcols);
+  hbuf[1] = (int*)malloc(sizeof(int) * (size_t)dcols);
+  for (int dx = 0; dx < dcols; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floor(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= cols - 1) { fx = 0.f; sx = cols - 1; }
+    xofs[dx] = sx;
+    /* saturate_cast<short>((1 - fx) * 2048), saturate_cast<short>(fx * 2048): cvRound, ties to even */
+    alpha[2 * dx] = (short)lrintf((1.f - fx) * 2048.f);
+    alpha[2 * dx + 1] = (short)lrintf(fx * 2048.f);
+  }
+  for (int dy = 0; dy < drows; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floor(fy);
+    fy -= (float)sy; /* the vertical pass keeps its weights at the border and clamps the row indices instead */
+    const short b0 = (short)lrintf((1.f - fy) * 2048.f), b1 = (short)lrintf(fy * 2048.f);
+    for (int k = 0; k < 2; ++k) {
+      int r = sy + k;
+      r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
+      const uint8_t* srow = src + (size_t)r * cols;
+      for (int dx = 0; dx < dcols; ++dx) {
+        const int sx = xofs[dx], sx1 = sx + 1 < cols ? sx + 1 : cols - 1;
+        hbuf[k][dx] = srow[sx] * alpha[2 * dx] + srow[sx1] * alpha[2 * dx + 1];
+      }
+    }
+    for (int dx = 0; dx < dcols; ++dx)
+      dst[(size_t)dy * dcols + dx] =
+          (uint8_t)((((b0 * (hbuf[0][dx] >> 4)) >> 16) + ((b1 * (hbuf[1][dx] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs);
+  free(alpha);
+  free(hbuf[0]);
+  free(hbuf[1]);
+}
+
 void pmo_flip_h_u8(const uint8_t* src, uint8_t* dst, int rows, int cols) {
   for (int y = 0; y < rows; ++y)
     for (int x = 0; x < cols; ++x) dst[(size_t)y * cols + x] = src[(size_t)y * cols + (cols - 1 - x)];

@@ -92,6 +92,14 @@ void pmo_get_rect_subpix_u8(const uint8_t* src, int rows, int cols, int pw, int 
 void pmo_get_rect_subpix_f32(const float* src, int rows, int cols, int pw, int ph,
                              float cx, float cy, float* dst);
 
+/* cv::resize(src, dst, Size(dcols, drows)) with the default INTER_LINEAR on 8-bit single-channel images -- what both
+ * reference PatchMatch tests apply to their inputs (test/stereo_matching/patchmatch_test.cpp:131-133,
+ * patchmatch_gpu_test.cpp:62-64: il.size() / 2).  OpenCV 3.4 imgproc/resize.cpp as remembered (parity unpinned):
+ *   - an exact integer shrink by 2 in both axes is routed to the INTER_AREA fast path ("INTER_AREA (fast) also is equal
+ *     to INTER_LINEAR"): dst = (a + b + c + d + 2) >> 2 over the 2x2 block;
+ *   - otherwise: source coordinate fx = (dx + 0.5) * scale - 0.5, clamped at the borders, 11-bit fixed-point weights
+ *     cvRound(w * 2048), horizontal pass in int, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2. */
+void pmo_resize_linear_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols);
 void pmo_flip_h_u8(const uint8_t* src, uint8_t* dst, int rows, int cols);
 void pmo_flip_h_f32(const float* src, float* dst, int rows, int cols);
 

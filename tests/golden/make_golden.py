@@ -3,6 +3,7 @@
     python tests/golden/make_golden.py            # synthetic cases only
     python tests/golden/make_golden.py --caddy    # also the CADDY 640x480 fixture (needs the
                                                   # reference tree's test/resources, this container only)
+    python tests/golden/make_golden.py --farmsim  # also the fsl1 / fsr1 pair of the reference's two PatchMatch tests
 
 Fixtures are data: inputs + expected outputs.  The CADDY fixture holds the two JPEGs of the
 reference's test/resources (caddy_32_{left,right}.jpg, used by its sgbm/feature tests and named by
@@ -106,7 +107,60 @@ def caddy():
     print("caddy: seed coverage %.3f, foreground after match %.3f" % ((seed_l > 0).mean(), (dl > 0).mean()))
 
 
+def png_rgb_to_gray(rgb):
+    """8-bit RGB -> gray as cv::imread(path, IMREAD_GRAYSCALE) gets it for a PNG file: OpenCV 3.4's PngDecoder asks
+    libpng for the conversion (png_set_rgb_to_gray(png_ptr, 1, 0.299, 0.587)), and libpng's png_do_rgb_to_gray computes
+    (rc * R + gc * G + bc * B + 16384) >> 15 with rc = 0.299 * 32768 = 9798 (rounded), gc = 19235, bc = 32768 - rc - gc.
+    Restated from the published algorithm; parity with the reference's binary stays unpinned."""
+    rc, gc = 9798, 19235
+    bc = 32768 - rc - gc
+    v = rgb.astype(np.int64)
+    g = (rc * v[..., 0] + gc * v[..., 1] + bc * v[..., 2] + 16384) >> 15
+    same = (rgb[..., 0] == rgb[..., 1]) & (rgb[..., 1] == rgb[..., 2])
+    return np.where(same, rgb[..., 0], g).astype(np.uint8)
+
+
+def farmsim():
+    """The inputs of BOTH reference PatchMatch tests (test/stereo_matching/patchmatch_test.cpp:121-133,
+    patchmatch_gpu_test.cpp:52-64): fsl1.png / fsr1.png, read as gray, halved with cv::resize (INTER_LINEAR) to
+    376x240.  The reference asserts nothing on them and ships no expected maps, so the fixture pins what this build's
+    restatement computes for the two recipes: per-row checksums of
+      (a) patchmatch_test.cpp:149-183 -- Initialize(il, ir, 1), noise 32 / 8 / 2 / 0.5 with 5x5, 5x5, 3x3, 3x3,
+          RemoveBackground(3x3, 1.5), one view;
+      (b) patchmatch_gpu_test.cpp:68-88 -- PatchmatchGpu with cost_alpha 0.9, 3 iterations, self-seeded by SparseInit(4),
+          both views + MaskOcclusions (Match is called five times on the same pair: the same result five times)."""
+    from PIL import Image
+    res = "/root/reference/test/resources/images"
+    gray = {}
+    for side, name in (("left", "fsl1.png"), ("right", "fsr1.png")):
+        rgb = np.asarray(Image.open(os.path.join(res, name)).convert("RGB"), dtype=np.uint8)
+        assert rgb.shape == (480, 752, 3), rgb.shape
+        gray[side] = O.resize_linear_u8(png_rgb_to_gray(rgb), 240, 376)
+    l, r = gray["left"], gray["right"]
+    rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)
+    # (a) the CPU recipe, seeded by Patchmatch::Initialize (matcher: 31x11 template, max_disp 128, cost 0.15)
+    sp = O.seed_params(templ_cols=31, templ_rows=11, max_disp=128, max_matching_cost=0.15)
+    seeds = O.cpu_initialize(l, r, 1, sp)
+    sched = dict(noise_amp=[32.0, 8.0, 2.0, 0.5], patch_w=[5, 5, 3, 3], patch_h=[5, 5, 3, 3])
+    prm = O.default_params(0, n_iters=4, bg_patch_w=3, bg_patch_h=3, bg_factor=1.5, left_right_check=0, nthreads=8,
+                           literal=1, **sched)
+    da, _ = O.match(prm, l, r, seeds, None)
+    # (b) the GPU module's test: both views self-seeded by SparseInit(4)
+    sl = O.sparse_init(l, r, 4, sp)
+    sr = O.sparse_init(np.ascontiguousarray(r[:, ::-1]), np.ascontiguousarray(l[:, ::-1]), 4, sp)[:, ::-1]
+    prm_b = O.default_params(1, n_iters=3, nthreads=8, cost_alpha=0.9)
+    dbl, dbr = O.match(prm_b, l, r, sl, np.ascontiguousarray(sr))
+    save("farmsim_fs1_376x240", left=l, right=r,
+         cpu_recipe_rows=rowsum(da), cpu_recipe_total=np.uint64(rowsum(da).sum()), cpu_recipe_fg=np.float32((da > 0).mean()),
+         gpu_test_rows_l=rowsum(dbl), gpu_test_rows_r=rowsum(dbr), gpu_test_fg=np.float32((dbl > 0).mean()))
+    print("farmsim: seeds %.3f; CPU recipe foreground %.3f; GPU-test recipe foreground %.3f" %
+          ((seeds > 0).mean(), (da > 0).mean(), (dbl > 0).mean()))
+
+
 if __name__ == "__main__":
+    if "--farmsim-only" in sys.argv:
+        farmsim()
+        sys.exit(0)
     if "--planes-only" in sys.argv:
         planes()
         sys.exit(0)
@@ -114,3 +168,5 @@ if __name__ == "__main__":
     planes()
     if "--caddy" in sys.argv:
         caddy()
+    if "--farmsim" in sys.argv:
+        farmsim()

@@ -85,6 +85,7 @@ def load():
     lib.pmo_match_view.argtypes = [C.POINTER(Params), C.POINTER(Images), vp]
     lib.pmo_match.argtypes = [C.POINTER(Params), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pmo_flip_h_u8.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.pmo_resize_linear_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     lib.pmo_flip_h_f32.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.pmo_seed_params_default.argtypes = [C.POINTER(SeedParams)]
     lib.pmo_seed_params_default.restype = None
@@ -100,7 +101,8 @@ def load():
                  "pmo_dilate_rect", "pmo_get_rect_subpix_u8", "pmo_get_rect_subpix_f32", "pmo_cpu_add_noise",
                  "pmo_cpu_propagate", "pmo_cpu_remove_background", "pmo_gpu_add_foreground_noise",
                  "pmo_gpu_propagate_row", "pmo_gpu_propagate_col", "pmo_gpu_mask_background",
-                 "pmo_gpu_mask_occlusions", "pmo_match_view", "pmo_match", "pmo_flip_h_u8", "pmo_flip_h_f32"):
+                 "pmo_gpu_mask_occlusions", "pmo_match_view", "pmo_match", "pmo_flip_h_u8", "pmo_flip_h_f32",
+                 "pmo_resize_linear_u8"):
         getattr(lib, name).restype = None
     _lib = lib
     return lib
@@ -160,6 +162,14 @@ def gradient_magnitude(im):
     g = np.empty(im.shape, np.float32)
     load().pmo_gradient_magnitude(_p(im), im.shape[0], im.shape[1], _p(g))
     return g
+
+
+def resize_linear_u8(src, drows, dcols):
+    """cv::resize(src, Size(dcols, drows)) with INTER_LINEAR on an 8-bit gray image (oracle/pm_oracle.h)."""
+    src = c_u8(src)
+    dst = np.empty((drows, dcols), np.uint8)
+    load().pmo_resize_linear_u8(_p(src), src.shape[0], src.shape[1], _p(dst), drows, dcols)
+    return dst
 
 
 def dilate_rect(src, k):

@@ -179,3 +179,34 @@ def test_lerp_weights_fit_16_bits_when_clamped():
         full = (r0 * a11 + r1 * a12 + (1 << 15)) >> 16
         clamped = (r0 * min(a11, 65535) + r1 * min(a12, 65535) + (1 << 15)) >> 16
         assert full.max() <= 255 and np.array_equal(full & 0xff, clamped & 0xff), (a11, a12)
+
+
+def test_resize_linear_u8_known_answers(oracle):
+    """cv::resize INTER_LINEAR on 8-bit images as both reference PatchMatch tests use it (size / 2,
+    patchmatch_test.cpp:131-133): an exact 2x2 shrink is the rounded block mean; the general path is checked by hand
+    on small cases (11-bit fixed-point weights; parity with OpenCV itself is unpinned)."""
+    a = np.array([[10, 20, 30, 41], [12, 22, 33, 44], [0, 255, 255, 255], [1, 2, 254, 255]], np.uint8)
+    half = oracle.resize_linear_u8(a, 2, 2)
+    assert half.tolist() == [[(10 + 20 + 12 + 22 + 2) >> 2, (30 + 41 + 33 + 44 + 2) >> 2],
+                             [(0 + 255 + 1 + 2 + 2) >> 2, (255 + 255 + 254 + 255 + 2) >> 2]]
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+    h = oracle.resize_linear_u8(img, 240, 376)
+    want = (img[0::2, 0::2].astype(np.int32) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(h, want.astype(np.uint8))
+    # identity size: every pixel keeps its value (weight 2048 / 0)
+    assert np.array_equal(oracle.resize_linear_u8(img[:9, :13], 9, 13), img[:9, :13])
+    # a constant image stays constant through the general path; a horizontal ramp 4 -> 3 columns by hand:
+    # fx = (dx + 0.5) * 4/3 - 0.5 = 1/6, 1.5, 17/6 -> sx 0, 1, 2 with weights (1707, 341), (1024, 1024), (341, 1707)
+    assert (oracle.resize_linear_u8(np.full((7, 10), 77, np.uint8), 5, 6) == 77).all()
+    ramp = np.array([[0, 60, 120, 180]] * 2, np.uint8)
+    got = oracle.resize_linear_u8(ramp, 2, 3)
+    f = [np.float32((dx + 0.5) * (4.0 / 3.0) - 0.5) for dx in range(3)]
+    w = [(int(np.rint((np.float32(1) - (v - np.floor(v))) * np.float32(2048))),
+          int(np.rint((v - np.floor(v)) * np.float32(2048)))) for v in f]
+    assert w == [(1707, 341), (1024, 1024), (341, 1707)]
+    # vertical scale 1: fy = 0, weights (2048, 0): out = (((2048 * (h >> 4)) >> 16) + 0 + 2) >> 2
+    hs = [0 * w[0][0] + 60 * w[0][1], 60 * w[1][0] + 120 * w[1][1], 120 * w[2][0] + 180 * w[2][1]]
+    want = [(((2048 * (h >> 4)) >> 16) + 2) >> 2 for h in hs]
+    assert want == [10, 90, 170]
+    assert got.tolist() == [want, want]

@@ -394,3 +394,50 @@ def test_differential_fuzz_against_the_definition():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_planes.py"), "--cases", "40", "--seed", "9"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@gpu
+def test_configs4_workload_bgr_enhanced_f16_planes_full_size(pm, oracle, synth):
+    """BASELINE configs[4] as ONE workload at its full shape: a 1280x720 BGR pair -> pm_stereo_ready of both images on
+    the device (imaging::Normalize(NormalizeColorIlluminant(.)) -> gray, normalization.cpp:43-69,178-185) ->
+    PM_MODE_PLANES with fp16 plane / cost state, 8 iterations, 11x11, through pm_match_device on the same stream, no
+    host round trip.  Checks: run-to-run determinism; the enhanced gray images equal pm_enhance_oracle bit for bit at
+    full size; the quality bar against the synthetic truth; and a 64-row full-width band of the enhanced pair, matched
+    as its own problem by the engine, against pm_enhance_oracle o pm_planes_oracle bit for bit."""
+    import torch
+    import oracle_lib as O
+    rows, cols = 720, 1280
+    p = synth.make_pair(0, rows, cols)
+    bl, br = synth.to_bgr(p["left"], 1), synth.to_bgr(p["right"], 2)
+    prm = pparams(pm, iters=8, f16=1)
+    dev = torch.device("cuda")
+    BL, BR = torch.from_numpy(bl).to(dev).contiguous(), torch.from_numpy(br).to(dev).contiguous()
+    GL = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    GR = torch.empty_like(GL)
+    DL = torch.empty((1, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        def frame():
+            e.stereo_ready(BL.data_ptr(), rows, cols, None, GL.data_ptr())
+            e.stereo_ready(BR.data_ptr(), rows, cols, None, GR.data_ptr())
+            e.match_device(1, GL.data_ptr(), GR.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+            e.synchronize()
+        frame()
+        first_l, first_r = DL.clone(), DR.clone()
+        frame()
+        assert torch.equal(first_l, DL) and torch.equal(first_r, DR), "configs[4] frame is not deterministic"
+    gl, gr = GL.cpu().numpy(), GR.cpu().numpy()
+    _, ol = O.stereo_ready(bl)
+    _, orr = O.stereo_ready(br)
+    assert np.array_equal(gl, ol) and np.array_equal(gr, orr), "stereo-ready gray images differ from pm_enhance_oracle"
+    dl = DL[0].cpu().numpy()
+    ok = dl > 0
+    assert ok.mean() > 0.8
+    assert (np.abs(dl - p["gt"])[ok] < 1).mean() >= 0.97
+    # a 64-row full-width band of the ENHANCED pair as its own problem: engine (f16 state) == the mode's definition
+    band = np.s_[328:392, :]
+    with pm.Engine(prm, max_rows=64, max_cols=cols) as e:
+        b_l, b_r = e.match(np.ascontiguousarray(gl[band]), np.ascontiguousarray(gr[band]))
+    e_l, e_r = oracle.planes_match(oracle.planes_params(**okw(prm)), ol[band], orr[band])
+    assert_same(b_l, e_l, "configs[4] band, left")
+    assert_same(b_r, e_r, "configs[4] band, right")
