@@ -9,6 +9,8 @@
 namespace pm_internal __attribute__((visibility("hidden"))) {
 int device(const pm_handle* h);
 hipStream_t stream(pm_handle* h);
+const pm_params& params(const pm_handle* h);
+void plan_size(const pm_handle* h, int* max_rows, int* max_cols);
 void set_error(pm_handle* h, const char* fmt, ...);
 void** imaging_slot(pm_handle* h);     // storage for pm_imaging.hip's state
 void release_imaging(pm_handle* h);    // defined in pm_imaging.hip, called by pm_destroy

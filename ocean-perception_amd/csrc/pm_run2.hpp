@@ -37,7 +37,7 @@
 // rounds suffice.
 #pragma once
 
-#include "pm_kernels.hpp"
+#include "pm_sweep_defs.hpp"
 
 namespace pm {
 

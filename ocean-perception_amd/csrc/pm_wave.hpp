@@ -14,7 +14,7 @@
 // changed ones written back with one store per 64 steps.
 #pragma once
 
-#include "pm_kernels.hpp"
+#include "pm_sweep_defs.hpp"
 
 namespace pm {
 

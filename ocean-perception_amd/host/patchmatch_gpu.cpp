@@ -159,5 +159,64 @@ Image1f PatchmatchGpu::SparseInit(const Image1b& iml, const Image1b& imr, int di
   return seed;
 }
 
+// ---- TiledPatchmatchGpu ----------------------------------------------------------------------------------------------
+TiledPatchmatchGpu::TiledPatchmatchGpu(const PatchmatchGpu::Params& params, int rows, int cols,
+                                       const std::vector<int>& devices)
+    : rows_(rows), cols_(cols) {
+  if (devices.empty()) throw std::runtime_error("TiledPatchmatchGpu: no devices given");
+  pm_params p = params.ToC();
+  p.sparse_init = 0;  // the device seeder sees whole images only: seed maps come in through SetSeeds()
+  const int n = (int)devices.size();
+  const int band_rows = pm_tiled_band_rows(&p, rows, n);
+  if (band_rows < 0) throw std::runtime_error("TiledPatchmatchGpu: cannot split the image into that many bands");
+  auto cleanup = [&]() {
+    pm_tiled_destroy(plan_);
+    plan_ = nullptr;
+    for (pm_handle* h : bands_) pm_destroy(h);
+    bands_.clear();
+  };
+  for (int k = 0; k < n; ++k) {
+    pm_handle* h = nullptr;
+    const int rc = pm_create(&p, devices[(size_t)k], band_rows, cols, 1, &h);
+    if (rc != PM_OK) {
+      const std::string msg = std::string("TiledPatchmatchGpu: pm_create: ") + pm_status_string(rc) +
+                              (h ? std::string(" -- ") + pm_last_error(h) : std::string());
+      pm_destroy(h);
+      cleanup();
+      throw std::runtime_error(msg);
+    }
+    bands_.push_back(h);
+  }
+  const int rc = pm_tiled_create(bands_.data(), n, rows, cols, &plan_);
+  if (rc != PM_OK) {
+    const std::string msg = std::string("TiledPatchmatchGpu: pm_tiled_create: ") + pm_status_string(rc) + " -- " +
+                            pm_tiled_last_error(plan_);
+    cleanup();
+    throw std::runtime_error(msg);
+  }
+}
+
+TiledPatchmatchGpu::~TiledPatchmatchGpu() {
+  pm_tiled_destroy(plan_);
+  for (pm_handle* h : bands_) pm_destroy(h);
+}
+
+void TiledPatchmatchGpu::SetSeeds(const Image1f& seed_l, const Image1f& seed_r) {
+  seed_l_ = seed_l;
+  seed_r_ = seed_r;
+}
+
+void TiledPatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds) {
+  if (iml.rows != rows_ || iml.cols != cols_ || imr.rows != rows_ || imr.cols != cols_)
+    throw std::runtime_error("TiledPatchmatchGpu::Match: image size differs from the plan");
+  disp.create(rows_, cols_);
+  dispr.create(rows_, cols_);
+  const int rc = pm_tiled_match_u8(plan_, iml.data(), imr.data(), (size_t)iml.step, seed_l_.empty() ? nullptr : seed_l_.data(),
+                                   seed_r_.empty() ? nullptr : seed_r_.data(), 0, disp.data(), dispr.data(),
+                                   (size_t)disp.step, rounds, &info_);
+  if (rc != PM_OK)
+    throw std::runtime_error(std::string("pm_tiled_match_u8: ") + pm_status_string(rc) + " -- " + pm_tiled_last_error(plan_));
+}
+
 }  // namespace pm
 }  // namespace bm

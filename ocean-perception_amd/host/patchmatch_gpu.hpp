@@ -195,5 +195,30 @@ class PatchmatchGpu final {
   std::vector<std::pair<int, int>> in_flight_sizes_;  // (rows, cols) of the submitted pairs, oldest first
 };
 
+// One large rectified pair matched by several band handles of this process -- the C++ form of pm_tiled_*
+// (include/pm/patchmatch.h; BASELINE configs[3]).  Same construct-and-Match() shape as PatchmatchGpu
+// (patchmatch_gpu.h:94-102); `devices[k]` is the HIP device of band k (bands may share a device).  The result equals
+// PatchmatchGpu::Match() on the whole image bit for bit.  Seed maps are an input here (SetSeeds): the device seeder
+// works on whole images.
+class TiledPatchmatchGpu final {
+ public:
+  TiledPatchmatchGpu(const TiledPatchmatchGpu&) = delete;
+  TiledPatchmatchGpu& operator=(const TiledPatchmatchGpu&) = delete;
+  TiledPatchmatchGpu(const PatchmatchGpu::Params& params, int rows, int cols, const std::vector<int>& devices);
+  ~TiledPatchmatchGpu();
+
+  void SetSeeds(const Image1f& seed_l, const Image1f& seed_r);
+  // rounds: boundary exchange rounds per vertical sweep (2: the default of both drivers)
+  void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds = 2);
+  const pm_tiled_info& LastInfo() const { return info_; }
+
+ private:
+  int rows_, cols_;
+  std::vector<pm_handle*> bands_;
+  pm_tiled_plan* plan_ = nullptr;
+  pm_tiled_info info_{};
+  Image1f seed_l_, seed_r_;
+};
+
 }  // namespace pm
 }  // namespace bm

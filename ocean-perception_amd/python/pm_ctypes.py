@@ -40,6 +40,7 @@ EXPORTS = [
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
     "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
+    "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
 ]
 
 
@@ -86,6 +87,10 @@ class PmParams(C.Structure):
 
 class PmTile(C.Structure):
     _fields_ = [("global_rows", C.c_int), ("band_row0", C.c_int), ("own_row0", C.c_int), ("own_rows", C.c_int)]
+
+
+class PmTiledInfo(C.Structure):
+    _fields_ = [("rounds_used", C.c_int), ("repeated", C.c_int), ("exchanges", C.c_int)]
 
 
 class PmProfile(C.Structure):
@@ -195,6 +200,17 @@ def load():
     lib.pm_tile_set_row.argtypes = [vp, C.c_int, f32p]
     lib.pm_tile_background.argtypes = [vp]
     lib.pm_tile_finish.argtypes = [vp, f32p, f32p]
+    lib.pm_tiled_band_rows.argtypes = [C.POINTER(PmParams), C.c_int, C.c_int]
+    lib.pm_tiled_band_rows.restype = C.c_int
+    lib.pm_tiled_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pm_tiled_create.restype = C.c_int
+    lib.pm_tiled_destroy.argtypes = [vp]
+    lib.pm_tiled_destroy.restype = None
+    lib.pm_tiled_match_u8.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.c_int,
+                                      C.POINTER(PmTiledInfo)]
+    lib.pm_tiled_match_u8.restype = C.c_int
+    lib.pm_tiled_last_error.argtypes = [vp]
+    lib.pm_tiled_last_error.restype = C.c_char_p
     lib.pm_tile_restore_cols.argtypes = [vp, vp]
     lib.pm_tile_sweep_masked.argtypes = [vp, C.c_int, C.c_int, vp]
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
@@ -580,3 +596,55 @@ class Engine:
         self._check(self.lib.pm_profile_read(self.h, C.byref(prof)), "pm_profile_read")
         return {self.lib.pm_kernel_name(k).decode(): (int(prof.launches[k]), float(prof.total_ms[k]))
                 for k in range(PM_K_COUNT)}
+
+
+class TiledEngine:
+    """pm_tiled_*: one large pair row-tiled over `n_bands` handles of this process (devices[k] = the device of band k)."""
+
+    def __init__(self, params, rows, cols, n_bands, devices=None):
+        self.lib = load()
+        self.rows, self.cols, self.n = rows, cols, n_bands
+        self.params = params
+        band_rows = self.lib.pm_tiled_band_rows(C.byref(params), rows, n_bands)
+        if band_rows < 0:
+            raise PmError(band_rows, "pm_tiled_band_rows")
+        devices = devices or [0] * n_bands
+        self.bands = [Engine(params, device=devices[k], max_rows=band_rows, max_cols=cols) for k in range(n_bands)]
+        arr = (C.c_void_p * n_bands)(*[b.h for b in self.bands])
+        self.plan = C.c_void_p()
+        rc = self.lib.pm_tiled_create(arr, n_bands, rows, cols, C.byref(self.plan))
+        if rc != PM_OK:
+            msg = self.lib.pm_tiled_last_error(self.plan).decode() if self.plan else ""
+            self.close()
+            raise PmError(rc, "pm_tiled_create", msg)
+
+    def match(self, left, right, seed_l=None, seed_r=None, rounds=2):
+        left, right = _u8(left), _u8(right)
+        sl = _f32(seed_l) if seed_l is not None else None
+        sr = _f32(seed_r) if seed_r is not None else None
+        dl = np.empty((self.rows, self.cols), np.float32)
+        dr = np.empty((self.rows, self.cols), np.float32)
+        info = PmTiledInfo()
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        rc = self.lib.pm_tiled_match_u8(self.plan, ptr(left), ptr(right), 0, ptr(sl), ptr(sr), 0, ptr(dl), ptr(dr), 0,
+                                        rounds, C.byref(info))
+        if rc != PM_OK:
+            raise PmError(rc, "pm_tiled_match_u8", self.lib.pm_tiled_last_error(self.plan).decode())
+        return dl, (dr if self.params.left_right_check else None), {"rounds": info.rounds_used,
+                                                                     "repeated": bool(info.repeated),
+                                                                     "exchanges": info.exchanges}
+
+    def close(self):
+        if getattr(self, "plan", None):
+            self.lib.pm_tiled_destroy(self.plan)
+            self.plan = None
+        for b in getattr(self, "bands", []):
+            b.close()
+        self.bands = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+

@@ -14,7 +14,7 @@ OUT = "/tmp/isa/all_units.s"
 def build():
     os.makedirs("/tmp/isa", exist_ok=True)
     parts = []
-    for unit in ("pm_engine", "pm_imaging"):
+    for unit in ("pm_engine", "pm_sweeps", "pm_imaging", "pm_tiled"):
         out = "/tmp/isa/%s.s" % unit
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
