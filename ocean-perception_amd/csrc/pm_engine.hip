@@ -17,6 +17,7 @@
 
 #include "pm_kernels.hpp"
 #include "pm_sweeps.hpp"
+#include "pm_hostcopy.hpp"
 #include "pm_internal.hpp"
 #include "pm_seed.hpp"
 #include "pm_planes.hpp"
@@ -104,6 +105,8 @@ struct pm_handle {
   bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
   hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
   hipEvent_t left_out = nullptr;  // pm_match_u8: the left map has arrived in the pinned buffer
+  hipEvent_t right_out = nullptr;  // ... the right one
+  pm::CopyPool* copy_pool = nullptr;  // host threads sharing the pack / unpack copies of the host-buffer entry points
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
@@ -929,6 +932,7 @@ void pm_destroy(pm_handle* h) {
   if (h->ext_fork) (void)hipEventDestroy(h->ext_fork);
   if (h->ext_join) (void)hipEventDestroy(h->ext_join);
   if (h->left_out) (void)hipEventDestroy(h->left_out);
+  if (h->right_out) (void)hipEventDestroy(h->right_out);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->ev_pool) {
     (void)hipEventDestroy(r.start);
@@ -941,6 +945,7 @@ void pm_destroy(pm_handle* h) {
                  h->snap_cost, h->planes_state};
   for (void* p : dev)
     if (p) (void)hipFree(p);
+  delete h->copy_pool;
   if (h->pinned) (void)hipHostFree(h->pinned);
   for (int v = 0; v < 2; ++v) {
     if (h->view_stream[v]) (void)hipStreamSynchronize(h->view_stream[v]);
@@ -1359,15 +1364,11 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
   float* pdr = pdl + px;
   uint8_t* pl = (uint8_t*)(pdr + px);
   uint8_t* pr = pl + px;
-  // every plane is packed into the pinned buffer and its upload enqueued at once: the DMA of one plane runs while
-  // the host packs the next
+  // every plane is packed into the pinned buffer (a few host threads share each copy, pm_hostcopy.hpp) and its upload
+  // enqueued at once: the DMA of one plane runs while the host packs the next
+  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
   auto pack = [&](void* dst, const void* src, size_t step, size_t row_bytes) {
-    if (step == row_bytes) {
-      std::memcpy(dst, src, row_bytes * (size_t)rows);
-    } else {
-      for (int y = 0; y < rows; ++y)
-        std::memcpy((char*)dst + (size_t)y * row_bytes, (const char*)src + (size_t)y * step, row_bytes);
-    }
+    h->copy_pool->Copy2D(dst, row_bytes, src, step, row_bytes, rows);
   };
   pack(pl, left, image_step, (size_t)cols);
   PM_HIP(h, hipMemcpyAsync(h->st_left, pl, px, hipMemcpyHostToDevice, h->stream));
@@ -1385,22 +1386,23 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
                                seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
   // the left map is unpacked into the caller's buffer while the right one is still on the bus
-  if (!h->left_out) PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
+  if (!h->left_out) {
+    PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
+    PM_HIP(h, hipEventCreateWithFlags(&h->right_out, hipEventDisableTiming));
+  }
   PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
   PM_HIP(h, hipEventRecord(h->left_out, h->stream));
-  if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
-  auto unpack = [&](void* dst, const float* src) {
-    if (disp_step == sizeof(float) * (size_t)cols) {
-      std::memcpy(dst, src, sizeof(float) * px);
-    } else {
-      for (int y = 0; y < rows; ++y)
-        std::memcpy((char*)dst + (size_t)y * disp_step, src + (size_t)y * cols, sizeof(float) * cols);
-    }
-  };
+  if (lr) {
+    PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+    PM_HIP(h, hipEventRecord(h->right_out, h->stream));
+  }
+  const size_t row_bytes = sizeof(float) * (size_t)cols;
   PM_HIP(h, hipEventSynchronize(h->left_out));
-  unpack(disp_l, pdl);
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  if (lr) unpack(disp_r, pdr);
+  h->copy_pool->Copy2D(disp_l, disp_step, pdl, row_bytes, row_bytes, rows);
+  if (lr) {
+    PM_HIP(h, hipEventSynchronize(h->right_out));
+    h->copy_pool->Copy2D(disp_r, disp_step, pdr, row_bytes, row_bytes, rows);
+  }
   return PM_OK;
 }
 
@@ -1477,12 +1479,11 @@ int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
   const size_t px = (size_t)rows * cols;
   const size_t tight = (size_t)h->max_rows * h->max_cols;
   const PinnedSlot ps = pinned_slot(h, slot, px);
-  for (int y = 0; y < rows; ++y) {
-    std::memcpy(ps.l + (size_t)y * cols, left + (size_t)y * image_step, (size_t)cols);
-    std::memcpy(ps.r + (size_t)y * cols, right + (size_t)y * image_step, (size_t)cols);
-    if (seed_l) std::memcpy(ps.sl + (size_t)y * cols, (const char*)seed_l + (size_t)y * seed_step, sizeof(float) * cols);
-    if (seed_r) std::memcpy(ps.sr + (size_t)y * cols, (const char*)seed_r + (size_t)y * seed_step, sizeof(float) * cols);
-  }
+  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
+  h->copy_pool->Copy2D(ps.l, (size_t)cols, left, image_step, (size_t)cols, rows);
+  h->copy_pool->Copy2D(ps.r, (size_t)cols, right, image_step, (size_t)cols, rows);
+  if (seed_l) h->copy_pool->Copy2D(ps.sl, sizeof(float) * cols, seed_l, seed_step, sizeof(float) * cols, rows);
+  if (seed_r) h->copy_pool->Copy2D(ps.sr, sizeof(float) * cols, seed_r, seed_step, sizeof(float) * cols, rows);
   uint8_t* dl8 = h->st_left + slot * tight;
   uint8_t* dr8 = h->st_right + slot * tight;
   float* dsl = h->st_seed_l + slot * tight;
@@ -1533,10 +1534,9 @@ int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uin
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipEventSynchronize(sl.out_done));
   const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
-  for (int y = 0; y < rows; ++y) {
-    std::memcpy((char*)disp_l + (size_t)y * disp_step, ps.dl + (size_t)y * cols, sizeof(float) * cols);
-    if (lr) std::memcpy((char*)disp_r + (size_t)y * disp_step, ps.dr + (size_t)y * cols, sizeof(float) * cols);
-  }
+  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
+  h->copy_pool->Copy2D(disp_l, disp_step, ps.dl, sizeof(float) * cols, sizeof(float) * cols, rows);
+  if (lr) h->copy_pool->Copy2D(disp_r, disp_step, ps.dr, sizeof(float) * cols, sizeof(float) * cols, rows);
   if (tag) *tag = sl.tag;
   h->pipe_head = (h->pipe_head + 1) % h->max_batch;
   --h->pipe_count;
