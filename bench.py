@@ -292,27 +292,21 @@ class Workload:
                                             engine=args.engine, sparse_init=1 if args.self_seed else 0)
         self.eng = pm.Engine(self.params, device=local_rank, max_rows=args.rows, max_cols=args.cols, max_batch=nb)
         if enhance:
-            # BGR inputs; the enhanced gray images are produced on the device, on the engine's stream, in front of
-            # every Match (no host round trip): pm_stereo_ready (imaging::Normalize(NormalizeColorIlluminant(.)) -> gray)
+            # BGR inputs; the stereo-ready enhancement (imaging::Normalize(NormalizeColorIlluminant(.)) -> gray) runs on the
+            # device, on the engine's stream, folded into every Match's load path (pm_match_bgr_device)
             self.BL = [torch.from_numpy(np.stack([synth.to_bgr(p["left"], 1) for p in g])).to(dev).contiguous() for g in groups]
             self.BR = [torch.from_numpy(np.stack([synth.to_bgr(p["right"], 2) for p in g])).to(dev).contiguous() for g in groups]
-            self.J = torch.empty((args.rows, args.cols, 3), dtype=torch.float32, device=dev)
-            self.GL = torch.empty((nb, args.rows, args.cols), dtype=torch.uint8, device=dev)
-            self.GR = torch.empty_like(self.GL)
 
     def step(self, s):
         a, e, g = self.args, self.eng, s % N_ROTATE
         seeded = self.mode == "scalar" and not a.self_seed
         if self.enhance:
-            px = a.rows * a.cols
-            for i in range(self.nb):
-                e.stereo_ready(self.BL[g].data_ptr() + 3 * px * i, a.rows, a.cols, self.J.data_ptr(),
-                               self.GL.data_ptr() + px * i)
-                e.stereo_ready(self.BR[g].data_ptr() + 3 * px * i, a.rows, a.cols, self.J.data_ptr(),
-                               self.GR.data_ptr() + px * i)
-            left, right = self.GL.data_ptr(), self.GR.data_ptr()
-        else:
-            left, right = self.L[g].data_ptr(), self.R[g].data_ptr()
+            # BGR inputs: pm_match_bgr_device -- per image the two Gaussian passes and two small min / max passes, the
+            # per-pixel tail of the enhancement inside the prep kernel (no gray image in memory), then the Match
+            e.match_bgr_device(self.nb, self.BL[g].data_ptr(), self.BR[g].data_ptr(), a.rows, a.cols, None, None,
+                               self.DL.data_ptr(), self.DR.data_ptr())
+            return
+        left, right = self.L[g].data_ptr(), self.R[g].data_ptr()
         e.match_device(self.nb, left, right, a.rows, a.cols, self.SL[g].data_ptr() if seeded else None,
                        self.SR[g].data_ptr() if seeded else None, self.DL.data_ptr(), self.DR.data_ptr())
 
@@ -422,8 +416,8 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
     w.step(0)
     w.eng.synchronize()
     out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
-                       f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images on the device in "
-                                                      "front of every Match (BASELINE configs[4] per-GPU shape)" if enhance
+                       f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images fused into the "
+                                                      "Match's load path (pm_match_bgr_device; BASELINE configs[4] per-GPU shape)" if enhance
                                                       else " (BASELINE configs[1] shape)"),
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
            "step_ms": step_stats,

@@ -70,6 +70,16 @@ int pm_find_dark(pm_handle* h, const float* d_intensity, const float* d_range, i
  * outputs (at least one).  rows, cols >= 8.  Scratch for the image size is allocated on first use. */
 int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, float* d_J, uint8_t* d_gray8);
 
+/* Match() on 8-bit BGR pairs with that enhancement FOLDED INTO THE LOAD PATH (BASELINE config 5: "underwater enhancement
+ * fused into the cost kernel"): per image the two Gaussian passes of the illuminant estimate and two small min / max
+ * passes run as kernels; the whole per-pixel tail -- I / (2 blur), both HSV value stretches, gray, 8 bit -- is computed
+ * inside the prep kernel that produces the matcher's image / gradient planes, so neither the quotient image, nor the
+ * stretched images, nor the gray image is ever written to memory.  The result equals pm_stereo_ready on both images
+ * followed by pm_match_device, bit for bit, in every mode of the handle (scalar and PM_MODE_PLANES, f32 / f16 state).
+ * d_left_bgr8 / d_right_bgr8: [n][rows][cols][3] bytes on the device; the other arguments as pm_match_device. */
+int pm_match_bgr_device(pm_handle* h, int n, const uint8_t* d_left_bgr8, const uint8_t* d_right_bgr8, int rows, int cols,
+                        const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
+
 /* The two building blocks on float images, for callers that run them separately:
  * cv::GaussianBlur(src, dst, Size(ksize, ksize), sigma, sigma, BORDER_REPLICATE) for 1-4 interleaved channels
  * (EstimateIlluminantGaussian = 2 x this, illuminant.cpp:10-21), and imaging::Normalize. */

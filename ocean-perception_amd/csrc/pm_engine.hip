@@ -100,6 +100,8 @@ struct pm_handle {
   hipStream_t view_stream[2] = {nullptr, nullptr};
   hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
+  // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
+  const pm::BgrSource* bgr = nullptr;
   hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
   bool capturing = false;
   bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
@@ -298,6 +300,15 @@ int launch_check(pm_handle* h, const char* what) {
 }
 
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
+
+// k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)
+void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride) {
+  if (h->bgr)
+    hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
+                       dim3(256), 0, h->stream, ps, *h->bgr);
+  else
+    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride);
+}
 
 // The line-triple planes (about 80 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
 // scalar mode, the run engine.  Other handles (PM_SEM_GPU, PM_MODE_PLANES, the serial / wave anchors) neither
@@ -771,7 +782,7 @@ int planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
   PlaneSet ps = plane_set(h, rows, cols, nv);
   {
     Launch l(h, PM_K_PREP);
-    hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, (size_t)cols);
+    launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
   }
   if (int rc = launch_check(h, "prep")) return rc;
   const float* sl = d_seed_l;
@@ -1141,8 +1152,7 @@ static int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const u
   PlaneSet ps = plane_set(h, rows, cols, n_views);
   {
     Launch l(h, PM_K_PREP);
-    hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_left, d_right,
-                       (size_t)cols);
+    launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
   }
   if (int rc = launch_check(h, "prep")) return rc;
   {
@@ -2129,6 +2139,7 @@ void plan_size(const pm_handle* h, int* max_rows, int* max_cols) {
   *max_cols = h->max_cols;
 }
 void** imaging_slot(pm_handle* h) { return &h->imaging_state; }
+void set_bgr_source(pm_handle* h, const pm::BgrSource* src) { h->bgr = src; }
 void set_error(pm_handle* h, const char* fmt, ...) {
   if (!h) return;
   va_list ap;

@@ -15,6 +15,8 @@
 #include <cfloat>
 #include <cstdint>
 
+#include "pm_color.hpp"
+
 namespace pm {
 
 __device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -212,52 +214,6 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
   }
 }
 
-// ---- cv::cvtColor BGR2HSV / HSV2BGR on floats -----------------------------------------------------------------------
-__device__ __forceinline__ void bgr2hsv_d(float b, float g, float r, float& h, float& s, float& v) {
-  v = b;
-  float vmin = b;
-  if (g > v) v = g;
-  if (r > v) v = r;
-  if (g < vmin) vmin = g;
-  if (r < vmin) vmin = r;
-  float diff = v - vmin;
-  s = diff / (fabsf(v) + FLT_EPSILON);
-  diff = 60.f / (diff + FLT_EPSILON);
-  if (v == r) h = (g - b) * diff;
-  else if (v == g) h = (b - r) * diff + 120.f;
-  else h = (r - g) * diff + 240.f;
-  if (h < 0.f) h += 360.f;
-}
-
-__device__ __forceinline__ void hsv2bgr_d(float h, float s, float v, float& b, float& g, float& r) {
-  if (s == 0.f) {
-    b = g = r = v;
-    return;
-  }
-  h = h * (6.f / 360.f);
-  if (h < 0.f) {
-    do h += 6.f; while (h < 0.f);
-  } else if (h >= 6.f) {
-    do h -= 6.f; while (h >= 6.f);
-  }
-  int sector = (int)floorf(h);
-  h -= (float)sector;
-  if ((unsigned)sector >= 6u) {
-    sector = 0;
-    h = 0.f;
-  }
-  const float t0 = v, t1 = v * (1.f - s), t2 = v * (1.f - s * h), t3 = v * (1.f - s * (1.f - h));
-  // sector_data = {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}
-  switch (sector) {
-    case 0: b = t1; g = t3; r = t0; break;
-    case 1: b = t1; g = t0; r = t2; break;
-    case 2: b = t3; g = t0; r = t1; break;
-    case 3: b = t0; g = t2; r = t1; break;
-    case 4: b = t0; g = t1; r = t3; break;
-    default: b = t2; g = t1; r = t0; break;
-  }
-}
-
 __device__ __forceinline__ float value_of(const float* __restrict__ q, size_t px) {
   const float b = q[px * 3], g = q[px * 3 + 1], r = q[px * 3 + 2];
   float v = b;
@@ -321,29 +277,84 @@ __global__ void __launch_bounds__(256) k_value_minmax(const float* __restrict__ 
   }
 }
 
+// ---- the same min / max with the value computed on the fly from the 8-bit image and its blurred illuminant (the fused
+// path of pm_match_bgr_device: neither q = I / (2 blur) nor J1 = Normalize(q) is ever written to memory).
+// STAGE 1: V of q -> mm[0..1];  STAGE 2: V of J1 = Normalize(q; mm[0..1]) -> mm[2..3].
+template <int STAGE>
+__device__ __forceinline__ float fused_value(const uint8_t* __restrict__ bgr8, const float* __restrict__ blur, size_t px,
+                                             float a1, float b1) {
+  float b = illuminant_div(bgr8[px * 3], blur[px * 3]), g = illuminant_div(bgr8[px * 3 + 1], blur[px * 3 + 1]),
+        r = illuminant_div(bgr8[px * 3 + 2], blur[px * 3 + 2]);
+  if (STAGE == 2) {
+    float jb, jg, jr;
+    normalize_px(b, g, r, a1, b1, jb, jg, jr);
+    b = jb;
+    g = jg;
+    r = jr;
+  }
+  float v = b;
+  if (g > v) v = g;
+  if (r > v) v = r;
+  return v;
+}
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_value_minmax_fused(const uint8_t* __restrict__ bgr8, const float* __restrict__ blur,
+                                                            int rows, int cols, unsigned* mm) {
+  __shared__ float s_lo[4], s_hi[4];
+  const int dr = rows / 8, dc = cols / 8;
+  float a1 = 0.f, b1 = 0.f;
+  if (STAGE == 2) stretch_coeffs(mm, a1, b1);
+  float lo = FLT_MAX, hi = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dr * dc; i += gridDim.x * blockDim.x) {
+    const int dy = i / dc, dx = i - dy * dc;
+    int sy, sx;
+    float w0, w1, u0, u1;
+    linear_coeff_d(dy, rows, dr, sy, w0, w1);
+    linear_coeff_d(dx, cols, dc, sx, u0, u1);
+    const int sy1 = min(sy + 1, rows - 1), sx1 = min(sx + 1, cols - 1);
+    const float r0 = fused_value<STAGE>(bgr8, blur, (size_t)sy * cols + sx, a1, b1) * u0 +
+                     fused_value<STAGE>(bgr8, blur, (size_t)sy * cols + sx1, a1, b1) * u1;
+    const float r1 = fused_value<STAGE>(bgr8, blur, (size_t)sy1 * cols + sx, a1, b1) * u0 +
+                     fused_value<STAGE>(bgr8, blur, (size_t)sy1 * cols + sx1, a1, b1) * u1;
+    const float val = r0 * w0 + r1 * w1;
+    lo = val < lo ? val : lo;
+    hi = val > hi ? val : hi;
+  }
+#pragma unroll
+  for (int ofs = 32; ofs > 0; ofs >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, ofs, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, ofs, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    unsigned* out = mm + (STAGE == 2 ? 2 : 0);
+    atomicMin(&out[0], __float_as_uint(lo));
+    atomicMax(&out[1], __float_as_uint(hi));
+  }
+}
+
 // ---- Normalize's per-pixel part + BGR2GRAY + convertTo(CV_8U, 255) ------------------------------------------------
 // V' = V * (float)(1 / (vmax - vmin)) + (float)(-vmin / (vmax - vmin)); J (optional) and gray8 (optional) out.
 __global__ void __launch_bounds__(256) k_normalize_gray(const float* __restrict__ q, size_t n_px,
                                                         const unsigned* __restrict__ mm, float* __restrict__ J,
                                                         uint8_t* __restrict__ gray8) {
-  const double vmin = (double)__uint_as_float(mm[0]), vmax = (double)__uint_as_float(mm[1]);
-  const float alpha = (float)(1.0 / (vmax - vmin)), beta = (float)(-vmin / (vmax - vmin));
+  float alpha, beta;
+  stretch_coeffs(mm, alpha, beta);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (size_t)gridDim.x * blockDim.x) {
-    float h, s, v, b, g, r;
-    bgr2hsv_d(q[i * 3], q[i * 3 + 1], q[i * 3 + 2], h, s, v);
-    v = v * alpha + beta;
-    hsv2bgr_d(h, s, v, b, g, r);
+    float b, g, r;
+    normalize_px(q[i * 3], q[i * 3 + 1], q[i * 3 + 2], alpha, beta, b, g, r);
     if (J) {
       J[i * 3] = b;
       J[i * 3 + 1] = g;
       J[i * 3 + 2] = r;
     }
-    if (gray8) {
-      float gr = b * 0.114f;
-      gr = gr + g * 0.587f;
-      gr = gr + r * 0.299f;
-      gray8[i] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(gr * 255.f, 0, 0u);  // saturate_cast<uchar>
-    }
+    if (gray8) gray8[i] = gray_u8(b, g, r);
   }
 }
 

@@ -26,6 +26,11 @@ struct ImagingState {
   float* enh_q = nullptr;
   float* enh_taps = nullptr;
   size_t enh_values = 0;  // floats allocated in enh_tmp / enh_q
+  // pm_match_bgr_device: blurred illuminants of n pairs (left, right) and their value min / max words
+  float* bgr_blur = nullptr;
+  unsigned* bgr_mm = nullptr;
+  size_t bgr_values = 0;  // floats allocated in bgr_blur
+  int bgr_pairs = 0;      // pairs bgr_mm holds
   int enh_taps_cap = 0, enh_ksize = 0;
   double enh_sigma = 0;
 };
@@ -62,7 +67,7 @@ void pm_internal::release_imaging(pm_handle* h) {
   void** slot = pm_internal::imaging_slot(h);
   ImagingState* st = static_cast<ImagingState*>(*slot);
   if (!st) return;
-  void* dev[] = {st->img_scalars, st->enh_tmp, st->enh_q, st->enh_taps};
+  void* dev[] = {st->img_scalars, st->enh_tmp, st->enh_q, st->enh_taps, st->bgr_blur, st->bgr_mm};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   delete st;
@@ -386,6 +391,70 @@ int pm_stereo_ready(pm_handle* h, const uint8_t* d_bgr8, int rows, int cols, flo
   // Normalize (normalization.cpp:184): two value stretches.  The row-pass scratch is free again: it takes the first.
   if (int rc = run_normalize(h, state_of(h)->enh_q, rows, cols, state_of(h)->enh_tmp, nullptr)) return rc;
   return run_normalize(h, state_of(h)->enh_tmp, rows, cols, d_J, d_gray8);
+}
+
+// Match() on BGR inputs with the stereo-ready enhancement folded into the load path (BASELINE configs[4]): per image the
+// two Gaussian passes (illuminant estimate) and the two tiny min / max passes of the value stretches; everything per
+// pixel happens inside k_prep_bgr.  Results equal pm_stereo_ready x 2 followed by pm_match_device bit for bit.
+int pm_match_bgr_device(pm_handle* h, int n, const uint8_t* d_left_bgr8, const uint8_t* d_right_bgr8, int rows, int cols,
+                        const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+  if (int rc = imaging_begin(h, "pm_match_bgr_device", d_left_bgr8, d_right_bgr8, rows, cols)) return rc;
+  if (n < 1 || rows < 8 || cols < 8) {
+    set_err(h, "pm_match_bgr_device: n >= 1 pairs of at least 8x8 pixels");
+    return PM_ERR_INVALID_ARG;
+  }
+  ImagingState* st = state_of(h);
+  const size_t ipx = (size_t)rows * cols, values = ipx * 3;
+  if (st->bgr_values < values * 2 * (size_t)n) {
+    if (st->bgr_blur) PM_HIP(h, hipFree(st->bgr_blur));
+    st->bgr_blur = nullptr;
+    st->bgr_values = 0;
+    PM_HIP(h, hipMalloc((void**)&st->bgr_blur, sizeof(float) * values * 2 * (size_t)n));
+    st->bgr_values = values * 2 * (size_t)n;
+  }
+  if (st->bgr_pairs < n) {
+    if (st->bgr_mm) PM_HIP(h, hipFree(st->bgr_mm));
+    st->bgr_mm = nullptr;
+    st->bgr_pairs = 0;
+    PM_HIP(h, hipMalloc((void**)&st->bgr_mm, sizeof(unsigned) * 8 * (size_t)n));
+    st->bgr_pairs = n;
+  }
+  // NormalizeColorIlluminant (normalization.cpp:178-185): ksize = NextOddInt(cols / 3), sigma = (float)ksize / 4
+  const int third = cols / 3;
+  const int ksize = third + (1 - third % 2);
+  const double sigma = (double)((float)ksize / 4.0f);
+  std::vector<unsigned> init((size_t)n * 8);
+  for (size_t i = 0; i < init.size(); i += 2) {
+    init[i] = 0x7f7fffffu;  // min
+    init[i + 1] = 0u;       // max
+  }
+  PM_HIP(h, hipMemcpyAsync(st->bgr_mm, init.data(), sizeof(unsigned) * init.size(), hipMemcpyHostToDevice, pm_internal::stream(h)));
+  float* blur_l = st->bgr_blur;
+  float* blur_r = st->bgr_blur + values * (size_t)n;
+  const size_t small = (size_t)(rows / 8) * (cols / 8);
+  for (int b = 0; b < n; ++b)
+    for (int i = 0; i < 2; ++i) {
+      const uint8_t* img = (i == 0 ? d_left_bgr8 : d_right_bgr8) + (size_t)b * values;
+      float* blur = (i == 0 ? blur_l : blur_r) + (size_t)b * values;
+      unsigned* mm = st->bgr_mm + ((size_t)b * 2 + i) * 4;
+      if (int rc = run_gaussian<true>(h, img, rows, cols, 3, ksize, sigma, false, blur)) return rc;
+      hipLaunchKernelGGL((k_value_minmax_fused<1>), reduce_grid(small), dim3(256), 0, pm_internal::stream(h), img,
+                         (const float*)blur, rows, cols, mm);
+      hipLaunchKernelGGL((k_value_minmax_fused<2>), reduce_grid(small), dim3(256), 0, pm_internal::stream(h), img,
+                         (const float*)blur, rows, cols, mm);
+    }
+  if (int rc = launch_check(h, "value min / max")) return rc;
+  BgrSource src;
+  src.left = d_left_bgr8;
+  src.right = d_right_bgr8;
+  src.blur_l = blur_l;
+  src.blur_r = blur_r;
+  src.mm = st->bgr_mm;
+  pm_internal::set_bgr_source(h, &src);
+  // the image pointers below only have to be non-null: the prep stage reads `src`
+  const int rc = pm_match_device(h, n, d_left_bgr8, d_right_bgr8, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
+  pm_internal::set_bgr_source(h, nullptr);
+  return rc;
 }
 
 int pm_normalize_color_illuminant(pm_handle* h, const float* d_bgr, int rows, int cols, float* d_out) {

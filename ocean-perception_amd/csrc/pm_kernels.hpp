@@ -2,6 +2,7 @@
 // `file:line` citations are relative to the reference tree (/root/reference).
 #pragma once
 
+#include "pm_color.hpp"
 #include "pm_device.hpp"
 #include "pm_sweep_defs.hpp"
 
@@ -54,6 +55,59 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
     ps.img8[mirror] = p;
     ps.g32[direct] = g;
     ps.g32[mirror] = g;
+    ps.g8[direct] = g8;
+    ps.g8[mirror] = g8;
+    const uint16_t pk = (uint16_t)(p | ((unsigned)g8 << 8));
+    ps.pk16[direct] = pk;
+    ps.pk16[mirror] = pk;
+  }
+}
+
+// k_prep with the stereo-ready enhancement's per-pixel tail folded into its load (BASELINE configs[4], "enhancement fused
+// into the cost kernel's load path"): the inputs are the 8-bit BGR images and their blurred illuminants (the two
+// 427-tap Gaussian passes stay kernels of their own, pm_enhance.hpp); a block computes the enhanced 8-bit gray values
+// of its 64x4 tile plus a 1-pixel ring ONCE into LDS (pm_color.hpp::stereo_ready_gray: I / (2 blur), two HSV value
+// stretches, gray -- exactly the values pm_stereo_ready would have written) and then does what k_prep does.  Neither
+// the quotient image, nor the stretched images, nor the gray image ever goes through HBM.
+// src/vehicle/imaging/normalization.cpp:43-69,178-185.  grid = (ceil(cols/64), ceil(rows/4), B), block = 256.
+__global__ void __launch_bounds__(256) k_prep_bgr(PlaneSet ps, BgrSource src) {
+  constexpr int TW = 64, TH = 4, LW = TW + 2, LH = TH + 2;
+  __shared__ uint8_t s_gray[2][LH][LW + 2];
+  const int b = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const size_t ipx = (size_t)ps.rows * ps.cols;
+  for (int e = threadIdx.x; e < 2 * LH * LW; e += blockDim.x) {
+    const int i = e / (LH * LW), r = (e - i * LH * LW) / LW, c = e - i * LH * LW - r * LW;
+    // the ring follows the Sobel border rule (BORDER_REFLECT_101); positions beyond the image are never used
+    const int gy = reflect101(min(y0 - 1 + r, ps.rows), ps.rows), gx = reflect101(min(x0 - 1 + c, ps.cols), ps.cols);
+    const uint8_t* img = (i == 0 ? src.left : src.right) + (size_t)b * ipx * 3;
+    const float* blur = (i == 0 ? src.blur_l : src.blur_r) + (size_t)b * ipx * 3;
+    s_gray[i][r][c] = stereo_ready_gray(img, blur, (size_t)gy * ps.cols + gx, src.mm + ((size_t)b * 2 + i) * 4);
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= ps.cols || y >= ps.rows) return;
+  const int xm = ps.cols - 1 - x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint8_t(*g)[LW + 2] = s_gray[i];
+    const int r = ty + 1, c = tx + 1;
+    const uint8_t p = g[r][c];
+    const int dx = ((int)g[r - 1][c + 1] - (int)g[r - 1][c - 1]) + 2 * ((int)g[r][c + 1] - (int)g[r][c - 1]) +
+                   ((int)g[r + 1][c + 1] - (int)g[r + 1][c - 1]);
+    const int dy = ((int)g[r + 1][c - 1] - (int)g[r - 1][c - 1]) + 2 * ((int)g[r + 1][c] - (int)g[r - 1][c]) +
+                   ((int)g[r + 1][c + 1] - (int)g[r - 1][c + 1]);
+    const float fx = (float)dx, fy = (float)dy;
+    const float sx = fx * fx, sy = fy * fy;
+    const float gm = sqrtf(sx + sy);
+    const uint8_t g8 = (uint8_t)sat_u8(gm);
+    const size_t direct = ((size_t)b * 4 + i) * ps.plane + (size_t)y * ps.pitch + x;
+    const size_t mirror = ((size_t)b * 4 + 2 + i) * ps.plane + (size_t)y * ps.pitch + xm;
+    ps.img8[direct] = p;
+    ps.img8[mirror] = p;
+    ps.g32[direct] = gm;
+    ps.g32[mirror] = gm;
     ps.g8[direct] = g8;
     ps.g8[mirror] = g8;
     const uint16_t pk = (uint16_t)(p | ((unsigned)g8 << 8));

@@ -32,7 +32,7 @@ EXPORTS = [
     "pm_submit_u8", "pm_collect", "pm_in_flight", "pm_capture_begin", "pm_capture_end", "pm_replay",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
-    "pm_normalize_color_illuminant", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
+    "pm_normalize_color_illuminant", "pm_match_bgr_device", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
     "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
@@ -155,6 +155,8 @@ def load():
     lib.pm_compute_intensity.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.pm_find_dark.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, f3]
     lib.pm_stereo_ready.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.pm_match_bgr_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pm_match_bgr_device.restype = C.c_int
     lib.pm_gaussian_blur.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp]
     lib.pm_normalize.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.pm_normalize_color_illuminant.argtypes = [vp, vp, C.c_int, C.c_int, vp]
@@ -435,6 +437,12 @@ class Engine:
         self._pl_shape = (rows, cols)
         self._check(self.lib.pm_match_device(self.h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
                                              d_disp_r), "pm_match_device")
+
+    def match_bgr_device(self, n, d_left_bgr8, d_right_bgr8, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r):
+        """Match() on 8-bit BGR pairs, the stereo-ready enhancement folded into the load path (raw device addresses)."""
+        self._pl_shape = (rows, cols)
+        self._check(self.lib.pm_match_bgr_device(self.h, n, d_left_bgr8, d_right_bgr8, rows, cols, d_seed_l, d_seed_r,
+                                                 d_disp_l, d_disp_r), "pm_match_bgr_device")
 
     def match_view_device(self, d_iml, d_imr, d_gl, d_gr, rows, cols, step, d_disp, disp_step=0, stream=None):
         """One view with caller-supplied float images and gradients (device addresses as ints)."""

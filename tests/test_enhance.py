@@ -178,3 +178,36 @@ def test_enhanced_pair_feeds_match_without_host_round_trip(pm, oracle, synth):
     el, er = oracle.match(oracle.default_params(0, patch=5, n_iters=2, nthreads=8), gl, gr, p["seed_l"], p["seed_r"])
     assert np.array_equal(DL.cpu().numpy(), el) and np.array_equal(DR.cpu().numpy(), er)
     assert (el > 0).mean() > 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["scalar", "planes_f16", "planes_f32"])
+def test_fused_bgr_match_equals_stereo_ready_then_match(pm, synth, mode):
+    """pm_match_bgr_device (the enhancement's per-pixel tail inside the prep kernel, no gray image in memory) gives the
+    maps of pm_stereo_ready x 2 + pm_match_device bit for bit -- scalar mode and the plane mode with both state types,
+    a batch of two pairs, an image size that is not a multiple of the prep tile."""
+    import torch
+    rows, cols, n = 101, 163, 2
+    pairs = [synth.make_pair(20 + i, rows, cols) for i in range(n)]
+    bl = np.stack([synth.to_bgr(p["left"], 3 + i) for i, p in enumerate(pairs)])
+    br = np.stack([synth.to_bgr(p["right"], 7 + i) for i, p in enumerate(pairs)])
+    if mode == "scalar":
+        prm = pm.default_params(0, patch=7, patchmatch_iters=2, sparse_init=1)
+    else:
+        prm = pm.default_params(0, patch=7, patchmatch_iters=2, mode=pm.PM_MODE_PLANES, max_disp=64,
+                                state_dtype=pm.PM_STATE_F16 if mode == "planes_f16" else pm.PM_STATE_F32)
+    dev = torch.device("cuda")
+    BL, BR = torch.from_numpy(bl).to(dev).contiguous(), torch.from_numpy(br).to(dev).contiguous()
+    GL = torch.empty((n, rows, cols), dtype=torch.uint8, device=dev)
+    GR = torch.empty_like(GL)
+    D = [torch.empty((n, rows, cols), dtype=torch.float32, device=dev) for _ in range(4)]
+    px = rows * cols
+    with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=n) as e:
+        for i in range(n):
+            e.stereo_ready(BL.data_ptr() + 3 * px * i, rows, cols, None, GL.data_ptr() + px * i)
+            e.stereo_ready(BR.data_ptr() + 3 * px * i, rows, cols, None, GR.data_ptr() + px * i)
+        e.match_device(n, GL.data_ptr(), GR.data_ptr(), rows, cols, None, None, D[0].data_ptr(), D[1].data_ptr())
+        e.match_bgr_device(n, BL.data_ptr(), BR.data_ptr(), rows, cols, None, None, D[2].data_ptr(), D[3].data_ptr())
+        e.synchronize()
+    assert torch.equal(D[0], D[2]) and torch.equal(D[1], D[3])
+    assert float((D[2] > 0).float().mean()) > 0.2

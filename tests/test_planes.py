@@ -426,6 +426,11 @@ def test_configs4_workload_bgr_enhanced_f16_planes_full_size(pm, oracle, synth):
         first_l, first_r = DL.clone(), DR.clone()
         frame()
         assert torch.equal(first_l, DL) and torch.equal(first_r, DR), "configs[4] frame is not deterministic"
+        # the same frame with the enhancement's per-pixel tail folded into the prep kernel (what bench.py times)
+        FL, FR = torch.empty_like(DL), torch.empty_like(DR)
+        e.match_bgr_device(1, BL.data_ptr(), BR.data_ptr(), rows, cols, None, None, FL.data_ptr(), FR.data_ptr())
+        e.synchronize()
+        assert torch.equal(FL, DL) and torch.equal(FR, DR), "pm_match_bgr_device differs from pm_stereo_ready + Match"
     gl, gr = GL.cpu().numpy(), GR.cpu().numpy()
     _, ol = O.stereo_ready(bl)
     _, orr = O.stereo_ready(br)
