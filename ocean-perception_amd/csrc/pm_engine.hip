@@ -302,12 +302,14 @@ int launch_check(pm_handle* h, const char* what) {
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
 
 // k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)
-void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride) {
+void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
+                 int view = -1) {
   if (h->bgr)
     hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
                        dim3(256), 0, h->stream, ps, *h->bgr);
   else
-    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride);
+    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride,
+                       view);
 }
 
 // The line-triple planes (about 80 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
@@ -336,11 +338,13 @@ int pair_planes_alloc(pm_handle* h) {
 }
 
 // transposed copies of the 12 image-type planes of n pairs (run by every path that ran k_prep)
-int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
+// view >= 0: the planes of that view only (per-view streams: each stream derives its own planes)
+int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view = -1) {
   SetupGrid sg{};
+  sg.view = view;
   sg.tx = (unsigned)((ps.cols + 63) / 64);
   sg.ty = (unsigned)((ps.rows + 63) / 64);
-  sg.tz = (unsigned)(n * 4);
+  sg.tz = (unsigned)(n * (view < 0 ? 4 : 2));
   sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
   PlaneSet pp = ps;
   unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
@@ -351,10 +355,10 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n) {
     pp.cpg = h->cpg;
     sg.lx = (unsigned)((ps.cols + 255) / 256);
     sg.ly = (unsigned)ps.nrl;
-    sg.lz = (unsigned)(n * 2);
+    sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
     sg.cx = (unsigned)((ps.rows + 255) / 256);
     sg.cy = (unsigned)ps.ncl;
-    sg.cz = (unsigned)(n * 2);
+    sg.cz = (unsigned)(n * (view < 0 ? 2 : 1));
     blocks0 += 2 * sg.lx * sg.ly * sg.lz;
   }
   hipLaunchKernelGGL(k_setup, dim3(blocks0), dim3(256), 0, h->stream, pp, sg, 0);
@@ -580,7 +584,19 @@ int seed_views(pm_handle* h, const PlaneSet& ps, int n_pairs, int view, int scra
   return PM_OK;
 }
 
-int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
+// What a view stream needs to prepare its own planes (match_device_impl): with the views on their own streams the
+// prep / transpose / line-plane / seed kernels of a view run at the head of that view's stream, so the two halves of
+// the setup run side by side and neither view waits for the other's (round 2: eight launches in a row on the main
+// stream, then a cross-stream event in front of each view).
+struct ViewSetup {
+  const uint8_t* d_left;
+  const uint8_t* d_right;
+  const float* d_seed_l;
+  const float* d_seed_r;
+  int n;
+};
+
+int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
   if (ps.n_views != 2 || !view_streams_enabled()) {
     for (int v = 0; v < ps.n_views; ++v)
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
@@ -604,7 +620,21 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots) {
       break;
     }
     h->stream = h->view_stream[v];
-    rc = seed_views(h, ps, slots / 2, v, v);
+    if (setup) {
+      {
+        Launch l(h, PM_K_PREP);
+        launch_prep(h, ps, setup->d_left, setup->d_right, setup->n, (size_t)ps.cols, v);
+        rc = launch_check(h, "prep");
+        if (rc == PM_OK) rc = run_transpose(h, ps, setup->n, v);
+      }
+      if (rc == PM_OK) {
+        Launch l(h, PM_K_SEED);
+        hipLaunchKernelGGL(k_seed, pixel_grid(ps.cols, ps.rows, setup->n), dim3(256), 0, h->stream, ps, setup->d_seed_l,
+                           setup->d_seed_r, (size_t)ps.cols, v);
+        rc = launch_check(h, "seed");
+      }
+    }
+    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, v);
     h->stream = main_stream;
   }
   if (rc == PM_OK) rc = run_view_sets(h, pv, h->view_stream, 2, slots / 2);
@@ -1150,26 +1180,33 @@ static int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const u
     return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   PlaneSet ps = plane_set(h, rows, cols, n_views);
-  {
-    Launch l(h, PM_K_PREP);
-    launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
-  }
-  if (int rc = launch_check(h, "prep")) return rc;
-  {
-    Launch l(h, PM_K_PREP);
-    if (int rc = run_transpose(h, ps, n)) return rc;
-  }
-  {
-    Launch l(h, PM_K_SEED);
-    hipLaunchKernelGGL(k_seed, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
-                       (size_t)cols);
-  }
-  if (int rc = launch_check(h, "seed")) return rc;
   // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
   // the two views' seeders overlap on their own streams)
   h->need_seed[0] = h->params.sparse_init && !d_seed_l;
   h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
-  if (int rc = run_views(h, ps, n * n_views)) return rc;
+  // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
+  const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
+  if (per_view_setup) {
+    const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
+    if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
+  } else {
+    {
+      Launch l(h, PM_K_PREP);
+      launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
+    }
+    if (int rc = launch_check(h, "prep")) return rc;
+    {
+      Launch l(h, PM_K_PREP);
+      if (int rc = run_transpose(h, ps, n)) return rc;
+    }
+    {
+      Launch l(h, PM_K_SEED);
+      hipLaunchKernelGGL(k_seed, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
+                         (size_t)cols, -1);
+    }
+    if (int rc = launch_check(h, "seed")) return rc;
+    if (int rc = run_views(h, ps, n * n_views)) return rc;
+  }
   {
     Launch l(h, PM_K_FINALIZE);
     hipLaunchKernelGGL(k_finalize, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_disp_l, d_disp_r,
@@ -1569,7 +1606,7 @@ int stage_prep(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows
   PM_HIP(h, hipMemcpyAsync(h->st_right, right ? right : left, px, hipMemcpyHostToDevice, h->stream));
   const PlaneSet ps = plane_set(h, rows, cols, 1);
   hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, h->st_left, h->st_right,
-                     (size_t)cols);
+                     (size_t)cols, -1);
   if (int rc = launch_check(h, "prep")) return rc;
   if (int rc = run_transpose(h, ps, 1)) return rc;
   *ps_out = ps;
@@ -1802,11 +1839,11 @@ int pm_tile_begin(pm_handle* h, const pm_tile* tile, const uint8_t* d_left_band,
   h->tile_on = true;
   const PlaneSet ps = tile_plane_set(h);
   hipLaunchKernelGGL(k_prep, pixel_grid(cols, band_rows, 1), dim3(256), 0, h->stream, ps, d_left_band, d_right_band,
-                     (size_t)cols);
+                     (size_t)cols, -1);
   if (int rc = launch_check(h, "prep")) return rc;
   if (int rc = run_transpose(h, ps, 1)) return rc;
   hipLaunchKernelGGL(k_seed, pixel_grid(cols, band_rows, 1), dim3(256), 0, h->stream, ps, d_seed_l_band,
-                     d_seed_r_band, (size_t)cols);
+                     d_seed_r_band, (size_t)cols, -1);
   return launch_check(h, "seed");
 }
 

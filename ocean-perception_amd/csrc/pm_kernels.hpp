@@ -36,8 +36,10 @@ __device__ __forceinline__ float sobel_mag(const uint8_t* im, size_t stride, int
 }
 
 // in_left / in_right: [B][rows][in_stride] u8.  grid = (ceil(cols/256), rows, B).
+// view_sel: -1 = all four planes; 0 = the direct copies only (what view 0 works on), 1 = the mirrored copies only (view 1):
+// with the two views on their own streams each stream prepares its own planes and nothing waits for the other.
 __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __restrict__ in_left,
-                                              const uint8_t* __restrict__ in_right, size_t in_stride) {
+                                              const uint8_t* __restrict__ in_right, size_t in_stride, int view_sel) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
@@ -51,15 +53,19 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
     const uint8_t g8 = (uint8_t)sat_u8(g);
     const size_t direct = ((size_t)b * 4 + i) * ps.plane + (size_t)y * ps.pitch + x;
     const size_t mirror = ((size_t)b * 4 + 2 + i) * ps.plane + (size_t)y * ps.pitch + xm;
-    ps.img8[direct] = p;
-    ps.img8[mirror] = p;
-    ps.g32[direct] = g;
-    ps.g32[mirror] = g;
-    ps.g8[direct] = g8;
-    ps.g8[mirror] = g8;
     const uint16_t pk = (uint16_t)(p | ((unsigned)g8 << 8));
-    ps.pk16[direct] = pk;
-    ps.pk16[mirror] = pk;
+    if (view_sel != 1) {
+      ps.img8[direct] = p;
+      ps.g32[direct] = g;
+      ps.g8[direct] = g8;
+      ps.pk16[direct] = pk;
+    }
+    if (view_sel != 0) {
+      ps.img8[mirror] = p;
+      ps.g32[mirror] = g;
+      ps.g8[mirror] = g8;
+      ps.pk16[mirror] = pk;
+    }
   }
 }
 
@@ -235,19 +241,23 @@ struct SetupGrid {
   unsigned lx, ly, lz;  // row triples / quads: (ceil(cols/256), nrl, B * 2) each
   unsigned cx, cy, cz;  // column triples: (ceil(rows/256), ncl, B * 2)
   int with_lines;       // 0: transposes only (PM_SEM_GPU, plane mode, anchor engines)
+  int view;             // -1: both views (tz = B * 4, lz = cz = B * 2); 0 / 1: that view's planes only (tz = B * 2, lz = cz = B)
 };
 __global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int stage) {
   __shared__ float lds[64 * 65];
   unsigned b = blockIdx.x;
+  // plane / slot indices of a one-view launch: planes 2 * view, 2 * view + 1 of every pair; slot = pair * 2 + view
+  auto plane_of = [&](int bz) { return sg.view < 0 ? bz : (bz >> 1) * 4 + 2 * sg.view + (bz & 1); };
+  auto slot_of = [&](int z) { return sg.view < 0 ? z : z * 2 + sg.view; };
   if (stage == 1) {
-    triples_block(ps, 0, (int)(b % sg.cx), (int)((b / sg.cx) % sg.cy), (int)(b / (sg.cx * sg.cy)));
+    triples_block(ps, 0, (int)(b % sg.cx), (int)((b / sg.cx) % sg.cy), slot_of((int)(b / (sg.cx * sg.cy))));
     return;
   }
   const unsigned nt = sg.tx * sg.ty * sg.tz;
   if (b < 4 * nt) {
     const unsigned kind = b / nt;
     b -= kind * nt;
-    const int bx = (int)(b % sg.tx), by = (int)((b / sg.tx) % sg.ty), bz = (int)(b / (sg.tx * sg.ty));
+    const int bx = (int)(b % sg.tx), by = (int)((b / sg.tx) % sg.ty), bz = plane_of((int)(b / (sg.tx * sg.ty)));
     if (kind == 0)
       transpose_block<uint8_t>(ps.img8, ps.timg8, ps.rows, ps.cols, ps.pitch, ps.pitch_t, ps.plane, ps.plane_t, bx, by, bz, lds);
     else if (kind == 1)
@@ -260,7 +270,7 @@ __global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int st
   }
   b -= 4 * nt;
   const unsigned nl = sg.lx * sg.ly * sg.lz;
-  const int bx = (int)(b % sg.lx), l = (int)((b / sg.lx) % sg.ly), z = (int)((b % nl) / (sg.lx * sg.ly));
+  const int bx = (int)(b % sg.lx), l = (int)((b / sg.lx) % sg.ly), z = slot_of((int)((b % nl) / (sg.lx * sg.ly)));
   if (b < nl) triples_block(ps, 1, bx, l, z);
   else quads_block(ps, bx, l, z);
 }
@@ -268,14 +278,15 @@ __global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int st
 // seed maps -> disparity planes; the right-view seed is mirrored like the images
 // (patchmatch_gpu.cu:362-366).  A null seed pointer means "all background".
 __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restrict__ seed_l,
-                                              const float* __restrict__ seed_r, size_t seed_stride) {
+                                              const float* __restrict__ seed_r, size_t seed_stride, int view_sel) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
   const size_t sp = (size_t)ps.rows * seed_stride;
   const size_t o = (size_t)y * ps.pitch + x;
-  ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
-  if (ps.n_views > 1)
+  if (view_sel != 1)
+    ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
+  if (ps.n_views > 1 && view_sel != 0)
     ps.disp[((size_t)b * 2 + 1) * ps.plane + o] =
         seed_r ? seed_r[(size_t)b * sp + (size_t)y * seed_stride + (ps.cols - 1 - x)] : 0.f;
 }
