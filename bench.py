@@ -146,17 +146,23 @@ def pmc_traffic(kernel_class):
         return None
 
 
-def pmc_valu(kernel_class):
-    """The binding roof of the window kernels beside the HBM figure BASELINE.json asks for: vector-instruction issue,
-    from the committed SQ passes of this same command (profiles/valu.json, written by tools/make_valu.py from separate
-    rocprofv3 --pmc runs; rocprofv3 serialises the launches, so `issue_frac` is that of a kernel ALONE on the chip).
-    issue_frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles).  None if the file is missing."""
+def pmc_valu(kernel_class, prof=None, n_prof=0):
+    """The issue-side roofs of the window kernels beside the HBM figure BASELINE.json asks for, from the committed
+    rocprofv3 --pmc passes of this same command (profiles/valu.json, written by tools/make_valu.py from separate SQ /
+    TA / TD runs; rocprofv3 serialises the launches, so the fractions are those of a kernel ALONE on the chip):
+    issue_frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); ta / td_busy_frac = texture address / data
+    unit busy cycles over 256 CUs x kernel cycles.  insts_per_step = vector instructions of one timed step: per-launch
+    counts of the profiled classes x this run's launches per step.  None if the file is missing."""
     try:
         with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
             t = json.load(f)
-        out = dict(t["kernels"][kernel_class])
-        out["insts_per_step"] = t.get("insts_valu_per_step")
-        out["source"] = "profiles/valu.json"
+        k = t["kernels"][kernel_class]
+        out = {"issue_frac": k["valu_issue_frac"], "ta_busy_frac": k.get("ta_busy_frac"),
+               "td_busy_frac": k.get("td_busy_frac"), "insts_valu_per_launch": k.get("insts_valu_per_launch"),
+               "source": "profiles/valu.json (committed rocprofv3 --pmc passes of this command; kernels alone on the chip)"}
+        if prof and n_prof:
+            out["insts_per_step"] = sum(v["insts_valu_per_launch"] * prof[c][0] / n_prof
+                                        for c, v in t["kernels"].items() if c in prof and v.get("insts_valu_per_launch"))
         return out
     except Exception:
         return None
@@ -331,7 +337,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (nb == 1 and state == "f32") else None,
                 "traffic_source": "profiles/traffic.json" if (nb == 1 and state == "f32") else None,
-                "valu": pmc_valu(dom) if (nb == 1 and state == "f32") else None,
+                "valu": pmc_valu(dom, prof, n_prof) if (nb == 1 and state == "f32") else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
                 "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48 (two "
@@ -353,7 +359,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
             "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command, not measured in this run)" if nb == 1 else None,
-            "valu": pmc_valu(dom) if nb == 1 else None,
+            "valu": pmc_valu(dom, prof, n_prof) if nb == 1 else None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
             "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
             "achieved_all_concurrent": achieved * concurrency,

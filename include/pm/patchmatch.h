@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 3
+#define PM_ABI_VERSION 4
 #define PM_MAX_ITERS 16
 #define PM_MAX_PATCH 15 /* largest supported window side (odd) */
 

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-PM_ABI_VERSION = 3
+PM_ABI_VERSION = 4
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1

@@ -6,10 +6,10 @@ Per-launch averages in KiB for the dominant kernels (the counters report KiB; su
 import csv, collections, json, re, sys
 
 
-CLASSES = (("sweep_row", r"k_runblk2<\d+, \d+, 0,"), ("sweep_col", r"k_runblk2<\d+, \d+, 1,"),
+CLASSES = (("sweep_row", r"k_runblk3<\d+, 0,"), ("sweep_col", r"k_runblk3<\d+, 1,"),
            ("noise_cost", r"k_noise_cost_tiled"), ("planes_init", r"k_planes<\d+, 0,"),
            ("planes_spatial", r"k_planes<\d+, 1,"), ("planes_view", r"k_planes<\d+, 2,"),
-           ("planes_refine", r"k_planes<\d+, [34],"))
+           ("planes_refine", r"k_planes<\d+, 3,"), ("planes_view_refine", r"k_planes<\d+, 4,"))
 
 
 def per_launch(path, counter):
