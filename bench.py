@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="skip the plane-mode side legs of the default run")
     ap.add_argument("--tiled", action="store_true",
                     help="BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks (see python/tiled.py)")
+    ap.add_argument("--tiled-rccl", action="store_true",
+                    help="multi-rank configs[3] leg over RCCL (python/tiled.py, one rank per GPU) instead of the "
+                         "single-process C-ABI driver (pm_tiled_*)")
     ap.add_argument("--tiled-timeout", type=int, default=150,
                     help="deadline (s) of the crash-isolated configs[3] leg of a multi-rank run")
     ap.add_argument("--rehearse-tiled-leg", action="store_true",
@@ -442,20 +445,32 @@ def run_tiled(args, d):
 
 
 def tiled_children(args):
-    """The configs[3] leg of a multi-rank run, crash-isolated: every rank starts `python/tiled.py` as a CHILD process
-    (its own rendezvous on another port, same RANK / LOCAL_RANK) BEFORE this process touches the GPU or joins its
-    process group, waits for it with a deadline, and rank 0 keeps the child's JSON line.  The RCCL neighbour exchange
-    of that leg cannot be exercised on a one-GPU box; whatever it does on an 8-GPU node -- exception, hang, abort --
-    ends in an {"error": ...} entry here and never costs the headline."""
+    """The configs[3] leg of a multi-rank run, crash-isolated: a CHILD process started before this process touches the
+    GPU or joins its process group, waited for with a deadline; whatever it does -- exception, hang, abort -- ends in
+    an {"error": ...} entry and never costs the headline.  Default: rank 0 alone starts ONE child that drives all
+    WORLD_SIZE GPUs through the C-ABI driver (pm_tiled_*: one process, one band per GPU, boundary rows by
+    hipMemcpyPeerAsync + events) while the other ranks wait at the rendezvous.  --tiled-rccl: every rank starts a
+    `python/tiled.py` rank of its own (RCCL neighbour exchange on the engine's stream, own rendezvous port)."""
     import subprocess
     env = dict(os.environ)
-    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
-    env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 4099) % 60000 + 1024)
-    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
-        env.pop(k, None)  # the child rendezvous is a plain env:// TCP store of its own
-    cmd = [sys.executable, os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py"), "--rows", "2160", "--cols",
-           "4096", "--iters", str(args.iters), "--patch", str(args.patch), "--steps", "2", "--backend", args.backend]
     rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    script = os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py")
+    base = [sys.executable, script, "--rows", "2160", "--cols", "4096", "--iters", str(args.iters), "--patch",
+            str(args.patch), "--steps", "2"]
+    if args.tiled_rccl or args.dry_run:
+        env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+        env["MASTER_PORT"] = str((int(env.get("MASTER_PORT", "29500")) - 1024 + 4099) % 60000 + 1024)
+        for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+            env.pop(k, None)  # the child rendezvous is a plain env:// TCP store of its own
+        cmd = base + ["--backend", args.backend]
+    else:
+        if rank != 0:
+            return None
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                  "TORCHELASTIC_USE_AGENT_STORE"):
+            env.pop(k, None)
+        cmd = base + ["--single-process", str(world)]
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     except OSError as e:
@@ -658,6 +673,9 @@ def main():
             import tiled
             try:
                 tiled_result = tiled.bench(args, d, steps=2, quiet=True)
+                # the same pair through the C-ABI driver with 8 bands on this one device: the protocol (boundary rows,
+                # masked re-sweeps, flag) at work, its cost beside the untiled frame
+                tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:

@@ -308,10 +308,21 @@ int pm_tiled_band_rows(const pm_params* params, int global_rows, int n_bands);
 int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm_tiled_plan** out);
 void pm_tiled_destroy(pm_tiled_plan* plan);
 /* host buffers as in pm_match_u8 (seed maps may be NULL; the device seeder works on whole images and is not available
- * here); rounds = exchange rounds per vertical sweep (2 is the default of the python driver; clamped to n_bands - 1) */
+ * here); rounds = exchange rounds per vertical sweep: negative (recommended) or >= n_bands - 1 = n_bands - 1 rounds, which
+ * are always enough (band k is final after round k + 1) -- a round in which nothing changed is three empty launches per
+ * band, a repeated Match costs a whole Match (measured at 4096x2160 / 8 bands: 49 ms with 7 rounds, 88 ms with 2 rounds
+ * and the repeat they always end in, tools/tiled_rounds.py); fewer rounds only pay when values rarely cross bands */
 int pm_tiled_match_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* right, size_t image_step,
                       const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
                       size_t disp_step, int rounds, pm_tiled_info* info);
+/* The same in three steps, for callers that keep the pair resident (a timed region without PCIe, several runs of one
+ * pair): upload = band images and seed maps to the bands' devices (stream-ordered); run = the Match on the resident
+ * pair (returns after the one flag read that decides about a repeat; results stay in the bands' output buffers);
+ * download = owned rows into the caller's maps (waits for every band). */
+int pm_tiled_upload_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* right, size_t image_step,
+                       const float* seed_l, const float* seed_r, size_t seed_step);
+int pm_tiled_run(pm_tiled_plan* plan, int rounds, pm_tiled_info* info);
+int pm_tiled_download(pm_tiled_plan* plan, float* disp_l, float* disp_r, size_t disp_step);
 const char* pm_tiled_last_error(const pm_tiled_plan* plan);
 
 /* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------

@@ -47,6 +47,7 @@ struct Band {
 struct pm_tiled_plan {
   std::vector<Band> bands;
   int rows = 0, cols = 0, n_views = 1, halo = 0;
+  bool resident = false, have_seed_l = false, have_seed_r = false;  // a pair has been uploaded (pm_tiled_upload_u8)
   char err[512] = {0};
 };
 
@@ -86,15 +87,10 @@ void band_of(int k, int n, int rows, int halo, pm_tile* t, int* band_rows) {
   *band_rows = end - t->band_row0;
 }
 
-// one attempt with `rounds` exchange rounds per vertical sweep; *moved = some band's boundary row still changed
-int attempt(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t image_step, const float* seed_l,
-            const float* seed_r, size_t seed_step, float* disp_l, float* disp_r, size_t disp_step, int rounds,
-            bool* moved, int* exchanges) {
-  const int n = (int)p->bands.size(), cols = p->cols, nv = p->n_views;
-  const pm_params& prm = pm_internal::params(p->bands[0].h);
-  const int row_n = nv * cols;
-  const size_t row_bytes = sizeof(float) * (size_t)row_n;
-  const dim3 rgrid((unsigned)((row_n + 255) / 256)), rblock(256);
+// the band images and seed maps of a pair -> the bands' devices (stream-ordered, on every band's stream)
+int upload(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t image_step, const float* seed_l,
+           const float* seed_r, size_t seed_step) {
+  const int cols = p->cols;
   for (Band& b : p->bands) {
     TL_HIP(p, hipSetDevice(b.dev));
     const size_t w = (size_t)cols;
@@ -108,9 +104,45 @@ int attempt(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t 
     if (seed_r)
       TL_HIP(p, hipMemcpy2DAsync(b.d_seed_r, w * 4, (const char*)seed_r + (size_t)b.tile.band_row0 * seed_step, seed_step,
                                  w * 4, (size_t)b.band_rows, hipMemcpyHostToDevice, b.stream));
+  }
+  p->have_seed_l = seed_l != nullptr;
+  p->have_seed_r = seed_r != nullptr;
+  p->resident = true;
+  return PM_OK;
+}
+
+// the owned rows of every band -> the caller's maps; waits for all bands
+int download(pm_tiled_plan* p, float* disp_l, float* disp_r, size_t disp_step) {
+  const int cols = p->cols, nv = p->n_views;
+  for (Band& b : p->bands) {
+    TL_HIP(p, hipSetDevice(b.dev));
+    const size_t w4 = (size_t)cols * 4;
+    TL_HIP(p, hipMemcpy2DAsync((char*)disp_l + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_l, w4, w4,
+                               (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
+    if (nv > 1 && disp_r)
+      TL_HIP(p, hipMemcpy2DAsync((char*)disp_r + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_r, w4, w4,
+                                 (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
+  }
+  for (Band& b : p->bands) {
+    TL_HIP(p, hipSetDevice(b.dev));
+    TL_HIP(p, hipStreamSynchronize(b.stream));
+  }
+  return PM_OK;
+}
+
+// one attempt on the resident pair with `rounds` exchange rounds per vertical sweep, results into the bands' output
+// buffers; *moved = some band's boundary row still changed.  Waits for the flags (the one host read per attempt).
+int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
+  const int n = (int)p->bands.size(), cols = p->cols, nv = p->n_views;
+  const pm_params& prm = pm_internal::params(p->bands[0].h);
+  const int row_n = nv * cols;
+  const size_t row_bytes = sizeof(float) * (size_t)row_n;
+  const dim3 rgrid((unsigned)((row_n + 255) / 256)), rblock(256);
+  for (Band& b : p->bands) {
+    TL_HIP(p, hipSetDevice(b.dev));
     TL_HIP(p, hipMemsetAsync(b.flag, 0, sizeof(int), b.stream));
-    TL_PM(p, b, pm_tile_begin(b.h, &b.tile, b.d_left, b.d_right, b.band_rows, cols, seed_l ? b.d_seed_l : nullptr,
-                              seed_r ? b.d_seed_r : nullptr));
+    TL_PM(p, b, pm_tile_begin(b.h, &b.tile, b.d_left, b.d_right, b.band_rows, cols, p->have_seed_l ? b.d_seed_l : nullptr,
+                              p->have_seed_r ? b.d_seed_r : nullptr));
   }
   int cur = 0;
   // band k's boundary row -> sent[cur] (behind the successor's last read of that buffer)
@@ -193,13 +225,6 @@ int attempt(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t 
   for (Band& b : p->bands) {
     TL_PM(p, b, pm_tile_background(b.h));
     TL_PM(p, b, pm_tile_finish(b.h, b.d_out_l, nv > 1 ? b.d_out_r : nullptr));
-    TL_HIP(p, hipSetDevice(b.dev));
-    const size_t w4 = (size_t)cols * 4;
-    TL_HIP(p, hipMemcpy2DAsync((char*)disp_l + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_l, w4, w4,
-                               (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
-    if (nv > 1 && disp_r)
-      TL_HIP(p, hipMemcpy2DAsync((char*)disp_r + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_r, w4, w4,
-                                 (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
   }
   *moved = false;
   for (Band& b : p->bands) {
@@ -314,31 +339,30 @@ int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm
   return PM_OK;
 }
 
-int pm_tiled_match_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* right, size_t image_step,
-                      const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
-                      size_t disp_step, int rounds, pm_tiled_info* info) {
+int pm_tiled_upload_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* right, size_t image_step,
+                       const float* seed_l, const float* seed_r, size_t seed_step) {
   if (!plan) return PM_ERR_INVALID_ARG;
-  if (!left || !right || !disp_l) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_match_u8: null image / output pointer");
-  const int n = (int)plan->bands.size();
+  if (!left || !right) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_upload_u8: null image pointer");
   if (image_step == 0) image_step = (size_t)plan->cols;
   if (seed_step == 0) seed_step = (size_t)plan->cols * 4;
-  if (disp_step == 0) disp_step = (size_t)plan->cols * 4;
-  if (image_step < (size_t)plan->cols || seed_step < (size_t)plan->cols * 4 || disp_step < (size_t)plan->cols * 4)
-    return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_match_u8: a row step is smaller than a row");
-  if (rounds < 0) rounds = 0;
-  if (rounds > n - 1) rounds = n - 1;
+  if (image_step < (size_t)plan->cols || seed_step < (size_t)plan->cols * 4)
+    return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_upload_u8: a row step is smaller than a row");
+  return upload(plan, left, right, image_step, seed_l, seed_r, seed_step);
+}
+
+int pm_tiled_run(pm_tiled_plan* plan, int rounds, pm_tiled_info* info) {
+  if (!plan) return PM_ERR_INVALID_ARG;
+  if (!plan->resident) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_run: no pair uploaded (pm_tiled_upload_u8)");
+  const int n = (int)plan->bands.size();
+  if (rounds < 0 || rounds > n - 1) rounds = n - 1;  // negative: the exact count, no repeat possible
   bool moved = false;
   int exchanges = 0;
-  if (int rc = attempt(plan, left, right, image_step, seed_l, seed_r, seed_step, disp_l, disp_r, disp_step, rounds, &moved,
-                       &exchanges))
-    return rc;
+  if (int rc = attempt(plan, rounds, &moved, &exchanges)) return rc;
   int repeated = 0;
   if (moved && rounds < n - 1) {  // band k is final after round k + 1: n - 1 rounds are always enough
     rounds = n - 1;
     repeated = 1;
-    if (int rc = attempt(plan, left, right, image_step, seed_l, seed_r, seed_step, disp_l, disp_r, disp_step, rounds,
-                         &moved, &exchanges))
-      return rc;
+    if (int rc = attempt(plan, rounds, &moved, &exchanges)) return rc;
   }
   if (info) {
     info->rounds_used = rounds;
@@ -346,6 +370,22 @@ int pm_tiled_match_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* r
     info->exchanges = exchanges;
   }
   return PM_OK;
+}
+
+int pm_tiled_download(pm_tiled_plan* plan, float* disp_l, float* disp_r, size_t disp_step) {
+  if (!plan) return PM_ERR_INVALID_ARG;
+  if (!disp_l) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_download: null output pointer");
+  if (disp_step == 0) disp_step = (size_t)plan->cols * 4;
+  if (disp_step < (size_t)plan->cols * 4) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_download: a row step is smaller than a row");
+  return download(plan, disp_l, disp_r, disp_step);
+}
+
+int pm_tiled_match_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* right, size_t image_step,
+                      const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
+                      size_t disp_step, int rounds, pm_tiled_info* info) {
+  if (int rc = pm_tiled_upload_u8(plan, left, right, image_step, seed_l, seed_r, seed_step)) return rc;
+  if (int rc = pm_tiled_run(plan, rounds, info)) return rc;
+  return pm_tiled_download(plan, disp_l, disp_r, disp_step);
 }
 
 }  // extern "C"

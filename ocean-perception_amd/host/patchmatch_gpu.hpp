@@ -208,8 +208,8 @@ class TiledPatchmatchGpu final {
   ~TiledPatchmatchGpu();
 
   void SetSeeds(const Image1f& seed_l, const Image1f& seed_r);
-  // rounds: boundary exchange rounds per vertical sweep (2: the default of both drivers)
-  void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds = 2);
+  // rounds: boundary exchange rounds per vertical sweep; -1 = bands - 1, always exact without a repeat (pm_tiled_run)
+  void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds = -1);
   const pm_tiled_info& LastInfo() const { return info_; }
 
  private:

@@ -41,6 +41,7 @@ EXPORTS = [
     "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
+    "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download",
 ]
 
 
@@ -211,6 +212,12 @@ def load():
     lib.pm_tiled_match_u8.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.c_int,
                                       C.POINTER(PmTiledInfo)]
     lib.pm_tiled_match_u8.restype = C.c_int
+    lib.pm_tiled_upload_u8.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t]
+    lib.pm_tiled_upload_u8.restype = C.c_int
+    lib.pm_tiled_run.argtypes = [vp, C.c_int, C.POINTER(PmTiledInfo)]
+    lib.pm_tiled_run.restype = C.c_int
+    lib.pm_tiled_download.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.pm_tiled_download.restype = C.c_int
     lib.pm_tiled_last_error.argtypes = [vp]
     lib.pm_tiled_last_error.restype = C.c_char_p
     lib.pm_tile_restore_cols.argtypes = [vp, vp]
@@ -626,21 +633,37 @@ class TiledEngine:
             self.close()
             raise PmError(rc, "pm_tiled_create", msg)
 
-    def match(self, left, right, seed_l=None, seed_r=None, rounds=2):
-        left, right = _u8(left), _u8(right)
-        sl = _f32(seed_l) if seed_l is not None else None
-        sr = _f32(seed_r) if seed_r is not None else None
+    def match(self, left, right, seed_l=None, seed_r=None, rounds=-1):
+        self.upload(left, right, seed_l, seed_r)
+        info = self.run(rounds)
+        dl, dr = self.download()
+        return dl, dr, info
+
+    def _tcheck(self, rc, what):
+        if rc != PM_OK:
+            raise PmError(rc, what, self.lib.pm_tiled_last_error(self.plan).decode())
+
+    def upload(self, left, right, seed_l=None, seed_r=None):
+        (left, pl), (right, pr) = _u8(left), _u8(right)
+        sl, psl = _f32(seed_l) if seed_l is not None else (None, None)
+        sr, psr = _f32(seed_r) if seed_r is not None else (None, None)
+        if left.shape != (self.rows, self.cols) or right.shape != left.shape:
+            raise ValueError("image size differs from the plan")
+        self._tcheck(self.lib.pm_tiled_upload_u8(self.plan, pl, pr, 0, psl, psr, 0), "pm_tiled_upload_u8")
+        for b in self.bands:
+            b.synchronize()  # the host arrays may go away after this call
+
+    def run(self, rounds=-1):
+        info = PmTiledInfo()
+        self._tcheck(self.lib.pm_tiled_run(self.plan, rounds, C.byref(info)), "pm_tiled_run")
+        return {"rounds": info.rounds_used, "repeated": bool(info.repeated), "exchanges": info.exchanges}
+
+    def download(self):
         dl = np.empty((self.rows, self.cols), np.float32)
         dr = np.empty((self.rows, self.cols), np.float32)
-        info = PmTiledInfo()
-        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-        rc = self.lib.pm_tiled_match_u8(self.plan, ptr(left), ptr(right), 0, ptr(sl), ptr(sr), 0, ptr(dl), ptr(dr), 0,
-                                        rounds, C.byref(info))
-        if rc != PM_OK:
-            raise PmError(rc, "pm_tiled_match_u8", self.lib.pm_tiled_last_error(self.plan).decode())
-        return dl, (dr if self.params.left_right_check else None), {"rounds": info.rounds_used,
-                                                                     "repeated": bool(info.repeated),
-                                                                     "exchanges": info.exchanges}
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._tcheck(self.lib.pm_tiled_download(self.plan, ptr(dl), ptr(dr), 0), "pm_tiled_download")
+        return dl, (dr if self.params.left_right_check else None)
 
     def close(self):
         if getattr(self, "plan", None):

@@ -30,7 +30,7 @@ import torch
 
 import pm_ctypes as pm
 
-DEFAULT_ROUNDS = 2
+DEFAULT_ROUNDS = 1 << 20  # clamped to world - 1: always exact without a repeat (measured: tools/tiled_rounds.py)
 
 
 def band_of(rank, world, global_rows, halo):
@@ -331,6 +331,39 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
     return res
 
 
+def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1):
+    """BASELINE configs[3] through the C-ABI driver (pm_tiled_* of include/pm/patchmatch.h): ONE process, band k on
+    devices[k], boundary rows by hipMemcpyPeerAsync + events (no RCCL, no torch.distributed).  The pair is uploaded
+    once and stays resident in the bands' HBM; a timed step is one pm_tiled_run (it returns after the one flag read
+    per Match).  Returns the JSON object of the leg."""
+    import time
+
+    import synth
+    params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters)
+    pair = synth.make_pair(0, rows, cols, n_points=200 * (rows * cols) // (720 * 1280))
+    n = len(devices)
+    with pm.TiledEngine(params, rows, cols, n, devices) as te:
+        te.upload(pair["left"], pair["right"], pair["seed_l"], pair["seed_r"])
+        te.run(rounds)  # untimed: first-use allocations of the band handles
+        times, infos = [], []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            infos.append(te.run(rounds))
+            times.append(time.perf_counter() - t0)
+        dl, _ = te.download()
+    ms = 1e3 * float(np.median(times))
+    fg = dl > 0
+    return {"workload": f"one {cols}x{rows} pair row-tiled into {n} band(s) on device(s) {sorted(set(devices))} "
+                        f"(BASELINE.json configs[3]), {args.iters} iterations, {args.patch}x{args.patch}, PM_SEM_CPU",
+            "driver": "pm_tiled_* (C ABI, one process, hipMemcpyPeerAsync + events)", "n_gpus": len(set(devices)),
+            "bands": n, "ms_per_frame": ms, "pairs_per_s": 1e3 / ms, "steps": steps,
+            "exchange_rounds_per_vertical_sweep": 1 + infos[-1]["rounds"],
+            "boundary_rows_moved_per_match": infos[-1]["exchanges"],
+            "matches_repeated_with_more_rounds": sum(1 for i in infos if i["repeated"]),
+            "host_syncs_inside_a_match": "one flag read per attempt",
+            "foreground_within_1px": float((np.abs(dl - pair["gt"])[fg] < 1).mean()) if fg.any() else 0.0}
+
+
 def main():
     """torchrun entry (same as `bench.py --tiled`): one rank per GPU.
         python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -348,7 +381,16 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--single-process", type=int, default=0, metavar="N",
+                    help="run the C-ABI driver (pm_tiled_*) in THIS process over devices 0..N-1 instead of one rank per GPU")
+    ap.add_argument("--bands", type=int, default=0, help="--single-process: bands (default: one per device)")
     args = ap.parse_args()
+    if args.single_process > 0:
+        import json
+        nb = args.bands if args.bands > 0 else args.single_process
+        devices = [k * args.single_process // nb for k in range(nb)]
+        print(json.dumps(bench_single_process(args, devices, steps=args.steps, rows=args.rows, cols=args.cols)), flush=True)
+        return
     d = B.Dist(args)
     bench(args, d, rows=args.rows, cols=args.cols)
     d.close()

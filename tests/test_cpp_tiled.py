@@ -69,3 +69,23 @@ def test_cpp_tiled_configs3_full_size(tiled_exe, tmp_path, synth):
     assert_same(tr, ur, "4096x2160, 8 bands vs untiled (right)")
     fg = tl > 0
     assert fg.mean() > 0.15 and (np.abs(tl - p["gt"])[fg] < 1.0).mean() > 0.95
+
+
+@pytest.mark.gpu
+def test_python_tiled_engine_three_step_api(pm, oracle, synth):
+    """pm_tiled_upload_u8 / pm_tiled_run / pm_tiled_download through the ctypes TiledEngine (what bench.py's configs[3]
+    leg drives): the resident pair can be run repeatedly, every run gives the untiled result."""
+    rows, cols, bands = 150, 200, 4
+    l, r, sl, sr, _ = small_pair(synth, 97, rows, cols, n_points=60, dilate_factor=3)
+    prm = pm.default_params(0, patch=7, patchmatch_iters=3)
+    el, er = oracle.match(oracle.default_params(0, patch=7, n_iters=3, nthreads=8), l, r, sl, sr)
+    with pm.TiledEngine(prm, rows, cols, bands) as te:
+        te.upload(l, r, sl, sr)
+        for rounds in (2, 0, 1):
+            info = te.run(rounds)
+            dl, dr = te.download()
+            assert_same(dl, el, f"rounds {rounds} left")
+            assert_same(dr, er, f"rounds {rounds} right")
+            assert info["exchanges"] > 0 and (rounds != 0 or info["repeated"])
+        dl, dr, info = te.match(l, r, sl, sr)
+        assert_same(dl, el, "match() left")
