@@ -847,11 +847,11 @@ int planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r) {
   const PlanesParams pp = planes_params(h->params);
   Launch l(h, PM_K_FINALIZE);
   if (h->params.state_dtype == PM_STATE_F16) {
-    PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane};
+    PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane, ps.pitch / 2};
     hipLaunchKernelGGL(k_planes_finish<_Float16>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps,
                        st, pp, d_disp_l, d_disp_r, (size_t)ps.cols);
   } else {
-    PlaneState<float> st{(float*)h->planes_state, ps.plane};
+    PlaneState<float> st{(float*)h->planes_state, ps.plane, ps.pitch / 2};
     hipLaunchKernelGGL(k_planes_finish<float>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps, st,
                        pp, d_disp_l, d_disp_r, (size_t)ps.cols);
   }
@@ -2072,10 +2072,10 @@ static int planes_rw(pm_handle* h, int pair, int view, float* planes, int to_sta
   if (rc == PM_OK) {
     const dim3 grid((unsigned)((ps.cols + 255) / 256), (unsigned)ps.rows, 4);
     if (h->params.state_dtype == PM_STATE_F16) {
-      PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane};
+      PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane, ps.pitch / 2};
       hipLaunchKernelGGL(k_planes_copy<_Float16>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
     } else {
-      PlaneState<float> st{(float*)h->planes_state, ps.plane};
+      PlaneState<float> st{(float*)h->planes_state, ps.plane, ps.pitch / 2};
       hipLaunchKernelGGL(k_planes_copy<float>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
     }
     rc = launch_check(h, what);
