@@ -14,7 +14,7 @@ MAKEFLAGS += -j8
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-pass-failed
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra
 LIB     := $(PKG)/lib/libvehicle_pm_gpu.so
-HIP_UNITS  := pm_engine pm_sweeps pm_imaging pm_tiled
+HIP_UNITS  := pm_engine pm_launch pm_sweeps pm_seed pm_planes_host pm_hostpath pm_tile pm_tiled pm_imaging
 HOST_UNITS := patchmatch_gpu imaging dataset jpeg
 OBJS    := $(HIP_UNITS:%=$(OBJDIR)/%.o) $(HOST_UNITS:%=$(OBJDIR)/host_%.o)
 HDRS    := $(wildcard include/pm/*.h) $(wildcard $(PKG)/csrc/*.hpp) $(wildcard $(PKG)/host/*.hpp)

@@ -10,6 +10,24 @@
 
 namespace pm {
 
+// BORDER_REFLECT_101 index (one reflection: |overshoot| < len)
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * (len - 1) - p;
+  return p;
+}
+
+// The transposed planes carry kTransPad extra rows (= image columns cols .. cols + kTransPad - 1) that
+// replicate the last column: a window that leaves the image on the right reads them instead of clamping
+// its column index (cv::getRectSubPix replicates the border), which keeps the column sweep's target row
+// offsets affine in the window column (pm_run2.hpp).
+constexpr int kTransPad = 16;
+
+struct Interior {
+  int x_lo, x_hi, y_lo, y_hi;  // inclusive bounds of the pixels visited by the sweeps
+};
+
 // Device memory of one call: B pairs, each with four u8 images (L, R, mirrored L, mirrored R),
 // their Sobel magnitudes as f32 and as saturated u8, and per view a disparity plane and the
 // cost of that disparity.  All planes share one pitch (elements per row, multiple of 64) so that

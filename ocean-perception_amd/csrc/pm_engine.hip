@@ -1,8 +1,10 @@
-// pm_engine.hip -- C-ABI implementation (include/pm/patchmatch.h) of the gfx950 PatchMatch
-// stereo engine: handle, device memory plan, kernel launches, per-kernel timing.
+// pm_engine.hip -- C-ABI implementation (include/pm/patchmatch.h) of the gfx950 PatchMatch stereo engine: handle
+// lifecycle, device memory plan, parameter checks, the Match() schedule on device buffers (per-view streams,
+// iterations, background, cross-check), HIP-graph capture / replay, per-kernel timing.  The kernels live in the other
+// units (pm_handle.hpp lists them); this one is host logic over their launch functions.
 //
-// There is deliberately NO CPU fallback in this file: without a usable HIP device pm_create
-// fails with PM_ERR_NO_DEVICE.  `file:line` citations are relative to the reference tree.
+// There is deliberately NO CPU fallback in this library: without a usable HIP device pm_create fails with
+// PM_ERR_NO_DEVICE.  `file:line` citations are relative to the reference tree.
 #include "pm/patchmatch.h"
 
 #include <hip/hip_runtime.h>
@@ -15,114 +17,14 @@
 #include <new>
 #include <vector>
 
-#include "pm_kernels.hpp"
-#include "pm_sweeps.hpp"
-#include "pm_hostcopy.hpp"
+#include "pm_handle.hpp"
 #include "pm_internal.hpp"
-#include "pm_seed.hpp"
-#include "pm_planes.hpp"
 
 using namespace pm;
+using namespace pm::eng;
 
-namespace {
-
-constexpr int kMaxEvents = 16384;  // event pairs kept before a forced drain
-
-struct EventRec {
-  hipEvent_t start, stop;
-  int klass;
-};
-
-}  // namespace
-
-struct pm_handle {
-  pm_params params;
-  int device = 0;
-  int max_rows = 0, max_cols = 0, max_batch = 0;
-  int max_pitch = 0;
-  hipStream_t stream = nullptr;
-
-  // engine planes (see pm::PlaneSet)
-  uint8_t* img8 = nullptr;
-  float* g32 = nullptr;
-  uint8_t* g8 = nullptr;
-  uint8_t* timg8 = nullptr;  // transposed copies for the column sweeps
-  float* tg32 = nullptr;
-  uint8_t* tg8 = nullptr;
-  uint16_t* pk16 = nullptr;
-  uint16_t* tpk16 = nullptr;
-  float* rpg = nullptr;      // row / column PAIR planes of the run engine (pm::PlaneSet)
-  uint32_t* rqk = nullptr;
-  float* cpg = nullptr;
-  float* disp = nullptr;
-  float* cost = nullptr;
-  float* noise = nullptr;
-  unsigned long long* counters = nullptr;  // device, 8 words
-  bool counters_on = false;                // same-address atomics serialise: opt-in only
-  int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
-
-  // PM_MODE_PLANES: [max_batch][2 views][a, b, z, cost][rows][pitch], f32 or f16 (pm_planes.hpp)
-  void* planes_state = nullptr;
-  int pl_rows = 0, pl_cols = 0, pl_n = 0;  // what pm_planes_begin last prepared
-  bool pl_on = false;
-
-  SeedScratch seed{};   // scratch of the device seeder (pm_seed.hpp)
-  SeedScratch seed2{};  // second set for the right view's seeder (allocated on first use; per-view streams)
-  bool need_seed[2] = {false, false};  // set by pm_match_device: views whose seed map the device computes
-
-  // row-tiled mode (pm_tile_*)
-  bool tile_on = false;
-  pm_tile tile{};
-  int tile_band_rows = 0, tile_cols = 0;
-  float* snap_disp = nullptr;  // snapshot of the disparity / cost planes (2 views)
-  float* snap_cost = nullptr;
-  size_t noise_capacity = 0;   // floats allocated for the noise table
-
-  // staging for the host-buffer entry points: tightly packed [B][rows][cols]
-  uint8_t* st_left = nullptr;
-  uint8_t* st_right = nullptr;
-  float* st_seed_l = nullptr;
-  float* st_seed_r = nullptr;
-  float* st_disp_l = nullptr;
-  float* st_disp_r = nullptr;
-  void* pinned = nullptr;  // host staging, pinned
-  size_t pinned_bytes = 0;
-
-  // pipelined host-buffer path (pm_submit_u8 / pm_collect): slot k of the staging buffers, uploads on
-  // s_in, compute on `stream`, downloads on s_out
-  struct PipeSlot {
-    hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
-    uint64_t tag = 0;
-    int rows = 0, cols = 0;
-  };
-  // per-view streams: the two views are independent until the cross-check, so their launch chains run on
-  // two streams and one view's kernels fill the CUs the other view's kernel tails leave idle
-  hipStream_t view_stream[2] = {nullptr, nullptr};
-  hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
-  void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
-  // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
-  const pm::BgrSource* bgr = nullptr;
-  hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
-  bool capturing = false;
-  bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
-  hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
-  hipEvent_t left_out = nullptr;  // pm_match_u8: the left map has arrived in the pinned buffer
-  hipEvent_t right_out = nullptr;  // ... the right one
-  pm::CopyPool* copy_pool = nullptr;  // host threads sharing the pack / unpack copies of the host-buffer entry points
-  hipStream_t s_in = nullptr, s_out = nullptr;
-  std::vector<PipeSlot> pipe;
-  int pipe_head = 0, pipe_count = 0;
-
-  // profiling
-  bool profiling = false;
-  std::vector<EventRec> ev_pool;
-  int ev_used = 0;
-  pm_profile prof{};
-
-  char err[512] = {0};
-};
-
-namespace {
+namespace pm {
+namespace eng {
 
 void set_err(pm_handle* h, const char* fmt, ...) {
   if (!h) return;
@@ -131,17 +33,6 @@ void set_err(pm_handle* h, const char* fmt, ...) {
   vsnprintf(h->err, sizeof(h->err), fmt, ap);
   va_end(ap);
 }
-
-#define PM_HIP(h, call)                                                                      \
-  do {                                                                                       \
-    hipError_t e_ = (call);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      set_err((h), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      return PM_ERR_HIP;                                                                     \
-    }                                                                                        \
-  } while (0)
-
-inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 int check_patch(pm_handle* h, int pw, int ph) {
   if (pw < 3 || ph < 3 || pw > PM_MAX_PATCH || ph > PM_MAX_PATCH || (pw % 2) == 0 || (ph % 2) == 0) {
@@ -153,6 +44,7 @@ int check_patch(pm_handle* h, int pw, int ph) {
   return PM_OK;
 }
 
+namespace {
 // cv::RNG(seed) + RNG::fill(CV_32F, UNIFORM, -1, 1) (OpenCV 3.4 modules/core/src/rand.cpp
 // randf_32f): multiply-with-carry generator, out = (float)(int)next * 2^-31 + 0.  The generator
 // is inherently sequential and the image depends only on (seed, rows, cols): it is built once per
@@ -171,6 +63,7 @@ void fill_unit_noise(float* dst, int rows, int cols, int pitch, uint64_t seed) {
     for (int x = cols; x < pitch; ++x) row[x] = 0.f;
   }
 }
+}  // namespace
 
 PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   PlaneSet ps;
@@ -261,35 +154,6 @@ SweepGeom sweep_geom(const pm_params& p, const Interior& in, int k) {
   return g;
 }
 
-struct Launch {
-  pm_handle* h;
-  int klass;
-  bool timed;
-  EventRec* rec = nullptr;
-  Launch(pm_handle* h_, int k) : h(h_), klass(k), timed(h_->profiling) {
-    if (!timed) return;
-    if (h->ev_used == (int)h->ev_pool.size()) {
-      if ((int)h->ev_pool.size() >= kMaxEvents) {
-        timed = false;  // drained by pm_profile_read; never block inside a launch path
-        return;
-      }
-      EventRec r;
-      r.klass = k;
-      if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
-        timed = false;
-        return;
-      }
-      h->ev_pool.push_back(r);
-    }
-    rec = &h->ev_pool[h->ev_used++];
-    rec->klass = k;
-    (void)hipEventRecord(rec->start, h->stream);
-  }
-  ~Launch() {
-    if (timed && rec) (void)hipEventRecord(rec->stop, h->stream);
-  }
-};
-
 int launch_check(pm_handle* h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -297,19 +161,6 @@ int launch_check(pm_handle* h, const char* what) {
     return PM_ERR_HIP;
   }
   return PM_OK;
-}
-
-dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
-
-// k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)
-void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
-                 int view = -1) {
-  if (h->bgr)
-    hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
-                       dim3(256), 0, h->stream, ps, *h->bgr);
-  else
-    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride,
-                       view);
 }
 
 // The line-triple planes (about 80 B per pixel and pair) serve the fixed-window kernels of pm_run3.hpp only: PM_SEM_CPU,
@@ -337,36 +188,6 @@ int pair_planes_alloc(pm_handle* h) {
   return PM_OK;
 }
 
-// transposed copies of the 12 image-type planes of n pairs (run by every path that ran k_prep)
-// view >= 0: the planes of that view only (per-view streams: each stream derives its own planes)
-int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view = -1) {
-  SetupGrid sg{};
-  sg.view = view;
-  sg.tx = (unsigned)((ps.cols + 63) / 64);
-  sg.ty = (unsigned)((ps.rows + 63) / 64);
-  sg.tz = (unsigned)(n * (view < 0 ? 4 : 2));
-  sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
-  PlaneSet pp = ps;
-  unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
-  if (sg.with_lines) {
-    if (int rc = pair_planes_alloc(h)) return rc;
-    pp.rpg = h->rpg;
-    pp.rqk = h->rqk;
-    pp.cpg = h->cpg;
-    sg.lx = (unsigned)((ps.cols + 255) / 256);
-    sg.ly = (unsigned)ps.nrl;
-    sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
-    sg.cx = (unsigned)((ps.rows + 255) / 256);
-    sg.cy = (unsigned)ps.ncl;
-    sg.cz = (unsigned)(n * (view < 0 ? 2 : 1));
-    blocks0 += 2 * sg.lx * sg.ly * sg.lz;
-  }
-  hipLaunchKernelGGL(k_setup, dim3(blocks0), dim3(256), 0, h->stream, pp, sg, 0);
-  if (sg.with_lines)
-    hipLaunchKernelGGL(k_setup, dim3(sg.cx * sg.cy * sg.cz), dim3(256), 0, h->stream, pp, sg, 1);
-  return launch_check(h, "transpose");
-}
-
 SeedParams seed_params(const pm_params& p) {
   SeedParams sp;
   sp.max_features = p.max_features_per_frame;
@@ -380,28 +201,14 @@ SeedParams seed_params(const pm_params& p) {
   return sp;
 }
 
-// SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
-// mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
-  const size_t plane = (size_t)h->max_rows * h->max_pitch;
-  // every pixel can be a candidate: the 3x3 test is not strict, so plateaus of EQUAL responses (periodic images) pass
-  // whole; a capacity of a quarter of the pixels dropped candidates there in whatever order the atomics fell
-  sc.cap = (int)(plane + 64);
-  PM_HIP(h, hipMalloc((void**)&sc.eig, sizeof(float) * plane));
-  PM_HIP(h, hipMalloc((void**)&sc.keys, sizeof(unsigned long long) * sc.cap));
-  PM_HIP(h, hipMalloc((void**)&sc.keys_sorted, sizeof(unsigned long long) * sc.cap));
-  PM_HIP(h, hipMalloc((void**)&sc.counters, sizeof(unsigned) * kSeedCounters));
-  PM_HIP(h, hipMalloc((void**)&sc.kp_xy, sizeof(int) * 2 * kSeedMaxFeatures));
-  PM_HIP(h, hipMalloc((void**)&sc.kp_d, sizeof(float) * kSeedMaxFeatures));
-  sc.sort_tmp = nullptr;
-  sc.sort_tmp_bytes = 0;
-  PM_HIP(h, hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap,
-                                                        0, 64, h->stream));
-  PM_HIP(h, hipMalloc(&sc.sort_tmp, sc.sort_tmp_bytes));
+  PM_HIP(h, seed_scratch_alloc(sc, (size_t)h->max_rows * h->max_pitch, h->stream));
   return PM_OK;
 }
 
-int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0) {
+// SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
+// mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch) {
   if (scratch == 1 && !h->seed2.eig)
     if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
   SeedScratch& sc = scratch == 1 ? h->seed2 : h->seed;
@@ -456,60 +263,7 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
   return PM_OK;
 }
 
-int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
-              float amp = 1e30f) {
-  const int chains = g.c_hi - g.c_lo + 1;
-  if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
-  Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
-  launch_sweep(ps, cp, g, slots, h->params.engine, amp, h->stream);  // pm_sweeps.hip
-  return launch_check(h, "sweep");
-}
-
-// noise + clamp + cost of the current disparity; PM_SEM_CPU square windows use the LDS-tiled kernel
-void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float amount,
-                       int slots, int keep_zero) {
-  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
-  const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
-                   (unsigned)slots);
-  if (tiled && cp.pw == 3) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<3, 3>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 5) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<5, 5>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 7) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<7, 7>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 9) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<9, 9>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 11) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<11, 11>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else {
-    hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, amount);
-  }
-}
-
-// RemoveBackground / MaskBackground; PM_SEM_CPU square windows use the LDS-tiled kernel
-void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float factor,
-                       int cached, int slots) {
-  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
-  const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
-                   (unsigned)slots);
-#define PM_BG_CASE(W)                                                                                        \
-  case W:                                                                                                    \
-    hipLaunchKernelGGL((k_background_tiled<W, W>), tgrid, dim3(256), 0, h->stream, ps, cp, in, factor, cached); \
-    return;
-  if (tiled) {
-    switch (cp.pw) {
-      PM_BG_CASE(3)
-      PM_BG_CASE(5)
-      PM_BG_CASE(7)
-      PM_BG_CASE(9)
-      PM_BG_CASE(11)
-      default: break;
-    }
-  }
-#undef PM_BG_CASE
-  hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, factor,
-                     cached);
-}
+namespace {
 
 // iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
 // (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
@@ -563,10 +317,15 @@ int run_view_sets(pm_handle* h, const PlaneSet* pss, hipStream_t* streams, int s
   }
   return PM_OK;
 }
+
+}  // namespace
+
 int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots) {
   hipStream_t s = h->stream;
   return run_view_sets(h, &ps, &s, 1, slots);
 }
+
+namespace {
 
 bool view_streams_enabled() {
   static bool v = [] {
@@ -629,8 +388,7 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
       }
       if (rc == PM_OK) {
         Launch l(h, PM_K_SEED);
-        hipLaunchKernelGGL(k_seed, pixel_grid(ps.cols, ps.rows, setup->n), dim3(256), 0, h->stream, ps, setup->d_seed_l,
-                           setup->d_seed_r, (size_t)ps.cols, v);
+        launch_seed(h, ps, setup->d_seed_l, setup->d_seed_r, setup->n, v);
         rc = launch_check(h, "seed");
       }
     }
@@ -718,165 +476,8 @@ int validate_params(pm_handle* h, const pm_params& p) {
   return PM_OK;
 }
 
-// ---- PM_MODE_PLANES ------------------------------------------------------------------------------------------
-
-PlanesParams planes_params(const pm_params& p) {
-  PlanesParams pp;
-  pp.patch = p.patch_w[0];
-  pp.max_disp = p.max_disp;
-  pp.refine_steps = p.plane_refine_steps;
-  // the bound itself must be a fixed point of the state's rounding (oracle: slope_bound)
-  pp.slope_max = p.state_dtype == PM_STATE_F16 ? (float)(_Float16)p.plane_slope_max : p.plane_slope_max;
-  // columns a window can reach beyond [x - h - max_disp, x + h]: h * (|a| + |b|) on either side, + rounding slack
-  pp.margin = (int)std::ceil(2.0 * (pp.patch / 2) * (double)pp.slope_max) + 2;
-  pp.slope_init = p.plane_slope_init;
-  pp.slope_per_disp = p.plane_slope_per_disp;
-  pp.alpha = p.functor_alpha;
-  pp.one_minus_alpha = 1.f - p.functor_alpha;
-  pp.tau_color = p.functor_tau_color;
-  pp.tau_grad = p.functor_tau_grad;
-  pp.inv_n = 1.0f / (float)(pp.patch * pp.patch);
-  pp.lr_tol = p.plane_lr_tol;
-  pp.seed = p.noise_seed;
-  pp.n_views = p.left_right_check ? 2 : 1;
-  return pp;
-}
-
-int planes_alloc(pm_handle* h) {
-  if (h->planes_state) return PM_OK;
-  {  // the tile of the widest stage must fit the CU's LDS: (128 + P-1 + max_disp + slope margin) x (8 + P-1) entries
-    const PlanesParams pp = planes_params(h->params);
-    const size_t need = pl_lds_bytes<PL_SPATIAL>(pp.patch, pp);
-    if (need > kChainLdsMax) {
-      set_err(h, "PM_MODE_PLANES: window %d, max_disp %d and slope_max %.2f need %zu KB of LDS per tile (limit %zu KB): "
-                 "lower max_disp or the window", pp.patch, pp.max_disp, (double)pp.slope_max, need / 1024,
-              kChainLdsMax / 1024);
-      return PM_ERR_INVALID_ARG;
-    }
-  }
-  const size_t plane = (size_t)h->max_rows * h->max_pitch;
-  const size_t bytes = sizeof(float) * ((size_t)h->max_batch * 2 * 4 * plane + 64);
-  PM_HIP(h, hipMalloc(&h->planes_state, bytes));
-  PM_HIP(h, hipMemsetAsync(h->planes_state, 0, bytes, h->stream));
-  return PM_OK;
-}
-
-template <int STAGE>
-int planes_stage(pm_handle* h, const PlaneSet& ps, const PlArgs& ar, int slots, int klass, const char* what) {
-  Launch l(h, klass);
-  const hipError_t e = pl_launch<STAGE>(ps, h->planes_state, h->params.state_dtype == PM_STATE_F16,
-                                        planes_params(h->params), ar, slots, h->stream);
-  if (e != hipSuccess) {
-    set_err(h, "launch of planes %s failed: %s", what, hipGetErrorString(e));
-    return PM_ERR_HIP;
-  }
-  return PM_OK;
-}
-
-int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
-  const int nv = ps.n_views;
-  PlArgs ar{};
-  ar.stage = stage;
-  ar.arg = arg;
-  ar.view_fixed = -1;
-  switch (stage) {
-    case PM_PL_SPATIAL:
-      return planes_stage<PL_SPATIAL>(h, ps, ar, n * nv, PM_K_PL_SPATIAL, "spatial propagation");
-    case PM_PL_VIEW:
-      if (nv < 2) return PM_OK;
-      ar.view_fixed = arg;
-      return planes_stage<PL_VIEW>(h, ps, ar, n, PM_K_PL_VIEW, "view propagation");
-    case PM_PL_REFINE:
-      ar.refine_amp = h->params.noise_amp[arg];
-      return planes_stage<PL_REFINE>(h, ps, ar, n * nv, PM_K_PL_REFINE, "refinement");
-    case PM_PL_VIEW_REFINE: {  // arg = iteration * 2 + view: view propagation into `view`, then its refinement
-      const int view = arg & 1, it = arg >> 1;
-      if (view >= nv) return PM_OK;
-      ar.arg = it;
-      ar.view_fixed = view;
-      ar.refine_amp = h->params.noise_amp[it];
-      if (nv < 2) return planes_stage<PL_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "refinement");
-      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_VIEW_REFINE, "view propagation + refinement");
-    }
-    default:
-      set_err(h, "unknown planes stage %d", stage);
-      return PM_ERR_INVALID_ARG;
-  }
-}
-
-// prep (images, gradients, packed planes) + seeds + random initialisation of n pairs
-int planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                 const float* d_seed_l, const float* d_seed_r) {
-  if (int rc = planes_alloc(h)) return rc;
-  const int nv = h->params.left_right_check ? 2 : 1;
-  PlaneSet ps = plane_set(h, rows, cols, nv);
-  {
-    Launch l(h, PM_K_PREP);
-    launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
-  }
-  if (int rc = launch_check(h, "prep")) return rc;
-  const float* sl = d_seed_l;
-  const float* sr = d_seed_r;
-  PlArgs ar{};
-  if (h->params.sparse_init) {
-    // SparseInit on the device (patchmatch_gpu.cu:414-442) into the scalar engine's disparity planes, from
-    // which the initialisation kernel takes the seeds (view 1's plane is already in mirrored coordinates)
-    for (int v = 0; v < nv; ++v) {
-      if (v == 0 ? sl != nullptr : sr != nullptr) continue;
-      Launch l(h, PM_K_SEED);
-      for (int b = 0; b < n; ++b)
-        if (int rc = run_sparse_init(h, ps, b, v, 0)) return rc;
-      ar.seed_in_disp |= 1 << v;
-    }
-  }
-  ar.stage = PL_INIT;
-  ar.view_fixed = -1;
-  ar.seed_l = sl;
-  ar.seed_r = sr;
-  if (int rc = planes_stage<PL_INIT>(h, ps, ar, n * nv, PM_K_PL_INIT, "initialisation")) return rc;
-  h->pl_rows = rows;
-  h->pl_cols = cols;
-  h->pl_n = n;
-  h->pl_on = true;
-  return PM_OK;
-}
-
-int planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r) {
-  const int nv = h->params.left_right_check ? 2 : 1;
-  const PlaneSet ps = plane_set(h, h->pl_rows, h->pl_cols, nv);
-  const PlanesParams pp = planes_params(h->params);
-  Launch l(h, PM_K_FINALIZE);
-  if (h->params.state_dtype == PM_STATE_F16) {
-    PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane, ps.pitch / 2};
-    hipLaunchKernelGGL(k_planes_finish<_Float16>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps,
-                       st, pp, d_disp_l, d_disp_r, (size_t)ps.cols);
-  } else {
-    PlaneState<float> st{(float*)h->planes_state, ps.plane, ps.pitch / 2};
-    hipLaunchKernelGGL(k_planes_finish<float>, pixel_grid(ps.cols, ps.rows, h->pl_n), dim3(256), 0, h->stream, ps, st,
-                       pp, d_disp_l, d_disp_r, (size_t)ps.cols);
-  }
-  return launch_check(h, "planes finish");
-}
-
-// The whole schedule of oracle/pm_planes_oracle.c::pmo_planes_match.
-int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                 const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
-  if (int rc = planes_begin(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r)) return rc;
-  const int nv = h->params.left_right_check ? 2 : 1;
-  const PlaneSet ps = plane_set(h, rows, cols, nv);
-  for (int it = 0; it < h->params.patchmatch_iters; ++it) {
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 0)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 1)) return rc;
-    // per view: view propagation then refinement, fused in one launch (one tile fill for 1 + R candidates)
-    for (int v = 0; v < nv; ++v)
-      if (int rc = planes_step(h, ps, n, PM_PL_VIEW_REFINE, it * 2 + v)) return rc;
-  }
-  return planes_finish(h, d_disp_l, d_disp_r);
-}
-
 }  // namespace
 
-namespace {
 // Ends a capture in progress and throws the partial graph away (error paths, pm_destroy).
 void abort_capture(pm_handle* h) {
   if (!h->capturing) return;
@@ -891,7 +492,59 @@ int refuse_while_capturing(pm_handle* h, const char* what) {
   set_err(h, "%s: not allowed between pm_capture_begin and pm_capture_end", what);
   return PM_ERR_BUSY;
 }
-}  // namespace
+
+int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                             const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+  if (!d_left || !d_right || !d_disp_l) {
+    set_err(h, "pm_match_device: null image or output pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, n)) return rc;
+  PM_HIP(h, hipSetDevice(h->device));
+  const int n_views = h->params.left_right_check ? 2 : 1;
+  if (n_views == 2 && !d_disp_r) {
+    set_err(h, "pm_match_device: disp_r required when left_right_check is set");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (h->params.mode == PM_MODE_PLANES)
+    return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
+  if (int rc = ensure_noise(h, rows, cols)) return rc;
+  PlaneSet ps = plane_set(h, rows, cols, n_views);
+  // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
+  // the two views' seeders overlap on their own streams)
+  h->need_seed[0] = h->params.sparse_init && !d_seed_l;
+  h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
+  // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
+  const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
+  if (per_view_setup) {
+    const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
+    if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
+  } else {
+    {
+      Launch l(h, PM_K_PREP);
+      launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
+    }
+    if (int rc = launch_check(h, "prep")) return rc;
+    {
+      Launch l(h, PM_K_PREP);
+      if (int rc = run_transpose(h, ps, n)) return rc;
+    }
+    {
+      Launch l(h, PM_K_SEED);
+      launch_seed(h, ps, d_seed_l, d_seed_r, n);
+    }
+    if (int rc = launch_check(h, "seed")) return rc;
+    if (int rc = run_views(h, ps, n * n_views)) return rc;
+  }
+  {
+    Launch l(h, PM_K_FINALIZE);
+    launch_finalize(h, ps, d_disp_l, d_disp_r, n);
+  }
+  return launch_check(h, "finalize");
+}
+
+}  // namespace eng
+}  // namespace pm
 
 // =================================================================================================
 // C ABI
@@ -979,11 +632,12 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
-  void* dev[] = {h->rpg, h->rqk, h->cpg, h->img8, h->g32, h->g8, h->timg8, h->tg32, h->tg8, h->pk16, h->tpk16, h->disp, h->cost, h->noise, h->counters, h->st_left, h->st_right,
-                 h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r, h->seed.eig, h->seed.keys, h->seed.keys_sorted,
-                 h->seed.counters, h->seed.kp_xy, h->seed.kp_d, h->seed.sort_tmp, h->seed2.eig, h->seed2.keys, h->seed2.keys_sorted, h->seed2.counters, h->seed2.kp_xy, h->seed2.kp_d,
-                 h->seed2.sort_tmp, h->snap_disp,
-                 h->snap_cost, h->planes_state};
+  void* dev[] = {h->rpg,     h->rqk,      h->cpg,       h->img8,      h->g32,       h->g8,        h->timg8,
+                 h->tg32,    h->tg8,      h->pk16,      h->tpk16,     h->disp,      h->cost,      h->noise,
+                 h->counters, h->st_left, h->st_right,  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r,
+                 h->snap_disp, h->snap_cost, h->planes_state};
+  seed_scratch_free(h->seed);
+  seed_scratch_free(h->seed2);
   for (void* p : dev)
     if (p) (void)hipFree(p);
   delete h->copy_pool;
@@ -1163,58 +817,6 @@ int pm_replay(pm_handle* h) {
   return PM_OK;
 }
 
-static int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                             const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
-  if (!d_left || !d_right || !d_disp_l) {
-    set_err(h, "pm_match_device: null image or output pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, n)) return rc;
-  PM_HIP(h, hipSetDevice(h->device));
-  const int n_views = h->params.left_right_check ? 2 : 1;
-  if (n_views == 2 && !d_disp_r) {
-    set_err(h, "pm_match_device: disp_r required when left_right_check is set");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (h->params.mode == PM_MODE_PLANES)
-    return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
-  if (int rc = ensure_noise(h, rows, cols)) return rc;
-  PlaneSet ps = plane_set(h, rows, cols, n_views);
-  // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
-  // the two views' seeders overlap on their own streams)
-  h->need_seed[0] = h->params.sparse_init && !d_seed_l;
-  h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
-  // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
-  const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
-  if (per_view_setup) {
-    const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
-    if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
-  } else {
-    {
-      Launch l(h, PM_K_PREP);
-      launch_prep(h, ps, d_left, d_right, n, (size_t)cols);
-    }
-    if (int rc = launch_check(h, "prep")) return rc;
-    {
-      Launch l(h, PM_K_PREP);
-      if (int rc = run_transpose(h, ps, n)) return rc;
-    }
-    {
-      Launch l(h, PM_K_SEED);
-      hipLaunchKernelGGL(k_seed, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
-                         (size_t)cols, -1);
-    }
-    if (int rc = launch_check(h, "seed")) return rc;
-    if (int rc = run_views(h, ps, n * n_views)) return rc;
-  }
-  {
-    Launch l(h, PM_K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize, pixel_grid(cols, rows, n), dim3(256), 0, h->stream, ps, d_disp_l, d_disp_r,
-                       (size_t)cols);
-  }
-  return launch_check(h, "finalize");
-}
-
 int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                     const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
   if (!h) return PM_ERR_INVALID_ARG;
@@ -1258,8 +860,7 @@ int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, c
   PlaneSet ps = plane_set(h, rows, cols, 1);
   {
     Launch l(h, PM_K_PREP);
-    hipLaunchKernelGGL(k_prep_view, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_iml, d_imr, d_Gl, d_Gr,
-                       step / sizeof(float));
+    launch_prep_view(h, ps, d_iml, d_imr, d_Gl, d_Gr, step / sizeof(float));
   }
   if (int rc = launch_check(h, "prep_view")) return rc;
   {
@@ -1268,16 +869,14 @@ int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, c
   }
   {
     Launch l(h, PM_K_SEED);
-    hipLaunchKernelGGL(k_copy_disp_strided, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_disp,
-                       disp_step / sizeof(float), 0);
+    launch_copy_disp_strided(h, ps, d_disp, disp_step / sizeof(float), 0);
   }
   if (int rc = launch_check(h, "seed")) return rc;
   h->need_seed[0] = h->need_seed[1] = false;
   if (int rc = run_one_view_set(h, ps, 1)) return rc;
   {
     Launch l(h, PM_K_FINALIZE);
-    hipLaunchKernelGGL(k_copy_disp_strided, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, d_disp,
-                       disp_step / sizeof(float), 1);
+    launch_copy_disp_strided(h, ps, d_disp, disp_step / sizeof(float), 1);
   }
   if (int rc = launch_check(h, "copy out")) return rc;
   if (foreign) {
@@ -1302,807 +901,6 @@ int pm_set_unit_noise(pm_handle* h, const float* noise, int rows, int cols) {
   PM_HIP(h, hipMemcpy2D(h->noise, sizeof(float) * (size_t)pitch, noise, sizeof(float) * (size_t)cols,
                         sizeof(float) * (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
   return PM_OK;
-}
-
-int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int rows,
-                      int cols, const float* const* seed_l, const float* const* seed_r, float* const* disp_l,
-                      float* const* disp_r) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_match_batch_u8")) return rc;
-  if (!left || !right || !disp_l) {
-    set_err(h, "pm_match_batch_u8: null pointer array");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, n)) return rc;
-  const bool lr = h->params.left_right_check != 0;
-  if (lr && !disp_r) {
-    set_err(h, "pm_match_batch_u8: disp_r required when left_right_check is set");
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;  // uses the pinned buffer: before staging inputs
-  const size_t px = (size_t)rows * cols;
-  float* psl = (float*)h->pinned;  // floats first so every sub-buffer stays 4-byte aligned
-  float* psr = psl + n * px;
-  float* pdl = psr + n * px;
-  float* pdr = pdl + n * px;
-  uint8_t* pl = (uint8_t*)(pdr + n * px);
-  uint8_t* pr = pl + n * px;
-  bool any_sl = false, any_sr = false;
-  // With sparse_init a missing seed map means "seed this view on the device", which is decided per call, not per
-  // pair: a batch must give the seed map of a view for every pair or for none.
-  if (h->params.sparse_init) {
-    int nl = 0, nr = 0;
-    for (int i = 0; i < n; ++i) {
-      nl += (seed_l && seed_l[i]) ? 1 : 0;
-      nr += (seed_r && seed_r[i]) ? 1 : 0;
-    }
-    if ((nl != 0 && nl != n) || (nr != 0 && nr != n)) {
-      set_err(h, "pm_match_batch_u8: with sparse_init a view's seed maps must be given for all pairs or for none");
-      return PM_ERR_INVALID_ARG;
-    }
-  }
-  for (int i = 0; i < n; ++i) {
-    if (!left[i] || !right[i] || !disp_l[i] || (lr && !disp_r[i])) {
-      set_err(h, "pm_match_batch_u8: null pointer for pair %d", i);
-      return PM_ERR_INVALID_ARG;
-    }
-    std::memcpy(pl + i * px, left[i], px);
-    std::memcpy(pr + i * px, right[i], px);
-    if (seed_l && seed_l[i]) {
-      std::memcpy(psl + i * px, seed_l[i], sizeof(float) * px);
-      any_sl = true;
-    } else {
-      std::memset(psl + i * px, 0, sizeof(float) * px);
-    }
-    if (seed_r && seed_r[i]) {
-      std::memcpy(psr + i * px, seed_r[i], sizeof(float) * px);
-      any_sr = true;
-    } else {
-      std::memset(psr + i * px, 0, sizeof(float) * px);
-    }
-  }
-  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, n * px, hipMemcpyHostToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, n * px, hipMemcpyHostToDevice, h->stream));
-  if (any_sl) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
-  if (any_sr) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
-  if (int rc = match_device_impl(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
-                               any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
-    return rc;
-  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-  if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; ++i) {
-    std::memcpy(disp_l[i], pdl + i * px, sizeof(float) * px);
-    if (lr) std::memcpy(disp_r[i], pdr + i * px, sizeof(float) * px);
-  }
-  return PM_OK;
-}
-
-int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
-                const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
-                size_t disp_step) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_match_u8")) return rc;
-  if (!left || !right || !disp_l) {
-    set_err(h, "pm_match_u8: null image or output pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  const bool lr = h->params.left_right_check != 0;
-  if (lr && !disp_r) {
-    set_err(h, "pm_match_u8: disp_r required when left_right_check is set");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (image_step == 0) image_step = (size_t)cols;
-  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
-  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
-  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols ||
-      disp_step < sizeof(float) * (size_t)cols) {
-    set_err(h, "pm_match_u8: a row step is smaller than a row");
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;
-  const size_t px = (size_t)rows * cols;
-  float* psl = (float*)h->pinned;
-  float* psr = psl + px;
-  float* pdl = psr + px;
-  float* pdr = pdl + px;
-  uint8_t* pl = (uint8_t*)(pdr + px);
-  uint8_t* pr = pl + px;
-  // every plane is packed into the pinned buffer (a few host threads share each copy, pm_hostcopy.hpp) and its upload
-  // enqueued at once: the DMA of one plane runs while the host packs the next
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  auto pack = [&](void* dst, const void* src, size_t step, size_t row_bytes) {
-    h->copy_pool->Copy2D(dst, row_bytes, src, step, row_bytes, rows);
-  };
-  pack(pl, left, image_step, (size_t)cols);
-  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, px, hipMemcpyHostToDevice, h->stream));
-  pack(pr, right, image_step, (size_t)cols);
-  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, px, hipMemcpyHostToDevice, h->stream));
-  if (seed_l) {
-    pack(psl, seed_l, seed_step, sizeof(float) * (size_t)cols);
-    PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  }
-  if (seed_r) {
-    pack(psr, seed_r, seed_step, sizeof(float) * (size_t)cols);
-    PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  }
-  if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
-                               seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
-    return rc;
-  // the left map is unpacked into the caller's buffer while the right one is still on the bus
-  if (!h->left_out) {
-    PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&h->right_out, hipEventDisableTiming));
-  }
-  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipEventRecord(h->left_out, h->stream));
-  if (lr) {
-    PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
-    PM_HIP(h, hipEventRecord(h->right_out, h->stream));
-  }
-  const size_t row_bytes = sizeof(float) * (size_t)cols;
-  PM_HIP(h, hipEventSynchronize(h->left_out));
-  h->copy_pool->Copy2D(disp_l, disp_step, pdl, row_bytes, row_bytes, rows);
-  if (lr) {
-    PM_HIP(h, hipEventSynchronize(h->right_out));
-    h->copy_pool->Copy2D(disp_r, disp_step, pdr, row_bytes, row_bytes, rows);
-  }
-  return PM_OK;
-}
-
-// ---- pipelined host-buffer path ---------------------------------------------------------------------
-// What the Sequence caller of the reference does frame by frame (patchmatch_gpu_test.cpp:118-128) with
-// the copies taken off the critical path: while pair k is matched, pair k+1 is packed and uploaded and
-// pair k-1 is downloaded.  Depth = max_batch of the plan.
-namespace {
-
-int pipe_init(pm_handle* h) {
-  if (!h->pipe.empty()) return PM_OK;
-  PM_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
-  PM_HIP(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
-  h->pipe.resize((size_t)h->max_batch);
-  for (auto& sl : h->pipe) {
-    PM_HIP(h, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&sl.compute_done, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
-  }
-  return PM_OK;
-}
-
-struct PinnedSlot {
-  float *sl, *sr, *dl, *dr;
-  uint8_t *l, *r;
-};
-PinnedSlot pinned_slot(pm_handle* h, int slot, size_t px) {
-  const size_t tight = (size_t)h->max_rows * h->max_cols;
-  char* base = (char*)h->pinned + (size_t)slot * tight * (2 + 4 * sizeof(float));
-  PinnedSlot p;
-  p.sl = (float*)base;
-  p.sr = p.sl + px;
-  p.dl = p.sr + px;
-  p.dr = p.dl + px;
-  p.l = (uint8_t*)(p.dr + px);
-  p.r = p.l + px;
-  return p;
-}
-
-}  // namespace
-
-int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
-                 const float* seed_l, const float* seed_r, size_t seed_step, uint64_t tag) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_submit_u8")) return rc;
-  if (!left || !right) {
-    set_err(h, "pm_submit_u8: null image pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  if (image_step == 0) image_step = (size_t)cols;
-  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
-  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols) {
-    set_err(h, "pm_submit_u8: a row step is smaller than a row");
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = pipe_init(h)) return rc;
-  if (h->pipe_count == h->max_batch) {
-    set_err(h, "pm_submit_u8: %d pairs in flight (the plan's max_batch); collect one first", h->pipe_count);
-    return PM_ERR_BUSY;
-  }
-  if (h->noise_rows != rows || h->noise_cols != cols) {
-    // the noise table is staged through the pinned buffer the slots live in
-    if (h->pipe_count > 0) {
-      set_err(h, "pm_submit_u8: image size changed with pairs in flight; collect them first");
-      return PM_ERR_BUSY;
-    }
-    if (int rc = ensure_noise(h, rows, cols)) return rc;
-    PM_HIP(h, hipStreamSynchronize(h->stream));
-  }
-  const int slot = (h->pipe_head + h->pipe_count) % h->max_batch;
-  pm_handle::PipeSlot& sl = h->pipe[(size_t)slot];
-  const size_t px = (size_t)rows * cols;
-  const size_t tight = (size_t)h->max_rows * h->max_cols;
-  const PinnedSlot ps = pinned_slot(h, slot, px);
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  h->copy_pool->Copy2D(ps.l, (size_t)cols, left, image_step, (size_t)cols, rows);
-  h->copy_pool->Copy2D(ps.r, (size_t)cols, right, image_step, (size_t)cols, rows);
-  if (seed_l) h->copy_pool->Copy2D(ps.sl, sizeof(float) * cols, seed_l, seed_step, sizeof(float) * cols, rows);
-  if (seed_r) h->copy_pool->Copy2D(ps.sr, sizeof(float) * cols, seed_r, seed_step, sizeof(float) * cols, rows);
-  uint8_t* dl8 = h->st_left + slot * tight;
-  uint8_t* dr8 = h->st_right + slot * tight;
-  float* dsl = h->st_seed_l + slot * tight;
-  float* dsr = h->st_seed_r + slot * tight;
-  float* ddl = h->st_disp_l + slot * tight;
-  float* ddr = h->st_disp_r + slot * tight;
-  const bool lr = h->params.left_right_check != 0;
-  PM_HIP(h, hipMemcpyAsync(dl8, ps.l, px, hipMemcpyHostToDevice, h->s_in));
-  PM_HIP(h, hipMemcpyAsync(dr8, ps.r, px, hipMemcpyHostToDevice, h->s_in));
-  if (seed_l) PM_HIP(h, hipMemcpyAsync(dsl, ps.sl, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
-  if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
-  PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
-  PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
-  if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
-                               lr ? ddr : nullptr))
-    return rc;
-  PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
-  PM_HIP(h, hipStreamWaitEvent(h->s_out, sl.compute_done, 0));
-  PM_HIP(h, hipMemcpyAsync(ps.dl, ddl, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
-  if (lr) PM_HIP(h, hipMemcpyAsync(ps.dr, ddr, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
-  PM_HIP(h, hipEventRecord(sl.out_done, h->s_out));
-  sl.tag = tag;
-  sl.rows = rows;
-  sl.cols = cols;
-  ++h->pipe_count;
-  return PM_OK;
-}
-
-int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_collect")) return rc;
-  if (h->pipe_count == 0) {
-    set_err(h, "pm_collect: nothing in flight");
-    return PM_ERR_BUSY;
-  }
-  const bool lr = h->params.left_right_check != 0;
-  if (!disp_l || (lr && !disp_r)) {
-    set_err(h, "pm_collect: null output pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  pm_handle::PipeSlot& sl = h->pipe[(size_t)h->pipe_head];
-  const int rows = sl.rows, cols = sl.cols;
-  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
-  if (disp_step < sizeof(float) * (size_t)cols) {
-    set_err(h, "pm_collect: disp_step is smaller than a row");
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  PM_HIP(h, hipEventSynchronize(sl.out_done));
-  const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  h->copy_pool->Copy2D(disp_l, disp_step, ps.dl, sizeof(float) * cols, sizeof(float) * cols, rows);
-  if (lr) h->copy_pool->Copy2D(disp_r, disp_step, ps.dr, sizeof(float) * cols, sizeof(float) * cols, rows);
-  if (tag) *tag = sl.tag;
-  h->pipe_head = (h->pipe_head + 1) % h->max_batch;
-  --h->pipe_count;
-  return PM_OK;
-}
-
-int pm_in_flight(const pm_handle* h) { return h ? h->pipe_count : 0; }
-
-// ---- single stages ----------------------------------------------------------------------------
-
-namespace {
-
-// uploads a tightly packed pair into staging and runs prep for one pair / one view
-int stage_prep(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, PlaneSet* ps_out) {
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;
-  const size_t px = (size_t)rows * cols;
-  PM_HIP(h, hipMemcpyAsync(h->st_left, left, px, hipMemcpyHostToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->st_right, right ? right : left, px, hipMemcpyHostToDevice, h->stream));
-  const PlaneSet ps = plane_set(h, rows, cols, 1);
-  hipLaunchKernelGGL(k_prep, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, h->st_left, h->st_right,
-                     (size_t)cols, -1);
-  if (int rc = launch_check(h, "prep")) return rc;
-  if (int rc = run_transpose(h, ps, 1)) return rc;
-  *ps_out = ps;
-  return PM_OK;
-}
-
-int stage_disp_in(pm_handle* h, const PlaneSet& ps, const float* disp) {
-  const size_t px = (size_t)ps.rows * ps.cols;
-  PM_HIP(h, hipMemcpyAsync(h->st_disp_l, disp, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_copy_in, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, h->st_disp_l);
-  return launch_check(h, "copy_in");
-}
-
-int stage_out(pm_handle* h, const PlaneSet& ps, float* dst, int which) {
-  const size_t px = (size_t)ps.rows * ps.cols;
-  hipLaunchKernelGGL(k_copy_out, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, h->st_disp_l, which);
-  if (int rc = launch_check(h, "copy_out")) return rc;
-  PM_HIP(h, hipMemcpyAsync(dst, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  return PM_OK;
-}
-
-}  // namespace
-
-int pm_gradient_magnitude(pm_handle* h, const uint8_t* image, int rows, int cols, float* grad) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_gradient_magnitude")) return rc;
-  if (!image || !grad) {
-    set_err(h, "pm_gradient_magnitude: null pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  PlaneSet ps;
-  if (int rc = stage_prep(h, image, nullptr, rows, cols, &ps)) return rc;
-  return stage_out(h, ps, grad, 1);
-}
-
-int pm_unit_noise(pm_handle* h, int rows, int cols, float* noise) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_unit_noise")) return rc;
-  if (!noise) {
-    set_err(h, "pm_unit_noise: null pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;
-  return stage_out(h, plane_set(h, rows, cols, 1), noise, 2);
-}
-
-int pm_add_noise(pm_handle* h, float* disp, int rows, int cols, float amount) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_add_noise")) return rc;
-  if (!disp || !(amount >= 0.f)) {
-    set_err(h, "pm_add_noise: null pointer or negative amount");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;
-  const PlaneSet ps = plane_set(h, rows, cols, 1);
-  if (int rc = stage_disp_in(h, ps, disp)) return rc;
-  CostParams cp = cost_params(h->params, 3, 3);
-  const Interior none{1, 0, 1, 0};  // empty: noise only, no clamp / cost
-  hipLaunchKernelGGL(k_noise_cost, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, ps, cp, none, amount);
-  if (int rc = launch_check(h, "noise")) return rc;
-  return stage_out(h, ps, disp, 0);
-}
-
-int pm_propagate(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
-                 int patch_h, int patch_w, int pass_mask) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_propagate")) return rc;
-  if (!left || !right || !disp) {
-    set_err(h, "pm_propagate: null pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (h->params.semantics == PM_SEM_CPU)
-    if (int rc = check_patch(h, patch_w, patch_h)) return rc;
-  PlaneSet ps;
-  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
-  if (int rc = stage_disp_in(h, ps, disp)) return rc;
-  const CostParams cp = cost_params(h->params, patch_w, patch_h);
-  const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
-  launch_noise_cost(h, ps, cp, in, -1.f, 1, 0);
-  if (int rc = launch_check(h, "cost")) return rc;
-  for (int k = 0; k < 4; ++k)
-    if (pass_mask & (1 << k))
-      if (int rc = run_sweep(h, ps, cp, sweep_geom(h->params, in, k), 1)) return rc;
-  return stage_out(h, ps, disp, 0);
-}
-
-int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, float* disp,
-                         int patch_h, int patch_w, float factor) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_remove_background")) return rc;
-  if (!left || !right || !disp || !(factor > 0.f)) {
-    set_err(h, "pm_remove_background: null pointer or non-positive factor");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (h->params.semantics == PM_SEM_CPU)
-    if (int rc = check_patch(h, patch_w, patch_h)) return rc;
-  PlaneSet ps;
-  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
-  if (int rc = stage_disp_in(h, ps, disp)) return rc;
-  const CostParams cp = cost_params(h->params, patch_w, patch_h);
-  const Interior in = interior(h->params, rows, cols, cp.pw, cp.ph);
-  launch_background(h, ps, cp, in, factor, 0, 1);
-  if (int rc = launch_check(h, "background")) return rc;
-  return stage_out(h, ps, disp, 0);
-}
-
-int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
-                   float* seed) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_sparse_init")) return rc;
-  if (!left || !right || !seed || dilate_factor < 0 || dilate_factor > 8) {
-    set_err(h, "pm_sparse_init: null pointer or dilate_factor outside [0, 8]");
-    return PM_ERR_INVALID_ARG;
-  }
-  PlaneSet ps;
-  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
-  PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
-                             dilate_factor, ps.disp, ps.pitch, h->stream));
-  return stage_out(h, ps, seed, 0);
-}
-
-int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
-                  float* seed) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_initialize")) return rc;
-  if (!left || !right || !seed || downsample_factor < 1 || downsample_factor > 8 || rows / downsample_factor < 1 ||
-      cols / downsample_factor < 1) {
-    set_err(h, "pm_initialize: null pointer or downsample_factor outside [1, 8]");
-    return PM_ERR_INVALID_ARG;
-  }
-  PlaneSet ps;
-  if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
-  const int orows = rows / downsample_factor, ocols = cols / downsample_factor;
-  PM_HIP(h, seed_initialize(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
-                            downsample_factor, h->st_disp_l, ocols, h->stream));
-  PM_HIP(h, hipMemcpyAsync(seed, h->st_disp_l, sizeof(float) * (size_t)orows * ocols, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  return PM_OK;
-}
-
-int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_mask_occlusions")) return rc;
-  if (!disp_l || !disp_r) {
-    set_err(h, "pm_mask_occlusions: null pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  PM_HIP(h, hipSetDevice(h->device));
-  const size_t px = (size_t)rows * cols;
-  PM_HIP(h, hipMemcpyAsync(h->st_disp_l, disp_l, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->st_disp_r, disp_r, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_mask_occlusions, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, h->st_disp_l,
-                     h->st_disp_r, rows, cols);
-  if (int rc = launch_check(h, "mask_occlusions")) return rc;
-  PM_HIP(h, hipMemcpyAsync(disp_l, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  return PM_OK;
-}
-
-
-// ---- row-tiled mode --------------------------------------------------------------------------------------
-
-namespace {
-
-// PlaneSet of the band with the noise pointer moved to the band's slice of the whole-image table.
-PlaneSet tile_plane_set(pm_handle* h) {
-  const int n_views = h->params.left_right_check ? 2 : 1;
-  PlaneSet ps = plane_set(h, h->tile_band_rows, h->tile_cols, n_views);
-  ps.noise = h->noise + (size_t)h->tile.band_row0 * ps.pitch;
-  return ps;
-}
-
-// Rows this tile sweeps: owned rows that the sweeps of the whole image visit, in band coordinates.
-Interior tile_interior(pm_handle* h, int pw, int ph) {
-  const pm_tile& t = h->tile;
-  Interior in = interior(h->params, t.global_rows, h->tile_cols, pw, ph);  // whole-image rows / columns
-  const int lo = in.y_lo > t.own_row0 ? in.y_lo : t.own_row0;
-  const int hi = in.y_hi < t.own_row0 + t.own_rows - 1 ? in.y_hi : t.own_row0 + t.own_rows - 1;
-  in.y_lo = lo - t.band_row0;
-  in.y_hi = hi - t.band_row0;
-  return in;
-}
-
-int tile_check(pm_handle* h, const char* what) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (!h->tile_on) {
-    set_err(h, "%s: call pm_tile_begin first", what);
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  return PM_OK;
-}
-
-}  // namespace
-
-int pm_tile_begin(pm_handle* h, const pm_tile* tile, const uint8_t* d_left_band, const uint8_t* d_right_band,
-                  int band_rows, int cols, const float* d_seed_l_band, const float* d_seed_r_band) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (!tile || !d_left_band || !d_right_band) {
-    set_err(h, "pm_tile_begin: null pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, band_rows, cols, 1)) return rc;
-  const pm_params& p = h->params;
-  int max_ph = p.bg_patch_h;
-  for (int i = 0; i < p.patchmatch_iters; ++i) max_ph = p.patch_h[i] > max_ph ? p.patch_h[i] : max_ph;
-  const int halo = (p.semantics == PM_SEM_CPU ? max_ph / 2 : 1) + 1;  // window rows + one more for the Sobel
-  const int need_top = tile->own_row0 - halo > 0 ? tile->own_row0 - halo : 0;
-  const int own_end = tile->own_row0 + tile->own_rows;
-  const int need_end = own_end + halo < tile->global_rows ? own_end + halo : tile->global_rows;
-  if (tile->own_rows < 1 || tile->own_row0 < 0 || own_end > tile->global_rows || tile->band_row0 < 0 ||
-      tile->band_row0 > need_top || tile->band_row0 + band_rows < need_end ||
-      tile->band_row0 + band_rows > tile->global_rows) {
-    set_err(h, "pm_tile_begin: band [%d, %d) must cover rows [%d, %d) (owned [%d, %d) + %d halo rows) of %d",
-            tile->band_row0, tile->band_row0 + band_rows, need_top, need_end, tile->own_row0, own_end, halo,
-            tile->global_rows);
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, tile->global_rows, cols)) return rc;
-  h->tile = *tile;
-  h->tile_band_rows = band_rows;
-  h->tile_cols = cols;
-  h->tile_on = true;
-  const PlaneSet ps = tile_plane_set(h);
-  hipLaunchKernelGGL(k_prep, pixel_grid(cols, band_rows, 1), dim3(256), 0, h->stream, ps, d_left_band, d_right_band,
-                     (size_t)cols, -1);
-  if (int rc = launch_check(h, "prep")) return rc;
-  if (int rc = run_transpose(h, ps, 1)) return rc;
-  hipLaunchKernelGGL(k_seed, pixel_grid(cols, band_rows, 1), dim3(256), 0, h->stream, ps, d_seed_l_band,
-                     d_seed_r_band, (size_t)cols, -1);
-  return launch_check(h, "seed");
-}
-
-int pm_tile_noise(pm_handle* h, int it) {
-  if (int rc = tile_check(h, "pm_tile_noise")) return rc;
-  const pm_params& p = h->params;
-  if (it < 0 || it >= p.patchmatch_iters) {
-    set_err(h, "pm_tile_noise: iteration %d out of range", it);
-    return PM_ERR_INVALID_ARG;
-  }
-  const PlaneSet ps = tile_plane_set(h);
-  const CostParams cp = cost_params(p, p.patch_w[it], p.patch_h[it]);
-  const Interior in = tile_interior(h, cp.pw, cp.ph);
-  launch_noise_cost(h, ps, cp, in, p.noise_amp[it], ps.n_views, 0);
-  return launch_check(h, "noise_cost");
-}
-
-static int tile_sweep(pm_handle* h, int it, int k, const int* d_mask);
-int pm_tile_sweep(pm_handle* h, int it, int k) { return tile_sweep(h, it, k, nullptr); }
-int pm_tile_sweep_masked(pm_handle* h, int it, int k, const int* d_mask) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (!d_mask) {
-    set_err(h, "pm_tile_sweep_masked: null mask");
-    return PM_ERR_INVALID_ARG;
-  }
-  return tile_sweep(h, it, k, d_mask);
-}
-
-static int tile_sweep(pm_handle* h, int it, int k, const int* d_mask) {
-  if (int rc = tile_check(h, "pm_tile_sweep")) return rc;
-  const pm_params& p = h->params;
-  if (it < 0 || it >= p.patchmatch_iters || k < 0 || k > 3) {
-    set_err(h, "pm_tile_sweep: iteration %d / sweep %d out of range", it, k);
-    return PM_ERR_INVALID_ARG;
-  }
-  PlaneSet ps = tile_plane_set(h);
-  if (d_mask && (k & 1) == 0) {
-    set_err(h, "pm_tile_sweep_masked: the column mask applies to the vertical sweeps (k = 1, 3)");
-    return PM_ERR_INVALID_ARG;
-  }
-  ps.chain_mask = d_mask;
-  const CostParams cp = cost_params(p, p.patch_w[it], p.patch_h[it]);
-  // Geometry of the sweep on the WHOLE image (PM_SEM_GPU trims one position at the far end of each sweep,
-  // patchmatch_gpu.cu:156,214 -- that end is an end of the image, not of a band), then cut to the owned rows.
-  const pm_tile& t = h->tile;
-  SweepGeom g = sweep_geom(p, interior(p, t.global_rows, h->tile_cols, cp.pw, cp.ph), k);
-  const int own_lo = t.own_row0, own_hi = t.own_row0 + t.own_rows - 1;
-  if (g.axis == 0) {  // chains are rows
-    g.c_lo = (g.c_lo > own_lo ? g.c_lo : own_lo) - t.band_row0;
-    g.c_hi = (g.c_hi < own_hi ? g.c_hi : own_hi) - t.band_row0;
-    if (g.c_hi < g.c_lo) return PM_OK;
-  } else {  // positions along a chain are rows
-    if (g.dir > 0) {
-      g.s_first = g.s_first > own_lo ? g.s_first : own_lo;
-      g.s_last = g.s_last < own_hi ? g.s_last : own_hi;
-      if (g.s_last < g.s_first) return PM_OK;
-    } else {
-      g.s_first = g.s_first < own_hi ? g.s_first : own_hi;
-      g.s_last = g.s_last > own_lo ? g.s_last : own_lo;
-      if (g.s_last > g.s_first) return PM_OK;
-    }
-    g.s_first -= t.band_row0;
-    g.s_last -= t.band_row0;
-  }
-  return run_sweep(h, ps, cp, g, ps.n_views, p.noise_amp[it]);
-}
-
-int pm_tile_snapshot(pm_handle* h) {
-  if (int rc = tile_check(h, "pm_tile_snapshot")) return rc;
-  const size_t plane = (size_t)h->max_rows * h->max_pitch;
-  if (!h->snap_disp) {
-    PM_HIP(h, hipMalloc((void**)&h->snap_disp, sizeof(float) * 2 * plane));
-    PM_HIP(h, hipMalloc((void**)&h->snap_cost, sizeof(float) * 2 * plane));
-  }
-  const PlaneSet ps = tile_plane_set(h);
-  const size_t bytes = sizeof(float) * ps.plane * ps.n_views;
-  PM_HIP(h, hipMemcpyAsync(h->snap_disp, h->disp, bytes, hipMemcpyDeviceToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->snap_cost, h->cost, bytes, hipMemcpyDeviceToDevice, h->stream));
-  return PM_OK;
-}
-
-int pm_tile_restore(pm_handle* h) {
-  if (int rc = tile_check(h, "pm_tile_restore")) return rc;
-  if (!h->snap_disp) {
-    set_err(h, "pm_tile_restore: no snapshot");
-    return PM_ERR_INVALID_ARG;
-  }
-  const PlaneSet ps = tile_plane_set(h);
-  const size_t bytes = sizeof(float) * ps.plane * ps.n_views;
-  PM_HIP(h, hipMemcpyAsync(h->disp, h->snap_disp, bytes, hipMemcpyDeviceToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->cost, h->snap_cost, bytes, hipMemcpyDeviceToDevice, h->stream));
-  return PM_OK;
-}
-
-int pm_tile_restore_cols(pm_handle* h, const int* d_mask) {
-  if (int rc = tile_check(h, "pm_tile_restore_cols")) return rc;
-  if (!h->snap_disp || !d_mask) {
-    set_err(h, "pm_tile_restore_cols: no snapshot or null mask");
-    return PM_ERR_INVALID_ARG;
-  }
-  const PlaneSet ps = tile_plane_set(h);
-  hipLaunchKernelGGL(k_restore_cols, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps,
-                     (const float*)h->snap_disp, (const float*)h->snap_cost, d_mask);
-  return launch_check(h, "restore_cols");
-}
-
-static int tile_row_copy(pm_handle* h, int image_row, float* d_dst, const float* d_src, const char* what) {
-  if (int rc = tile_check(h, what)) return rc;
-  const int r = image_row - h->tile.band_row0;
-  if (r < 0 || r >= h->tile_band_rows || (!d_dst && !d_src)) {
-    set_err(h, "%s: row %d outside the band or null pointer", what, image_row);
-    return PM_ERR_INVALID_ARG;
-  }
-  const PlaneSet ps = tile_plane_set(h);
-  for (int v = 0; v < ps.n_views; ++v) {
-    float* plane_row = h->disp + (size_t)v * ps.plane + (size_t)r * ps.pitch;
-    if (d_dst)
-      PM_HIP(h, hipMemcpyAsync(d_dst + (size_t)v * ps.cols, plane_row, sizeof(float) * ps.cols,
-                               hipMemcpyDeviceToDevice, h->stream));
-    else
-      PM_HIP(h, hipMemcpyAsync(plane_row, d_src + (size_t)v * ps.cols, sizeof(float) * ps.cols,
-                               hipMemcpyDeviceToDevice, h->stream));
-  }
-  return PM_OK;
-}
-
-int pm_tile_get_row(pm_handle* h, int image_row, float* d_dst) {
-  return tile_row_copy(h, image_row, d_dst, nullptr, "pm_tile_get_row");
-}
-int pm_tile_set_row(pm_handle* h, int image_row, const float* d_src) {
-  return tile_row_copy(h, image_row, nullptr, d_src, "pm_tile_set_row");
-}
-
-int pm_tile_background(pm_handle* h) {
-  if (int rc = tile_check(h, "pm_tile_background")) return rc;
-  const pm_params& p = h->params;
-  const PlaneSet ps = tile_plane_set(h);
-  const CostParams bcp = cost_params(p, p.bg_patch_w, p.bg_patch_h);
-  const Interior in = tile_interior(h, bcp.pw, bcp.ph);
-  const int last = p.patchmatch_iters - 1;
-  const int cached = (last >= 0 && bcp.pw == (p.semantics == PM_SEM_CPU ? p.patch_w[last] : 3) &&
-                      bcp.ph == (p.semantics == PM_SEM_CPU ? p.patch_h[last] : 3)) ? 1 : 0;
-  const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
-  launch_background(h, ps, bcp, in, factor, cached, ps.n_views);
-  return launch_check(h, "background");
-}
-
-int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own) {
-  if (int rc = tile_check(h, "pm_tile_finish")) return rc;
-  const PlaneSet ps = tile_plane_set(h);
-  if (!d_disp_l_own || (ps.n_views > 1 && !d_disp_r_own)) {
-    set_err(h, "pm_tile_finish: null output");
-    return PM_ERR_INVALID_ARG;
-  }
-  hipLaunchKernelGGL(k_finalize, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, h->st_disp_l,
-                     ps.n_views > 1 ? h->st_disp_r : nullptr, (size_t)ps.cols);
-  if (int rc = launch_check(h, "finalize")) return rc;
-  const size_t ofs = (size_t)(h->tile.own_row0 - h->tile.band_row0) * ps.cols;
-  const size_t bytes = sizeof(float) * (size_t)h->tile.own_rows * ps.cols;
-  PM_HIP(h, hipMemcpyAsync(d_disp_l_own, h->st_disp_l + ofs, bytes, hipMemcpyDeviceToDevice, h->stream));
-  if (ps.n_views > 1)
-    PM_HIP(h, hipMemcpyAsync(d_disp_r_own, h->st_disp_r + ofs, bytes, hipMemcpyDeviceToDevice, h->stream));
-  h->tile_on = false;
-  return PM_OK;
-}
-
-// ---- PM_MODE_PLANES, stage by stage ------------------------------------------------------------------------
-
-namespace {
-int planes_check(pm_handle* h, const char* what, bool need_begin) {
-  if (!h) return PM_ERR_INVALID_ARG;
-  if (h->params.mode != PM_MODE_PLANES) {
-    set_err(h, "%s: the handle was created with mode != PM_MODE_PLANES", what);
-    return PM_ERR_INVALID_ARG;
-  }
-  if (need_begin && !h->pl_on) {
-    set_err(h, "%s: call pm_planes_begin (or a Match) first", what);
-    return PM_ERR_INVALID_ARG;
-  }
-  PM_HIP(h, hipSetDevice(h->device));
-  return PM_OK;
-}
-}  // namespace
-
-int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                    const float* d_seed_l, const float* d_seed_r) {
-  if (int rc = planes_check(h, "pm_planes_begin", false)) return rc;
-  if (!d_left || !d_right) {
-    set_err(h, "pm_planes_begin: null image pointer");
-    return PM_ERR_INVALID_ARG;
-  }
-  if (int rc = check_size(h, rows, cols, n)) return rc;
-  return planes_begin(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r);
-}
-
-int pm_planes_step(pm_handle* h, int stage, int arg) {
-  if (int rc = planes_check(h, "pm_planes_step", true)) return rc;
-  const int nv = h->params.left_right_check ? 2 : 1;
-  const bool ok = (stage == PM_PL_SPATIAL && (arg == 0 || arg == 1)) ||
-                  (stage == PM_PL_VIEW && (arg == 0 || arg == 1)) ||
-                  (stage == PM_PL_REFINE && arg >= 0 && arg < PM_MAX_ITERS) ||
-                  (stage == PM_PL_VIEW_REFINE && arg >= 0 && arg < 2 * PM_MAX_ITERS);
-  if (!ok) {
-    set_err(h, "pm_planes_step: stage %d / argument %d out of range", stage, arg);
-    return PM_ERR_INVALID_ARG;
-  }
-  return planes_step(h, plane_set(h, h->pl_rows, h->pl_cols, nv), h->pl_n, stage, arg);
-}
-
-static int planes_rw(pm_handle* h, int pair, int view, float* planes, int to_state, const char* what) {
-  if (int rc = planes_check(h, what, true)) return rc;
-  if (!planes || pair < 0 || pair >= h->pl_n || view < 0 || view > 1) {
-    set_err(h, "%s: null buffer or pair / view out of range", what);
-    return PM_ERR_INVALID_ARG;
-  }
-  const int nv = h->params.left_right_check ? 2 : 1;
-  const PlaneSet ps = plane_set(h, h->pl_rows, h->pl_cols, nv);
-  const size_t count = 4 * (size_t)ps.rows * ps.cols;
-  // staged through the disparity staging buffers (4 * rows * cols floats fit st_disp_l .. only when max_batch
-  // allows; a scratch allocation keeps this tool path independent of the plan)
-  float* d_buf = nullptr;
-  PM_HIP(h, hipMalloc((void**)&d_buf, sizeof(float) * count));
-  int rc = PM_OK;
-  if (to_state && hipMemcpyAsync(d_buf, planes, sizeof(float) * count, hipMemcpyHostToDevice, h->stream) != hipSuccess)
-    rc = PM_ERR_HIP;
-  if (rc == PM_OK) {
-    const dim3 grid((unsigned)((ps.cols + 255) / 256), (unsigned)ps.rows, 4);
-    if (h->params.state_dtype == PM_STATE_F16) {
-      PlaneState<_Float16> st{(_Float16*)h->planes_state, ps.plane, ps.pitch / 2};
-      hipLaunchKernelGGL(k_planes_copy<_Float16>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
-    } else {
-      PlaneState<float> st{(float*)h->planes_state, ps.plane, ps.pitch / 2};
-      hipLaunchKernelGGL(k_planes_copy<float>, grid, dim3(256), 0, h->stream, ps, st, pair, view, d_buf, to_state);
-    }
-    rc = launch_check(h, what);
-  }
-  if (rc == PM_OK && !to_state &&
-      hipMemcpyAsync(planes, d_buf, sizeof(float) * count, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
-    rc = PM_ERR_HIP;
-  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == PM_OK) rc = PM_ERR_HIP;
-  (void)hipFree(d_buf);
-  if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "%s: copy failed", what);
-  return rc;
-}
-
-int pm_planes_read(pm_handle* h, int pair, int view, float* planes) {
-  return planes_rw(h, pair, view, planes, 0, "pm_planes_read");
-}
-int pm_planes_write(pm_handle* h, int pair, int view, const float* planes) {
-  return planes_rw(h, pair, view, const_cast<float*>(planes), 1, "pm_planes_write");
-}
-
-int pm_planes_finish(pm_handle* h, float* d_disp_l, float* d_disp_r) {
-  if (int rc = planes_check(h, "pm_planes_finish", true)) return rc;
-  if (!d_disp_l || (h->params.left_right_check && !d_disp_r)) {
-    set_err(h, "pm_planes_finish: null output");
-    return PM_ERR_INVALID_ARG;
-  }
-  return planes_finish(h, d_disp_l, d_disp_r);
 }
 
 // ---- profiling ----------------------------------------------------------------------------------

@@ -1,0 +1,226 @@
+// pm_handle.hpp -- the engine handle and the host-side helpers its translation units share.  Not part of the ABI.
+//
+//   pm_engine.hip        handle lifecycle, parameter checks, Match() on device buffers, capture / replay, profiling
+//   pm_launch.hip        the ONLY unit that includes the scalar-mode kernels (pm_kernels.hpp): one launch function each
+//   pm_sweeps.hip        the directional sweep kernels (pm_run3.hpp, pm_run2.hpp, pm_wave.hpp, pm_serial.hpp)
+//   pm_seed.hip          the device seeder (pm_seed.hpp)
+//   pm_planes_host.hip   PM_MODE_PLANES: kernels (pm_planes.hpp), schedule, pm_planes_* entry points
+//   pm_hostpath.hip      host-buffer entry points (pm_match_u8, submit / collect, the single-stage functions)
+//   pm_tile.hip          the row-tiled phase API pm_tile_*
+//   pm_tiled.hip         pm_tiled_*: n band handles of one process driven over that API
+//   pm_imaging.hip       the imaging rows; sees the handle through pm_internal.hpp only
+// Every __global__ kernel lives in exactly one unit; the others reach it through the launch functions declared here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "pm/patchmatch.h"
+#include "pm_color.hpp"
+#include "pm_device.hpp"
+#include "pm_hostcopy.hpp"
+#include "pm_seed_api.hpp"
+#include "pm_sweep_defs.hpp"
+
+namespace pm {
+namespace eng {
+
+constexpr int kMaxEvents = 16384;  // event pairs kept before a forced drain
+
+struct EventRec {
+  hipEvent_t start, stop;
+  int klass;
+};
+
+}  // namespace eng
+}  // namespace pm
+
+
+struct pm_handle {
+  pm_params params;
+  int device = 0;
+  int max_rows = 0, max_cols = 0, max_batch = 0;
+  int max_pitch = 0;
+  hipStream_t stream = nullptr;
+
+  // engine planes (see pm::PlaneSet)
+  uint8_t* img8 = nullptr;
+  float* g32 = nullptr;
+  uint8_t* g8 = nullptr;
+  uint8_t* timg8 = nullptr;  // transposed copies for the column sweeps
+  float* tg32 = nullptr;
+  uint8_t* tg8 = nullptr;
+  uint16_t* pk16 = nullptr;
+  uint16_t* tpk16 = nullptr;
+  float* rpg = nullptr;      // row / column PAIR planes of the run engine (pm::PlaneSet)
+  uint32_t* rqk = nullptr;
+  float* cpg = nullptr;
+  float* disp = nullptr;
+  float* cost = nullptr;
+  float* noise = nullptr;
+  unsigned long long* counters = nullptr;  // device, 8 words
+  bool counters_on = false;                // same-address atomics serialise: opt-in only
+  int noise_rows = 0, noise_cols = 0, noise_pitch = 0;
+
+  // PM_MODE_PLANES: [max_batch][2 views][a, b, z, cost][rows][pitch], f32 or f16 (pm_planes.hpp)
+  void* planes_state = nullptr;
+  int pl_rows = 0, pl_cols = 0, pl_n = 0;  // what pm_planes_begin last prepared
+  bool pl_on = false;
+
+  pm::SeedScratch seed{};   // scratch of the device seeder (pm_seed.hpp)
+  pm::SeedScratch seed2{};  // second set for the right view's seeder (allocated on first use; per-view streams)
+  bool need_seed[2] = {false, false};  // set by pm_match_device: views whose seed map the device computes
+
+  // row-tiled mode (pm_tile_*)
+  bool tile_on = false;
+  pm_tile tile{};
+  int tile_band_rows = 0, tile_cols = 0;
+  float* snap_disp = nullptr;  // snapshot of the disparity / cost planes (2 views)
+  float* snap_cost = nullptr;
+  size_t noise_capacity = 0;   // floats allocated for the noise table
+
+  // staging for the host-buffer entry points: tightly packed [B][rows][cols]
+  uint8_t* st_left = nullptr;
+  uint8_t* st_right = nullptr;
+  float* st_seed_l = nullptr;
+  float* st_seed_r = nullptr;
+  float* st_disp_l = nullptr;
+  float* st_disp_r = nullptr;
+  void* pinned = nullptr;  // host staging, pinned
+  size_t pinned_bytes = 0;
+
+  // pipelined host-buffer path (pm_submit_u8 / pm_collect): slot k of the staging buffers, uploads on
+  // s_in, compute on `stream`, downloads on s_out
+  struct PipeSlot {
+    hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
+    uint64_t tag = 0;
+    int rows = 0, cols = 0;
+  };
+  // per-view streams: the two views are independent until the cross-check, so their launch chains run on
+  // two streams and one view's kernels fill the CUs the other view's kernel tails leave idle
+  hipStream_t view_stream[2] = {nullptr, nullptr};
+  hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
+  void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
+  // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
+  const pm::BgrSource* bgr = nullptr;
+  hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
+  bool capturing = false;
+  bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
+  hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
+  hipEvent_t left_out = nullptr;  // pm_match_u8: the left map has arrived in the pinned buffer
+  hipEvent_t right_out = nullptr;  // ... the right one
+  pm::CopyPool* copy_pool = nullptr;  // host threads sharing the pack / unpack copies of the host-buffer entry points
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  std::vector<PipeSlot> pipe;
+  int pipe_head = 0, pipe_count = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<pm::eng::EventRec> ev_pool;
+  int ev_used = 0;
+  pm_profile prof{};
+
+  char err[512] = {0};
+};
+
+namespace pm {
+namespace eng __attribute__((visibility("hidden"))) {
+
+void set_err(pm_handle* h, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define PM_HIP(h, call)                                                                               \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      pm::eng::set_err((h), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return PM_ERR_HIP;                                                                              \
+    }                                                                                                 \
+  } while (0)
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Brackets the launches of one kernel class with a pair of events while the handle is profiling.
+struct Launch {
+  pm_handle* h;
+  int klass;
+  bool timed;
+  EventRec* rec = nullptr;
+  Launch(pm_handle* h_, int k) : h(h_), klass(k), timed(h_->profiling) {
+    if (!timed) return;
+    if (h->ev_used == (int)h->ev_pool.size()) {
+      if ((int)h->ev_pool.size() >= kMaxEvents) {
+        timed = false;  // drained by pm_profile_read; never block inside a launch path
+        return;
+      }
+      EventRec r;
+      r.klass = k;
+      if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+        timed = false;
+        return;
+      }
+      h->ev_pool.push_back(r);
+    }
+    rec = &h->ev_pool[h->ev_used++];
+    rec->klass = k;
+    (void)hipEventRecord(rec->start, h->stream);
+  }
+  ~Launch() {
+    if (timed && rec) (void)hipEventRecord(rec->stop, h->stream);
+  }
+};
+
+// ---- pm_engine.hip: geometry, checks, the Match() schedule -------------------------------------------------------
+int check_patch(pm_handle* h, int pw, int ph);
+int check_size(pm_handle* h, int rows, int cols, int n);
+PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views);
+CostParams cost_params(const pm_params& p, int pw, int ph);
+Interior interior(const pm_params& p, int rows, int cols, int pw, int ph);
+SweepGeom sweep_geom(const pm_params& p, const Interior& in, int k);  // k: 0 = row +1, 1 = col +1, 2 = row -1, 3 = col -1
+int launch_check(pm_handle* h, const char* what);
+int ensure_noise(pm_handle* h, int rows, int cols);
+void abort_capture(pm_handle* h);
+int refuse_while_capturing(pm_handle* h, const char* what);
+bool pair_planes_wanted(const pm_handle* h);
+int pair_planes_alloc(pm_handle* h);
+int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots);
+int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
+SeedParams seed_params(const pm_params& p);
+int alloc_seed_scratch(pm_handle* h, SeedScratch& sc);
+// SparseInit (or Patchmatch::Initialize(.., 1)) for view `view` of pair `b` straight into its disparity plane
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0);
+
+// ---- pm_launch.hip: one function per scalar-mode kernel, enqueued on h->stream -----------------------------------
+// k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)
+void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
+                 int view = -1);
+void launch_prep_view(pm_handle* h, const PlaneSet& ps, const float* d_iml, const float* d_imr, const float* d_Gl,
+                      const float* d_Gr, size_t stride);
+// transposed copies + line-triple / quad planes of n pairs (run by every path that ran a prep kernel);
+// view >= 0: the planes of that view only (per-view streams: each stream derives its own planes)
+int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view = -1);
+void launch_seed(pm_handle* h, const PlaneSet& ps, const float* d_seed_l, const float* d_seed_r, int n, int view = -1);
+// noise + clamp + cost of the current disparity (amount < 0: cost only); RemoveBackground / MaskBackground
+void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float amount,
+                       int slots, int keep_zero);
+void launch_noise_only(pm_handle* h, const PlaneSet& ps, const CostParams& cp, float amount);
+void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float factor,
+                       int cached, int slots);
+int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, float amp = 1e30f);
+void launch_finalize(pm_handle* h, const PlaneSet& ps, float* d_disp_l, float* d_disp_r, int n);
+void launch_mask_occlusions(pm_handle* h, float* d_disp_l, const float* d_disp_r, int rows, int cols);
+void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
+                         const int* d_mask);
+void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src);
+void launch_copy_out(pm_handle* h, const PlaneSet& ps, float* d_dst, int which);
+void launch_copy_disp_strided(pm_handle* h, const PlaneSet& ps, float* d_buf, size_t stride, int to_buf);
+
+// ---- pm_planes_host.hip ------------------------------------------------------------------------------------------
+int planes_alloc(pm_handle* h);
+int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                 const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
+
+}  // namespace eng
+}  // namespace pm

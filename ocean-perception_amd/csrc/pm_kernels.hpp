@@ -16,13 +16,6 @@ namespace pm {
 // Sobel: kernels [-1 0 1]x[1 2 1]^T, unnormalised, BORDER_REFLECT_101 (OpenCV default); every
 // intermediate is an integer < 2^24, the only rounding is the correctly rounded sqrt.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int p, int len) {
-  if (len == 1) return 0;
-  if (p < 0) p = -p;
-  if (p >= len) p = 2 * (len - 1) - p;
-  return p;
-}
-
 __device__ __forceinline__ float sobel_mag(const uint8_t* im, size_t stride, int rows, int cols, int x, int y) {
   const uint8_t* r0 = im + (size_t)reflect101(y - 1, rows) * stride;
   const uint8_t* r1 = im + (size_t)y * stride;
@@ -151,11 +144,6 @@ __global__ void __launch_bounds__(256) k_prep_view(PlaneSet ps, const float* __r
 // Transposes `planes` planes of rows x cols (pitch `sp`) into cols x rows (pitch `dp`) through a
 // 64x64 LDS tile (+1 column of padding: conflict-free for 4-byte elements, 2-way for bytes) so that
 // both the reads and the writes are coalesced.  Block (bx, by, bz) of a (ceil(cols/64), ceil(rows/64), planes) grid, 256 threads.
-// The transposed planes carry kTransPad extra rows (= image columns cols .. cols + kTransPad - 1) that
-// replicate the last column: a window that leaves the image on the right reads them instead of clamping
-// its column index (cv::getRectSubPix replicates the border), which keeps the column sweep's target row
-// offsets affine in the window column (pm_run2.hpp).
-constexpr int kTransPad = 16;
 template <typename T>
 __device__ __forceinline__ void transpose_block(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols, int sp,
                                                 int dp, size_t src_plane, size_t dst_plane, int bx, int by, int bz,
@@ -303,10 +291,6 @@ __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restri
 // amount < 0 skips the noise (used by the single-stage entry points).
 // grid = (ceil(cols/256), rows, slots).
 // ---------------------------------------------------------------------------------------------
-struct Interior {
-  int x_lo, x_hi, y_lo, y_hi;  // inclusive bounds of the pixels visited by the sweeps
-};
-
 __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, Interior in, float amount) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, slot = blockIdx.z;

@@ -1,0 +1,156 @@
+// pm_launch.hip -- the translation unit of the scalar-mode kernels (pm_kernels.hpp): one launch function per kernel,
+// declared in pm_handle.hpp, each enqueuing on the handle's current stream.  No other unit includes pm_kernels.hpp.
+#include "pm_handle.hpp"
+#include "pm_kernels.hpp"
+#include "pm_sweeps.hpp"
+
+namespace pm {
+namespace eng {
+
+namespace {
+dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
+}  // namespace
+
+void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
+                 int view) {
+  if (h->bgr)
+    hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
+                       dim3(256), 0, h->stream, ps, *h->bgr);
+  else
+    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride,
+                       view);
+}
+
+void launch_prep_view(pm_handle* h, const PlaneSet& ps, const float* d_iml, const float* d_imr, const float* d_Gl,
+                      const float* d_Gr, size_t stride) {
+  hipLaunchKernelGGL(k_prep_view, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, d_iml, d_imr, d_Gl, d_Gr,
+                     stride);
+}
+
+int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view) {
+  SetupGrid sg{};
+  sg.view = view;
+  sg.tx = (unsigned)((ps.cols + 63) / 64);
+  sg.ty = (unsigned)((ps.rows + 63) / 64);
+  sg.tz = (unsigned)(n * (view < 0 ? 4 : 2));
+  sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
+  PlaneSet pp = ps;
+  unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
+  if (sg.with_lines) {
+    if (int rc = pair_planes_alloc(h)) return rc;
+    pp.rpg = h->rpg;
+    pp.rqk = h->rqk;
+    pp.cpg = h->cpg;
+    sg.lx = (unsigned)((ps.cols + 255) / 256);
+    sg.ly = (unsigned)ps.nrl;
+    sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
+    sg.cx = (unsigned)((ps.rows + 255) / 256);
+    sg.cy = (unsigned)ps.ncl;
+    sg.cz = (unsigned)(n * (view < 0 ? 2 : 1));
+    blocks0 += 2 * sg.lx * sg.ly * sg.lz;
+  }
+  hipLaunchKernelGGL(k_setup, dim3(blocks0), dim3(256), 0, h->stream, pp, sg, 0);
+  if (sg.with_lines)
+    hipLaunchKernelGGL(k_setup, dim3(sg.cx * sg.cy * sg.cz), dim3(256), 0, h->stream, pp, sg, 1);
+  return launch_check(h, "transpose");
+}
+
+// seed maps (tightly packed [n][rows][cols], null = zeros) into the disparity planes; view 1 mirrored
+void launch_seed(pm_handle* h, const PlaneSet& ps, const float* d_seed_l, const float* d_seed_r, int n, int view) {
+  hipLaunchKernelGGL(k_seed, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_seed_l, d_seed_r,
+                     (size_t)ps.cols, view);
+}
+
+int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots,
+              float amp) {
+  const int chains = g.c_hi - g.c_lo + 1;
+  if (chains <= 0 || (g.s_last - g.s_first) * g.dir < 0) return PM_OK;
+  Launch l(h, g.axis == 0 ? PM_K_SWEEP_ROW : PM_K_SWEEP_COL);
+  launch_sweep(ps, cp, g, slots, h->params.engine, amp, h->stream);  // pm_sweeps.hip
+  return launch_check(h, "sweep");
+}
+
+// noise + clamp + cost of the current disparity; PM_SEM_CPU square windows use the LDS-tiled kernel
+void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float amount,
+                       int slots, int keep_zero) {
+  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
+  const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
+                   (unsigned)slots);
+  if (tiled && cp.pw == 3) {
+    hipLaunchKernelGGL((k_noise_cost_tiled<3, 3>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
+  } else if (tiled && cp.pw == 5) {
+    hipLaunchKernelGGL((k_noise_cost_tiled<5, 5>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
+  } else if (tiled && cp.pw == 7) {
+    hipLaunchKernelGGL((k_noise_cost_tiled<7, 7>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
+  } else if (tiled && cp.pw == 9) {
+    hipLaunchKernelGGL((k_noise_cost_tiled<9, 9>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
+  } else if (tiled && cp.pw == 11) {
+    hipLaunchKernelGGL((k_noise_cost_tiled<11, 11>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
+  } else {
+    hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, amount);
+  }
+}
+
+// RemoveBackground / MaskBackground; PM_SEM_CPU square windows use the LDS-tiled kernel
+void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const Interior& in, float factor,
+                       int cached, int slots) {
+  const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
+  const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
+                   (unsigned)slots);
+#define PM_BG_CASE(W)                                                                                        \
+  case W:                                                                                                    \
+    hipLaunchKernelGGL((k_background_tiled<W, W>), tgrid, dim3(256), 0, h->stream, ps, cp, in, factor, cached); \
+    return;
+  if (tiled) {
+    switch (cp.pw) {
+      PM_BG_CASE(3)
+      PM_BG_CASE(5)
+      PM_BG_CASE(7)
+      PM_BG_CASE(9)
+      PM_BG_CASE(11)
+      default: break;
+    }
+  }
+#undef PM_BG_CASE
+  hipLaunchKernelGGL(k_background, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, factor,
+                     cached);
+}
+
+// the noise step alone (pm_add_noise): an empty interior skips the clamp and the cost
+void launch_noise_only(pm_handle* h, const PlaneSet& ps, const CostParams& cp, float amount) {
+  const Interior none{1, 0, 1, 0};
+  hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, cp, none, amount);
+}
+
+// cross-check (when two views ran) + un-mirroring + tight [n][rows][cols] output
+void launch_finalize(pm_handle* h, const PlaneSet& ps, float* d_disp_l, float* d_disp_r, int n) {
+  hipLaunchKernelGGL(k_finalize, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_disp_l, d_disp_r,
+                     (size_t)ps.cols);
+}
+
+void launch_mask_occlusions(pm_handle* h, float* d_disp_l, const float* d_disp_r, int rows, int cols) {
+  hipLaunchKernelGGL(k_mask_occlusions, pixel_grid(cols, rows, 1), dim3(256), 0, h->stream, d_disp_l, d_disp_r, rows,
+                     cols);
+}
+
+void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
+                         const int* d_mask) {
+  hipLaunchKernelGGL(k_restore_cols, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps, snap_disp,
+                     snap_cost, d_mask);
+}
+
+void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src) {
+  hipLaunchKernelGGL(k_copy_in, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, d_src);
+}
+
+void launch_copy_out(pm_handle* h, const PlaneSet& ps, float* d_dst, int which) {
+  hipLaunchKernelGGL(k_copy_out, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, d_dst, which);
+}
+
+void launch_copy_disp_strided(pm_handle* h, const PlaneSet& ps, float* d_buf, size_t stride, int to_buf) {
+  hipLaunchKernelGGL(k_copy_disp_strided, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, d_buf, stride,
+                     to_buf);
+}
+
+}  // namespace eng
+}  // namespace pm

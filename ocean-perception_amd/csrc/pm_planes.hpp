@@ -23,7 +23,8 @@
 // (the channels sit 16 bits apart in the dword and cannot carry into each other), four taps per v_sad_u8.
 #pragma once
 
-#include "pm_kernels.hpp"
+#include "pm_device.hpp"
+#include "pm_sweep_defs.hpp"
 
 namespace pm {
 

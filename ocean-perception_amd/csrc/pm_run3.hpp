@@ -259,11 +259,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         // lane = image column X (its own position's column -+ half), window rows in the lane, three per load
         constexpr int NT = (TP + 2) / 3, NQR = (TP + 3) / 4;
         const int X = clamp_med3(pos - DIR * half, cols - 1);
-#ifdef PM_EXP_ALIGN  // experiment (wrong results): what would 64-byte aligned quads of lanes buy?
-        const int R0 = clamp_med3((ipx_r & ~3) + k.rofs, cols - 1);
-#else
         const int R0 = clamp_med3(ipx_r + k.rofs, cols - 1);
-#endif
         const unsigned rv = (unsigned)R0 << 4;  // the lane's byte offset inside every line
         unsigned tcol[4 * NQR + 4];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
         float gv[3 * NT + 1];
@@ -338,11 +334,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         // TP + 1 consecutive image columns from ipx_r: whole triples of the line-indexed plane
         constexpr int NTC = (TP + 3) / 3, NQ = (TP + 3) / 4;
         const int pt = ps.pitch_t;
-#ifdef PM_EXP_ALIGN
-        const int Y = clamp_med3(((g.s_first + DIR * (ipm - k.mpos) - DIR * half) & ~3) + (DIR > 0 ? k.gl : 3 - k.gl), rows - 1);
-#else
         const int Y = clamp_med3(pos - DIR * half, rows - 1);
-#endif
         const int ipx_c = clamp_med3(ipx_r, cols - 1);  // (a group that cannot adopt may carry any ipx_r)
         // element (line ipx_c, row Y); both factors < 2^16: the 24-bit multiply-add is exact and full rate
         const unsigned cv = (__umul24((unsigned)ipx_c, (unsigned)pt) + (unsigned)Y) << 4;

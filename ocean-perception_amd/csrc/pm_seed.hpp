@@ -25,31 +25,10 @@
 
 #include <hipcub/hipcub.hpp>
 
-#include "pm_kernels.hpp"
+#include "pm_device.hpp"
+#include "pm_seed_api.hpp"
 
 namespace pm {
-
-struct SeedParams {
-  int max_features, min_distance, block_size;
-  int templ_cols, templ_rows, max_disp;
-  double quality_level, max_matching_cost;
-};
-
-constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list
-
-// Scratch owned by the handle (sized for max_rows x max_cols).
-struct SeedScratch {
-  float* eig;                // [rows][pitch]
-  unsigned long long* keys;  // [cap] candidates, then sorted
-  unsigned long long* keys_sorted;
-  unsigned* counters;        // [kSeedCounters]: [0] = max response bits, [1] = candidate count, [2] = accepted
-                             // count, [3] = grid overflow flag
-  int* kp_xy;                // [kSeedMaxFeatures][2]
-  float* kp_d;               // [kSeedMaxFeatures] matched disparity of a corner, < 0 = no match
-  void* sort_tmp;
-  size_t sort_tmp_bytes;
-  int cap;
-};
 
 // General reflect-101 (the box window may reach further out than one pixel).
 __device__ __forceinline__ int reflect101n(int p, int len) {
@@ -169,7 +148,6 @@ __global__ void __launch_bounds__(256) k_seed_response(const uint8_t* __restrict
 constexpr int kSelChunk = 2048;
 constexpr int kSelBins = 2048, kSelDigit = 11, kSelUnroll = 16;
 constexpr int kSelHist = kSelBins + kSelBins / 32;  // bin b lives at b + (b >> 5): 32-bin runs fall on distinct banks
-constexpr int kSeedCounters = 8;                     // SeedScratch::counters
 __host__ __device__ inline size_t seed_select_lds_bytes(int gx, int gy) {
   return sizeof(unsigned long long) * 2 * kSelChunk + sizeof(unsigned) * (kSelHist + 8) +
          sizeof(int) * 4 * (size_t)(gx + 2) * (gy + 2);
@@ -735,7 +713,7 @@ inline bool seed_fused_enabled() {
 //   PatchmatchGpu::SparseInit(iml, imr, f)   k = 2^f + 1,     out = image size, inv_scale = 1   (patchmatch_gpu.cu:436)
 //   Patchmatch::Initialize(iml, imr, f)      k = 2^(f-1) + 1, out = size / f,   inv_scale = 2^-f (patchmatch.cpp:75-81)
 // Enqueue-only.
-inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
+static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                            int rows, int cols, int pitch, int k, int out_rows, int out_cols, float inv_scale, float* out,
                            int out_pitch, hipStream_t stream) {
   const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
@@ -802,14 +780,14 @@ inline hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                        stream, (const float*)full, rows, cols, full_pitch, out, out_rows, out_cols, out_pitch);
   return hipGetLastError();
 }
-inline hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
+hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
                                    const uint8_t* right, int rows, int cols, int pitch, int dilate_factor, float* out,
                                    int out_pitch, hipStream_t stream) {
   return seed_map(sc, sp, left, right, rows, cols, pitch, (1 << dilate_factor) + 1, rows, cols, 1.0f, out, out_pitch,
                   stream);
 }
 // downsample_factor >= 1
-inline hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
+hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
                                   const uint8_t* right, int rows, int cols, int pitch, int downsample_factor, float* out,
                                   int out_pitch, hipStream_t stream) {
   const float inv = 1.0f / (float)(1 << downsample_factor);

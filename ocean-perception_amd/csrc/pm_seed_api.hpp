@@ -1,0 +1,51 @@
+// pm_seed_api.hpp -- what the engine sees of the device seeder (pm_seed.hpp holds the kernels, pm_seed.hip is their
+// translation unit): parameters, the scratch a handle owns, and the enqueue-only entry points.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace pm {
+
+struct SeedParams {
+  int max_features, min_distance, block_size;
+  int templ_cols, templ_rows, max_disp;
+  double quality_level, max_matching_cost;
+};
+
+constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list
+constexpr int kSeedCounters = 8;        // SeedScratch::counters
+
+// Scratch owned by the handle (sized for max_rows x max_cols).
+struct SeedScratch {
+  float* eig;                // [rows][pitch]
+  unsigned long long* keys;  // [cap] candidates, then sorted
+  unsigned long long* keys_sorted;
+  unsigned* counters;        // [kSeedCounters]: [0] = max response bits, [1] = candidate count, [2] = accepted
+                             // count, [3] = grid overflow flag
+  int* kp_xy;                // [kSeedMaxFeatures][2]
+  float* kp_d;               // [kSeedMaxFeatures] matched disparity of a corner, < 0 = no match
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int cap;
+};
+
+// Allocates the scratch for planes of `plane_elems` pixels (rows x pitch of the plan).  Every pixel can be a candidate:
+// the 3x3 test is not strict, so plateaus of EQUAL responses (periodic images) pass whole; a capacity of a quarter of the
+// pixels dropped candidates there in whatever order the atomics fell.
+hipError_t seed_scratch_alloc(SeedScratch& sc, size_t plane_elems, hipStream_t stream);
+void seed_scratch_free(SeedScratch& sc);
+
+// PatchmatchGpu::SparseInit(iml, imr, f)  (patchmatch_gpu.cu:414-442): dilation half-width 2^f + 1, map at image size
+hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
+                            int rows, int cols, int pitch, int dilate_factor, float* out, int out_pitch,
+                            hipStream_t stream);
+// Patchmatch::Initialize(iml, imr, f)  (patchmatch.cpp:60-84): half-width 2^(f-1) + 1, map of size / f, scaled by 2^-f;
+// downsample_factor >= 1
+hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
+                           int rows, int cols, int pitch, int downsample_factor, float* out, int out_pitch,
+                           hipStream_t stream);
+
+}  // namespace pm

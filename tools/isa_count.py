@@ -2,7 +2,7 @@
 """Static instruction mix of the engine's kernels (no GPU needed).
 
 usage: tools/isa_count.py [substring-of-mangled-kernel-name ...]
-Compiles pm_engine.hip to gfx950 assembly and prints, per kernel whose mangled name contains one of
+Compiles the kernel-holding units to gfx950 assembly and prints, per kernel whose mangled name contains one of
 the substrings (default: the 11x11 RUNBLK2 kernels), VGPR/SGPR use and the count of VALU / SALU /
 VMEM / LDS instructions of the whole body and of its largest loop."""
 import os, re, subprocess, sys, collections
@@ -14,7 +14,7 @@ OUT = "/tmp/isa/all_units.s"
 def build():
     os.makedirs("/tmp/isa", exist_ok=True)
     parts = []
-    for unit in ("pm_engine", "pm_sweeps", "pm_imaging", "pm_tiled"):
+    for unit in ("pm_launch", "pm_sweeps", "pm_seed", "pm_planes_host", "pm_imaging", "pm_tiled"):  # the units that hold kernels
         out = "/tmp/isa/%s.s" % unit
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
@@ -24,13 +24,6 @@ def build():
         subprocess.run(cmd, check=True)
         parts.append(open(out).read())
     open(OUT, "w").write("\n".join(parts))
-    return
-
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-pass-failed", "-Wno-unused-command-line-argument",
-           "-I" + ROOT + "/include", "-I" + ROOT + "/ocean-perception_amd/csrc", "-I" + ROOT + "/ocean-perception_amd/host",
-           "-S", "--cuda-device-only", "-o", OUT, ROOT + "/ocean-perception_amd/csrc/pm_engine.hip"]
-    subprocess.run(cmd, check=True)
 
 
 def kinds(lines):

@@ -1,4 +1,5 @@
-"""Run-step statistics of the sweep engine (needs a build with -DPM_RUN2_STATS, loaded through PM_LIB).
+"""Run-step statistics of the sweep engine (the device counters of the run engine, opt-in through pm_debug_counters_enable; a build with -DPM_RUN3_STATS,
+loaded through PM_LIB, additionally prints the per-workgroup round / tick statistics of pm_run3.hpp on stderr).
 
     PM_LIB=ocean-perception_amd/lib/ab_stats.so python tools/step_stats.py
 """
