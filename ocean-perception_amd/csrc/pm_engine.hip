@@ -265,56 +265,57 @@ int check_size(pm_handle* h, int rows, int cols, int n) {
 
 namespace {
 
-// iterations {noise, 4 sweeps} + background for all slots: PatchmatchGpu::Match(GpuMat...)
-// (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183.
-// `sets` plane sets are advanced in step, each on its own stream (one set on the handle's stream, or the two
+// Launch number `idx` of a view's schedule -- per iteration {noise + cost, sweeps A B C D}, then the background mask:
+// PatchmatchGpu::Match(GpuMat...) (patchmatch_gpu.cu:379-411) / the recipe of patchmatch_test.cpp:173-183 -- enqueued
+// on h->stream for all `slots` of plane set `ps`.
+int view_op(pm_handle* h, const PlaneSet& ps, int idx, int slots) {
+  const pm_params& p = h->params;
+  const int it = idx / 5, k = idx % 5;
+  if (it < p.patchmatch_iters) {
+    const CostParams cp = cost_params(p, p.patch_w[it], p.patch_h[it]);
+    const Interior in = interior(p, ps.rows, ps.cols, cp.pw, cp.ph);
+    if (k > 0) return run_sweep(h, ps, cp, sweep_geom(p, in, k - 1), slots, p.noise_amp[it]);
+    {
+      Launch l(h, PM_K_NOISE);
+      // from the second iteration on the cost plane is valid for this window if the window is unchanged
+      const CostParams prev = it > 0 ? cost_params(p, p.patch_w[it - 1], p.patch_h[it - 1]) : cp;
+      const int keep_zero = (it > 0 && cp.pw == prev.pw && cp.ph == prev.ph) ? 1 : 0;
+      launch_noise_cost(h, ps, cp, in, p.noise_amp[it], slots, keep_zero);
+    }
+    return launch_check(h, "noise_cost");
+  }
+  const CostParams bcp = cost_params(p, p.bg_patch_w, p.bg_patch_h);
+  const Interior in = interior(p, ps.rows, ps.cols, bcp.pw, bcp.ph);
+  int cached = 0;
+  if (p.patchmatch_iters > 0) {
+    const CostParams last = cost_params(p, p.patch_w[p.patchmatch_iters - 1], p.patch_h[p.patchmatch_iters - 1]);
+    cached = (bcp.pw == last.pw && bcp.ph == last.ph) ? 1 : 0;
+  }
+  const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
+  {
+    Launch l(h, PM_K_BACKGROUND);
+    launch_background(h, ps, bcp, in, factor, cached, slots);
+  }
+  return launch_check(h, "background");
+}
+
+// `sets` plane sets are advanced side by side, each on its own stream (one set on the handle's stream, or the two
 // views on their view streams): the host enqueues launch k of EVERY set before launch k + 1 of any, so all
 // streams have work from the first microsecond on.  (Enqueuing one view's whole chain of ~45 launches first left
 // the other stream empty for the 0.2-0.4 ms that takes: visible in the rocprofv3 kernel trace.)
 int run_view_sets(pm_handle* h, const PlaneSet* pss, hipStream_t* streams, int sets, int slots) {
-  const pm_params& p = h->params;
   hipStream_t keep = h->stream;
   struct Restore {
     pm_handle* h;
     hipStream_t s;
     ~Restore() { h->stream = s; }
   } restore{h, keep};
-  CostParams cp{};
-  int last_pw = 0, last_ph = 0;
-  for (int it = 0; it < p.patchmatch_iters; ++it) {
-    const int pw = p.patch_w[it], ph = p.patch_h[it];
-    cp = cost_params(p, pw, ph);
-    const Interior in = interior(p, pss[0].rows, pss[0].cols, cp.pw, cp.ph);
+  const int n_ops = 5 * h->params.patchmatch_iters + 1;
+  for (int idx = 0; idx < n_ops; ++idx)
     for (int s = 0; s < sets; ++s) {
       h->stream = streams[s];  // every launch helper enqueues on h->stream
-      {
-        Launch l(h, PM_K_NOISE);
-        // from the second iteration on the cost plane is valid for this window if the window is unchanged
-        const int keep_zero = (it > 0 && cp.pw == last_pw && cp.ph == last_ph) ? 1 : 0;
-        launch_noise_cost(h, pss[s], cp, in, p.noise_amp[it], slots, keep_zero);
-      }
-      if (int rc = launch_check(h, "noise_cost")) return rc;
+      if (int rc = view_op(h, pss[s], idx, slots)) return rc;
     }
-    for (int k = 0; k < 4; ++k)
-      for (int s = 0; s < sets; ++s) {
-        h->stream = streams[s];
-        if (int rc = run_sweep(h, pss[s], cp, sweep_geom(p, in, k), slots, p.noise_amp[it])) return rc;
-      }
-    last_pw = cp.pw;
-    last_ph = cp.ph;
-  }
-  for (int s = 0; s < sets; ++s) {
-    h->stream = streams[s];
-    const CostParams bcp = cost_params(p, p.bg_patch_w, p.bg_patch_h);
-    const Interior in = interior(p, pss[s].rows, pss[s].cols, bcp.pw, bcp.ph);
-    const int cached = (p.patchmatch_iters > 0 && bcp.pw == last_pw && bcp.ph == last_ph) ? 1 : 0;
-    const float factor = p.semantics == PM_SEM_CPU ? p.win_by_factor : p.cost_improve_factor;
-    {
-      Launch l(h, PM_K_BACKGROUND);
-      launch_background(h, pss[s], bcp, in, factor, cached, slots);
-    }
-    if (int rc = launch_check(h, "background")) return rc;
-  }
   return PM_OK;
 }
 
@@ -355,36 +356,41 @@ struct ViewSetup {
   int n;
 };
 
-int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
-  if (ps.n_views != 2 || !view_streams_enabled()) {
-    for (int v = 0; v < ps.n_views; ++v)
-      if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
-    return run_one_view_set(h, ps, slots);
-  }
-  if (!h->view_fork) {
-    PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
+int lanes_create(pm_handle* h, int n_lanes) {
+  if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
+  for (int l = 0; l < n_lanes; ++l)
     for (int v = 0; v < 2; ++v) {
-      PM_HIP(h, hipStreamCreateWithFlags(&h->view_stream[v], hipStreamNonBlocking));
-      PM_HIP(h, hipEventCreateWithFlags(&h->view_join[v], hipEventDisableTiming));
+      pm_handle::ViewLane& ln = h->lanes[l];
+      if (ln.view_stream[v]) continue;
+      PM_HIP(h, hipStreamCreateWithFlags(&ln.view_stream[v], hipStreamNonBlocking));
+      PM_HIP(h, hipEventCreateWithFlags(&ln.view_join[v], hipEventDisableTiming));
     }
-  }
+  return PM_OK;
+}
+
+// Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
+// (recorded by the caller on the main stream).  Enqueue only; the caller joins.
+int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, int lane) {
+  pm_handle::ViewLane& ln = h->lanes[lane];
   hipStream_t main_stream = h->stream;
-  PM_HIP(h, hipEventRecord(h->view_fork, main_stream));
   int rc = PM_OK;
   PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
     pv[v].view_fixed = v;
-    if (hipStreamWaitEvent(h->view_stream[v], h->view_fork, 0) != hipSuccess) {
+    if (hipStreamWaitEvent(ln.view_stream[v], h->view_fork, 0) != hipSuccess) {
       rc = PM_ERR_HIP;
       break;
     }
-    h->stream = h->view_stream[v];
+    h->stream = ln.view_stream[v];
     if (setup) {
       {
         Launch l(h, PM_K_PREP);
         launch_prep(h, ps, setup->d_left, setup->d_right, setup->n, (size_t)ps.cols, v);
         rc = launch_check(h, "prep");
-        if (rc == PM_OK) rc = run_transpose(h, ps, setup->n, v);
+      }
+      if (rc == PM_OK) {
+        Launch l(h, PM_K_PREP);
+        rc = run_transpose(h, ps, setup->n, v);
       }
       if (rc == PM_OK) {
         Launch l(h, PM_K_SEED);
@@ -395,15 +401,91 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
     if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, v);
     h->stream = main_stream;
   }
-  if (rc == PM_OK) rc = run_view_sets(h, pv, h->view_stream, 2, slots / 2);
-  for (int v = 0; v < 2 && rc == PM_OK; ++v)
-    if (hipEventRecord(h->view_join[v], h->view_stream[v]) != hipSuccess) rc = PM_ERR_HIP;
-  if (rc != PM_OK) {
-    if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
-    return rc;
-  }
-  for (int v = 0; v < 2; ++v) PM_HIP(h, hipStreamWaitEvent(main_stream, h->view_join[v], 0));
+  if (rc == PM_OK) rc = run_view_sets(h, pv, ln.view_stream, 2, slots / 2);
+  if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
+  return rc;
+}
+
+int lanes_join(pm_handle* h, int n_lanes) {
+  for (int l = 0; l < n_lanes; ++l)
+    for (int v = 0; v < 2; ++v) {
+      PM_HIP(h, hipEventRecord(h->lanes[l].view_join[v], h->lanes[l].view_stream[v]));
+      PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[l].view_join[v], 0));
+    }
   return PM_OK;
+}
+
+int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
+  if (ps.n_views != 2 || !view_streams_enabled()) {
+    for (int v = 0; v < ps.n_views; ++v)
+      if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
+    return run_one_view_set(h, ps, slots);
+  }
+  if (int rc = lanes_create(h, 1)) return rc;
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
+  if (int rc = run_views_on_lane(h, ps, slots, setup, 0)) return rc;
+  return lanes_join(h, 1);
+}
+
+// The plane set of pair b alone (every per-pair array advanced to that pair; see make_view for the strides).
+PlaneSet plane_set_of_pair(const PlaneSet& ps, int b) {
+  PlaneSet q = ps;
+  const size_t b4 = (size_t)b * 4, b2 = (size_t)b * 2;
+  q.img8 += b4 * ps.plane;
+  q.g32 += b4 * ps.plane;
+  q.g8 += b4 * ps.plane;
+  q.pk16 += b4 * ps.plane;
+  q.timg8 += b4 * ps.plane_t;
+  q.tg32 += b4 * ps.plane_t;
+  q.tg8 += b4 * ps.plane_t;
+  q.tpk16 += b4 * ps.plane_t;
+  if (q.rpg) q.rpg += b2 * (size_t)ps.nrl * ps.pitch * 4;
+  if (q.rqk) q.rqk += b2 * (size_t)ps.nrl * ps.pitch * 2;
+  if (q.cpg) q.cpg += b2 * (size_t)ps.ncl * ps.pitch_t * 4;
+  q.disp += b2 * ps.plane;
+  q.cost += b2 * ps.plane;
+  return q;
+}
+
+// Lanes a batch uses (PM_PAIR_LANES, read once; 0 or 1: a batch advances all its pairs through every launch together,
+// round 2's schedule).  Default 2 lanes x 2 pairs per pipeline: measured best at 720p (profiles/r03_pair_lanes.txt).
+int pair_lanes() {
+  static const int v = [] {
+    const char* e = getenv("PM_PAIR_LANES");
+    const int x = e ? atoi(e) : 2;
+    return x < 0 ? 0 : (x > pm_handle::kLanes ? pm_handle::kLanes : x);
+  }();
+  return v;
+}
+
+// pairs per pipeline (PM_PAIR_CHUNK, read once)
+int pair_chunk() {
+  static const int v = [] {
+    const char* e = getenv("PM_PAIR_CHUNK");
+    const int x = e ? atoi(e) : 2;
+    return x < 1 ? 1 : x;
+  }();
+  return v;
+}
+
+// A batch of pairs as independent pipelines of pair_chunk() pairs each that take the lanes in rotation: pipeline k runs
+// on lane k % L, after pipeline k - L (stream order).  What a rotation over three handles gives a caller
+// (tools/multi_handle.py), inside one handle and one call; DESIGN §7 has the measurements.
+int run_pairs_on_lanes(pm_handle* h, const PlaneSet& ps, int n, const ViewSetup& vs) {
+  const int chunk = pair_chunk();
+  const int pipes = (n + chunk - 1) / chunk;
+  const int L = pipes < pair_lanes() ? pipes : pair_lanes();
+  if (int rc = lanes_create(h, L)) return rc;
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
+  const size_t px = (size_t)ps.rows * ps.cols;
+  for (int k = 0; k < pipes; ++k) {
+    const int b = k * chunk, c = n - b < chunk ? n - b : chunk;
+    const PlaneSet pb = plane_set_of_pair(ps, b);
+    const ViewSetup sb{vs.d_left + b * px, vs.d_right + b * px, vs.d_seed_l ? vs.d_seed_l + b * px : nullptr,
+                       vs.d_seed_r ? vs.d_seed_r + b * px : nullptr, c};
+    if (int rc = run_views_on_lane(h, pb, 2 * c, &sb, k % L)) return rc;
+  }
+  return lanes_join(h, L);
 }
 
 int validate_params(pm_handle* h, const pm_params& p) {
@@ -516,7 +598,10 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
   h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
   // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
   const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
-  if (per_view_setup) {
+  if (per_view_setup && n > pair_chunk() && pair_lanes() > 1 && !h->need_seed[0] && !h->need_seed[1]) {
+    const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
+    if (int rc = run_pairs_on_lanes(h, ps, n, vs)) return rc;
+  } else if (per_view_setup) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
     if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
   } else {
@@ -642,11 +727,12 @@ void pm_destroy(pm_handle* h) {
     if (p) (void)hipFree(p);
   delete h->copy_pool;
   if (h->pinned) (void)hipHostFree(h->pinned);
-  for (int v = 0; v < 2; ++v) {
-    if (h->view_stream[v]) (void)hipStreamSynchronize(h->view_stream[v]);
-    if (h->view_join[v]) (void)hipEventDestroy(h->view_join[v]);
-    if (h->view_stream[v]) (void)hipStreamDestroy(h->view_stream[v]);
-  }
+  for (auto& ln : h->lanes)
+    for (int v = 0; v < 2; ++v) {
+      if (ln.view_stream[v]) (void)hipStreamSynchronize(ln.view_stream[v]);
+      if (ln.view_join[v]) (void)hipEventDestroy(ln.view_join[v]);
+      if (ln.view_stream[v]) (void)hipStreamDestroy(ln.view_stream[v]);
+    }
   if (h->view_fork) (void)hipEventDestroy(h->view_fork);
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);

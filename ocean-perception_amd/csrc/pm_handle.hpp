@@ -100,8 +100,16 @@ struct pm_handle {
   };
   // per-view streams: the two views are independent until the cross-check, so their launch chains run on
   // two streams and one view's kernels fill the CUs the other view's kernel tails leave idle
-  hipStream_t view_stream[2] = {nullptr, nullptr};
-  hipEvent_t view_fork = nullptr, view_join[2] = {nullptr, nullptr};
+  // A batch of pairs runs as independent per-pair pipelines that take the lanes in rotation (pm_engine.hip::run_pairs_on_lanes):
+  // a pair's head and tail -- a dozen small launches -- then run beside another pair's sweeps.  Lane 0 serves the
+  // single pair.
+  static constexpr int kLanes = 4;
+  struct ViewLane {
+    hipStream_t view_stream[2] = {nullptr, nullptr};
+    hipEvent_t view_join[2] = {nullptr, nullptr};
+  };
+  ViewLane lanes[kLanes];
+  hipEvent_t view_fork = nullptr;
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;

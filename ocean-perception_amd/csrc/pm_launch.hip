@@ -37,10 +37,12 @@ int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view) {
   PlaneSet pp = ps;
   unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
   if (sg.with_lines) {
-    if (int rc = pair_planes_alloc(h)) return rc;
-    pp.rpg = h->rpg;
-    pp.rqk = h->rqk;
-    pp.cpg = h->cpg;
+    if (!pp.rpg) {  // (a plane set made before the line planes existed; pm_create allocates them for the handles that use them)
+      if (int rc = pair_planes_alloc(h)) return rc;
+      pp.rpg = h->rpg;
+      pp.rqk = h->rqk;
+      pp.cpg = h->cpg;
+    }
     sg.lx = (unsigned)((ps.cols + 255) / 256);
     sg.ly = (unsigned)ps.nrl;
     sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));

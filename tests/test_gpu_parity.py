@@ -216,6 +216,52 @@ def test_batch_equals_singles(pm, oracle, synth, sem):
         assert_same(drs[i], er, f"pair {i} right")
 
 
+@pytest.mark.parametrize("sem,patch", [(0, 11), (0, 3), (1, 3)])
+def test_batch_pipelines_on_lanes_equal_singles(pm, oracle, synth, sem, patch):
+    """A batch of more than two pairs runs as pipelines of two pairs that take two lanes of view streams in rotation
+    (pm_engine.hip::run_pairs_on_lanes): 5 pairs = pipelines {0,1} {2,3} {4}.  Every slot must equal the Match of its
+    pair alone, twice in a row (the lanes are re-used), and -- recorded as ONE HIP graph -- on replay with new inputs."""
+    torch = pytest.importorskip("torch")
+    rows, cols, nb = 72, 100, 5
+    dev = torch.device("cuda:0")
+    sets = [[small_pair(synth, 300 + 10 * k + i, rows, cols, n_points=25, dilate_factor=2) for i in range(nb)]
+            for k in range(2)]
+    st = lambda prs, j, dt: torch.from_numpy(np.stack([p[j] for p in prs])).to(dev, dt).contiguous()
+    bufs = [st(sets[0], 0, torch.uint8), st(sets[0], 1, torch.uint8), st(sets[0], 2, torch.float32),
+            st(sets[0], 3, torch.float32)]
+    DL = torch.empty((nb, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    singles = []
+    with mk(pm, sem, patch=patch, iters=3, rows=rows, cols=cols) as e:
+        for prs in sets:
+            singles.append([e.match(p[0], p[1], p[2], p[3]) for p in prs])
+    with mk(pm, sem, patch=patch, iters=3, rows=rows, cols=cols, batch=nb) as e:
+        run = lambda: e.match_device(nb, bufs[0].data_ptr(), bufs[1].data_ptr(), rows, cols, bufs[2].data_ptr(),
+                                     bufs[3].data_ptr(), DL.data_ptr(), DR.data_ptr())
+        for rep in range(2):
+            DL.zero_(); DR.zero_()
+            torch.cuda.synchronize()
+            run()
+            e.synchronize()
+            for i in range(nb):
+                assert_same(DL[i].cpu().numpy(), singles[0][i][0], f"call {rep}, slot {i}, left")
+                assert_same(DR[i].cpu().numpy(), singles[0][i][1], f"call {rep}, slot {i}, right")
+        e.capture_begin()
+        run()
+        e.capture_end()
+        for j, dt in ((0, torch.uint8), (1, torch.uint8), (2, torch.float32), (3, torch.float32)):
+            bufs[j].copy_(st(sets[1], j, dt))
+        torch.cuda.synchronize()
+        e.replay()
+        e.synchronize()
+        for i in range(nb):
+            assert_same(DL[i].cpu().numpy(), singles[1][i][0], f"replay, slot {i}, left")
+            assert_same(DR[i].cpu().numpy(), singles[1][i][1], f"replay, slot {i}, right")
+    el, er = oracle.match(oparams(oracle, sem, patch, 3), *sets[1][4][:4])
+    assert_same(singles[1][4][0], el, "the single-pair anchor against the oracle, left")
+    assert_same(singles[1][4][1], er, "right")
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("depth", [1, 3])
 def test_pipelined_sequence_equals_single_matches(pm, oracle, synth, depth):
@@ -317,8 +363,9 @@ def test_device_entry_point_with_torch_buffers(pm, oracle, synth):
         e.match_device(2, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),
                        DR.data_ptr())
         prof = e.profile_read()
-    # 2 iterations x 2 row sweeps (and column sweeps), x 2 when the views run on their own streams (default)
-    assert prof["sweep_row"][0] in (4, 8) and prof["sweep_col"][0] == prof["sweep_row"][0]
+    # 2 iterations x 2 row sweeps (and column sweeps), x 2 when the views run on their own streams (default), x 2 when
+    # the two pairs run as pipelines of their own (PM_PAIR_CHUNK=1)
+    assert prof["sweep_row"][0] in (4, 8, 16) and prof["sweep_col"][0] == prof["sweep_row"][0]
     assert prof["noise_cost"][0] == prof["sweep_row"][0] // 2
     assert prof["sweep_row"][1] > 0
     for i, p in enumerate(pairs):

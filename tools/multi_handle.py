@@ -1,0 +1,34 @@
+"""Aggregate Match() throughput of NH handles of one process, one host thread each, inputs resident (pm_match_device):
+    python tools/multi_handle.py NH [start offset between the threads in ms]"""
+import os, sys, time, threading
+ROOT = "/root/repo"
+sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
+import numpy as np, torch
+import pm_ctypes as pm, synth
+pm.load()
+ROWS, COLS = 720, 1280
+dev = torch.device("cuda:0")
+NH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+OFFSET_MS = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+N = 40
+prm = pm.default_params(0, patch=11, patchmatch_iters=8)
+engines = [pm.Engine(prm, max_rows=ROWS, max_cols=COLS) for _ in range(NH)]
+bufs = []
+for i in range(NH):
+    p = synth.make_pair(i, ROWS, COLS)
+    t = [torch.from_numpy(p[k]).to(dev) for k in ("left", "right", "seed_l", "seed_r")]
+    t += [torch.empty((ROWS, COLS), dtype=torch.float32, device=dev) for _ in range(2)]
+    bufs.append(t)
+def run(i, n):
+    e, t = engines[i], bufs[i]
+    if OFFSET_MS and n > 3:
+        time.sleep(i * OFFSET_MS / 1000.0)
+    for _ in range(n):
+        e.match_device(1, t[0].data_ptr(), t[1].data_ptr(), ROWS, COLS, t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr())
+    e.synchronize()
+for i in range(NH): run(i, 3)
+t0 = time.perf_counter()
+th = [threading.Thread(target=run, args=(i, N)) for i in range(NH)]
+[x.start() for x in th]; [x.join() for x in th]
+dt = time.perf_counter() - t0
+print(f"{NH} handles (start offset {OFFSET_MS} ms): {NH * N / dt:.1f} pairs/s ({1000 * dt / (NH * N):.3f} ms/frame)")
