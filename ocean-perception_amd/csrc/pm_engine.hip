@@ -370,38 +370,37 @@ int lanes_create(pm_handle* h, int n_lanes) {
 
 // Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
 // (recorded by the caller on the main stream).  Enqueue only; the caller joins.
-int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, int lane) {
+int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, int lane,
+                      bool view0_on_main = false) {
   pm_handle::ViewLane& ln = h->lanes[lane];
   hipStream_t main_stream = h->stream;
+  // view0_on_main: the first view stays on the caller's stream (no fork / join for it), the second forks off
+  hipStream_t vstream[2] = {view0_on_main ? main_stream : ln.view_stream[0], ln.view_stream[1]};
   int rc = PM_OK;
   PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
     pv[v].view_fixed = v;
-    if (hipStreamWaitEvent(ln.view_stream[v], h->view_fork, 0) != hipSuccess) {
+    if (vstream[v] != main_stream && hipStreamWaitEvent(vstream[v], h->view_fork, 0) != hipSuccess) {
       rc = PM_ERR_HIP;
       break;
     }
-    h->stream = ln.view_stream[v];
+    h->stream = vstream[v];
     if (setup) {
       {
         Launch l(h, PM_K_PREP);
-        launch_prep(h, ps, setup->d_left, setup->d_right, setup->n, (size_t)ps.cols, v);
+        const PrepSeedMaps seeds{setup->d_seed_l, setup->d_seed_r};  // the seed copy rides along (one launch less)
+        launch_prep(h, ps, setup->d_left, setup->d_right, setup->n, (size_t)ps.cols, v, &seeds);
         rc = launch_check(h, "prep");
       }
       if (rc == PM_OK) {
         Launch l(h, PM_K_PREP);
         rc = run_transpose(h, ps, setup->n, v);
       }
-      if (rc == PM_OK) {
-        Launch l(h, PM_K_SEED);
-        launch_seed(h, ps, setup->d_seed_l, setup->d_seed_r, setup->n, v);
-        rc = launch_check(h, "seed");
-      }
     }
     if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, v);
     h->stream = main_stream;
   }
-  if (rc == PM_OK) rc = run_view_sets(h, pv, ln.view_stream, 2, slots / 2);
+  if (rc == PM_OK) rc = run_view_sets(h, pv, vstream, 2, slots / 2);
   if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
   return rc;
 }
@@ -423,8 +422,15 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
   }
   if (int rc = lanes_create(h, 1)) return rc;
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  if (int rc = run_views_on_lane(h, ps, slots, setup, 0)) return rc;
-  return lanes_join(h, 1);
+  static const bool on_main = [] {
+    const char* e = getenv("PM_VIEW0_ON_MAIN");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (int rc = run_views_on_lane(h, ps, slots, setup, 0, on_main)) return rc;
+  if (!on_main) return lanes_join(h, 1);
+  PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));
+  PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[1], 0));
+  return PM_OK;
 }
 
 // The plane set of pair b alone (every per-pair array advanced to that pair; see make_view for the strides).

@@ -202,8 +202,14 @@ int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scrat
 
 // ---- pm_launch.hip: one function per scalar-mode kernel, enqueued on h->stream -----------------------------------
 // k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)
+// seeds != null: the launch also copies the seed maps (null members = all background) into the disparity planes of its
+// view(s), i.e. what launch_seed does
+struct PrepSeedMaps {
+  const float* l;
+  const float* r;
+};
 void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
-                 int view = -1);
+                 int view = -1, const PrepSeedMaps* seeds = nullptr);
 void launch_prep_view(pm_handle* h, const PlaneSet& ps, const float* d_iml, const float* d_imr, const float* d_Gl,
                       const float* d_Gr, size_t stride);
 // transposed copies + line-triple / quad planes of n pairs (run by every path that ran a prep kernel);

@@ -31,11 +31,26 @@ __device__ __forceinline__ float sobel_mag(const uint8_t* im, size_t stride, int
 // in_left / in_right: [B][rows][in_stride] u8.  grid = (ceil(cols/256), rows, B).
 // view_sel: -1 = all four planes; 0 = the direct copies only (what view 0 works on), 1 = the mirrored copies only (view 1):
 // with the two views on their own streams each stream prepares its own planes and nothing waits for the other.
+// seeds.on != 0: also what k_seed does for the view(s) of this launch (seed maps -> disparity planes), one launch less
+// at the head of a Match.
+struct PrepSeeds {
+  const float* l;  // tightly packed [B][rows][cols] seed maps in left / right image coordinates, or null = all background
+  const float* r;
+  int on;
+};
 __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __restrict__ in_left,
-                                              const uint8_t* __restrict__ in_right, size_t in_stride, int view_sel) {
+                                              const uint8_t* __restrict__ in_right, size_t in_stride, int view_sel,
+                                              PrepSeeds seeds) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
+  if (seeds.on) {
+    const size_t sp = (size_t)ps.rows * ps.cols, so = (size_t)b * sp + (size_t)y * ps.cols;
+    const size_t o = (size_t)y * ps.pitch + x;
+    if (view_sel != 1) ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seeds.l ? seeds.l[so + x] : 0.f;
+    if (ps.n_views > 1 && view_sel != 0)
+      ps.disp[((size_t)b * 2 + 1) * ps.plane + o] = seeds.r ? seeds.r[so + (ps.cols - 1 - x)] : 0.f;
+  }
   const size_t in_plane = (size_t)ps.rows * in_stride;
   const uint8_t* srcs[2] = {in_left + (size_t)b * in_plane, in_right + (size_t)b * in_plane};
   const int xm = ps.cols - 1 - x;

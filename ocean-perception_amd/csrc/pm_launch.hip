@@ -12,13 +12,16 @@ dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255)
 }  // namespace
 
 void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
-                 int view) {
-  if (h->bgr)
+                 int view, const PrepSeedMaps* seeds) {
+  if (h->bgr) {
     hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
                        dim3(256), 0, h->stream, ps, *h->bgr);
-  else
-    hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride,
-                       view);
+    if (seeds) launch_seed(h, ps, seeds->l, seeds->r, n, view);
+    return;
+  }
+  const PrepSeeds sd{seeds ? seeds->l : nullptr, seeds ? seeds->r : nullptr, seeds ? 1 : 0};
+  hipLaunchKernelGGL(k_prep, pixel_grid(ps.cols, ps.rows, n), dim3(256), 0, h->stream, ps, d_left, d_right, stride, view,
+                     sd);
 }
 
 void launch_prep_view(pm_handle* h, const PlaneSet& ps, const float* d_iml, const float* d_imr, const float* d_Gl,
