@@ -421,11 +421,11 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
     return run_one_view_set(h, ps, slots);
   }
   if (int rc = lanes_create(h, 1)) return rc;
-  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
   static const bool on_main = [] {
     const char* e = getenv("PM_VIEW0_ON_MAIN");
     return e ? atoi(e) != 0 : true;
   }();
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
   if (int rc = run_views_on_lane(h, ps, slots, setup, 0, on_main)) return rc;
   if (!on_main) return lanes_join(h, 1);
   PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));

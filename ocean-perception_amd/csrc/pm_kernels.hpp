@@ -233,29 +233,61 @@ __device__ __forceinline__ void quads_block(const PlaneSet& ps, int bx, int l, i
   ps.rqk[dst + 1] = gw;
 }
 
-// The planes derived from k_prep's output, in TWO launches instead of eight (each of these passes is a few microseconds
-// of work behind ~10 us of launch latency, and a Match starts with all of them in a row):
-//   stage 0: the four transposes (u8 image, f32 gradient, u8 gradient, u16 packed), the row triples and the reference
-//            quads -- all read k_prep's planes only;
-//   stage 1: the column triples, which read the transposed planes.
-// One linear grid per stage; a block finds its section and its (bx, by, bz) there from the section sizes.
+// Column triples (PlaneSet::cpg) straight from the ROW-MAJOR target planes, transposed through LDS: the same records
+// triples_block(rows_mode = 0) builds from the transposed planes (line x of the transposed plane = image column
+// min(x, cols - 1): the pad lines replicate the last column), without waiting for those planes to exist -- so every
+// derived plane of a Match comes out of ONE launch.  Block (bx, by, z): lines 32 bx .. 32 bx + 31, rows 64 by .. 64 by + 63;
+// `lds` holds 64 x 35 floats + 64 x 36 bytes.
+__device__ __forceinline__ void col_triples_tile(const PlaneSet& ps, int bx, int by, int z, void* lds) {
+  constexpr int TL = 32, TE = 64, GW = TL + 3, CW = TL + 4;
+  float(*tg)[GW] = (float(*)[GW])lds;
+  uint8_t(*tc)[CW] = (uint8_t(*)[CW])((float*)lds + TE * GW);
+  const int view = z & 1, b = z >> 1;
+  const int itgt = view == 0 ? 1 : 2;
+  const size_t tp = ((size_t)b * 4 + itgt) * ps.plane;
+  const float* g = ps.g32 + tp;
+  const uint8_t* c = ps.img8 + tp;
+  const int x0 = bx * TL, y0 = by * TE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int r = w; r < TE; r += 4) {
+    const size_t row = (size_t)min(y0 + r, ps.rows - 1) * ps.pitch;
+    if (lane < TL + 2) {
+      const int x = min(x0 + lane, ps.cols - 1);
+      tg[r][lane] = g[row + x];
+      tc[r][lane] = c[row + x];
+    }
+  }
+  __syncthreads();
+  const int e = y0 + lane;
+  float4* dst = (float4*)ps.cpg;
+  for (int xi = w; xi < TL; xi += 4) {
+    const int l = x0 + xi;
+    if (l >= ps.ncl || e >= ps.rows) continue;
+    float4 rec;
+    rec.x = tg[lane][xi];
+    rec.y = tg[lane][xi + 1];
+    rec.z = tg[lane][xi + 2];
+    rec.w = __builtin_bit_cast(float, (uint32_t)tc[lane][xi] | ((uint32_t)tc[lane][xi + 1] << 8) |
+                                          ((uint32_t)tc[lane][xi + 2] << 16));
+    dst[((size_t)z * ps.ncl + l) * ps.pitch_t + e] = rec;
+  }
+}
+
+// The planes derived from k_prep's output in ONE launch instead of nine (each of these passes is a few microseconds of
+// work behind ~10 us of launch latency, and a Match starts with all of them in a row): the four transposes (u8 image,
+// f32 gradient, u8 gradient, u16 packed), the row triples, the reference quads and the column triples -- all read
+// k_prep's planes only.  One linear grid; a block finds its section and its (bx, by, bz) there from the section sizes.
 struct SetupGrid {
   unsigned tx, ty, tz;  // transpose sections: (ceil(cols/64), ceil(rows/64), B * 4) each
   unsigned lx, ly, lz;  // row triples / quads: (ceil(cols/256), nrl, B * 2) each
-  unsigned cx, cy, cz;  // column triples: (ceil(rows/256), ncl, B * 2)
+  unsigned cx, cy, cz;  // column triples: (ceil(ncl/32), ceil(rows/64), B * 2)
   int with_lines;       // 0: transposes only (PM_SEM_GPU, plane mode, anchor engines)
   int view;             // -1: both views (tz = B * 4, lz = cz = B * 2); 0 / 1: that view's planes only (tz = B * 2, lz = cz = B)
 };
-__global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int stage) {
-  __shared__ float lds[64 * 65];
-  unsigned b = blockIdx.x;
+__device__ __forceinline__ void setup_block(const PlaneSet& ps, const SetupGrid& sg, unsigned b, float* lds) {
   // plane / slot indices of a one-view launch: planes 2 * view, 2 * view + 1 of every pair; slot = pair * 2 + view
   auto plane_of = [&](int bz) { return sg.view < 0 ? bz : (bz >> 1) * 4 + 2 * sg.view + (bz & 1); };
   auto slot_of = [&](int z) { return sg.view < 0 ? z : z * 2 + sg.view; };
-  if (stage == 1) {
-    triples_block(ps, 0, (int)(b % sg.cx), (int)((b / sg.cx) % sg.cy), slot_of((int)(b / (sg.cx * sg.cy))));
-    return;
-  }
   const unsigned nt = sg.tx * sg.ty * sg.tz;
   if (b < 4 * nt) {
     const unsigned kind = b / nt;
@@ -273,9 +305,22 @@ __global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg, int st
   }
   b -= 4 * nt;
   const unsigned nl = sg.lx * sg.ly * sg.lz;
-  const int bx = (int)(b % sg.lx), l = (int)((b / sg.lx) % sg.ly), z = slot_of((int)((b % nl) / (sg.lx * sg.ly)));
-  if (b < nl) triples_block(ps, 1, bx, l, z);
-  else quads_block(ps, bx, l, z);
+  if (b < 2 * nl) {
+    const int bx = (int)(b % sg.lx), l = (int)((b / sg.lx) % sg.ly), z = slot_of((int)((b % nl) / (sg.lx * sg.ly)));
+    if (b < nl) triples_block(ps, 1, bx, l, z);
+    else quads_block(ps, bx, l, z);
+    return;
+  }
+  b -= 2 * nl;
+  col_triples_tile(ps, (int)(b % sg.cx), (int)((b / sg.cx) % sg.cy), slot_of((int)(b / (sg.cx * sg.cy))), lds);
+}
+// blocks of a SetupGrid
+inline unsigned setup_blocks(const SetupGrid& sg) {
+  return 4 * sg.tx * sg.ty * sg.tz + (sg.with_lines ? 2 * sg.lx * sg.ly * sg.lz + sg.cx * sg.cy * sg.cz : 0);
+}
+__global__ void __launch_bounds__(256) k_setup(PlaneSet ps, SetupGrid sg) {
+  __shared__ float lds[64 * 65];
+  setup_block(ps, sg, blockIdx.x, lds);
 }
 
 // seed maps -> disparity planes; the right-view seed is mirrored like the images

@@ -11,6 +11,24 @@ namespace {
 dim3 pixel_grid(int cols, int rows, int z) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows, (unsigned)z); }
 }  // namespace
 
+static SetupGrid setup_grid(pm_handle* h, const PlaneSet& ps, int n, int view) {
+  SetupGrid sg{};
+  sg.view = view;
+  sg.tx = (unsigned)((ps.cols + 63) / 64);
+  sg.ty = (unsigned)((ps.rows + 63) / 64);
+  sg.tz = (unsigned)(n * (view < 0 ? 4 : 2));
+  sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
+  if (sg.with_lines) {
+    sg.lx = (unsigned)((ps.cols + 255) / 256);
+    sg.ly = (unsigned)ps.nrl;
+    sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
+    sg.cx = (unsigned)((ps.ncl + 31) / 32);
+    sg.cy = (unsigned)((ps.rows + 63) / 64);
+    sg.cz = (unsigned)(n * (view < 0 ? 2 : 1));
+  }
+  return sg;
+}
+
 void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
                  int view, const PrepSeedMaps* seeds) {
   if (h->bgr) {
@@ -30,33 +48,17 @@ void launch_prep_view(pm_handle* h, const PlaneSet& ps, const float* d_iml, cons
                      stride);
 }
 
+
 int run_transpose(pm_handle* h, const PlaneSet& ps, int n, int view) {
-  SetupGrid sg{};
-  sg.view = view;
-  sg.tx = (unsigned)((ps.cols + 63) / 64);
-  sg.ty = (unsigned)((ps.rows + 63) / 64);
-  sg.tz = (unsigned)(n * (view < 0 ? 4 : 2));
-  sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
+  const SetupGrid sg = setup_grid(h, ps, n, view);
   PlaneSet pp = ps;
-  unsigned blocks0 = 4 * sg.tx * sg.ty * sg.tz;
-  if (sg.with_lines) {
-    if (!pp.rpg) {  // (a plane set made before the line planes existed; pm_create allocates them for the handles that use them)
-      if (int rc = pair_planes_alloc(h)) return rc;
-      pp.rpg = h->rpg;
-      pp.rqk = h->rqk;
-      pp.cpg = h->cpg;
-    }
-    sg.lx = (unsigned)((ps.cols + 255) / 256);
-    sg.ly = (unsigned)ps.nrl;
-    sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
-    sg.cx = (unsigned)((ps.rows + 255) / 256);
-    sg.cy = (unsigned)ps.ncl;
-    sg.cz = (unsigned)(n * (view < 0 ? 2 : 1));
-    blocks0 += 2 * sg.lx * sg.ly * sg.lz;
+  if (sg.with_lines && !pp.rpg) {  // (a plane set made before the line planes existed; pm_create allocates them for the handles that use them)
+    if (int rc = pair_planes_alloc(h)) return rc;
+    pp.rpg = h->rpg;
+    pp.rqk = h->rqk;
+    pp.cpg = h->cpg;
   }
-  hipLaunchKernelGGL(k_setup, dim3(blocks0), dim3(256), 0, h->stream, pp, sg, 0);
-  if (sg.with_lines)
-    hipLaunchKernelGGL(k_setup, dim3(sg.cx * sg.cy * sg.cz), dim3(256), 0, h->stream, pp, sg, 1);
+  hipLaunchKernelGGL(k_setup, dim3(setup_blocks(sg)), dim3(256), 0, h->stream, pp, sg);
   return launch_check(h, "transpose");
 }
 
@@ -81,19 +83,22 @@ void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
   const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
   const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
                    (unsigned)slots);
-  if (tiled && cp.pw == 3) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<3, 3>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 5) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<5, 5>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 7) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<7, 7>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 9) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<9, 9>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else if (tiled && cp.pw == 11) {
-    hipLaunchKernelGGL((k_noise_cost_tiled<11, 11>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);
-  } else {
-    hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, amount);
+#define PM_NC_CASE(W)                                                                                                 \
+  case W:                                                                                                             \
+    hipLaunchKernelGGL((k_noise_cost_tiled<W, W>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);    \
+    return;
+  if (tiled) {
+    switch (cp.pw) {
+      PM_NC_CASE(3)
+      PM_NC_CASE(5)
+      PM_NC_CASE(7)
+      PM_NC_CASE(9)
+      PM_NC_CASE(11)
+      default: break;
+    }
   }
+#undef PM_NC_CASE
+  hipLaunchKernelGGL(k_noise_cost, pixel_grid(ps.cols, ps.rows, slots), dim3(256), 0, h->stream, ps, cp, in, amount);
 }
 
 // RemoveBackground / MaskBackground; PM_SEM_CPU square windows use the LDS-tiled kernel
