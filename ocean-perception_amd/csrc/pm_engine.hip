@@ -384,6 +384,7 @@ int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSet
       rc = PM_ERR_HIP;
       break;
     }
+    if (vstream[v] != main_stream) prof_break(h, vstream[v]);
     h->stream = vstream[v];
     if (setup) {
       {
@@ -410,6 +411,7 @@ int lanes_join(pm_handle* h, int n_lanes) {
     for (int v = 0; v < 2; ++v) {
       PM_HIP(h, hipEventRecord(h->lanes[l].view_join[v], h->lanes[l].view_stream[v]));
       PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[l].view_join[v], 0));
+      prof_break(h, h->stream);
     }
   return PM_OK;
 }
@@ -430,6 +432,7 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
   if (!on_main) return lanes_join(h, 1);
   PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));
   PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[1], 0));
+  prof_break(h, h->stream);
   return PM_OK;
 }
 
@@ -589,6 +592,7 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
   }
   if (int rc = check_size(h, rows, cols, n)) return rc;
   PM_HIP(h, hipSetDevice(h->device));
+  prof_break_all(h);  // whatever sits between two calls on the streams is not a kernel's time
   const int n_views = h->params.left_right_check ? 2 : 1;
   if (n_views == 2 && !d_disp_r) {
     set_err(h, "pm_match_device: disp_r required when left_right_check is set");
@@ -938,6 +942,7 @@ int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, c
     return PM_ERR_INVALID_ARG;
   }
   PM_HIP(h, hipSetDevice(h->device));
+  prof_break_all(h);
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   hipStream_t user = (hipStream_t)stream;
   const bool foreign = user != nullptr && user != h->stream;
@@ -1031,6 +1036,7 @@ int pm_profile_enable(pm_handle* h, int on) {
   if (on)
     if (int rc = refuse_while_capturing(h, "pm_profile_enable")) return rc;  // events would be recorded into the graph
   h->profiling = on != 0;
+  prof_break_all(h);
   return PM_OK;
 }
 
@@ -1042,11 +1048,13 @@ int pm_profile_read(pm_handle* h, pm_profile* out) {
   for (int i = 0; i < h->ev_used; ++i) {
     float ms = 0.f;
     const EventRec& r = h->ev_pool[i];
-    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+    const hipEvent_t start = r.start_ref >= 0 ? h->ev_pool[r.start_ref].stop : r.start;
+    if (hipEventElapsedTime(&ms, start, r.stop) == hipSuccess) {
       h->prof.launches[r.klass] += 1;
       h->prof.total_ms[r.klass] += (double)ms;
     }
   }
+  prof_break_all(h);
   h->ev_used = 0;
   *out = h->prof;
   std::memset(&h->prof, 0, sizeof(h->prof));

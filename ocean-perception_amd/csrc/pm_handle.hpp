@@ -32,6 +32,7 @@ constexpr int kMaxEvents = 16384;  // event pairs kept before a forced drain
 struct EventRec {
   hipEvent_t start, stop;
   int klass;
+  int start_ref;  // >= 0: the stop event of that record is this one's start (the launch before it on the same stream)
 };
 
 }  // namespace eng
@@ -128,6 +129,13 @@ struct pm_handle {
   bool profiling = false;
   std::vector<pm::eng::EventRec> ev_pool;
   int ev_used = 0;
+  static constexpr int kProfTails = 16;
+  struct ProfTail {
+    hipStream_t stream;
+    int rec;
+  };
+  ProfTail prof_tail[kProfTails];  // per stream: the last bracket, whose stop event can start the next (pm::eng::Launch)
+  int n_prof_tail = 0;
   pm_profile prof{};
 
   char err[512] = {0};
@@ -150,32 +158,59 @@ void set_err(pm_handle* h, const char* fmt, ...) __attribute__((format(printf, 2
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // Brackets the launches of one kernel class with a pair of events while the handle is profiling.
+// While the handle is profiling, the launches of one kernel class are bracketed by events on the current stream.  An
+// in-stream event before a launch fires when the launch in front of it has finished: the stop event of the previous
+// bracket on the same stream IS the start of the next one, so a chain of launches costs one event per launch, not two
+// (each record is a serialising packet in the queue: with two per launch a profiled Match ran 7 % longer).  prof_break()
+// ends a chain where something else was put on the stream (an event wait, the boundary of an API call).
+inline void prof_break(pm_handle* h, hipStream_t stream) {
+  for (int i = 0; i < h->n_prof_tail; ++i)
+    if (h->prof_tail[i].stream == stream) {
+      h->prof_tail[i] = h->prof_tail[--h->n_prof_tail];
+      return;
+    }
+}
+inline void prof_break_all(pm_handle* h) { h->n_prof_tail = 0; }
+
 struct Launch {
   pm_handle* h;
   int klass;
   bool timed;
-  EventRec* rec = nullptr;
+  int rec = -1;
   Launch(pm_handle* h_, int k) : h(h_), klass(k), timed(h_->profiling) {
     if (!timed) return;
     if (h->ev_used == (int)h->ev_pool.size()) {
       if ((int)h->ev_pool.size() >= kMaxEvents) {
         timed = false;  // drained by pm_profile_read; never block inside a launch path
+        prof_break(h, h->stream);
         return;
       }
       EventRec r;
       r.klass = k;
+      r.start_ref = -1;
       if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
         timed = false;
         return;
       }
       h->ev_pool.push_back(r);
     }
-    rec = &h->ev_pool[h->ev_used++];
-    rec->klass = k;
-    (void)hipEventRecord(rec->start, h->stream);
+    rec = h->ev_used++;
+    EventRec& r = h->ev_pool[rec];
+    r.klass = k;
+    r.start_ref = -1;
+    for (int i = 0; i < h->n_prof_tail; ++i)
+      if (h->prof_tail[i].stream == h->stream) r.start_ref = h->prof_tail[i].rec;
+    if (r.start_ref < 0) (void)hipEventRecord(r.start, h->stream);
   }
   ~Launch() {
-    if (timed && rec) (void)hipEventRecord(rec->stop, h->stream);
+    if (!timed || rec < 0) return;
+    (void)hipEventRecord(h->ev_pool[rec].stop, h->stream);
+    for (int i = 0; i < h->n_prof_tail; ++i)
+      if (h->prof_tail[i].stream == h->stream) {
+        h->prof_tail[i].rec = rec;
+        return;
+      }
+    if (h->n_prof_tail < pm_handle::kProfTails) h->prof_tail[h->n_prof_tail++] = {h->stream, rec};
   }
 };
 

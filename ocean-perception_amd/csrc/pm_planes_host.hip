@@ -172,6 +172,7 @@ int planes_check(pm_handle* h, const char* what, bool need_begin) {
     return PM_ERR_INVALID_ARG;
   }
   PM_HIP(h, hipSetDevice(h->device));
+  prof_break_all(h);  // (profiling brackets do not chain across API calls)
   return PM_OK;
 }
 
