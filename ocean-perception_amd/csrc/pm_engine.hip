@@ -209,9 +209,14 @@ int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
 // SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
 // mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
 int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch) {
-  if (scratch == 1 && !h->seed2.eig)
-    if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
-  SeedScratch& sc = scratch == 1 ? h->seed2 : h->seed;
+  SeedScratch& sc = h->seeds[scratch];
+  if (!sc.eig) {
+    if (h->capturing) {
+      set_err(h, "the seeder scratch of this lane does not exist yet: run this call once before capturing it");
+      return PM_ERR_BUSY;
+    }
+    if (int rc = alloc_seed_scratch(h, sc)) return rc;
+  }
   const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
   const uint8_t* tgt = ps.img8 + ((size_t)b * 4 + (view == 0 ? 1 : 2)) * ps.plane;
   float* out = ps.disp + ((size_t)b * 2 + view) * ps.plane;
@@ -356,6 +361,8 @@ struct ViewSetup {
   int n;
 };
 
+}  // namespace
+
 int lanes_create(pm_handle* h, int n_lanes) {
   if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
   for (int l = 0; l < n_lanes; ++l)
@@ -367,6 +374,8 @@ int lanes_create(pm_handle* h, int n_lanes) {
     }
   return PM_OK;
 }
+
+namespace {
 
 // Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
 // (recorded by the caller on the main stream).  Enqueue only; the caller joins.
@@ -398,7 +407,7 @@ int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSet
         rc = run_transpose(h, ps, setup->n, v);
       }
     }
-    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, v);
+    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, lane * 2 + v);
     h->stream = main_stream;
   }
   if (rc == PM_OK) rc = run_view_sets(h, pv, vstream, 2, slots / 2);
@@ -416,24 +425,29 @@ int lanes_join(pm_handle* h, int n_lanes) {
   return PM_OK;
 }
 
-int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
+int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr, int lane = 0) {
   if (ps.n_views != 2 || !view_streams_enabled()) {
     for (int v = 0; v < ps.n_views; ++v)
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
     return run_one_view_set(h, ps, slots);
   }
-  if (int rc = lanes_create(h, 1)) return rc;
+  if (int rc = lanes_create(h, lane + 1)) return rc;
   static const bool on_main = [] {
     const char* e = getenv("PM_VIEW0_ON_MAIN");
     return e ? atoi(e) != 0 : true;
   }();
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  if (int rc = run_views_on_lane(h, ps, slots, setup, 0, on_main)) return rc;
-  if (!on_main) return lanes_join(h, 1);
-  PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));
-  PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[1], 0));
-  prof_break(h, h->stream);
-  return PM_OK;
+  if (lane > 0 || on_main) {
+    // the first view stays on the caller's stream, only the second forks off: one fork / join pair less per Match
+    // (a cross-queue signal costs 20-26 us, tools/trace_gaps.py)
+    if (int rc = run_views_on_lane(h, ps, slots, setup, lane, true)) return rc;
+    PM_HIP(h, hipEventRecord(h->lanes[lane].view_join[1], h->lanes[lane].view_stream[1]));
+    PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[lane].view_join[1], 0));
+    prof_break(h, h->stream);
+    return PM_OK;
+  }
+  if (int rc = run_views_on_lane(h, ps, slots, setup, 0, false)) return rc;
+  return lanes_join(h, 1);
 }
 
 // The plane set of pair b alone (every per-pair array advanced to that pair; see make_view for the strides).
@@ -584,8 +598,13 @@ int refuse_while_capturing(pm_handle* h, const char* what) {
   return PM_ERR_BUSY;
 }
 
+bool pipe_lanes_usable(const pm_handle* h) {
+  return h->params.mode == PM_MODE_SCALAR && h->params.left_right_check && view_streams_enabled() && !h->bgr;
+}
+
 int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                             const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, int lane,
+                      int pair_base) {
   if (!d_left || !d_right || !d_disp_l) {
     set_err(h, "pm_match_device: null image or output pointer");
     return PM_ERR_INVALID_ARG;
@@ -602,18 +621,27 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
     return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   PlaneSet ps = plane_set(h, rows, cols, n_views);
+  if (lane > 0) {
+    // a frame of the submit / collect pipeline: the planes of pair `pair_base`, the streams of lane `lane` (h->stream
+    // is that lane's first stream for the duration of this call, pm_hostpath.hip)
+    ps = plane_set_of_pair(ps, pair_base);
+  } else if (h->pipe_count > 0 && !h->pipe.empty()) {
+    // frames of the pipeline may be running on their lanes, on planes this call is about to use
+    for (const auto& sl : h->pipe)
+      if (sl.compute_done) PM_HIP(h, hipStreamWaitEvent(h->stream, sl.compute_done, 0));
+  }
   // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
   // the two views' seeders overlap on their own streams)
   h->need_seed[0] = h->params.sparse_init && !d_seed_l;
   h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
   // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
   const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
-  if (per_view_setup && n > pair_chunk() && pair_lanes() > 1 && !h->need_seed[0] && !h->need_seed[1]) {
+  if (per_view_setup && n > pair_chunk() && pair_lanes() > 1) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
     if (int rc = run_pairs_on_lanes(h, ps, n, vs)) return rc;
   } else if (per_view_setup) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
-    if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
+    if (int rc = run_views(h, ps, n * n_views, &vs, lane)) return rc;
   } else {
     {
       Launch l(h, PM_K_PREP);
@@ -731,8 +759,7 @@ void pm_destroy(pm_handle* h) {
                  h->tg32,    h->tg8,      h->pk16,      h->tpk16,     h->disp,      h->cost,      h->noise,
                  h->counters, h->st_left, h->st_right,  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r,
                  h->snap_disp, h->snap_cost, h->planes_state};
-  seed_scratch_free(h->seed);
-  seed_scratch_free(h->seed2);
+  for (auto& sc : h->seeds) seed_scratch_free(sc);
   for (void* p : dev)
     if (p) (void)hipFree(p);
   delete h->copy_pool;
@@ -744,6 +771,7 @@ void pm_destroy(pm_handle* h) {
       if (ln.view_stream[v]) (void)hipStreamDestroy(ln.view_stream[v]);
     }
   if (h->view_fork) (void)hipEventDestroy(h->view_fork);
+  if (h->pipe_order) (void)hipEventDestroy(h->pipe_order);
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   for (auto& sl : h->pipe) {
@@ -824,7 +852,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   h->noise_capacity = plane;
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 16));  // [8..13]: timing builds only
   PM_HIP(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 16, h->stream));
-  if (int rc = alloc_seed_scratch(h, h->seed)) return rc;
+  if (int rc = alloc_seed_scratch(h, h->seeds[0])) return rc;
   if (params->mode == PM_MODE_PLANES)
     if (int rc = planes_alloc(h)) return rc;
   const size_t tight = (size_t)max_rows * max_cols;
@@ -878,8 +906,12 @@ int pm_capture_begin(pm_handle* h) {
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   // lazily created resources must exist before the capture starts (creating them is not capturable)
-  if (h->params.sparse_init && !h->seed2.eig)
-    if (int rc = alloc_seed_scratch(h, h->seed2)) return rc;
+  if (h->params.sparse_init) {
+    const int sets = h->max_batch > pair_chunk() ? 2 * (pair_lanes() > 1 ? pair_lanes() : 1) : 2;
+    for (int i = 1; i < sets; ++i)
+      if (!h->seeds[i].eig)
+        if (int rc = alloc_seed_scratch(h, h->seeds[i])) return rc;
+  }
   PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   h->capturing = true;
   return PM_OK;

@@ -168,6 +168,16 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
 
 namespace {
 
+// lanes the frames of the pipeline rotate over (PM_PIPE_LANES, read once; 0: every frame on the handle's stream)
+int pipe_lanes() {
+  static const int v = [] {
+    const char* e = getenv("PM_PIPE_LANES");
+    const int x = e ? atoi(e) : 3;
+    return x < 0 ? 0 : (x > pm_handle::kLanes - 1 ? pm_handle::kLanes - 1 : x);
+  }();
+  return v;
+}
+
 int pipe_init(pm_handle* h) {
   if (!h->pipe.empty()) return PM_OK;
   PM_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
@@ -254,11 +264,34 @@ int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
   if (seed_l) PM_HIP(h, hipMemcpyAsync(dsl, ps.sl, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
   if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
   PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
-  PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
-  if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
-                               lr ? ddr : nullptr))
-    return rc;
-  PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
+  // The frames in flight do not share a stream: frame k computes on lane 1 + k % pipe_lanes() -- that lane's two view
+  // streams, the planes of pair `slot` -- so the head and tail of a frame run beside the sweeps of its neighbours
+  // (what a rotation over several handles gives a caller, tools/multi_handle.py, behind Submit() / Collect()).
+  const int n_pipe = pipe_lanes();
+  const bool on_lane = n_pipe > 0 && h->max_batch > 1 && pipe_lanes_usable(h);
+  const int lane = on_lane ? 1 + slot % n_pipe : 0;
+  hipStream_t compute = h->stream;
+  if (on_lane) {
+    if (int rc = lanes_create(h, lane + 1)) return rc;
+    compute = h->lanes[lane].view_stream[0];
+    // whatever the handle's own stream holds (a pm_match_device on the same planes) comes first
+    if (!h->pipe_order) PM_HIP(h, hipEventCreateWithFlags(&h->pipe_order, hipEventDisableTiming));
+    PM_HIP(h, hipEventRecord(h->pipe_order, h->stream));
+    PM_HIP(h, hipStreamWaitEvent(compute, h->pipe_order, 0));
+  }
+  PM_HIP(h, hipStreamWaitEvent(compute, sl.in_done, 0));
+  {
+    struct StreamSwap {
+      pm_handle* h;
+      hipStream_t keep;
+      ~StreamSwap() { h->stream = keep; }
+    } swap{h, h->stream};
+    h->stream = compute;
+    if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
+                                   lr ? ddr : nullptr, lane, on_lane ? slot : 0))
+      return rc;
+  }
+  PM_HIP(h, hipEventRecord(sl.compute_done, compute));
   PM_HIP(h, hipStreamWaitEvent(h->s_out, sl.compute_done, 0));
   PM_HIP(h, hipMemcpyAsync(ps.dl, ddl, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
   if (lr) PM_HIP(h, hipMemcpyAsync(ps.dr, ddr, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
@@ -441,7 +474,7 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
   }
   PlaneSet ps;
   if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
-  PM_HIP(h, seed_sparse_init(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
+  PM_HIP(h, seed_sparse_init(h->seeds[0], seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
                              dilate_factor, ps.disp, ps.pitch, h->stream));
   return stage_out(h, ps, seed, 0);
 }
@@ -458,7 +491,7 @@ int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int r
   PlaneSet ps;
   if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
   const int orows = rows / downsample_factor, ocols = cols / downsample_factor;
-  PM_HIP(h, seed_initialize(h->seed, seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
+  PM_HIP(h, seed_initialize(h->seeds[0], seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
                             downsample_factor, h->st_disp_l, ocols, h->stream));
   PM_HIP(h, hipMemcpyAsync(seed, h->st_disp_l, sizeof(float) * (size_t)orows * ocols, hipMemcpyDeviceToHost, h->stream));
   PM_HIP(h, hipStreamSynchronize(h->stream));
