@@ -361,8 +361,6 @@ struct ViewSetup {
   int n;
 };
 
-}  // namespace
-
 int lanes_create(pm_handle* h, int n_lanes) {
   if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
   for (int l = 0; l < n_lanes; ++l)
@@ -374,8 +372,6 @@ int lanes_create(pm_handle* h, int n_lanes) {
     }
   return PM_OK;
 }
-
-namespace {
 
 // Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
 // (recorded by the caller on the main stream).  Enqueue only; the caller joins.
@@ -425,24 +421,24 @@ int lanes_join(pm_handle* h, int n_lanes) {
   return PM_OK;
 }
 
-int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr, int lane = 0) {
+int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
   if (ps.n_views != 2 || !view_streams_enabled()) {
     for (int v = 0; v < ps.n_views; ++v)
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
     return run_one_view_set(h, ps, slots);
   }
-  if (int rc = lanes_create(h, lane + 1)) return rc;
+  if (int rc = lanes_create(h, 1)) return rc;
   static const bool on_main = [] {
     const char* e = getenv("PM_VIEW0_ON_MAIN");
     return e ? atoi(e) != 0 : true;
   }();
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  if (lane > 0 || on_main) {
+  if (on_main) {
     // the first view stays on the caller's stream, only the second forks off: one fork / join pair less per Match
     // (a cross-queue signal costs 20-26 us, tools/trace_gaps.py)
-    if (int rc = run_views_on_lane(h, ps, slots, setup, lane, true)) return rc;
-    PM_HIP(h, hipEventRecord(h->lanes[lane].view_join[1], h->lanes[lane].view_stream[1]));
-    PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[lane].view_join[1], 0));
+    if (int rc = run_views_on_lane(h, ps, slots, setup, 0, true)) return rc;
+    PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));
+    PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[1], 0));
     prof_break(h, h->stream);
     return PM_OK;
   }
@@ -598,13 +594,8 @@ int refuse_while_capturing(pm_handle* h, const char* what) {
   return PM_ERR_BUSY;
 }
 
-bool pipe_lanes_usable(const pm_handle* h) {
-  return h->params.mode == PM_MODE_SCALAR && h->params.left_right_check && view_streams_enabled() && !h->bgr;
-}
-
 int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, int lane,
-                      int pair_base) {
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
   if (!d_left || !d_right || !d_disp_l) {
     set_err(h, "pm_match_device: null image or output pointer");
     return PM_ERR_INVALID_ARG;
@@ -621,15 +612,6 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
     return planes_match(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   PlaneSet ps = plane_set(h, rows, cols, n_views);
-  if (lane > 0) {
-    // a frame of the submit / collect pipeline: the planes of pair `pair_base`, the streams of lane `lane` (h->stream
-    // is that lane's first stream for the duration of this call, pm_hostpath.hip)
-    ps = plane_set_of_pair(ps, pair_base);
-  } else if (h->pipe_count > 0 && !h->pipe.empty()) {
-    // frames of the pipeline may be running on their lanes, on planes this call is about to use
-    for (const auto& sl : h->pipe)
-      if (sl.compute_done) PM_HIP(h, hipStreamWaitEvent(h->stream, sl.compute_done, 0));
-  }
   // a missing seed map is computed on the device, as the reference's Match() does (inside run_views, so that
   // the two views' seeders overlap on their own streams)
   h->need_seed[0] = h->params.sparse_init && !d_seed_l;
@@ -641,7 +623,7 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
     if (int rc = run_pairs_on_lanes(h, ps, n, vs)) return rc;
   } else if (per_view_setup) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
-    if (int rc = run_views(h, ps, n * n_views, &vs, lane)) return rc;
+    if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
   } else {
     {
       Launch l(h, PM_K_PREP);
@@ -771,7 +753,6 @@ void pm_destroy(pm_handle* h) {
       if (ln.view_stream[v]) (void)hipStreamDestroy(ln.view_stream[v]);
     }
   if (h->view_fork) (void)hipEventDestroy(h->view_fork);
-  if (h->pipe_order) (void)hipEventDestroy(h->pipe_order);
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);
   for (auto& sl : h->pipe) {

@@ -112,7 +112,6 @@ struct pm_handle {
   };
   ViewLane lanes[kLanes];
   hipEvent_t view_fork = nullptr;
-  hipEvent_t pipe_order = nullptr;  // pm_submit_u8: the handle's stream -> a frame's lane
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
@@ -230,13 +229,8 @@ int refuse_while_capturing(pm_handle* h, const char* what);
 bool pair_planes_wanted(const pm_handle* h);
 int pair_planes_alloc(pm_handle* h);
 int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots);
-// lane > 0: one pair of the submit / collect pipeline on the planes of pair `pair_base` and the streams of that lane
-// (the caller has made h->stream that lane's first stream); lane 0: the handle's stream, pairs 0 .. n - 1
 int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
-                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, int lane = 0,
-                      int pair_base = 0);
-bool pipe_lanes_usable(const pm_handle* h);  // frames of the pipeline can run on lanes of their own (scalar mode, two views)
-int lanes_create(pm_handle* h, int n_lanes);
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
 SeedParams seed_params(const pm_params& p);
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc);
 // SparseInit (or Patchmatch::Initialize(.., 1)) for view `view` of pair `b` straight into its disparity plane

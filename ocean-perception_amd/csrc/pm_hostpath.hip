@@ -168,16 +168,6 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
 
 namespace {
 
-// lanes the frames of the pipeline rotate over (PM_PIPE_LANES, read once; 0: every frame on the handle's stream)
-int pipe_lanes() {
-  static const int v = [] {
-    const char* e = getenv("PM_PIPE_LANES");
-    const int x = e ? atoi(e) : 3;
-    return x < 0 ? 0 : (x > pm_handle::kLanes - 1 ? pm_handle::kLanes - 1 : x);
-  }();
-  return v;
-}
-
 int pipe_init(pm_handle* h) {
   if (!h->pipe.empty()) return PM_OK;
   PM_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
@@ -264,34 +254,13 @@ int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int ro
   if (seed_l) PM_HIP(h, hipMemcpyAsync(dsl, ps.sl, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
   if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
   PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
-  // The frames in flight do not share a stream: frame k computes on lane 1 + k % pipe_lanes() -- that lane's two view
-  // streams, the planes of pair `slot` -- so the head and tail of a frame run beside the sweeps of its neighbours
-  // (what a rotation over several handles gives a caller, tools/multi_handle.py, behind Submit() / Collect()).
-  const int n_pipe = pipe_lanes();
-  const bool on_lane = n_pipe > 0 && h->max_batch > 1 && pipe_lanes_usable(h);
-  const int lane = on_lane ? 1 + slot % n_pipe : 0;
-  hipStream_t compute = h->stream;
-  if (on_lane) {
-    if (int rc = lanes_create(h, lane + 1)) return rc;
-    compute = h->lanes[lane].view_stream[0];
-    // whatever the handle's own stream holds (a pm_match_device on the same planes) comes first
-    if (!h->pipe_order) PM_HIP(h, hipEventCreateWithFlags(&h->pipe_order, hipEventDisableTiming));
-    PM_HIP(h, hipEventRecord(h->pipe_order, h->stream));
-    PM_HIP(h, hipStreamWaitEvent(compute, h->pipe_order, 0));
-  }
-  PM_HIP(h, hipStreamWaitEvent(compute, sl.in_done, 0));
-  {
-    struct StreamSwap {
-      pm_handle* h;
-      hipStream_t keep;
-      ~StreamSwap() { h->stream = keep; }
-    } swap{h, h->stream};
-    h->stream = compute;
-    if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
-                                   lr ? ddr : nullptr, lane, on_lane ? slot : 0))
-      return rc;
-  }
-  PM_HIP(h, hipEventRecord(sl.compute_done, compute));
+  // Every frame computes on the handle's stream.  (Frames on lanes of their own -- what helps device-resident callers,
+  // tools/multi_handle.py -- lose here: 368 -> 350 pairs/s with one to three lanes, tools/pipe_timing.py.)
+  PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
+  if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
+                               lr ? ddr : nullptr))
+    return rc;
+  PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
   PM_HIP(h, hipStreamWaitEvent(h->s_out, sl.compute_done, 0));
   PM_HIP(h, hipMemcpyAsync(ps.dl, ddl, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
   if (lr) PM_HIP(h, hipMemcpyAsync(ps.dr, ddr, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));

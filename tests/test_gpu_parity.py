@@ -262,6 +262,32 @@ def test_batch_pipelines_on_lanes_equal_singles(pm, oracle, synth, sem, patch):
     assert_same(singles[1][4][1], er, "right")
 
 
+@pytest.mark.parametrize("sem", SEMS)
+def test_self_seeded_batch_on_lanes_equals_singles(pm, oracle, synth, sem):
+    """sparse_init with no seed maps: every pipeline of a batch seeds its views on the device, with the seeder scratch of
+    its own lane and view (pm_handle::seeds) -- lanes run side by side."""
+    torch = pytest.importorskip("torch")
+    rows, cols, nb = 96, 160, 5
+    dev = torch.device("cuda:0")
+    prs = [small_pair(synth, 500 + i, rows, cols, n_points=25, dilate_factor=2) for i in range(nb)]
+    L = torch.from_numpy(np.stack([p[0] for p in prs])).to(dev).contiguous()
+    R = torch.from_numpy(np.stack([p[1] for p in prs])).to(dev).contiguous()
+    DL = torch.empty((nb, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    kw = dict(sparse_init=1, max_features_per_frame=60, min_distance_btw_features=8, max_disp=48, templ_cols=15,
+              templ_rows=7)
+    with mk(pm, sem, patch=3, iters=2, rows=rows, cols=cols, **kw) as e:
+        singles = [e.match(p[0], p[1], None, None) for p in prs]
+    assert any((s[0] > 0).any() for s in singles), "the seeder found nothing: the test would compare zeros"
+    with mk(pm, sem, patch=3, iters=2, rows=rows, cols=cols, batch=nb, **kw) as e:
+        for rep in range(2):
+            e.match_device(nb, L.data_ptr(), R.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+            e.synchronize()
+            for i in range(nb):
+                assert_same(DL[i].cpu().numpy(), singles[i][0], f"call {rep}, slot {i}, left")
+                assert_same(DR[i].cpu().numpy(), singles[i][1], f"call {rep}, slot {i}, right")
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("depth", [1, 3])
 def test_pipelined_sequence_equals_single_matches(pm, oracle, synth, depth):
