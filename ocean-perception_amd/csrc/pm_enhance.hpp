@@ -21,22 +21,37 @@ namespace pm {
 
 __device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Several images of one size through one launch (blockIdx.z = image).
+constexpr int kBlurBatch = 8;
+struct BlurBatch {
+  const void* src[kBlurBatch];  // 8-bit or float source images
+  float* dst[kBlurBatch];
+  float* tmp;                   // row-pass output: image z at tmp + z * tmp_stride
+  size_t tmp_stride;
+};
+
 // ---- row pass: dst[y][x][q] = sum_t k[t] * src[y][clamp(x - c + t)][q], t = 0 .. ksize-1 in order -------------
 // SRC_U8: the source is the 8-bit image, cast like CastImage3bTo3f (x * (float)(1/255.)).
 // One thread per FOUR consecutive pixels: every window sample is read from LDS once and feeds four outputs with
 // four different taps (register blocking: the first version, one pixel per thread, was LDS-bandwidth bound --
 // 3 x 427 reads per pixel).  Each output still adds its taps in ascending order, so the result is unchanged.
-// LDS is planar per channel with one pad word every 32 (lane stride 4 would hit 8 banks only).
-// grid = (ceil(cols / 512), rows), block = 128, dynamic LDS = (CH * (skew(512 + ksize - 1) + 1) + ksize) floats.
+// LDS is planar per channel with one pad word after every FOUR samples (index p + p / 4): a thread's four pixels start
+// at 4 * lane, i.e. at word 5 * lane -- an odd lane stride, conflict-free -- and window sample u = 4 k + m of a thread
+// lies at its base + 5 k + m: the tap loop advances one pointer per four taps and addresses the samples by immediate
+// offsets.  (The first layout, a pad word every 32, cost an address computation per tap: 17 vector instructions per
+// tap against the 12 packed multiplies and adds that do the work.)
+// grid = (ceil(cols / 512), rows, images), block = 128, dynamic LDS = (CH * (pad(512 + ksize - 1) + 1) + ksize) floats.
 constexpr int kBlurRowThreads = 128;
 constexpr int kBlurRowPx = 4 * kBlurRowThreads;
-__host__ __device__ inline int blur_skew(int p) { return p + (p >> 5); }
+__host__ __device__ inline int blur_skew(int p) { return p + (p >> 2); }
 template <bool SRC_U8, int CH>
-__global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __restrict__ src, int rows, int cols,
-                                                               int ksize, const float* __restrict__ taps,
-                                                               float* __restrict__ dst) {
+__global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(BlurBatch bb, int rows, int cols, int ksize,
+                                                               const float* __restrict__ taps) {
   extern __shared__ float lds[];
+  const void* __restrict__ src = bb.src[blockIdx.z];
+  float* __restrict__ dst = bb.tmp + (size_t)blockIdx.z * bb.tmp_stride;
   constexpr int R = 4;
+  typedef float f2 __attribute__((ext_vector_type(2)));
   const int y = blockIdx.y, x0 = blockIdx.x * kBlurRowPx, c = ksize / 2;
   const int span = kBlurRowPx + ksize - 1;
   const int plane = blur_skew(span) + 1;
@@ -52,15 +67,15 @@ __global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __res
   __syncthreads();
   const int p0 = threadIdx.x * R;  // first output pixel of this thread, relative to x0
   if (x0 + p0 >= cols) return;
+  const float* base = lds + 5 * threadIdx.x;  // = lds + blur_skew(p0); sample u at base[u + (u >> 2)]
   float s[R][CH];
   // window position u (sample x0 - c + p0 + u) contributes tap j = u - r to output r.
   // prologue u < R: the first taps of outputs 0 .. u (the sum starts WITH k[0] * w, it is not added to 0)
 #pragma unroll
   for (int u = 0; u < R; ++u) {
-    const int sp = blur_skew(p0 + u);
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-      const float w = lds[q * plane + sp];
+      const float w = base[q * plane + u];
 #pragma unroll
       for (int r = 0; r <= u; ++r) {
         const float prod = s_k[u - r] * w;
@@ -69,45 +84,52 @@ __global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __res
     }
   }
   // main part: every output has a tap at this position.  Outputs are paired (0,1) and (2,3): packed-f32
-  // multiply and add, the same two IEEE operations per tap as the scalar form.
-  {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 a[2][CH];
+  // multiply and add, the same two IEEE operations per tap as the scalar form.  The taps are uniform: they come
+  // through the scalar unit (s_load), not from LDS.
+  f2 a[2][CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    a[0][q] = (f2){s[0][q], s[1][q]};
+    a[1][q] = (f2){s[2][q], s[3][q]};
+  }
+  auto tap = [&](const float* g, int m, int u) {  // sample u = 4 k + m at g[m], g = base + 5 k
+    const f2 k01 = {taps[u], taps[u - 1]}, k23 = {taps[u - 2], taps[u - 3]};
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-      a[0][q] = (f2){s[0][q], s[1][q]};
-      a[1][q] = (f2){s[2][q], s[3][q]};
+      const float w = g[q * plane + m];
+      const f2 ww = {w, w};
+      a[0][q] = a[0][q] + k01 * ww;
+      a[1][q] = a[1][q] + k23 * ww;
     }
-#pragma unroll 2
-    for (int u = R; u < ksize; ++u) {
-      const int sp = blur_skew(p0 + u);
-      const f2 k01 = {s_k[u], s_k[u - 1]}, k23 = {s_k[u - 2], s_k[u - 3]};
+  };
+  int u = R;
+  const float* g = base + 5;  // group k = 1
+  for (; u + 3 < ksize; u += 4, g += 5) {
+    tap(g, 0, u);
+    tap(g, 1, u + 1);
+    tap(g, 2, u + 2);
+    tap(g, 3, u + 3);
+  }
+  if (u < ksize) tap(g, 0, u);
+  if (u + 1 < ksize) tap(g, 1, u + 1);
+  if (u + 2 < ksize) tap(g, 2, u + 2);
 #pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const float w = lds[q * plane + sp];
-        const f2 ww = {w, w};
-        a[0][q] = a[0][q] + k01 * ww;
-        a[1][q] = a[1][q] + k23 * ww;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      s[0][q] = a[0][q].x;
-      s[1][q] = a[0][q].y;
-      s[2][q] = a[1][q].x;
-      s[3][q] = a[1][q].y;
-    }
+  for (int q = 0; q < CH; ++q) {
+    s[0][q] = a[0][q].x;
+    s[1][q] = a[0][q].y;
+    s[2][q] = a[1][q].x;
+    s[3][q] = a[1][q].y;
   }
   // epilogue: the last taps of outputs 1 .. R-1
 #pragma unroll
   for (int v = 0; v < R - 1; ++v) {
-    const int u = ksize + v;
-    const int sp = blur_skew(p0 + u);
+    const int ue = ksize + v;
+    const int sp = ue + (ue >> 2);
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-      const float w = lds[q * plane + sp];
+      const float w = base[q * plane + sp];
 #pragma unroll
-      for (int r = v + 1; r < R; ++r) s[r][q] = s[r][q] + s_k[u - r] * w;
+      for (int r = v + 1; r < R; ++r) s[r][q] = s[r][q] + s_k[ue - r] * w;
     }
   }
 #pragma unroll
@@ -124,32 +146,38 @@ __global__ void __launch_bounds__(kBlurRowThreads) k_blur_rows(const void* __res
 // the kernel writes orig / (2 * s) (0 where the divisor is 0), orig being the 8-bit (cast) or float source image.
 // A thread owns TWO adjacent columns (packed-f32 adds and multiplies: the same IEEE operations, two per
 // instruction) and walks its share of the tile's T output rows.
-// grid = (ceil(width / W), ceil(rows / T)), block = 256, dynamic LDS = ((T + 2c + 3) * W + c + 1) floats, W even.
+// grid = (ceil(width / W), ceil(rows / T), images), block = 128 or 256, dynamic LDS = ((T + 2c + 3) * (W + 2) + c + 1)
+// floats, W a power of two.  T = (threads / (W / 2)) * 4: every thread has exactly one group of four rows (a tile of 66 rows
+// for 32 row groups left half the threads without work for the whole tap loop).
 template <bool DIVIDE, bool ORIG_U8>
-__global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp, int rows, int width, int ksize,
-                                                   const float* __restrict__ taps, int W, int T,
-                                                   const void* __restrict__ orig, float* __restrict__ dst) {
+__global__ void __launch_bounds__(256) k_blur_cols(BlurBatch bb, int rows, int width, int ksize,
+                                                   const float* __restrict__ taps, int W, int T) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   extern __shared__ float lds[];
+  const float* __restrict__ tmp = bb.tmp + (size_t)blockIdx.z * bb.tmp_stride;
+  const void* __restrict__ orig = bb.src[blockIdx.z];
+  float* __restrict__ dst = bb.dst[blockIdx.z];
   const int c = ksize / 2;
   const int x0 = blockIdx.x * W, y0 = blockIdx.y * T;
   const int span = T + 2 * c;
-  float* s_k = lds + (span + 3) * W;  // taps[c .. ksize-1], behind three spare rows (the four-row windows of the last
+  const int P = W + 2;  // row pitch: four rows apart (the row groups of a wavefront) are 4 P = 8 (mod 32) banks apart, not 0
+  const int NT = blockDim.x;
+  float* s_k = lds + (span + 3) * P;  // taps[c .. ksize-1], behind three spare rows (the four-row windows of the last
                                       // row group read up to three rows past the tile; those outputs are not stored)
   {
     // W is a power of two (8, 16 or 32): every thread keeps its column and walks down the rows -- no division per
     // element (with a run-time W the fill cost more vector instructions than the taps)
-    const int fw = threadIdx.x & (W - 1), fr = threadIdx.x / W, fstep = 256 / W;
+    const int fw = threadIdx.x & (W - 1), fr = threadIdx.x / W, fstep = NT / W;
     const int sx = min(x0 + fw, width - 1);
     for (int r = fr; r < span; r += fstep) {
       const int sy = clampi_d(y0 - c + r, 0, rows - 1);
-      lds[r * W + fw] = tmp[(size_t)sy * width + sx];
+      lds[r * P + fw] = tmp[(size_t)sy * width + sx];
     }
   }
-  for (int e = threadIdx.x; e <= c; e += 256) s_k[e] = taps[c + e];
+  for (int e = threadIdx.x; e <= c; e += NT) s_k[e] = taps[c + e];
   __syncthreads();
   const int W2 = W / 2;
-  const int w = (threadIdx.x % W2) * 2, g = threadIdx.x / W2, G = 256 / W2;
+  const int w = (threadIdx.x % W2) * 2, g = threadIdx.x / W2, G = NT / W2;
   const int x = x0 + w;
   if (x >= width) return;
   const float cast = (float)(1.0 / 255.0);
@@ -175,12 +203,12 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
   // is a compile-time constant.  Each output still adds its taps in the same order: bit-identical.
   constexpr int RB = 4;
   for (int yb = g * RB; yb < T && y0 + yb < rows; yb += G * RB) {
-    const float* col = lds + (yb + c) * W + w;  // S[y0 + yb] of this column pair
+    const float* col = lds + (yb + c) * P + w;  // S[y0 + yb] of this column pair
     const float kc = s_k[0];
     f2 acc[RB], up[RB], dn[RB];  // up[k & 3] = S[yb + k], k = j .. j + 3;  dn[k & 3] = S[yb + k], k = -j .. 3 - j
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const f2 v = *(const f2*)(col + r * W);
+      const f2 v = *(const f2*)(col + r * P);
       acc[r] = v * (f2){kc, kc};
       up[r] = v;
       dn[r] = v;
@@ -188,9 +216,9 @@ __global__ void __launch_bounds__(256) k_blur_cols(const float* __restrict__ tmp
     // before tap j: up holds S[yb + j - 1 .. yb + j + 2], dn holds S[yb - j + 1 .. yb - j + 4]
     auto tap = [&](int j, int jm) {  // jm = j & 3 as a compile-time constant at every call site
       // slide: up gains S[yb + j + 3] in place of S[yb + j - 1]; dn gains S[yb - j] in place of S[yb - j + 4]
-      up[(jm + 3) & 3] = *(const f2*)(col + (j + 3) * W);
-      dn[(4 - jm) & 3] = *(const f2*)(col - j * W);
-      const float kj = s_k[j];
+      up[(jm + 3) & 3] = *(const f2*)(col + (j + 3) * P);
+      dn[(4 - jm) & 3] = *(const f2*)(col - j * P);
+      const float kj = taps[c + j];  // uniform: a scalar load, not an LDS read
       const f2 kk = {kj, kj};
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
@@ -297,10 +325,13 @@ __device__ __forceinline__ float fused_value(const uint8_t* __restrict__ bgr8, c
   if (r > v) v = r;
   return v;
 }
+// blockIdx.y = image: bb.src / bb.dst are the 8-bit images and their blurred illuminants, image y's words at mm + 4 y
 template <int STAGE>
-__global__ void __launch_bounds__(256) k_value_minmax_fused(const uint8_t* __restrict__ bgr8, const float* __restrict__ blur,
-                                                            int rows, int cols, unsigned* mm) {
+__global__ void __launch_bounds__(256) k_value_minmax_fused(BlurBatch bb, int rows, int cols, unsigned* mm_all) {
   __shared__ float s_lo[4], s_hi[4];
+  const uint8_t* __restrict__ bgr8 = (const uint8_t*)bb.src[blockIdx.y];
+  const float* __restrict__ blur = bb.dst[blockIdx.y];
+  unsigned* mm = mm_all + 4 * blockIdx.y;
   const int dr = rows / 8, dc = cols / 8;
   float a1 = 0.f, b1 = 0.f;
   if (STAGE == 2) stretch_coeffs(mm, a1, b1);

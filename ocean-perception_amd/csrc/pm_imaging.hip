@@ -290,56 +290,97 @@ int ensure_enh_scratch(pm_handle* h, size_t values) {
   return PM_OK;
 }
 
-// separable Gaussian, replicate border; divide: dst = orig / (2 * blur) (the illuminant normalisation)
+// separable Gaussian, replicate border, of `count` <= kBlurBatch images of one size in one launch per pass; divide:
+// dst = orig / (2 * blur) (the illuminant normalisation)
 template <bool SRC_U8>
-int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, int ksize, double sigma, bool divide,
-                 float* d_dst) {
+int run_gaussian_batch(pm_handle* h, const void* const* d_src, float* const* d_dst, int count, int rows, int cols, int ch,
+                       int ksize, double sigma, bool divide) {
   if (ksize < 1 || (ksize % 2) == 0 || !(sigma > 0)) {
     set_err(h, "gaussian: ksize %d must be odd and sigma %g positive", ksize, sigma);
     return PM_ERR_INVALID_ARG;
   }
+  if (count < 1 || count > kBlurBatch) {
+    set_err(h, "gaussian: %d images in one batch (1 .. %d)", count, kBlurBatch);
+    return PM_ERR_INVALID_ARG;
+  }
   const size_t values = (size_t)rows * cols * ch;
-  if (int rc = ensure_enh_scratch(h, values)) return rc;
+  if (int rc = ensure_enh_scratch(h, values * (size_t)count)) return rc;
   if (int rc = ensure_taps(h, ksize, sigma)) return rc;
   const size_t row_lds = sizeof(float) * ((size_t)(blur_skew(kBlurRowPx + ksize - 1) + 1) * ch + ksize);
   if (row_lds > 64 * 1024) {
     set_err(h, "gaussian: kernel of %d taps x %d channels exceeds the row tile", ksize, ch);
     return PM_ERR_SIZE;
   }
-  const dim3 rgrid((unsigned)((cols + kBlurRowPx - 1) / kBlurRowPx), (unsigned)rows);
+  BlurBatch bb{};
+  for (int i = 0; i < count; ++i) {
+    bb.src[i] = d_src[i];
+    bb.dst[i] = d_dst[i];
+  }
+  bb.tmp = state_of(h)->enh_tmp;
+  bb.tmp_stride = values;
+  const dim3 rgrid((unsigned)((cols + kBlurRowPx - 1) / kBlurRowPx), (unsigned)rows, (unsigned)count);
   const float* taps = state_of(h)->enh_taps;
+  hipStream_t stream = pm_internal::stream(h);
   switch (ch) {
-    case 1: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 1>), rgrid, dim3(kBlurRowThreads), row_lds, pm_internal::stream(h), d_src, rows, cols, ksize, taps, state_of(h)->enh_tmp); break;
-    case 2: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 2>), rgrid, dim3(kBlurRowThreads), row_lds, pm_internal::stream(h), d_src, rows, cols, ksize, taps, state_of(h)->enh_tmp); break;
-    case 3: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 3>), rgrid, dim3(kBlurRowThreads), row_lds, pm_internal::stream(h), d_src, rows, cols, ksize, taps, state_of(h)->enh_tmp); break;
-    default: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 4>), rgrid, dim3(kBlurRowThreads), row_lds, pm_internal::stream(h), d_src, rows, cols, ksize, taps, state_of(h)->enh_tmp); break;
+    case 1: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 1>), rgrid, dim3(kBlurRowThreads), row_lds, stream, bb, rows, cols, ksize, taps); break;
+    case 2: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 2>), rgrid, dim3(kBlurRowThreads), row_lds, stream, bb, rows, cols, ksize, taps); break;
+    case 3: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 3>), rgrid, dim3(kBlurRowThreads), row_lds, stream, bb, rows, cols, ksize, taps); break;
+    default: hipLaunchKernelGGL((k_blur_rows<SRC_U8, 4>), rgrid, dim3(kBlurRowThreads), row_lds, stream, bb, rows, cols, ksize, taps); break;
   }
-  // column tile: W columns x T rows of outputs, ((T + 2c) x W + c + 1) floats of LDS within 64 KB; a smaller
-  // tile (32 KB) doubles the blocks per CU, which pays more than the extra halo re-reads
+  // column tile: W columns x T rows of outputs with T = (threads / (W / 2)) * 4 -- one group of four rows per thread --
+  // and ((T + 2c + 3) x (W + 2) + c + 1) floats of LDS; the widest tile that fits 48 KB (wider = better coalesced fill)
   const int c = ksize / 2;
-  int W = 0, T = 0;
-  for (size_t kb : {32, 64}) {
-    const size_t budget = kb * 1024 - sizeof(float) * (size_t)(c + 1 + 3 * 32);  // taps + three spare rows
-    W = 32;
-    while (W > 8 && (size_t)(32 + 2 * c) * W * sizeof(float) > budget) W /= 2;
-    T = (int)(budget / (sizeof(float) * W)) - 2 * c;
-    if (T > 256) T = 256;
-    if (T >= 512 / W) break;
-  }
-  if (T < 512 / W) {
-    set_err(h, "gaussian: kernel of %d taps exceeds the column tile", ksize);
-    return PM_ERR_SIZE;
+  int W = 0, T = 0, NT = 256;
+  {
+    static const int forced[3] = {[] {
+      const char* e = getenv("PM_BLUR_COL");  // "W,T,threads" (experiments)
+      int w = 0, t = 0, n = 0;
+      if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return w;
+      return 0;
+    }(), [] {
+      const char* e = getenv("PM_BLUR_COL");
+      int w = 0, t = 0, n = 0;
+      if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return t;
+      return 0;
+    }(), [] {
+      const char* e = getenv("PM_BLUR_COL");
+      int w = 0, t = 0, n = 0;
+      if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return n;
+      return 0;
+    }()};
+    auto lds_of = [&](int w, int t) { return sizeof(float) * ((size_t)(t + 2 * c + 3) * (w + 2) + c + 1); };
+    if (forced[0]) {
+      W = forced[0];
+      T = forced[1];
+      NT = forced[2];
+    } else {
+      for (int w : {32, 16, 8}) {
+        const int t = (256 / (w / 2)) * 4;
+        if (lds_of(w, t) <= 48 * 1024) {
+          W = w;
+          T = t;
+          break;
+        }
+      }
+    }
+    if (!W || lds_of(W, T) > 64 * 1024) {
+      set_err(h, "gaussian: kernel of %d taps exceeds the column tile", ksize);
+      return PM_ERR_SIZE;
+    }
   }
   const int width = cols * ch;
-  const size_t col_lds = sizeof(float) * ((size_t)(T + 2 * c + 3) * W + c + 1);
-  const dim3 cgrid((unsigned)((width + W - 1) / W), (unsigned)((rows + T - 1) / T));
+  const size_t col_lds = sizeof(float) * ((size_t)(T + 2 * c + 3) * (W + 2) + c + 1);
+  const dim3 cgrid((unsigned)((width + W - 1) / W), (unsigned)((rows + T - 1) / T), (unsigned)count);
   if (divide)
-    hipLaunchKernelGGL((k_blur_cols<true, SRC_U8>), cgrid, dim3(256), col_lds, pm_internal::stream(h), (const float*)state_of(h)->enh_tmp, rows,
-                       width, ksize, taps, W, T, d_src, d_dst);
+    hipLaunchKernelGGL((k_blur_cols<true, SRC_U8>), cgrid, dim3(NT), col_lds, stream, bb, rows, width, ksize, taps, W, T);
   else
-    hipLaunchKernelGGL((k_blur_cols<false, SRC_U8>), cgrid, dim3(256), col_lds, pm_internal::stream(h), (const float*)state_of(h)->enh_tmp,
-                       rows, width, ksize, taps, W, T, d_src, d_dst);
+    hipLaunchKernelGGL((k_blur_cols<false, SRC_U8>), cgrid, dim3(NT), col_lds, stream, bb, rows, width, ksize, taps, W, T);
   return launch_check(h, "gaussian");
+}
+template <bool SRC_U8>
+int run_gaussian(pm_handle* h, const void* d_src, int rows, int cols, int ch, int ksize, double sigma, bool divide,
+                 float* d_dst) {
+  return run_gaussian_batch<SRC_U8>(h, &d_src, &d_dst, 1, rows, cols, ch, ksize, sigma, divide);
 }
 
 // imaging::Normalize on d_q -> J and / or gray8
@@ -432,17 +473,26 @@ int pm_match_bgr_device(pm_handle* h, int n, const uint8_t* d_left_bgr8, const u
   float* blur_l = st->bgr_blur;
   float* blur_r = st->bgr_blur + values * (size_t)n;
   const size_t small = (size_t)(rows / 8) * (cols / 8);
-  for (int b = 0; b < n; ++b)
-    for (int i = 0; i < 2; ++i) {
-      const uint8_t* img = (i == 0 ? d_left_bgr8 : d_right_bgr8) + (size_t)b * values;
-      float* blur = (i == 0 ? blur_l : blur_r) + (size_t)b * values;
-      unsigned* mm = st->bgr_mm + ((size_t)b * 2 + i) * 4;
-      if (int rc = run_gaussian<true>(h, img, rows, cols, 3, ksize, sigma, false, blur)) return rc;
-      hipLaunchKernelGGL((k_value_minmax_fused<1>), reduce_grid(small), dim3(256), 0, pm_internal::stream(h), img,
-                         (const float*)blur, rows, cols, mm);
-      hipLaunchKernelGGL((k_value_minmax_fused<2>), reduce_grid(small), dim3(256), 0, pm_internal::stream(h), img,
-                         (const float*)blur, rows, cols, mm);
+  // image z = b * 2 + i (pair b, left / right); up to kBlurBatch images per launch of each pass
+  for (int z0 = 0; z0 < 2 * n; z0 += kBlurBatch) {
+    const int count = 2 * n - z0 < kBlurBatch ? 2 * n - z0 : kBlurBatch;
+    const void* srcs[kBlurBatch];
+    float* dsts[kBlurBatch];
+    BlurBatch bb{};
+    for (int k = 0; k < count; ++k) {
+      const int b = (z0 + k) >> 1, i = (z0 + k) & 1;
+      srcs[k] = (i == 0 ? d_left_bgr8 : d_right_bgr8) + (size_t)b * values;
+      dsts[k] = (i == 0 ? blur_l : blur_r) + (size_t)b * values;
+      bb.src[k] = srcs[k];
+      bb.dst[k] = dsts[k];
     }
+    if (int rc = run_gaussian_batch<true>(h, srcs, dsts, count, rows, cols, 3, ksize, sigma, false)) return rc;
+    dim3 mgrid = reduce_grid(small);
+    mgrid.y = (unsigned)count;
+    unsigned* mm = st->bgr_mm + (size_t)z0 * 4;
+    hipLaunchKernelGGL((k_value_minmax_fused<1>), mgrid, dim3(256), 0, pm_internal::stream(h), bb, rows, cols, mm);
+    hipLaunchKernelGGL((k_value_minmax_fused<2>), mgrid, dim3(256), 0, pm_internal::stream(h), bb, rows, cols, mm);
+  }
   if (int rc = launch_check(h, "value min / max")) return rc;
   BgrSource src;
   src.left = d_left_bgr8;
