@@ -447,40 +447,36 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
     return out
 
 
-def frames_in_flight_leg(args, pm, torch, w, local_rank, handles=3, frames=36):
-    """The headline workload with consecutive frames overlapped: `handles` handles of this process take the frames in
-    rotation from ONE host thread (pm_match_device only enqueues), so the head and tail of a frame -- a dozen small
-    launches with the chip nearly empty -- run beside another frame's sweeps.  Whole-job throughput of a stream of
-    pairs; a frame's latency is not improved.  Never `value`."""
-    engines = [pm.Engine(w.params, device=local_rank, max_rows=args.rows, max_cols=args.cols) for _ in range(handles)]
-    outs = [(torch.empty_like(w.DL), torch.empty_like(w.DR)) for _ in range(handles)]
-
-    def frame(k):
-        e, g, (dl, dr) = engines[k % handles], k % N_ROTATE, outs[k % handles]
-        e.match_device(1, w.L[g].data_ptr(), w.R[g].data_ptr(), args.rows, args.cols, w.SL[g].data_ptr(),
-                       w.SR[g].data_ptr(), dl.data_ptr(), dr.data_ptr())
-
-    for k in range(2 * handles):
-        frame(k)
-    for e in engines:
-        e.synchronize()
-    t0 = time.perf_counter()
-    for k in range(frames):
-        frame(k)
-    for e in engines:
-        e.synchronize()
-    dt = time.perf_counter() - t0
-    # frame k of the rotation went to handle k % handles with pair k % N_ROTATE: compare one against the headline handle
-    k = frames - 1
-    w.step(k % N_ROTATE)
-    w.eng.synchronize()
-    same = bool(torch.equal(outs[k % handles][0], w.DL) and torch.equal(outs[k % handles][1], w.DR))
-    for e in engines:
-        e.close()
-    return {"handles": handles, "frames": frames, "value": frames / dt, "unit": "pairs/s",
-            "ms_per_frame": 1e3 * dt / frames, "bit_identical_to_the_headline_handle": same,
-            "note": "consecutive frames overlapped on the chip (rotation over independent handles, one host thread); "
-                    "throughput of a stream of pairs, not a frame's latency"}
+def batch_child(args, nb=4, steps=8):
+    """The headline workload as a batch -- `nb` pairs per pm_match_device call, BASELINE configs[2]'s per-GPU shape in
+    small -- measured by a CHILD process started before this process touches the GPU.  The engine runs a batch as
+    pipelines of two pairs over two lanes of view streams; four in-order chains side by side need the process's four
+    hardware queues to themselves (with any other queue-owning stream in the process two chains share a queue and the
+    rate falls back to the lockstep schedule's: 418 -> 362 pairs/s, tools/batch_after.py), hence the clean process.
+    Whole-job throughput of pairs that are at hand together; a pair's latency is not improved.  Never `value`."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+              "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--pairs-per-gpu", str(nb), "--steps", str(steps), "--warmup", "2",
+           "--rows", str(args.rows), "--cols", str(args.cols), "--iters", str(args.iters), "--patch", str(args.patch),
+           "--semantics", str(args.semantics), "--no-cpu-baseline", "--host-pairs", "0", "--no-side-legs", "--no-profile"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": "batch leg: %r" % (e,)}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                j = json.loads(line)
+                return {"pairs_per_call": nb, "calls": steps, "value": j["value"], "unit": "pairs/s",
+                        "ms_per_pair": j["ms_per_frame"], "check": j.get("check"),
+                        "note": "one pm_match_device call per batch (pipelines of two pairs over two lanes of view "
+                                "streams), measured in a process of its own: `bench.py --pairs-per-gpu %d`" % nb}
+            except (ValueError, KeyError):
+                break
+    return {"error": "batch leg exited with code %d" % r.returncode, "stderr_tail": r.stderr[-300:]}
 
 
 def run_tiled(args, d):
@@ -616,6 +612,10 @@ def main():
             and max(1, args.pairs_per_gpu) == 1 and (not args.dry_run or args.rehearse_tiled_leg)):
         import torch  # noqa: F401 -- pages the libraries in before the children import them
         tiled_result = tiled_children(args)
+    batch_result = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not planes and not args.no_side_legs and not args.tiled
+            and max(1, args.pairs_per_gpu) == 1 and not args.self_seed and not args.dry_run):
+        batch_result = batch_child(args)
     if os.environ.get("PM_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # fault injection of tests/test_dist.py
         sys.exit(7)
     d = Dist(args)
@@ -708,8 +708,8 @@ def main():
             result["run_engine_counters_per_step"] = counters
         if d.world == 1 and not planes and args.host_pairs > 0:
             result["host_buffers"] = host_buffer_leg(pm, w.params, args, w.pairs[0], d.local_rank)
-        if d.world == 1 and not planes and not args.no_side_legs and nb == 1 and not args.self_seed:
-            result["frames_in_flight"] = frames_in_flight_leg(args, pm, torch, w, d.local_rank)
+        if batch_result is not None:
+            result["batch"] = batch_result
     eng.close()
     del w
     if not planes and not args.no_side_legs and nb == 1:

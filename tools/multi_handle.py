@@ -11,6 +11,8 @@ dev = torch.device("cuda:0")
 NH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 OFFSET_MS = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 N = 40
+# DUMMY=n: n streams created first (shifts the streams of the handles onto other hardware queues)
+dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY", "0")))]
 prm = pm.default_params(0, patch=11, patchmatch_iters=8)
 engines = [pm.Engine(prm, max_rows=ROWS, max_cols=COLS) for _ in range(NH)]
 bufs = []
