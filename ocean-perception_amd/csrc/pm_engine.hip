@@ -361,6 +361,29 @@ struct ViewSetup {
   int n;
 };
 
+// The stream the second view of a single pair forks onto (the first stays on the handle's stream).  It gets the HIGH
+// priority: streams of different priorities never share a hardware queue, and if this one landed on the queue of the
+// handle's own stream the two views would run one after the other (measured with two other queue-owning streams in the
+// process: 384 -> 275 pairs/s; with the priority 380, tools/multi_handle.py).  PM_VIEW_PRIO=0: default priority, -1: low.
+// (The lanes of a batch keep the default priority: a high-priority stream among the four costs them 427 -> 362.)
+int view1_stream_create(pm_handle* h) {
+  if (h->view1_stream) return PM_OK;
+  static const int prio_knob = [] {
+    const char* e = getenv("PM_VIEW_PRIO");
+    return e ? atoi(e) : 1;
+  }();
+  if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
+  if (prio_knob != 0) {
+    int lo = 0, hi = 0;
+    PM_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PM_HIP(h, hipStreamCreateWithPriority(&h->view1_stream, hipStreamNonBlocking, prio_knob > 0 ? hi : lo));
+  } else {
+    PM_HIP(h, hipStreamCreateWithFlags(&h->view1_stream, hipStreamNonBlocking));
+  }
+  PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
+  return PM_OK;
+}
+
 int lanes_create(pm_handle* h, int n_lanes) {
   if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
   for (int l = 0; l < n_lanes; ++l)
@@ -380,7 +403,8 @@ int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSet
   pm_handle::ViewLane& ln = h->lanes[lane];
   hipStream_t main_stream = h->stream;
   // view0_on_main: the first view stays on the caller's stream (no fork / join for it), the second forks off
-  hipStream_t vstream[2] = {view0_on_main ? main_stream : ln.view_stream[0], ln.view_stream[1]};
+  hipStream_t vstream[2] = {view0_on_main ? main_stream : ln.view_stream[0],
+                            view0_on_main ? h->view1_stream : ln.view_stream[1]};
   int rc = PM_OK;
   PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
@@ -427,21 +451,23 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
     return run_one_view_set(h, ps, slots);
   }
-  if (int rc = lanes_create(h, 1)) return rc;
   static const bool on_main = [] {
     const char* e = getenv("PM_VIEW0_ON_MAIN");
     return e ? atoi(e) != 0 : true;
   }();
-  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
   if (on_main) {
     // the first view stays on the caller's stream, only the second forks off: one fork / join pair less per Match
     // (a cross-queue signal costs 20-26 us, tools/trace_gaps.py)
+    if (int rc = view1_stream_create(h)) return rc;
+    PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
     if (int rc = run_views_on_lane(h, ps, slots, setup, 0, true)) return rc;
-    PM_HIP(h, hipEventRecord(h->lanes[0].view_join[1], h->lanes[0].view_stream[1]));
-    PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[1], 0));
+    PM_HIP(h, hipEventRecord(h->view1_join, h->view1_stream));
+    PM_HIP(h, hipStreamWaitEvent(h->stream, h->view1_join, 0));
     prof_break(h, h->stream);
     return PM_OK;
   }
+  if (int rc = lanes_create(h, 1)) return rc;
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
   if (int rc = run_views_on_lane(h, ps, slots, setup, 0, false)) return rc;
   return lanes_join(h, 1);
 }
@@ -752,6 +778,11 @@ void pm_destroy(pm_handle* h) {
       if (ln.view_join[v]) (void)hipEventDestroy(ln.view_join[v]);
       if (ln.view_stream[v]) (void)hipStreamDestroy(ln.view_stream[v]);
     }
+  if (h->view1_stream) {
+    (void)hipStreamSynchronize(h->view1_stream);
+    (void)hipStreamDestroy(h->view1_stream);
+  }
+  if (h->view1_join) (void)hipEventDestroy(h->view1_join);
   if (h->view_fork) (void)hipEventDestroy(h->view_fork);
   if (h->s_in) (void)hipStreamSynchronize(h->s_in);
   if (h->s_out) (void)hipStreamSynchronize(h->s_out);

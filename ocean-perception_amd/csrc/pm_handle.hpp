@@ -112,6 +112,8 @@ struct pm_handle {
   };
   ViewLane lanes[kLanes];
   hipEvent_t view_fork = nullptr;
+  hipStream_t view1_stream = nullptr;  // the second view of a single pair (high priority: a hardware queue of its own)
+  hipEvent_t view1_join = nullptr;
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;

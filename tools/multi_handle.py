@@ -13,6 +13,10 @@ OFFSET_MS = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 N = 40
 # DUMMY=n: n streams created first (shifts the streams of the handles onto other hardware queues)
 dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY", "0")))]
+for sd in dummies:  # a stream takes its hardware queue with its first submission
+    with torch.cuda.stream(sd):
+        torch.zeros(1024, device=dev).add_(1)
+torch.cuda.synchronize()
 prm = pm.default_params(0, patch=11, patchmatch_iters=8)
 engines = [pm.Engine(prm, max_rows=ROWS, max_cols=COLS) for _ in range(NH)]
 bufs = []
