@@ -479,6 +479,32 @@ def batch_child(args, nb=4, steps=8):
     return {"error": "batch leg exited with code %d" % r.returncode, "stderr_tail": r.stderr[-300:]}
 
 
+def eight_bands_child(args):
+    """One 4096x2160 pair through the C-ABI driver with 8 bands on ONE device -- the protocol (boundary rows, masked
+    re-sweeps, flag) at work, its cost beside the untiled frame -- in a process of its own, started before this one
+    touches the GPU: eight band streams beside the priority stream a single-pair handle creates run 2.2x slower
+    (any stream of another priority in the process does that to them), and a real caller has one band per GPU."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+              "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py"), "--rows", "2160", "--cols",
+           "4096", "--iters", str(args.iters), "--patch", str(args.patch), "--steps", "2", "--single-process", "1",
+           "--bands", "8"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.tiled_timeout)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return {"error": "eight-band leg: %r" % (e,)}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "eight-band leg exited with code %d" % r.returncode, "stderr_tail": r.stderr[-300:]}
+
+
 def run_tiled(args, d):
     """BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks; delegates to python/tiled.py."""
     import tiled
@@ -612,10 +638,11 @@ def main():
             and max(1, args.pairs_per_gpu) == 1 and (not args.dry_run or args.rehearse_tiled_leg)):
         import torch  # noqa: F401 -- pages the libraries in before the children import them
         tiled_result = tiled_children(args)
-    batch_result = None
+    batch_result = eight_bands_result = None
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not planes and not args.no_side_legs and not args.tiled
             and max(1, args.pairs_per_gpu) == 1 and not args.self_seed and not args.dry_run):
         batch_result = batch_child(args)
+        eight_bands_result = eight_bands_child(args)
     if os.environ.get("PM_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # fault injection of tests/test_dist.py
         sys.exit(7)
     d = Dist(args)
@@ -720,9 +747,8 @@ def main():
             import tiled
             try:
                 tiled_result = tiled.bench(args, d, steps=2, quiet=True)
-                # the same pair through the C-ABI driver with 8 bands on this one device: the protocol (boundary rows,
-                # masked re-sweeps, flag) at work, its cost beside the untiled frame
-                tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
+                if eight_bands_result is not None:
+                    tiled_result["eight_bands_on_this_device"] = eight_bands_result
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:
