@@ -399,12 +399,13 @@ int lanes_create(pm_handle* h, int n_lanes) {
 // Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
 // (recorded by the caller on the main stream).  Enqueue only; the caller joins.
 int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, int lane,
-                      bool view0_on_main = false) {
+                      bool view0_on_main = false, bool view1_on_prio = false) {
   pm_handle::ViewLane& ln = h->lanes[lane];
   hipStream_t main_stream = h->stream;
   // view0_on_main: the first view stays on the caller's stream (no fork / join for it), the second forks off
+  // view1_on_prio: the second view on the handle's priority stream (a hardware queue of its own) instead of the lane's
   hipStream_t vstream[2] = {view0_on_main ? main_stream : ln.view_stream[0],
-                            view0_on_main ? h->view1_stream : ln.view_stream[1]};
+                            (view0_on_main || view1_on_prio) ? h->view1_stream : ln.view_stream[1]};
   int rc = PM_OK;
   PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
@@ -492,12 +493,14 @@ PlaneSet plane_set_of_pair(const PlaneSet& ps, int b) {
   return q;
 }
 
-// Lanes a batch uses (PM_PAIR_LANES, read once; 0 or 1: a batch advances all its pairs through every launch together,
-// round 2's schedule).  Default 2 lanes x 2 pairs per pipeline: measured best at 720p (profiles/r03_pair_lanes.txt).
+// Lanes a batch uses (PM_PAIR_LANES, read once; 0: a batch advances all its pairs through every launch together, round 2's
+// schedule; 1: its pipelines run one after the other on one lane; more: they take the lanes in rotation).  Default: ONE lane,
+// 2 pairs per pipeline -- as fast as two lanes in a process of its own (425 pairs/s) and, with the priority stream, not
+// at the mercy of the process's other streams (profiles/r03_pair_lanes.txt).
 int pair_lanes() {
   static const int v = [] {
     const char* e = getenv("PM_PAIR_LANES");
-    const int x = e ? atoi(e) : 2;
+    const int x = e ? atoi(e) : 1;
     return x < 0 ? 0 : (x > pm_handle::kLanes ? pm_handle::kLanes : x);
   }();
   return v;
@@ -520,7 +523,12 @@ int run_pairs_on_lanes(pm_handle* h, const PlaneSet& ps, int n, const ViewSetup&
   const int chunk = pair_chunk();
   const int pipes = (n + chunk - 1) / chunk;
   const int L = pipes < pair_lanes() ? pipes : pair_lanes();
+  // One lane (the default): its second view stream is the handle's priority stream, so the two chains have a hardware
+  // queue each whatever else the process holds (two default-priority streams on one queue: 425 -> 331 pairs/s).
+  const bool prio = L == 1;
   if (int rc = lanes_create(h, L)) return rc;
+  if (prio)
+    if (int rc = view1_stream_create(h)) return rc;
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
   const size_t px = (size_t)ps.rows * ps.cols;
   for (int k = 0; k < pipes; ++k) {
@@ -528,9 +536,15 @@ int run_pairs_on_lanes(pm_handle* h, const PlaneSet& ps, int n, const ViewSetup&
     const PlaneSet pb = plane_set_of_pair(ps, b);
     const ViewSetup sb{vs.d_left + b * px, vs.d_right + b * px, vs.d_seed_l ? vs.d_seed_l + b * px : nullptr,
                        vs.d_seed_r ? vs.d_seed_r + b * px : nullptr, c};
-    if (int rc = run_views_on_lane(h, pb, 2 * c, &sb, k % L)) return rc;
+    if (int rc = run_views_on_lane(h, pb, 2 * c, &sb, k % L, false, prio)) return rc;
   }
-  return lanes_join(h, L);
+  if (!prio) return lanes_join(h, L);
+  PM_HIP(h, hipEventRecord(h->lanes[0].view_join[0], h->lanes[0].view_stream[0]));
+  PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[0], 0));
+  PM_HIP(h, hipEventRecord(h->view1_join, h->view1_stream));
+  PM_HIP(h, hipStreamWaitEvent(h->stream, h->view1_join, 0));
+  prof_break(h, h->stream);
+  return PM_OK;
 }
 
 int validate_params(pm_handle* h, const pm_params& p) {
@@ -644,7 +658,7 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
   h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
   // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
   const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
-  if (per_view_setup && n > pair_chunk() && pair_lanes() > 1) {
+  if (per_view_setup && n > pair_chunk() && pair_lanes() >= 1) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
     if (int rc = run_pairs_on_lanes(h, ps, n, vs)) return rc;
   } else if (per_view_setup) {
