@@ -240,10 +240,21 @@ struct PlArgs {
 
 // grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 512, dynamic LDS = pl_lds_bytes().
 constexpr int kPlThreads = 512;
+// Tile width.  The spatial stage updates one colour: 64 active lanes per row of a 128-wide tile.  The other stages update
+// every pixel: 64-wide tiles, one pixel per lane.  -DPL_WIDE_TW=128 gives them 128-wide tiles whose lanes take two pixels
+// of a row one after the other (half as many blocks per launch, the 164 extra target columns of a tile row amortised
+// over 128 pixels); tried for the last, partly filled round of blocks of a launch (900 blocks on 512 slots instead of
+// 1800 on 768) and dropped: 241 -> 231 pairs/s -- two blocks per CU instead of three leave 4 wavefronts per SIMD
+// instead of 6, which costs more than the tail gains (bit-identical either way).
+#ifndef PL_WIDE_TW
+#define PL_WIDE_TW 64
+#endif
+__host__ __device__ constexpr int pl_tile_w(int stage) { return stage == PL_SPATIAL ? 128 : PL_WIDE_TW; }
 template <int P, int STAGE, typename ST>
 __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
   constexpr int h = P / 2;
-  constexpr int TW = STAGE == PL_SPATIAL ? 128 : 64;  // 64 lanes per tile row either way
+  constexpr int TW = pl_tile_w(STAGE);  // 64 lanes per tile row either way
+  constexpr int SUBS = STAGE == PL_SPATIAL ? 1 : TW / 64;  // pixels of a row per lane
   constexpr int TR = kPlTileH + P - 1;
   constexpr int LW = TW + P - 1;
   constexpr int LWW = (LW + 3) / 4 + 1;          // dwords per reference row (+1: a shifted copy reads 3 bytes further)
@@ -262,9 +273,6 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   const int view = ar.view_fixed >= 0 ? ar.view_fixed : (int)blockIdx.z - pair * pp.n_views;
   const int rows = ps.rows, cols = ps.cols, pitch = ps.pitch;
   const int y = y0 + ty;
-  const int lx = STAGE == PL_SPATIAL ? 2 * tx + ((y + ar.arg) & 1) : tx;
-  const int x = x0 + lx;
-  const bool on = x < cols && y < rows;
 
   // images of this view: reference / target packed planes (colour | gradient << 8)
   const int iref = view == 0 ? 0 : 3, itgt = view == 0 ? 1 : 2;
@@ -328,9 +336,14 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   t.rw = rw;
   t.lww = LWW;
   t.copy_w = COPYW;
+  const float smax = pp.slope_max;
+#pragma unroll 1
+  for (int sub = 0; sub < SUBS; ++sub) {
+  const int lx = STAGE == PL_SPATIAL ? 2 * tx + ((y + ar.arg) & 1) : tx + 64 * sub;
+  const int x = x0 + lx;
+  const bool on = x < cols && y < rows;
   const int xrel = lx + pp.max_disp + pp.margin;
   const size_t o = st.idx(min(x, cols - 1), min(y, rows - 1));  // (lanes beyond the image never use it)
-  const float smax = pp.slope_max;
 
   PlPix px = {0.f, 0.f, 0.f, 0.f};
   if constexpr (STAGE == PL_INIT) {
@@ -430,12 +443,13 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
     pl_store(pz, o, px.z);
     pl_store(pc, o, px.c);
   }
+  }  // sub
 }
 
 template <int STAGE>
 inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
   const int h = P / 2;
-  const int TW = STAGE == PL_SPATIAL ? 128 : 64;
+  const int TW = pl_tile_w(STAGE);
   const int TR = kPlTileH + P - 1, LW = TW + P - 1;
   const int nref = (4 * TR * ((LW + 3) / 4 + 1) + 1) & ~1;
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
@@ -447,7 +461,7 @@ inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
 template <int P, int STAGE, typename ST>
 inline hipError_t pl_launch_t(const PlaneSet& ps, void* state, const PlanesParams& pp, const PlArgs& ar, int slots,
                               hipStream_t stream) {
-  const int TW = STAGE == PL_SPATIAL ? 128 : 64;
+  const int TW = pl_tile_w(STAGE);
   const size_t lds = pl_lds_bytes<STAGE>(P, pp);
   if (lds > kChainLdsMax) return hipErrorInvalidValue;
   allow_big_lds(k_planes<P, STAGE, ST>, lds);
