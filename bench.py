@@ -104,7 +104,9 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
-        if self.world > 1:
+        # PM_BENCH_FORCE_DIST=1: a process group of ONE rank (rehearsal on a one-GPU box: the barrier and the all-reduce
+        # then run real RCCL kernels on RCCL's own stream beside the engine's streams)
+        if self.world > 1 or os.environ.get("PM_BENCH_FORCE_DIST") == "1":
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
