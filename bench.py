@@ -389,6 +389,8 @@ def timed_loop(w, d, steps, warmup, every, no_profile):
     events only see torch's current stream): per-step durations without any host synchronisation, for the median."""
     torch = w.torch
     eng = w.eng
+    d.barrier()  # (the first collective builds the communicator -- hundreds of ms with the GPU idle: before the warm-up,
+                 # not between it and the timed steps)
     for s in range(warmup):
         w.step(s)
     eng.synchronize()
