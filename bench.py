@@ -433,8 +433,10 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
         def max_over_ranks(self, v):
             return v
     w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance)
-    steps = 8
-    elapsed, prof, n_prof, step_stats = timed_loop(w, NoDist(), steps, 2, 2, False)
+    steps = 12
+    # (six warm-up steps: the engine's creation leaves the GPU idle for a few hundred ms and its clocks take ~20 ms of
+    # work to come back; with two warm-up steps the leg read 3 % low)
+    elapsed, prof, n_prof, step_stats = timed_loop(w, NoDist(), steps, 6, 4, False)
     w.step(0)
     w.eng.synchronize()
     out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
