@@ -80,12 +80,13 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
 // k_prep with the stereo-ready enhancement's per-pixel tail folded into its load (BASELINE configs[4], "enhancement fused
 // into the cost kernel's load path"): the inputs are the 8-bit BGR images and their blurred illuminants (the two
 // 427-tap Gaussian passes stay kernels of their own, pm_enhance.hpp); a block computes the enhanced 8-bit gray values
-// of its 64x4 tile plus a 1-pixel ring ONCE into LDS (pm_color.hpp::stereo_ready_gray: I / (2 blur), two HSV value
+// of its 64x8 tile plus a 1-pixel ring ONCE into LDS (pm_color.hpp::stereo_ready_gray: I / (2 blur), two HSV value
 // stretches, gray -- exactly the values pm_stereo_ready would have written) and then does what k_prep does.  Neither
 // the quotient image, nor the stretched images, nor the gray image ever goes through HBM.
-// src/vehicle/imaging/normalization.cpp:43-69,178-185.  grid = (ceil(cols/64), ceil(rows/4), B), block = 256.
+// src/vehicle/imaging/normalization.cpp:43-69,178-185.  grid = (ceil(cols/64), ceil(rows/8), B), block = 256.
+constexpr int kPrepBgrTileH = 8;  // rows per block: (66 x 10) / (64 x 8) = 1.29 enhanced-gray evaluations per pixel (4 rows: 1.55)
 __global__ void __launch_bounds__(256) k_prep_bgr(PlaneSet ps, BgrSource src) {
-  constexpr int TW = 64, TH = 4, LW = TW + 2, LH = TH + 2;
+  constexpr int TW = 64, TH = kPrepBgrTileH, LW = TW + 2, LH = TH + 2;
   __shared__ uint8_t s_gray[2][LH][LW + 2];
   const int b = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -99,10 +100,13 @@ __global__ void __launch_bounds__(256) k_prep_bgr(PlaneSet ps, BgrSource src) {
     s_gray[i][r][c] = stereo_ready_gray(img, blur, (size_t)gy * ps.cols + gx, src.mm + ((size_t)b * 2 + i) * 4);
   }
   __syncthreads();
-  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
-  const int x = x0 + tx, y = y0 + ty;
-  if (x >= ps.cols || y >= ps.rows) return;
+  const int tx = threadIdx.x & (TW - 1);
+  const int x = x0 + tx;
+  if (x >= ps.cols) return;
   const int xm = ps.cols - 1 - x;
+  for (int ty = threadIdx.x / TW; ty < TH; ty += 256 / TW) {
+  const int y = y0 + ty;
+  if (y >= ps.rows) break;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const uint8_t(*g)[LW + 2] = s_gray[i];
@@ -127,6 +131,7 @@ __global__ void __launch_bounds__(256) k_prep_bgr(PlaneSet ps, BgrSource src) {
     const uint16_t pk = (uint16_t)(p | ((unsigned)g8 << 8));
     ps.pk16[direct] = pk;
     ps.pk16[mirror] = pk;
+  }
   }
 }
 

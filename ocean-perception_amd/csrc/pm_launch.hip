@@ -32,7 +32,7 @@ static SetupGrid setup_grid(pm_handle* h, const PlaneSet& ps, int n, int view) {
 void launch_prep(pm_handle* h, const PlaneSet& ps, const uint8_t* d_left, const uint8_t* d_right, int n, size_t stride,
                  int view, const PrepSeedMaps* seeds) {
   if (h->bgr) {
-    hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + 3) / 4), (unsigned)n),
+    hipLaunchKernelGGL(k_prep_bgr, dim3((unsigned)((ps.cols + 63) / 64), (unsigned)((ps.rows + kPrepBgrTileH - 1) / kPrepBgrTileH), (unsigned)n),
                        dim3(256), 0, h->stream, ps, *h->bgr);
     if (seeds) launch_seed(h, ps, seeds->l, seeds->r, n, view);
     return;
