@@ -102,6 +102,35 @@ void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp,
         "pm_match_u8");
 }
 
+void PatchmatchGpu::MatchBatch(const std::vector<Image1b>& imls, const std::vector<Image1b>& imrs,
+                               std::vector<Image1f>& disps, std::vector<Image1f>& disprs) {
+  const size_t n = imls.size();
+  if (n == 0 || imrs.size() != n) throw std::invalid_argument("PatchmatchGpu::MatchBatch: no pairs, or left / right counts differ");
+  if ((int)n > params_.max_batch)
+    throw std::invalid_argument("PatchmatchGpu::MatchBatch: more pairs than Params::max_batch");
+  if (!seed_l_.empty() || !seed_r_.empty())
+    throw std::invalid_argument("PatchmatchGpu::MatchBatch: seed maps set through SetSeeds() apply to single pairs only");
+  const int rows = imls[0].rows, cols = imls[0].cols;
+  for (size_t i = 0; i < n; ++i)
+    if (imls[i].empty() || imls[i].rows != rows || imls[i].cols != cols || imrs[i].rows != rows || imrs[i].cols != cols)
+      throw std::invalid_argument("PatchmatchGpu::MatchBatch: all images of a batch must have one size");
+  EnsurePlan(rows, cols);
+  disps.resize(n);
+  disprs.resize(n);
+  std::vector<const uint8_t*> pl(n), pr(n);
+  std::vector<float*> dl(n), dr(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (disps[i].rows != rows || disps[i].cols != cols) disps[i].create(rows, cols);
+    if (disprs[i].rows != rows || disprs[i].cols != cols) disprs[i].create(rows, cols);
+    pl[i] = imls[i].data();
+    pr[i] = imrs[i].data();
+    dl[i] = disps[i].data();
+    dr[i] = disprs[i].data();
+  }
+  Check(pm_match_batch_u8(handle_, (int)n, pl.data(), pr.data(), rows, cols, nullptr, nullptr, dl.data(), dr.data()),
+        "pm_match_batch_u8");
+}
+
 bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, uint64_t tag) {
   if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
     throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size");

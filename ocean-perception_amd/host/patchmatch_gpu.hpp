@@ -156,6 +156,13 @@ class PatchmatchGpu final {
   void Match(const GpuImage1f& iml, const GpuImage1f& imr, const GpuImage1f& Gl, const GpuImage1f& Gr,
              GpuImage1f& disp, void* stream = nullptr);
 
+  // Several pairs of one size in ONE call (BASELINE configs[2]'s per-GPU share; at most Params::max_batch): the engine
+  // runs them as pipelines side by side, 390-418 pairs/s at 720p where pair-by-pair Match() calls reach 320.  Every
+  // pair seeds itself like Match() does (seed maps set through SetSeeds() are for single pairs: not allowed here).
+  // Results equal Match()'s, pair by pair.
+  void MatchBatch(const std::vector<Image1b>& imls, const std::vector<Image1b>& imrs, std::vector<Image1f>& disps,
+                  std::vector<Image1f>& disprs);
+
   // Match() for a sequence of frames (the callback loop of patchmatch_gpu_test.cpp:118-128) with the
   // copies off the critical path: Submit() returns once the pair is packed and enqueued, Collect() waits
   // for the oldest submitted pair.  At most Params::max_batch pairs in flight (Submit() returns false

@@ -90,6 +90,31 @@ int main(int argc, char** argv) {
       }
       if (collected != 7) return 6;
     }
+    // a batch in one call: three pairs (the pair, the pair with left and right swapped, the pair again), every map
+    // equal to what Match() returns for that pair alone
+    {
+      PatchmatchGpu::Params p3 = params;
+      p3.max_batch = 3;
+      PatchmatchGpu batch(p3);
+      std::vector<Image1b> ls = {il, ir, il}, rs = {ir, il, ir};
+      std::vector<Image1f> dls, drs;
+      batch.MatchBatch(ls, rs, dls, drs);
+      if (dls.size() != 3 || drs.size() != 3) return 11;
+      Image1f sw_l, sw_r;
+      pm.Match(ir, il, sw_l, sw_r);
+      const size_t bytes = sizeof(float) * (size_t)rows * cols;
+      if (std::memcmp(dls[0].data(), auto_l.data(), bytes) != 0 || std::memcmp(drs[0].data(), auto_r.data(), bytes) != 0) return 12;
+      if (std::memcmp(dls[1].data(), sw_l.data(), bytes) != 0 || std::memcmp(drs[1].data(), sw_r.data(), bytes) != 0) return 12;
+      if (std::memcmp(dls[2].data(), auto_l.data(), bytes) != 0 || std::memcmp(drs[2].data(), auto_r.data(), bytes) != 0) return 12;
+      bool threw = false;
+      try {
+        std::vector<Image1b> four = {il, il, il, il};
+        batch.MatchBatch(four, four, dls, drs);
+      } catch (const std::invalid_argument&) {
+        threw = true;
+      }
+      if (!threw) return 13;
+    }
     // the nested parameter types carry the reference's names (patchmatch_gpu.h:82-83)
     static_assert(std::is_same<decltype(params.detector_params), bm::ft::FeatureDetector::Params>::value, "nested Params");
     static_assert(std::is_same<decltype(params.matcher_params), bm::ft::StereoMatcher::Params>::value, "nested Params");
