@@ -7,6 +7,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -92,3 +94,25 @@ def test_bench_gpus_flag_reports_a_failed_rank(tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "rank(s) failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_with_a_one_rank_rccl_group_on_the_gpu():
+    """The nccl (= RCCL) side of bench.py on hardware, as far as a one-GPU box allows: a process group of ONE rank
+    (PM_BENCH_FORCE_DIST=1), so the barriers around the timed region and the max-over-ranks all-reduce run real RCCL
+    kernels on RCCL's own stream beside the engine's streams.  The line must carry the headline fields, the world size
+    the barrier saw, and a rate that shows the two views did not end up on one hardware queue."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--host-pairs", "0", "--no-side-legs"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["unit"] == "pairs/s"
+    assert out["check"]["deterministic_across_steps"] is True
+    assert out["value"] > 150.0, out["value"]  # (one queue for both views reads ~275 on an MI355X; far lower = broken)
