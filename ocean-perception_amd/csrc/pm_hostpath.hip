@@ -49,39 +49,56 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
       return PM_ERR_INVALID_ARG;
     }
   }
+  // every pair is packed into the pinned buffer by a few host threads (pm_hostcopy.hpp) and its upload enqueued at
+  // once: the DMA of pair i runs while the host packs pair i + 1
+  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
+  const size_t frow = sizeof(float) * (size_t)cols;
   for (int i = 0; i < n; ++i) {
     if (!left[i] || !right[i] || !disp_l[i] || (lr && !disp_r[i])) {
       set_err(h, "pm_match_batch_u8: null pointer for pair %d", i);
       return PM_ERR_INVALID_ARG;
     }
-    std::memcpy(pl + i * px, left[i], px);
-    std::memcpy(pr + i * px, right[i], px);
+    h->copy_pool->Copy2D(pl + i * px, (size_t)cols, left[i], (size_t)cols, (size_t)cols, rows);
+    PM_HIP(h, hipMemcpyAsync(h->st_left + i * px, pl + i * px, px, hipMemcpyHostToDevice, h->stream));
+    h->copy_pool->Copy2D(pr + i * px, (size_t)cols, right[i], (size_t)cols, (size_t)cols, rows);
+    PM_HIP(h, hipMemcpyAsync(h->st_right + i * px, pr + i * px, px, hipMemcpyHostToDevice, h->stream));
     if (seed_l && seed_l[i]) {
-      std::memcpy(psl + i * px, seed_l[i], sizeof(float) * px);
+      h->copy_pool->Copy2D(psl + i * px, frow, seed_l[i], frow, frow, rows);
+      PM_HIP(h, hipMemcpyAsync(h->st_seed_l + i * px, psl + i * px, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
       any_sl = true;
-    } else {
-      std::memset(psl + i * px, 0, sizeof(float) * px);
     }
     if (seed_r && seed_r[i]) {
-      std::memcpy(psr + i * px, seed_r[i], sizeof(float) * px);
+      h->copy_pool->Copy2D(psr + i * px, frow, seed_r[i], frow, frow, rows);
+      PM_HIP(h, hipMemcpyAsync(h->st_seed_r + i * px, psr + i * px, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
       any_sr = true;
-    } else {
-      std::memset(psr + i * px, 0, sizeof(float) * px);
     }
   }
-  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, n * px, hipMemcpyHostToDevice, h->stream));
-  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, n * px, hipMemcpyHostToDevice, h->stream));
-  if (any_sl) PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
-  if (any_sr) PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * n * px, hipMemcpyHostToDevice, h->stream));
+  // a view whose maps were given for some pairs only (allowed without sparse_init): the others start from zeros
+  for (int i = 0; i < n; ++i) {
+    if (any_sl && !(seed_l && seed_l[i])) PM_HIP(h, hipMemsetAsync(h->st_seed_l + i * px, 0, sizeof(float) * px, h->stream));
+    if (any_sr && !(seed_r && seed_r[i])) PM_HIP(h, hipMemsetAsync(h->st_seed_r + i * px, 0, sizeof(float) * px, h->stream));
+  }
   if (int rc = match_device_impl(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
                                any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
+  // the left maps are unpacked into the caller's buffers while the right ones are still on the bus
+  if (!h->left_out) {
+    PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
+    PM_HIP(h, hipEventCreateWithFlags(&h->right_out, hipEventDisableTiming));
+  }
   PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-  if (lr) PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; ++i) {
-    std::memcpy(disp_l[i], pdl + i * px, sizeof(float) * px);
-    if (lr) std::memcpy(disp_r[i], pdr + i * px, sizeof(float) * px);
+  PM_HIP(h, hipEventRecord(h->left_out, h->stream));
+  if (lr) {
+    PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
+    PM_HIP(h, hipEventRecord(h->right_out, h->stream));
+  }
+  PM_HIP(h, hipEventSynchronize(h->left_out));
+  for (int i = 0; i < n; ++i)
+    h->copy_pool->Copy2D(disp_l[i], frow, pdl + i * px, frow, frow, rows);
+  if (lr) {
+    PM_HIP(h, hipEventSynchronize(h->right_out));
+    for (int i = 0; i < n; ++i)
+      h->copy_pool->Copy2D(disp_r[i], frow, pdr + i * px, frow, frow, rows);
   }
   return PM_OK;
 }

@@ -157,9 +157,10 @@ class PatchmatchGpu final {
              GpuImage1f& disp, void* stream = nullptr);
 
   // Several pairs of one size in ONE call (BASELINE configs[2]'s per-GPU share; at most Params::max_batch): the engine
-  // runs them as pipelines side by side, 390-418 pairs/s at 720p where pair-by-pair Match() calls reach 320.  Every
-  // pair seeds itself like Match() does (seed maps set through SetSeeds() are for single pairs: not allowed here).
-  // Results equal Match()'s, pair by pair.
+  // runs them as pipelines side by side.  From host images the copies stand in front of and behind the whole batch:
+  // 315-320 pairs/s at 720p, what pair-by-pair Match() calls reach; a caller whose pairs are already on the device
+  // gets 390-418 through pm_match_device(handle(), n, ...).  Every pair seeds itself like Match() does (seed maps set
+  // through SetSeeds() are for single pairs: not allowed here).  Results equal Match()'s, pair by pair.
   void MatchBatch(const std::vector<Image1b>& imls, const std::vector<Image1b>& imrs, std::vector<Image1f>& disps,
                   std::vector<Image1f>& disprs);
 
