@@ -490,12 +490,8 @@ def batch_child(args, nb=4, steps=8):
     out = {"pairs_per_call": nb, "calls": steps, "value": j["value"], "unit": "pairs/s", "ms_per_pair": j["ms_per_frame"],
            "check": j.get("check"),
            "note": "one pm_match_device call per batch, measured in a process of its own (`bench.py --pairs-per-gpu %d`).  "
-                   "Default schedule: pipelines of two pairs on one lane whose second view stream has the high priority "
-                   "(a hardware queue of its own whatever else the process holds).  `two_lanes`: PM_PAIR_LANES=2, four "
-                   "default-priority streams -- faster in a process that owns all four hardware queues, as here, and "
-                   "back at the lockstep schedule's ~362 pairs/s beside any other queue-owning stream" % nb}
-    j2 = child({"PM_PAIR_LANES": "2"})
-    out["two_lanes"] = j2.get("value", j2)
+                   "Pipelines of two pairs, one after the other on two view streams of the high priority class (hardware "
+                   "queues of their own whatever else the process holds)" % nb}
     return out
 
 

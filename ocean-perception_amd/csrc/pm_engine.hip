@@ -34,6 +34,29 @@ void set_err(pm_handle* h, const char* fmt, ...) {
   va_end(ap);
 }
 
+hipError_t create_stream(hipStream_t* s, int kind) {
+  // PM_STREAM_PRIO = "main,view,copy,lane" priorities (1 high, 0 default, -1 low), read once
+  static const struct Prio {
+    int v[4];
+    Prio() {
+      v[0] = 0; v[1] = 1; v[2] = 0; v[3] = 1;
+      const char* e = getenv("PM_STREAM_PRIO");
+      if (e) {
+        int a = 0, b = 1, c = 0, d = 1;
+        const int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
+        if (n == 1) b = c = d = a;
+        v[0] = a; v[1] = b; v[2] = c; v[3] = d;
+      }
+    }
+  } prio;
+  const int p = prio.v[kind & 3];
+  if (p == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int lo = 0, hi = 0;
+  const hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p > 0 ? hi : lo);
+}
+
 int check_patch(pm_handle* h, int pw, int ph) {
   if (pw < 3 || ph < 3 || pw > PM_MAX_PATCH || ph > PM_MAX_PATCH || (pw % 2) == 0 || (ph % 2) == 0) {
     // patchmatch.cpp:257-258 CHECKs oddness; 1x1 is excluded because its passes A/B and C/D visit
@@ -361,25 +384,12 @@ struct ViewSetup {
   int n;
 };
 
-// The stream the second view of a single pair forks onto (the first stays on the handle's stream).  It gets the HIGH
-// priority: streams of different priorities never share a hardware queue, and if this one landed on the queue of the
-// handle's own stream the two views would run one after the other (measured with two other queue-owning streams in the
-// process: 384 -> 275 pairs/s; with the priority 380, tools/multi_handle.py).  PM_VIEW_PRIO=0: default priority, -1: low.
-// (The lanes of a batch keep the default priority: a high-priority stream among the four costs them 427 -> 362.)
+// The stream the second view of a single pair forks onto (the first stays on the handle's stream); see create_stream
+// for why the engine's streams have a priority class of their own.
 int view1_stream_create(pm_handle* h) {
   if (h->view1_stream) return PM_OK;
-  static const int prio_knob = [] {
-    const char* e = getenv("PM_VIEW_PRIO");
-    return e ? atoi(e) : 1;
-  }();
   if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
-  if (prio_knob != 0) {
-    int lo = 0, hi = 0;
-    PM_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    PM_HIP(h, hipStreamCreateWithPriority(&h->view1_stream, hipStreamNonBlocking, prio_knob > 0 ? hi : lo));
-  } else {
-    PM_HIP(h, hipStreamCreateWithFlags(&h->view1_stream, hipStreamNonBlocking));
-  }
+  PM_HIP(h, create_stream(&h->view1_stream, kStreamView));
   PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
   return PM_OK;
 }
@@ -390,7 +400,7 @@ int lanes_create(pm_handle* h, int n_lanes) {
     for (int v = 0; v < 2; ++v) {
       pm_handle::ViewLane& ln = h->lanes[l];
       if (ln.view_stream[v]) continue;
-      PM_HIP(h, hipStreamCreateWithFlags(&ln.view_stream[v], hipStreamNonBlocking));
+      PM_HIP(h, create_stream(&ln.view_stream[v], kStreamLane));
       PM_HIP(h, hipEventCreateWithFlags(&ln.view_join[v], hipEventDisableTiming));
     }
   return PM_OK;
@@ -842,7 +852,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
     return PM_ERR_NO_DEVICE;
   }
   PM_HIP(h, hipSetDevice(device));
-  PM_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  PM_HIP(h, create_stream(&h->stream, kStreamMain));
 
   h->max_rows = max_rows;
   h->max_cols = max_cols;

@@ -160,6 +160,21 @@ void set_err(pm_handle* h, const char* fmt, ...) __attribute__((format(printf, 2
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// Every stream of the engine is created through this.  PM_STREAM_PRIO = "main,view,copy,lane" (read once; one number
+// = all four): the priority class of the handle's stream, the second view's stream, the upload / download streams and
+// the lanes' streams -- 1 high, 0 default, -1 low.  Default "0,1,0,1": the streams the views of a pair and the
+// pipelines of a batch run on are HIGH, not for the priority but because streams of different classes never share a
+// hardware queue and a class of their own keeps them off the queues of whatever else the process creates (with
+// default-priority streams, where a stream lands depends on the process's other queue-owning streams, and some
+// constellations put both views of a pair on ONE queue: 384 -> 275 pairs/s; taking the queues in a fixed order in
+// pm_create does not prevent that -- the runtime reassigns).  The handle's own stream and the copy streams stay
+// default: copies on streams of a non-default class are slower (pm_match_u8 x 4: 12.3 -> 14.4 ms).  The price:
+// default-priority streams that work side by side slow down while a stream of another class exists in the process
+// (pm_submit_u8's upload / download streams beside the compute stream: 343 -> 280-300 pairs/s; eight band handles on
+// one device 49 -> 117 ms); "0" restores one class for everything (tools/multi_handle.py, batch_after.py, pipe_timing.py).
+enum StreamKind { kStreamMain = 0, kStreamView = 1, kStreamCopy = 2, kStreamLane = 3 };
+hipError_t create_stream(hipStream_t* s, int kind);
+
 // Brackets the launches of one kernel class with a pair of events while the handle is profiling.
 // While the handle is profiling, the launches of one kernel class are bracketed by events on the current stream.  An
 // in-stream event before a launch fires when the launch in front of it has finished: the stop event of the previous

@@ -187,8 +187,8 @@ namespace {
 
 int pipe_init(pm_handle* h) {
   if (!h->pipe.empty()) return PM_OK;
-  PM_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
-  PM_HIP(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+  PM_HIP(h, create_stream(&h->s_in, kStreamCopy));
+  PM_HIP(h, create_stream(&h->s_out, kStreamCopy));
   h->pipe.resize((size_t)h->max_batch);
   for (auto& sl : h->pipe) {
     PM_HIP(h, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));

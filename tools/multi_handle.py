@@ -19,6 +19,12 @@ for sd in dummies:  # a stream takes its hardware queue with its first submissio
 torch.cuda.synchronize()
 prm = pm.default_params(0, patch=11, patchmatch_iters=8)
 engines = [pm.Engine(prm, max_rows=ROWS, max_cols=COLS) for _ in range(NH)]
+# DUMMY_AFTER=n: n more streams that take their queues AFTER the handles exist but before their first Match
+after = [torch.cuda.Stream() for _ in range(int(os.environ.get("DUMMY_AFTER", "0")))]
+for sd in after:
+    with torch.cuda.stream(sd):
+        torch.zeros(1024, device=dev).add_(1)
+torch.cuda.synchronize()
 bufs = []
 for i in range(NH):
     p = synth.make_pair(i, ROWS, COLS)
