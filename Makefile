@@ -31,11 +31,24 @@ $(OBJDIR)/host_%.o: $(PKG)/host/%.cpp $(HDRS)
 
 $(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-soname,libvehicle_pm_gpu.so -o $@ $(OBJS) -lz
 
 oracle:
 	$(MAKE) -C oracle
 
+# The tuning build: the same sources with -DPM_TUNING, in which the A/B knobs of pm_tune.hpp are read from the
+# environment.  Not part of `all`; tools/ load it through PM_LIB.  The shipped library reads no environment variable.
+TOBJDIR := $(PKG)/build/tuning
+TLIB    := $(PKG)/lib/libvehicle_pm_gpu_tuning.so
+TOBJS   := $(HIP_UNITS:%=$(TOBJDIR)/%.o) $(HOST_UNITS:%=$(OBJDIR)/host_%.o)
+$(TOBJDIR)/%.o: $(PKG)/csrc/%.hip $(HDRS)
+	@mkdir -p $(TOBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DPM_TUNING -Iinclude -I$(PKG)/csrc -c -o $@ $<
+$(TLIB): $(TOBJS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(TOBJS) -lz
+tuning: $(TLIB)
+
 clean:
-	rm -rf $(OBJDIR) $(LIB); $(MAKE) -C oracle clean
-.PHONY: all oracle clean
+	rm -rf $(OBJDIR) $(LIB) $(TLIB); $(MAKE) -C oracle clean
+.PHONY: all oracle clean tuning

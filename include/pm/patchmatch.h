@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 4
+#define PM_ABI_VERSION 5
 #define PM_MAX_ITERS 16
 #define PM_MAX_PATCH 15 /* largest supported window side (odd) */
 
@@ -43,7 +43,9 @@ typedef enum pm_status {
   PM_ERR_HIP = -3,         /* a HIP runtime call failed; pm_last_error() has the text       */
   PM_ERR_NO_DEVICE = -4,   /* no usable gfx950 device (the engine has NO CPU fallback)      */
   PM_ERR_NOMEM = -5,
-  PM_ERR_BUSY = -6         /* pm_submit_u8 with max_batch pairs in flight / pm_collect with none */
+  PM_ERR_BUSY = -6,        /* pm_submit_u8 with max_batch pairs in flight / pm_collect with none */
+  PM_ERR_STATE = -7        /* the call is not valid in the handle's current state (e.g. pm_capture_end on a capture
+                              whose forked streams never joined back)                                   */
 } pm_status;
 
 /* Which reference code the sweeps/cost reproduce bit for bit. */
@@ -124,6 +126,12 @@ typedef struct pm_params {
   int templ_rows;                 /* 11    (:22)                                                        */
   int max_disp;                   /* 128   (:23)                                                        */
   double max_matching_cost;       /* 0.15  (:24)                                                        */
+  int gftt_use_harris;            /* 0     gftt_use_harris_corner_detector (feature_detector.hpp:34): corner response
+                                           det(M) - k trace(M)^2 instead of the smaller eigenvalue               */
+  double gftt_k;                  /* 0.04  gftt_k (:35), used with gftt_use_harris only                          */
+  int subpixel_corners;           /* 0     cv::cornerSubPix on the detected corners (feature_detector.cpp:110-120) and */
+  int subpixel_refinement;        /* 0     on the matches (stereo_matcher.cpp:94-103): NOT BUILT -- pm_create refuses
+                                           a non-zero value with PM_ERR_INVALID_ARG rather than ignoring it        */
   int cpu_initialize_factor;      /* 0: a self-seeded Match() seeds with SparseInit (patchmatch_gpu.cu:414-442);
                                      1: with Patchmatch::Initialize(il, ir, 1) as the CPU recipe does
                                         (patchmatch.cpp:52-87 called at patchmatch_test.cpp:149-150): dilation
@@ -171,17 +179,45 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
                       float* const* disp_l, float* const* disp_r);
 
 /* The same Match() for a SEQUENCE of pairs (the per-frame callback loop of
- * test/stereo_matching/patchmatch_gpu_test.cpp:118-128) with the copies off the critical path:
- * pm_submit_u8 packs and uploads a pair and enqueues its match without waiting; pm_collect waits for
- * the OLDEST submitted pair and copies its maps out.  Up to max_batch pairs may be in flight (then
- * pm_submit_u8 returns PM_ERR_BUSY); results are those of pm_match_u8, in submission order.
- * `tag` is handed back by the matching pm_collect.  The other host-buffer entry points must not be
- * called while pairs are in flight (they share the staging buffers). */
+ * test/stereo_matching/patchmatch_gpu_test.cpp:118-128) with the copies off the critical path and the frames
+ * overlapping on the device: pm_submit_u8 uploads a pair and enqueues its match without waiting; pm_collect waits for
+ * the OLDEST submitted pair and hands its maps out.  Up to max_batch pairs may be in flight (then pm_submit_u8 returns
+ * PM_ERR_BUSY); results are those of pm_match_u8, in submission order.  `tag` is handed back by the matching
+ * pm_collect.  The input buffers may be reused as soon as pm_submit_u8 returns UNLESS they lie in memory made known
+ * through pm_host_alloc / pm_host_register (below): such buffers are read by DMA and must stay untouched until the
+ * frame has been collected.  While the device is busy with earlier frames a submitted frame may be HELD until the
+ * next pm_submit (two frames advanced through every launch together run 10 % faster than one after the other);
+ * pm_collect and pm_flush enqueue a held frame at once.  The other host-buffer entry points must not be called while
+ * pairs are in flight (they share the staging buffers). */
 int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
                  size_t image_step, const float* seed_l, const float* seed_r, size_t seed_step,
                  uint64_t tag);
+/* pm_submit_u8 with the output maps bound at submission: the matching pm_collect may pass NULL maps (or the same
+ * pointers).  If the maps lie in pm_host_alloc / pm_host_register memory the download goes straight into them -- no
+ * staging copy on either side of the frame. */
+int pm_submit_bound_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
+                       size_t image_step, const float* seed_l, const float* seed_r, size_t seed_step,
+                       float* disp_l, float* disp_r, size_t disp_step, uint64_t tag);
+/* The same sequence for callers whose frames are DEVICE resident (tightly packed rows x cols planes, as for
+ * pm_match_device): nothing is copied; inputs must stay untouched and outputs unread until the frame is collected
+ * (pm_collect with NULL maps waits for it). */
+int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                     const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag);
 int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag);
+/* enqueues a frame that is being held for a partner (see pm_submit_u8); never needed for correctness */
+int pm_flush(pm_handle* h);
 int pm_in_flight(const pm_handle* h);
+
+/* Caller memory the host-buffer entry points may DMA from and into WITHOUT the staging copy through the handle's
+ * pinned slab: pm_host_alloc hands out page-locked memory (for the cv::Mat / Image buffers of a capture loop),
+ * pm_host_register page-locks a range the caller already owns (hipHostRegister; fails with PM_ERR_HIP where the
+ * platform refuses).  Every image, seed map or output map that lies ENTIRELY inside such a range is transferred
+ * straight from / to it (strided buffers by a 2-D copy); anything else is staged as before.  The reference's host
+ * Match() uploads and downloads pageable cv::Mat memory synchronously (patchmatch_gpu.cu:343-375). */
+int pm_host_alloc(pm_handle* h, size_t bytes, void** ptr);
+int pm_host_free(pm_handle* h, void* ptr);
+int pm_host_register(pm_handle* h, void* ptr, size_t bytes);
+int pm_host_unregister(pm_handle* h, void* ptr);
 
 /* Replaces void PatchmatchGpu::Match(const cu::GpuMat& ...) (patchmatch_gpu.h:104-108,
  * patchmatch_gpu.cu:379-411) widened to whole pairs: all pointers are DEVICE memory holding n
@@ -215,6 +251,9 @@ int pm_synchronize(pm_handle* h);
 int pm_capture_begin(pm_handle* h);
 int pm_capture_end(pm_handle* h);
 int pm_replay(pm_handle* h);
+/* test hook: forks an empty dependency onto an internal stream of an open capture and leaves it unjoined, so that the
+ * guard in pm_capture_end (PM_ERR_STATE instead of a fault inside the runtime) can be exercised */
+int pm_debug_capture_fork(pm_handle* h);
 /* The hipStream_t the handle enqueues on (as void*), for event timing by the caller. */
 void* pm_stream(pm_handle* h);
 

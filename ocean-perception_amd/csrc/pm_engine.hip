@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,14 +36,22 @@ void set_err(pm_handle* h, const char* fmt, ...) {
 }
 
 hipError_t create_stream(hipStream_t* s, int kind) {
-  // PM_STREAM_PRIO = "main,view,copy,lane" priorities (1 high, 0 default, -1 low), read once
+  // ONE class for every stream of the engine: high priority -- not for the priority, but because streams of different
+  // classes never share a hardware queue, so a class of their own keeps the engine's streams off the queues of whatever
+  // else the process creates (torch's side streams, RCCL), and the engine's own streams do not slow each other down
+  // the way default-priority streams do while a stream of another class exists (round 3 had only the view streams
+  // high: eight band handles 49 -> 117 ms and pm_match_u8 314 -> 218 pairs/s as soon as a single-pair handle lived in
+  // the same process).  Measured with every handle kind alive in one process (tools/stream_matrix.py,
+  // profiles/r04_stream_matrix.txt): single 384, batch 429, pm_match_u8 310-323, eight bands 47.6 ms -- each within
+  // 1 % of the same leg in a process of its own.  The tuning build reads PM_STREAM_PRIO = "main,view,copy,lane"
+  // (1 high, 0 default, -1 low; one number = all four).
   static const struct Prio {
     int v[4];
     Prio() {
-      v[0] = 0; v[1] = 1; v[2] = 0; v[3] = 1;
-      const char* e = getenv("PM_STREAM_PRIO");
+      v[0] = v[1] = v[2] = v[3] = 1;
+      const char* e = pm::tune_env("PM_STREAM_PRIO");
       if (e) {
-        int a = 0, b = 1, c = 0, d = 1;
+        int a = 1, b = 1, c = 1, d = 1;
         const int n = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
         if (n == 1) b = c = d = a;
         v[0] = a; v[1] = b; v[2] = c; v[3] = d;
@@ -51,10 +60,53 @@ hipError_t create_stream(hipStream_t* s, int kind) {
   } prio;
   const int p = prio.v[kind & 3];
   if (p == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  if (p == 2) {
+    // a stream with a CU mask never shares its hardware queue (the runtime keeps such queues out of the shared pools);
+    // with every CU enabled the mask restricts nothing
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+    if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask.data());
+  }
   int lo = 0, hi = 0;
   const hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
   if (e != hipSuccess) return e;
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p > 0 ? hi : lo);
+}
+
+// The four streams of a handle, created TOGETHER and in a rotating order.  A process has four hardware queues per
+// priority class (GPU_MAX_HW_QUEUES); the runtime binds a stream to a queue when the stream is created: a new queue
+// while the class has fewer than four, else the queue with the fewest streams, the first such in a fixed order
+// (rocprofv3 --kernel-trace shows the queue of every dispatch: profiles/r04_queue_assignment.txt).  Streams created one
+// by one on first use therefore collide as history dictates -- the round-4 trace has a batch handle whose two view
+// streams shared one queue because the class filled up between them (430 -> 329 pairs/s), and a fifth stream of a handle
+// always shares.  Four streams created back to back land on four different queues whenever the class is balanced,
+// and every handle adds one stream to every queue, so it stays balanced as handles come and go.  The rotation (handle k
+// creates role r at position (r + k) mod 4) spreads the SAME role of different handles over the queues: eight band
+// handles of a row-tiled image, which only ever use their own stream, take the four queues in turn instead of one.
+int create_handle_streams(pm_handle* h) {
+  static std::atomic<unsigned> handles_created{0};
+  const unsigned k = handles_created.fetch_add(1u);
+  hipStream_t grp[4] = {nullptr, nullptr, nullptr, nullptr};
+  const int kinds[4] = {kStreamMain, kStreamView, kStreamCopy, kStreamCopy};
+  hipStream_t* roles[4] = {&h->stream, &h->view1_stream, &h->s_out, &h->s_in};
+  for (int pos = 0; pos < 4; ++pos) {
+    const int role = (int)((pos + 4u - (k & 3u)) & 3u);  // the role created at this position: (role + k) % 4 == pos
+    const hipError_t e = create_stream(&grp[pos], kinds[role]);
+    if (e != hipSuccess) {
+      for (hipStream_t st : grp)
+        if (st) (void)hipStreamDestroy(st);
+      set_err(h, "stream creation failed: %s", hipGetErrorString(e));
+      return PM_ERR_HIP;
+    }
+    *roles[role] = grp[pos];
+  }
+  return PM_OK;
 }
 
 int check_patch(pm_handle* h, int pw, int ph) {
@@ -221,6 +273,8 @@ SeedParams seed_params(const pm_params& p) {
   sp.max_disp = p.max_disp;
   sp.quality_level = p.gftt_quality_level;
   sp.max_matching_cost = p.max_matching_cost;
+  sp.use_harris = p.gftt_use_harris;
+  sp.harris_k = p.gftt_k;
   return sp;
 }
 
@@ -358,7 +412,7 @@ namespace {
 
 bool view_streams_enabled() {
   static bool v = [] {
-    const char* e = getenv("PM_VIEW_STREAMS");
+    const char* e = pm::tune_env("PM_VIEW_STREAMS");
     return e ? atoi(e) != 0 : true;
   }();
   return v;
@@ -384,47 +438,88 @@ struct ViewSetup {
   int n;
 };
 
-// The stream the second view of a single pair forks onto (the first stays on the handle's stream); see create_stream
-// for why the engine's streams have a priority class of their own.
-int view1_stream_create(pm_handle* h) {
-  if (h->view1_stream) return PM_OK;
-  if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
-  PM_HIP(h, create_stream(&h->view1_stream, kStreamView));
-  PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
-  return PM_OK;
+// Fork / join bookkeeping.  While a capture is open, every stream work was forked onto is remembered until the
+// handle's stream has waited for an event recorded behind that work: hipStreamEndCapture on a capture with an unjoined
+// fork does not return an error on this runtime, it faults (gpurun_out/r03/crash.log), so pm_capture_end checks first.
+void mark_forked(pm_handle* h, hipStream_t s) {
+  if (!h->capturing || s == h->stream) return;
+  for (hipStream_t t : h->cap_unjoined)
+    if (t == s) return;
+  h->cap_unjoined.push_back(s);
 }
-
-int lanes_create(pm_handle* h, int n_lanes) {
-  if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
-  for (int l = 0; l < n_lanes; ++l)
-    for (int v = 0; v < 2; ++v) {
-      pm_handle::ViewLane& ln = h->lanes[l];
-      if (ln.view_stream[v]) continue;
-      PM_HIP(h, create_stream(&ln.view_stream[v], kStreamLane));
-      PM_HIP(h, hipEventCreateWithFlags(&ln.view_join[v], hipEventDisableTiming));
+void mark_joined(pm_handle* h, hipStream_t s) {
+  for (size_t i = 0; i < h->cap_unjoined.size(); ++i)
+    if (h->cap_unjoined[i] == s) {
+      h->cap_unjoined[i] = h->cap_unjoined.back();
+      h->cap_unjoined.pop_back();
+      return;
     }
+}
+// `onto` waits for everything `from` holds now
+int join_stream(pm_handle* h, hipStream_t from, hipEvent_t ev, hipStream_t onto) {
+  PM_HIP(h, hipEventRecord(ev, from));
+  PM_HIP(h, hipStreamWaitEvent(onto, ev, 0));
+  if (onto == h->stream) mark_joined(h, from);
+  prof_break(h, onto);
   return PM_OK;
 }
 
-// Both views of the pairs of `ps` on the streams of lane `lane`, each view stream waiting for h->view_fork first
-// (recorded by the caller on the main stream).  Enqueue only; the caller joins.
-int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, int lane,
-                      bool view0_on_main = false, bool view1_on_prio = false) {
-  pm_handle::ViewLane& ln = h->lanes[lane];
+}  // namespace
+
+// The roles of a handle's four streams (create_handle_streams):
+//   stream        the handle's own: every single-pair call, the FIRST view of every chunk
+//   view1_stream  the second view of a single pair and of every chunk
+//   s_out         chunks only: the cross-check of a chunk behind both of its views, then the downloads
+//   s_in          host-buffer sequences only: uploads
+// A fifth stream would share the hardware queue of one of the four (with five, a frame sequence ran at 313-331 pairs/s in
+// a process of its own and at 400-435 beside other handles, depending on whether a view stream ended up behind the
+// download stream's waits: profiles/r04_stream_matrix.txt).  This creates the events the view streams fork and join on.
+int view_streams_create(pm_handle* h) {
+  if (h->view_fork && h->view1_join && h->out_join) return PM_OK;
+  if (h->capturing) {
+    set_err(h, "the view events do not exist yet: run this call once before capturing it");
+    return PM_ERR_BUSY;
+  }
+  if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
+  if (!h->view1_join) PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
+  if (!h->out_join) PM_HIP(h, hipEventCreateWithFlags(&h->out_join, hipEventDisableTiming));
+  return PM_OK;
+}
+
+// The per-slot events of chunks and frame sequences (h->pipe[b]: batch / ring slot b).
+int seq_events_create(pm_handle* h) {
+  if (!h->pipe.empty()) return PM_OK;
+  if (h->capturing) {
+    set_err(h, "the chunk events do not exist yet: run this call once before capturing it");
+    return PM_ERR_BUSY;
+  }
+  std::vector<pm_handle::PipeSlot> slots((size_t)h->max_batch);
+  for (auto& sl : slots) {
+    hipEvent_t* evs[] = {&sl.in_done, &sl.v_done[0], &sl.v_done[1], &sl.fin_done, &sl.out_done};
+    for (hipEvent_t* e : evs) PM_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  h->pipe.swap(slots);
+  return PM_OK;
+}
+
+namespace {
+
+// Both views of the pairs of `ps` on vstream[0] / vstream[1]; a stream other than the handle's (the handle's too with
+// wait_on_main) first waits for the non-null events of `waits`.  Enqueue only; the caller joins.  `scratch` = seeder scratch set of view 0 (view 1: + 1).
+int run_views_on(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup, hipStream_t vstream[2],
+                 const hipEvent_t* waits, int n_waits, bool wait_on_main = false, int scratch = 0) {
   hipStream_t main_stream = h->stream;
-  // view0_on_main: the first view stays on the caller's stream (no fork / join for it), the second forks off
-  // view1_on_prio: the second view on the handle's priority stream (a hardware queue of its own) instead of the lane's
-  hipStream_t vstream[2] = {view0_on_main ? main_stream : ln.view_stream[0],
-                            (view0_on_main || view1_on_prio) ? h->view1_stream : ln.view_stream[1]};
   int rc = PM_OK;
   PlaneSet pv[2] = {ps, ps};
   for (int v = 0; v < 2 && rc == PM_OK; ++v) {
     pv[v].view_fixed = v;
-    if (vstream[v] != main_stream && hipStreamWaitEvent(vstream[v], h->view_fork, 0) != hipSuccess) {
-      rc = PM_ERR_HIP;
-      break;
+    if (vstream[v] != main_stream || wait_on_main) {
+      for (int w = 0; w < n_waits && rc == PM_OK; ++w)
+        if (waits[w] && hipStreamWaitEvent(vstream[v], waits[w], 0) != hipSuccess) rc = PM_ERR_HIP;
+      if (rc != PM_OK) break;
+      mark_forked(h, vstream[v]);
+      prof_break(h, vstream[v]);
     }
-    if (vstream[v] != main_stream) prof_break(h, vstream[v]);
     h->stream = vstream[v];
     if (setup) {
       {
@@ -438,22 +533,12 @@ int run_views_on_lane(pm_handle* h, const PlaneSet& ps, int slots, const ViewSet
         rc = run_transpose(h, ps, setup->n, v);
       }
     }
-    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, lane * 2 + v);
+    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, scratch + v);
     h->stream = main_stream;
   }
   if (rc == PM_OK) rc = run_view_sets(h, pv, vstream, 2, slots / 2);
   if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
   return rc;
-}
-
-int lanes_join(pm_handle* h, int n_lanes) {
-  for (int l = 0; l < n_lanes; ++l)
-    for (int v = 0; v < 2; ++v) {
-      PM_HIP(h, hipEventRecord(h->lanes[l].view_join[v], h->lanes[l].view_stream[v]));
-      PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[l].view_join[v], 0));
-      prof_break(h, h->stream);
-    }
-  return PM_OK;
 }
 
 int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setup = nullptr) {
@@ -462,25 +547,12 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
     return run_one_view_set(h, ps, slots);
   }
-  static const bool on_main = [] {
-    const char* e = getenv("PM_VIEW0_ON_MAIN");
-    return e ? atoi(e) != 0 : true;
-  }();
-  if (on_main) {
-    // the first view stays on the caller's stream, only the second forks off: one fork / join pair less per Match
-    // (a cross-queue signal costs 20-26 us, tools/trace_gaps.py)
-    if (int rc = view1_stream_create(h)) return rc;
-    PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-    if (int rc = run_views_on_lane(h, ps, slots, setup, 0, true)) return rc;
-    PM_HIP(h, hipEventRecord(h->view1_join, h->view1_stream));
-    PM_HIP(h, hipStreamWaitEvent(h->stream, h->view1_join, 0));
-    prof_break(h, h->stream);
-    return PM_OK;
-  }
-  if (int rc = lanes_create(h, 1)) return rc;
+  // the first view stays on the caller's stream, only the second forks off
+  if (int rc = view_streams_create(h)) return rc;
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  if (int rc = run_views_on_lane(h, ps, slots, setup, 0, false)) return rc;
-  return lanes_join(h, 1);
+  hipStream_t vs[2] = {h->stream, h->view1_stream};
+  if (int rc = run_views_on(h, ps, slots, setup, vs, &h->view_fork, 1)) return rc;
+  return join_stream(h, h->view1_stream, h->view1_join, h->stream);
 }
 
 // The plane set of pair b alone (every per-pair array advanced to that pair; see make_view for the strides).
@@ -503,58 +575,83 @@ PlaneSet plane_set_of_pair(const PlaneSet& ps, int b) {
   return q;
 }
 
-// Lanes a batch uses (PM_PAIR_LANES, read once; 0: a batch advances all its pairs through every launch together, round 2's
-// schedule; 1: its pipelines run one after the other on one lane; more: they take the lanes in rotation).  Default: ONE lane,
-// 2 pairs per pipeline -- as fast as two lanes in a process of its own (425 pairs/s) and, with the priority stream, not
-// at the mercy of the process's other streams (profiles/r03_pair_lanes.txt).
-int pair_lanes() {
-  static const int v = [] {
-    const char* e = getenv("PM_PAIR_LANES");
-    const int x = e ? atoi(e) : 1;
-    return x < 0 ? 0 : (x > pm_handle::kLanes ? pm_handle::kLanes : x);
-  }();
-  return v;
-}
-
-// pairs per pipeline (PM_PAIR_CHUNK, read once)
+// pairs per chunk (PM_PAIR_CHUNK in the tuning build).  Two pairs advanced through every launch together run at 408
+// pairs/s where one runs at 373 -- a single pair leaves SIMDs short of wavefronts -- while 4 or 32 in lockstep fall back
+// to 368 / 357 (working sets): profiles/r03_pair_lanes.txt.
 int pair_chunk() {
   static const int v = [] {
-    const char* e = getenv("PM_PAIR_CHUNK");
+    const char* e = pm::tune_env("PM_PAIR_CHUNK");
     const int x = e ? atoi(e) : 2;
     return x < 1 ? 1 : x;
   }();
   return v;
 }
 
-// A batch of pairs as independent pipelines of pair_chunk() pairs each that take the lanes in rotation: pipeline k runs
-// on lane k % L, after pipeline k - L (stream order).  What a rotation over three handles gives a caller
-// (tools/multi_handle.py), inside one handle and one call; DESIGN §7 has the measurements.
-int run_pairs_on_lanes(pm_handle* h, const PlaneSet& ps, int n, const ViewSetup& vs) {
-  const int chunk = pair_chunk();
-  const int pipes = (n + chunk - 1) / chunk;
-  const int L = pipes < pair_lanes() ? pipes : pair_lanes();
-  // One lane (the default): its second view stream is the handle's priority stream, so the two chains have a hardware
-  // queue each whatever else the process holds (two default-priority streams on one queue: 425 -> 331 pairs/s).
-  const bool prio = L == 1;
-  if (int rc = lanes_create(h, L)) return rc;
-  if (prio)
-    if (int rc = view1_stream_create(h)) return rc;
-  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  const size_t px = (size_t)ps.rows * ps.cols;
-  for (int k = 0; k < pipes; ++k) {
-    const int b = k * chunk, c = n - b < chunk ? n - b : chunk;
-    const PlaneSet pb = plane_set_of_pair(ps, b);
-    const ViewSetup sb{vs.d_left + b * px, vs.d_right + b * px, vs.d_seed_l ? vs.d_seed_l + b * px : nullptr,
-                       vs.d_seed_r ? vs.d_seed_r + b * px : nullptr, c};
-    if (int rc = run_views_on_lane(h, pb, 2 * c, &sb, k % L, false, prio)) return rc;
+}  // namespace
+
+int seq_chunk_pairs() { return pair_chunk(); }
+
+bool seq_pipelined(const pm_handle* h) {
+  return h->params.mode == PM_MODE_SCALAR && h->params.left_right_check != 0 && view_streams_enabled() && !h->bgr;
+}
+
+// One CHUNK of a batch or of a frame sequence: pairs [b, b + c) of the plan, the first view on the handle's stream, the
+// second on view1_stream, both behind the non-null events `ready` (the chunk's inputs are in device memory) and
+// `slot_free` (whoever last used these plane slots is done with them); then, on s_out behind both views (events
+// v_done[0 / 1]), the cross-check / un-mirror into d_disp_l / d_disp_r ([c][rows][cols]).  Chunks enqueued one after the
+// other run back to back on the two view streams -- the head and the tail of one (a dozen small launches) beside the
+// sweeps of its neighbour, nothing forks or joins in between.  Enqueue only; the caller orders what follows behind s_out.
+int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, hipEvent_t ready,
+                      hipEvent_t slot_free, hipEvent_t v_done[2]) {
+  if (int rc = view_streams_create(h)) return rc;
+  const PlaneSet ps = plane_set(h, rows, cols, 2);
+  const PlaneSet pb = plane_set_of_pair(ps, b);
+  h->need_seed[0] = h->params.sparse_init && !d_seed_l;
+  h->need_seed[1] = h->params.sparse_init && !d_seed_r;
+  const ViewSetup sb{d_left, d_right, d_seed_l, d_seed_r, c};
+  hipStream_t keep = h->stream;
+  hipStream_t vs[2] = {keep, h->view1_stream};
+  const hipEvent_t waits[2] = {ready, slot_free};
+  if (int rc = run_views_on(h, pb, 2 * c, &sb, vs, waits, 2, true)) return rc;
+  for (int v = 0; v < 2; ++v) {
+    PM_HIP(h, hipEventRecord(v_done[v], vs[v]));
+    PM_HIP(h, hipStreamWaitEvent(h->s_out, v_done[v], 0));
+    mark_joined(h, vs[v]);
   }
-  if (!prio) return lanes_join(h, L);
-  PM_HIP(h, hipEventRecord(h->lanes[0].view_join[0], h->lanes[0].view_stream[0]));
-  PM_HIP(h, hipStreamWaitEvent(h->stream, h->lanes[0].view_join[0], 0));
-  PM_HIP(h, hipEventRecord(h->view1_join, h->view1_stream));
-  PM_HIP(h, hipStreamWaitEvent(h->stream, h->view1_join, 0));
-  prof_break(h, h->stream);
-  return PM_OK;
+  mark_forked(h, h->s_out);
+  prof_break(h, h->s_out);
+  h->stream = h->s_out;
+  int rc;
+  {
+    Launch l(h, PM_K_FINALIZE);
+    launch_finalize(h, pb, d_disp_l, d_disp_r, c);
+    rc = launch_check(h, "finalize");
+  }
+  h->stream = keep;
+  return rc;
+}
+
+namespace {
+
+// A batch of pairs as chunks of pair_chunk() pairs, one after the other on the two view streams, every chunk's
+// cross-check on s_out as soon as its two views are through; the handle's stream joins s_out at the end of the call.
+int run_pairs_as_chunks(pm_handle* h, int n, const ViewSetup& vs, int rows, int cols, float* d_disp_l, float* d_disp_r) {
+  const int chunk = pair_chunk();
+  if (int rc = view_streams_create(h)) return rc;
+  if (int rc = seq_events_create(h)) return rc;
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
+  const size_t px = (size_t)rows * cols;
+  for (int b = 0; b < n; b += chunk) {
+    const int c = n - b < chunk ? n - b : chunk;
+    if (int rc = seq_enqueue_chunk(h, b, c, vs.d_left + b * px, vs.d_right + b * px, rows, cols,
+                                   vs.d_seed_l ? vs.d_seed_l + b * px : nullptr,
+                                   vs.d_seed_r ? vs.d_seed_r + b * px : nullptr, d_disp_l + b * px,
+                                   d_disp_r ? d_disp_r + b * px : nullptr, b == 0 ? h->view_fork : nullptr, nullptr,
+                                   h->pipe[(size_t)b].v_done))
+      return rc;
+  }
+  return join_stream(h, h->s_out, h->out_join, h->stream);
 }
 
 int validate_params(pm_handle* h, const pm_params& p) {
@@ -595,6 +692,15 @@ int validate_params(pm_handle* h, const pm_params& p) {
     set_err(h, "seeder parameters out of range");
     return PM_ERR_INVALID_ARG;
   }
+  if ((p.gftt_use_harris != 0 && p.gftt_use_harris != 1) || !(p.gftt_k >= 0.0) || !(p.gftt_k <= 1.0)) {
+    set_err(h, "gftt_use_harris must be 0 or 1 and gftt_k within [0, 1]");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (p.subpixel_corners != 0 || p.subpixel_refinement != 0) {
+    // cv::cornerSubPix (feature_detector.cpp:110-120, stereo_matcher.cpp:94-103) is not built: refuse, never ignore
+    set_err(h, "subpixel_corners / subpixel_refinement (cv::cornerSubPix) are not supported by this engine");
+    return PM_ERR_INVALID_ARG;
+  }
   for (int i = 0; i < p.patchmatch_iters; ++i)
     if (!(p.noise_amp[i] >= 0.f)) {
       set_err(h, "noise_amp[%d] must be >= 0", i);
@@ -632,6 +738,11 @@ int validate_params(pm_handle* h, const pm_params& p) {
 // Ends a capture in progress and throws the partial graph away (error paths, pm_destroy).
 void abort_capture(pm_handle* h) {
   if (!h->capturing) return;
+  for (hipStream_t st : h->cap_unjoined) {  // see pm_capture_end: an unjoined fork must not reach hipStreamEndCapture
+    hipEvent_t ev = st == h->s_out ? h->out_join : h->view1_join;
+    if (ev && hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
+  }
+  h->cap_unjoined.clear();
   h->capturing = false;
   hipGraph_t graph = nullptr;
   (void)hipStreamEndCapture(h->stream, &graph);
@@ -668,10 +779,12 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
   h->need_seed[1] = h->params.sparse_init && !d_seed_r && n_views > 1;
   // two views on their own streams: each stream prepares its own planes (run_views); otherwise here
   const bool per_view_setup = n_views == 2 && view_streams_enabled() && !h->bgr;
-  if (per_view_setup && n > pair_chunk() && pair_lanes() >= 1) {
+  if (per_view_setup && n > pair_chunk()) {
+    // chunks of pairs, each with its own cross-check launch (run_pairs_as_chunks)
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
-    if (int rc = run_pairs_on_lanes(h, ps, n, vs)) return rc;
-  } else if (per_view_setup) {
+    return run_pairs_as_chunks(h, n, vs, rows, cols, d_disp_l, d_disp_r);
+  }
+  if (per_view_setup) {
     const ViewSetup vs{d_left, d_right, d_seed_l, d_seed_r, n};
     if (int rc = run_views(h, ps, n * n_views, &vs)) return rc;
   } else {
@@ -740,6 +853,10 @@ void pm_params_default(pm_params* p, int semantics) {
   p->templ_rows = 11;                // :22
   p->max_disp = 128;                 // :23
   p->max_matching_cost = 0.15;       // :24
+  p->gftt_use_harris = 0;            // feature_detector.hpp:34
+  p->gftt_k = 0.04;                  // :35
+  p->subpixel_corners = 0;           // :39
+  p->subpixel_refinement = 0;        // stereo_matcher.hpp:26
   p->cpu_initialize_factor = 0;
   p->mode = PM_MODE_SCALAR;
   p->state_dtype = PM_STATE_F32;
@@ -759,6 +876,7 @@ const char* pm_status_string(int status) {
     case PM_ERR_NO_DEVICE: return "no usable HIP device";
     case PM_ERR_NOMEM: return "out of memory";
     case PM_ERR_BUSY: return "pipeline full / nothing to collect";
+    case PM_ERR_STATE: return "call not valid in the handle's current state";
     default: return "unknown status";
   }
 }
@@ -776,16 +894,23 @@ void pm_destroy(pm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   abort_capture(h);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  // frames of a sequence may still be running on streams that never join the handle's own: wait for all of them
+  hipStream_t streams[] = {h->stream, h->view1_stream, h->s_in, h->s_out};
+  for (hipStream_t st : streams)
+    if (st) (void)hipStreamSynchronize(st);
   pm_internal::release_imaging(h);
-  if (h->ext_fork) (void)hipEventDestroy(h->ext_fork);
-  if (h->ext_join) (void)hipEventDestroy(h->ext_join);
-  if (h->left_out) (void)hipEventDestroy(h->left_out);
-  if (h->right_out) (void)hipEventDestroy(h->right_out);
+  hipEvent_t events[] = {h->ext_fork, h->ext_join, h->left_out, h->right_out, h->view1_join, h->out_join, h->view_fork};
+  for (hipEvent_t e : events)
+    if (e) (void)hipEventDestroy(e);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->ev_pool) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
+  }
+  for (auto& sl : h->pipe) {
+    hipEvent_t evs[] = {sl.in_done, sl.v_done[0], sl.v_done[1], sl.fin_done, sl.out_done};
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
   }
   void* dev[] = {h->rpg,     h->rqk,      h->cpg,       h->img8,      h->g32,       h->g8,        h->timg8,
                  h->tg32,    h->tg8,      h->pk16,      h->tpk16,     h->disp,      h->cost,      h->noise,
@@ -796,28 +921,13 @@ void pm_destroy(pm_handle* h) {
     if (p) (void)hipFree(p);
   delete h->copy_pool;
   if (h->pinned) (void)hipHostFree(h->pinned);
-  for (auto& ln : h->lanes)
-    for (int v = 0; v < 2; ++v) {
-      if (ln.view_stream[v]) (void)hipStreamSynchronize(ln.view_stream[v]);
-      if (ln.view_join[v]) (void)hipEventDestroy(ln.view_join[v]);
-      if (ln.view_stream[v]) (void)hipStreamDestroy(ln.view_stream[v]);
-    }
-  if (h->view1_stream) {
-    (void)hipStreamSynchronize(h->view1_stream);
-    (void)hipStreamDestroy(h->view1_stream);
+  // memory handed out by pm_host_alloc and still held, registrations still standing
+  for (auto& r : h->host_ranges) {
+    if (r.owned) (void)hipHostFree(r.base);
+    else (void)hipHostUnregister(r.base);
   }
-  if (h->view1_join) (void)hipEventDestroy(h->view1_join);
-  if (h->view_fork) (void)hipEventDestroy(h->view_fork);
-  if (h->s_in) (void)hipStreamSynchronize(h->s_in);
-  if (h->s_out) (void)hipStreamSynchronize(h->s_out);
-  for (auto& sl : h->pipe) {
-    if (sl.in_done) (void)hipEventDestroy(sl.in_done);
-    if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
-    if (sl.out_done) (void)hipEventDestroy(sl.out_done);
-  }
-  if (h->s_in) (void)hipStreamDestroy(h->s_in);
-  if (h->s_out) (void)hipStreamDestroy(h->s_out);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipStream_t st : streams)
+    if (st) (void)hipStreamDestroy(st);
   delete h;
 }
 
@@ -832,7 +942,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   *out = h;
   h->params = *params;
   h->device = device;
-  h->no_tiled = getenv("PM_NO_TILED") != nullptr;
+  h->no_tiled = pm::tune_env("PM_NO_TILED") != nullptr;
   if (int rc = validate_params(h, *params)) return rc;
   // the sweep kernels address a view's planes with 32-bit byte offsets (12 bytes per pair element at most)
   if ((size_t)(max_rows + 64) * (size_t)(max_cols + 128) >= ((size_t)1 << 28)) {
@@ -852,7 +962,7 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
     return PM_ERR_NO_DEVICE;
   }
   PM_HIP(h, hipSetDevice(device));
-  PM_HIP(h, create_stream(&h->stream, kStreamMain));
+  if (int rc = create_handle_streams(h)) return rc;
 
   h->max_rows = max_rows;
   h->max_cols = max_cols;
@@ -903,6 +1013,11 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   const size_t noise_bytes = sizeof(float) * plane;
   if (h->pinned_bytes < noise_bytes) h->pinned_bytes = noise_bytes;
   PM_HIP(h, hipHostMalloc(&h->pinned, h->pinned_bytes, hipHostMallocDefault));
+  {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, h->pinned, 0) == hipSuccess) h->pinned_dev = (char*)dp;
+    (void)hipGetLastError();
+  }
   // the cost planes are read only where the noise kernel wrote them; clear once so that tools that
   // scan whole planes never see uninitialised memory
   PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
@@ -942,12 +1057,15 @@ int pm_capture_begin(pm_handle* h) {
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   // lazily created resources must exist before the capture starts (creating them is not capturable)
-  if (h->params.sparse_init) {
-    const int sets = h->max_batch > pair_chunk() ? 2 * (pair_lanes() > 1 ? pair_lanes() : 1) : 2;
-    for (int i = 1; i < sets; ++i)
+  if (h->params.left_right_check && h->params.mode == PM_MODE_SCALAR) {
+    if (int rc = view_streams_create(h)) return rc;
+    if (int rc = seq_events_create(h)) return rc;
+  }
+  if (h->params.sparse_init)
+    for (int i = 1; i < 2; ++i)
       if (!h->seeds[i].eig)
         if (int rc = alloc_seed_scratch(h, h->seeds[i])) return rc;
-  }
+  h->cap_unjoined.clear();
   PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   h->capturing = true;
   return PM_OK;
@@ -955,9 +1073,28 @@ int pm_capture_begin(pm_handle* h) {
 
 int pm_capture_end(pm_handle* h) {
   if (!h || !h->capturing) return PM_ERR_INVALID_ARG;
+  // Every stream the recorded calls forked work onto must have been joined back into the handle's stream: ending a
+  // capture with an unjoined fork is an error the runtime answers with a fault, not a status (gpurun_out/r03/crash.log:
+  // a schedule experiment that left a side stream forked).  The forks are joined here so that the capture can be ended
+  // at all, the graph is thrown away, and the caller gets PM_ERR_STATE.
+  const size_t unjoined = h->cap_unjoined.size();
+  if (unjoined) {
+    std::vector<hipStream_t> open_streams = h->cap_unjoined;
+    for (hipStream_t st : open_streams) {
+      hipEvent_t ev = st == h->s_out ? h->out_join : h->view1_join;
+      if (hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
+      mark_joined(h, st);
+    }
+  }
   h->capturing = false;
   hipGraph_t graph = nullptr;
   PM_HIP(h, hipStreamEndCapture(h->stream, &graph));
+  if (unjoined) {
+    if (graph) (void)hipGraphDestroy(graph);
+    set_err(h, "pm_capture_end: %zu stream(s) the recorded calls forked work onto were never joined back; the capture "
+               "was discarded", unjoined);
+    return PM_ERR_STATE;
+  }
   if (h->graph_exec) {
     (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
@@ -968,6 +1105,20 @@ int pm_capture_end(pm_handle* h) {
     set_err(h, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return PM_ERR_HIP;
   }
+  return PM_OK;
+}
+
+// Test hook for the guard above: while a capture is open, forks an (empty) dependency onto the second-view stream and
+// does NOT join it -- what a broken schedule would do.
+int pm_debug_capture_fork(pm_handle* h) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!h->capturing || !h->view1_stream) {
+    set_err(h, "pm_debug_capture_fork: only between pm_capture_begin and pm_capture_end of a handle with view streams");
+    return PM_ERR_STATE;
+  }
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
+  PM_HIP(h, hipStreamWaitEvent(h->view1_stream, h->view_fork, 0));
+  mark_forked(h, h->view1_stream);
   return PM_OK;
 }
 
@@ -984,6 +1135,10 @@ int pm_replay(pm_handle* h) {
 int pm_match_device(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                     const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r) {
   if (!h) return PM_ERR_INVALID_ARG;
+  if (h->pipe_count > 0) {  // the frames of a sequence live in the same plane slots
+    set_err(h, "pm_match_device: pairs are in flight (pm_collect them first)");
+    return PM_ERR_BUSY;
+  }
   const int rc = match_device_impl(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r);
   if (rc != PM_OK) abort_capture(h);  // a failed call must not leave the stream in capture mode
   return rc;
@@ -993,6 +1148,10 @@ int pm_match_view_device(pm_handle* h, const float* d_iml, const float* d_imr, c
                          int rows, int cols, size_t step, float* d_disp, size_t disp_step, void* stream) {
   if (!h) return PM_ERR_INVALID_ARG;
   if (int rc = refuse_while_capturing(h, "pm_match_view_device")) return rc;
+  if (h->pipe_count > 0) {
+    set_err(h, "pm_match_view_device: pairs are in flight (pm_collect them first)");
+    return PM_ERR_BUSY;
+  }
   if (!d_iml || !d_imr || !d_Gl || !d_Gr || !d_disp) {
     set_err(h, "pm_match_view_device: null pointer");
     return PM_ERR_INVALID_ARG;

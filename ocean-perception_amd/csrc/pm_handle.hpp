@@ -23,6 +23,7 @@
 #include "pm_hostcopy.hpp"
 #include "pm_seed_api.hpp"
 #include "pm_sweep_defs.hpp"
+#include "pm_tune.hpp"
 
 namespace pm {
 namespace eng {
@@ -92,28 +93,49 @@ struct pm_handle {
   float* st_disp_r = nullptr;
   void* pinned = nullptr;  // host staging, pinned
   size_t pinned_bytes = 0;
+  char* pinned_dev = nullptr;  // the device's address of the staging slab (k_download writes the maps through it)
 
-  // pipelined host-buffer path (pm_submit_u8 / pm_collect): slot k of the staging buffers, uploads on
-  // s_in, compute on `stream`, downloads on s_out
+  // The frame SEQUENCE (pm_submit_* / pm_collect, pm_match_batch_u8; pm_engine.hip::seq_enqueue_chunk): frame k lives in
+  // ring slot k % max_batch -- plane slot, device staging slot and slab slot of that index.  Uploads run on s_in, the two
+  // views of a chunk (one frame, or two frames advanced through every launch together) on the two sequence streams,
+  // the cross-check and the download on s_out; the handle's own stream is not involved, so nothing joins and nothing
+  // forks per frame.
   struct PipeSlot {
-    hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
+    hipEvent_t in_done = nullptr;   // s_in: the slot's inputs are in device memory
+    hipEvent_t v_done[2] = {nullptr, nullptr};  // view stream v: the chunk that STARTS at this slot has run
+    hipEvent_t fin_done = nullptr;  // s_out: cross-check done, the slot's planes and input staging are free again
+    hipEvent_t out_done = nullptr;  // s_out: the slot's maps have arrived on the host
     uint64_t tag = 0;
     int rows = 0, cols = 0;
+    int state = 0;                  // 0 free, 1 uploaded and held for a partner, 2 enqueued
+    bool has_sl = false, has_sr = false;
+    const uint8_t *d_left = nullptr, *d_right = nullptr;  // where the chunk reads this frame (staging or caller memory)
+    const float *d_seed_l = nullptr, *d_seed_r = nullptr;
+    float *d_out_l = nullptr, *d_out_r = nullptr;         // where the cross-check writes (staging or caller memory)
+    bool device_io = false;         // pm_submit_device: no copies at all
+    float *out_l = nullptr, *out_r = nullptr;  // host maps bound at submit (null: handed to pm_collect)
+    size_t out_step = 0;
+    bool direct_l = false, direct_r = false;   // the download goes straight into the bound (registered) host map
   };
-  // per-view streams: the two views are independent until the cross-check, so their launch chains run on
-  // two streams and one view's kernels fill the CUs the other view's kernel tails leave idle
-  // A batch of pairs runs as independent per-pair pipelines that take the lanes in rotation (pm_engine.hip::run_pairs_on_lanes):
-  // a pair's head and tail -- a dozen small launches -- then run beside another pair's sweeps.  Lane 0 serves the
-  // single pair.
-  static constexpr int kLanes = 4;
-  struct ViewLane {
-    hipStream_t view_stream[2] = {nullptr, nullptr};
-    hipEvent_t view_join[2] = {nullptr, nullptr};
+  // caller memory the engine may DMA from / into without staging (pm_host_alloc, pm_host_register)
+  struct HostRange {
+    char* base;
+    size_t bytes;
+    bool owned;
+    char* dev_base;  // the device's address of `base` (null: not mapped -- downloads into it go through hipMemcpyAsync)
   };
-  ViewLane lanes[kLanes];
+  std::vector<HostRange> host_ranges;
+  // streams a capture forked work onto and has not joined back yet (pm_capture_end refuses to end such a capture)
+  std::vector<hipStream_t> cap_unjoined;
+  // Per-view streams: the two views are independent until the cross-check, so their launch chains run on two streams and
+  // one view's kernels fill the CUs the other view's kernel tails leave idle.  A single pair keeps its first view on the
+  // handle's stream and forks the second onto view1_stream; the chunks of a batch or of a frame sequence run on the same
+  // two streams, one chunk behind the other, with their cross-checks on s_out (pm_engine.hip::view_streams_create,
+  // seq_enqueue_chunk).
   hipEvent_t view_fork = nullptr;
-  hipStream_t view1_stream = nullptr;  // the second view of a single pair (high priority: a hardware queue of its own)
+  hipStream_t view1_stream = nullptr;
   hipEvent_t view1_join = nullptr;
+  hipEvent_t out_join = nullptr;  // s_out -> the handle's stream at the end of a batch
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
@@ -127,6 +149,7 @@ struct pm_handle {
   hipStream_t s_in = nullptr, s_out = nullptr;
   std::vector<PipeSlot> pipe;
   int pipe_head = 0, pipe_count = 0;
+  int seq_last = -1;  // ring slot of the frame enqueued last (is the device still busy with it?), -1: none
 
   // profiling
   bool profiling = false;
@@ -174,6 +197,7 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // one device 49 -> 117 ms); "0" restores one class for everything (tools/multi_handle.py, batch_after.py, pipe_timing.py).
 enum StreamKind { kStreamMain = 0, kStreamView = 1, kStreamCopy = 2, kStreamLane = 3 };
 hipError_t create_stream(hipStream_t* s, int kind);
+int create_handle_streams(pm_handle* h);  // the handle's four streams, together (pm_engine.hip)
 
 // Brackets the launches of one kernel class with a pair of events while the handle is profiling.
 // While the handle is profiling, the launches of one kernel class are bracketed by events on the current stream.  An
@@ -248,6 +272,14 @@ int pair_planes_alloc(pm_handle* h);
 int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots);
 int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                       const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
+// view streams, chunk events, and one chunk of a batch / frame sequence (pm_engine.hip)
+int view_streams_create(pm_handle* h);
+int seq_events_create(pm_handle* h);
+int seq_chunk_pairs();
+bool seq_pipelined(const pm_handle* h);
+int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, hipEvent_t ready,
+                      hipEvent_t slot_free, hipEvent_t v_done[2]);
 SeedParams seed_params(const pm_params& p);
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc);
 // SparseInit (or Patchmatch::Initialize(.., 1)) for view `view` of pair `b` straight into its disparity plane
@@ -280,6 +312,9 @@ void launch_finalize(pm_handle* h, const PlaneSet& ps, float* d_disp_l, float* d
 void launch_mask_occlusions(pm_handle* h, float* d_disp_l, const float* d_disp_r, int rows, int cols);
 void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
                          const int* d_mask);
+// rows x cols floats from tight device memory into page-locked host memory (its DEVICE address), row stride in floats
+void launch_download(pm_handle* h, float* dst_dev, size_t dst_step_floats, const float* d_src, int rows, int cols,
+                     hipStream_t stream);
 void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src);
 void launch_copy_out(pm_handle* h, const PlaneSet& ps, float* d_dst, int which);
 void launch_copy_disp_strided(pm_handle* h, const PlaneSet& ps, float* d_buf, size_t stride, int to_buf);

@@ -9,8 +9,318 @@
 using namespace pm;
 using namespace pm::eng;
 
+namespace {
+
+// ---- caller memory known to be page-locked (pm_host_alloc / pm_host_register) ---------------------------------------
+bool host_pinned(const pm_handle* h, const void* p, size_t span) {
+  const char* c = (const char*)p;
+  for (const auto& r : h->host_ranges)
+    if (c >= r.base && c + span <= r.base + r.bytes) return true;
+  return false;
+}
+size_t span_bytes(int rows, size_t step, size_t row_bytes) { return (size_t)(rows - 1) * step + row_bytes; }
+
+// rows x row_bytes from host memory (row stride `step`) into tight device memory on `stream`: by DMA straight from the
+// caller's buffer when it is page-locked, else packed into `slab` (page-locked, the handle's) by the copy pool first.
+int upload_plane(pm_handle* h, void* d_dst, const void* src, size_t step, size_t row_bytes, int rows, void* slab,
+                 hipStream_t stream) {
+  if (host_pinned(h, src, span_bytes(rows, step, row_bytes))) {
+    if (step == row_bytes)
+      PM_HIP(h, hipMemcpyAsync(d_dst, src, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+    else
+      PM_HIP(h, hipMemcpy2DAsync(d_dst, row_bytes, src, step, row_bytes, (size_t)rows, hipMemcpyHostToDevice, stream));
+    return PM_OK;
+  }
+  h->copy_pool->Copy2D(slab, row_bytes, src, step, row_bytes, rows);
+  PM_HIP(h, hipMemcpyAsync(d_dst, slab, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+  return PM_OK;
+}
+// the device's address of page-locked host memory, or null
+char* host_dev_address(const pm_handle* h, const void* p, size_t span) {
+  const char* c = (const char*)p;
+  if (h->pinned_dev && c >= (const char*)h->pinned && c + span <= (const char*)h->pinned + h->pinned_bytes)
+    return h->pinned_dev + (c - (const char*)h->pinned);
+  for (const auto& r : h->host_ranges)
+    if (r.dev_base && c >= r.base && c + span <= r.base + r.bytes) return r.dev_base + (c - r.base);
+  return nullptr;
+}
+
+// The other way, for float maps: *direct = the map goes straight into `dst` (else it waits in `slab` for the unpack).
+// Page-locked targets the device can address are written by k_download (a handful of wavefronts), not by the runtime's
+// device-to-host copy, which on a busy stream is a full-size blit kernel (pm_kernels.hpp).
+int download_plane(pm_handle* h, void* dst, size_t step, const void* d_src, size_t row_bytes, int rows, void* slab,
+                   hipStream_t stream, bool* direct) {
+  *direct = dst && host_pinned(h, dst, span_bytes(rows, step, row_bytes));
+  void* target = *direct ? dst : slab;
+  const size_t tstep = *direct ? step : row_bytes;
+  char* dev = (tstep % sizeof(float)) == 0 ? host_dev_address(h, target, span_bytes(rows, tstep, row_bytes)) : nullptr;
+  if (dev) {
+    launch_download(h, (float*)dev, tstep / sizeof(float), (const float*)d_src, rows, (int)(row_bytes / sizeof(float)), stream);
+    return launch_check(h, "download");
+  }
+  if (tstep == row_bytes)
+    PM_HIP(h, hipMemcpyAsync(target, d_src, row_bytes * (size_t)rows, hipMemcpyDeviceToHost, stream));
+  else
+    PM_HIP(h, hipMemcpy2DAsync(target, tstep, d_src, row_bytes, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, stream));
+  return PM_OK;
+}
+
+struct PinnedSlot {
+  float *sl, *sr, *dl, *dr;
+  uint8_t *l, *r;
+};
+PinnedSlot pinned_slot(pm_handle* h, int slot, size_t px) {
+  const size_t tight = (size_t)h->max_rows * h->max_cols;
+  char* base = (char*)h->pinned + (size_t)slot * tight * (2 + 4 * sizeof(float));
+  PinnedSlot p;
+  p.sl = (float*)base;  // floats first so every sub-buffer stays 4-byte aligned
+  p.sr = p.sl + px;
+  p.dl = p.sr + px;
+  p.dr = p.dl + px;
+  p.l = (uint8_t*)(p.dr + px);
+  p.r = p.l + px;
+  return p;
+}
+
+int pipe_init(pm_handle* h) {
+  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
+  if (int rc = seq_events_create(h)) return rc;
+  if (seq_pipelined(h))
+    if (int rc = view_streams_create(h)) return rc;
+  return PM_OK;
+}
+
+// Frames [b, b + c) of the ring -- uploaded (or device resident) -- become ONE chunk of the sequence: both views on the
+// view streams behind the later frame's upload, cross-check and downloads on s_out.  Handles that cannot run as chunks
+// (plane mode, one view only) run the frame on the handle's stream instead, one frame after the other.
+int enqueue_frames(pm_handle* h, int b, int c) {
+  pm_handle::PipeSlot& f0 = h->pipe[(size_t)b];
+  const int rows = f0.rows, cols = f0.cols;
+  const size_t px = (size_t)rows * cols;
+  const bool lr = h->params.left_right_check != 0;
+  hipEvent_t ready = f0.device_io ? nullptr : h->pipe[(size_t)(b + c - 1)].in_done;  // s_in runs in order
+  if (seq_pipelined(h)) {
+    if (int rc = seq_enqueue_chunk(h, b, c, f0.d_left, f0.d_right, rows, cols, f0.d_seed_l, f0.d_seed_r, f0.d_out_l,
+                                   f0.d_out_r, ready, nullptr, f0.v_done))
+      return rc;
+  } else {
+    if (ready) PM_HIP(h, hipStreamWaitEvent(h->stream, ready, 0));
+    for (int i = 0; i < c; ++i) {
+      pm_handle::PipeSlot& f = h->pipe[(size_t)(b + i)];
+      if (int rc = match_device_impl(h, 1, f.d_left, f.d_right, rows, cols, f.d_seed_l, f.d_seed_r, f.d_out_l,
+                                     lr ? f.d_out_r : nullptr))
+        return rc;
+    }
+    PM_HIP(h, hipEventRecord(f0.v_done[0], h->stream));
+    PM_HIP(h, hipStreamWaitEvent(h->s_out, f0.v_done[0], 0));
+  }
+  for (int i = 0; i < c; ++i) {
+    pm_handle::PipeSlot& f = h->pipe[(size_t)(b + i)];
+    if (!f.device_io) {
+      const PinnedSlot ps = pinned_slot(h, b + i, px);
+      const size_t row_bytes = sizeof(float) * (size_t)cols;
+      const size_t step = f.out_step ? f.out_step : row_bytes;
+      if (int rc = download_plane(h, f.out_l, step, f.d_out_l, row_bytes, rows, ps.dl, h->s_out, &f.direct_l)) return rc;
+      if (lr)
+        if (int rc = download_plane(h, f.out_r, step, f.d_out_r, row_bytes, rows, ps.dr, h->s_out, &f.direct_r)) return rc;
+    }
+    PM_HIP(h, hipEventRecord(f.out_done, h->s_out));
+    f.state = 2;
+  }
+  h->seq_last = b + c - 1;
+  return PM_OK;
+}
+
+// Is the device still busy with the chunk enqueued last?  (Only then does holding a frame for a partner cost nothing.)
+bool device_busy(const pm_handle* h) {
+  if (h->seq_last < 0) return false;
+  const pm_handle::PipeSlot& f = h->pipe[(size_t)h->seq_last];
+  return f.state == 2 && hipEventQuery(f.out_done) == hipErrorNotReady;
+}
+
+// the ring slot being held for a partner, or -1
+int held_slot(const pm_handle* h) {
+  for (int i = 0; i < h->pipe_count; ++i) {
+    const int s = (h->pipe_head + i) % h->max_batch;
+    if (h->pipe[(size_t)s].state == 1) return s;
+  }
+  return -1;
+}
+
+// two frames can be advanced through every launch together if they are neighbours in device memory
+bool can_gang(const pm_handle* h, const pm_handle::PipeSlot& a, const pm_handle::PipeSlot& b, int sa, int sb) {
+  if (sb != sa + 1 || a.rows != b.rows || a.cols != b.cols || a.has_sl != b.has_sl || a.has_sr != b.has_sr) return false;
+  const size_t px = (size_t)a.rows * a.cols;
+  return b.d_left == a.d_left + px && b.d_right == a.d_right + px && (!a.has_sl || b.d_seed_l == a.d_seed_l + px) &&
+         (!a.has_sr || b.d_seed_r == a.d_seed_r + px) && b.d_out_l == a.d_out_l + px &&
+         (!h->params.left_right_check || b.d_out_r == a.d_out_r + px);
+}
+
+struct SubmitArgs {
+  const uint8_t *left, *right;
+  int rows, cols;
+  size_t image_step;
+  const float *seed_l, *seed_r;
+  size_t seed_step;
+  float *out_l, *out_r;  // host maps bound at submit, or (device_io) the device maps
+  size_t out_step;
+  uint64_t tag;
+  bool device_io;
+};
+
+int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
+  if (int rc = refuse_while_capturing(h, what)) return rc;
+  if (!a.left || !a.right) {
+    set_err(h, "%s: null image pointer", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  const int rows = a.rows, cols = a.cols;
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  const size_t image_step = a.image_step ? a.image_step : (size_t)cols;
+  const size_t frow = sizeof(float) * (size_t)cols;
+  const size_t seed_step = a.seed_step ? a.seed_step : frow;
+  const size_t out_step = a.out_step ? a.out_step : frow;
+  if (image_step < (size_t)cols || seed_step < frow || out_step < frow) {
+    set_err(h, "%s: a row step is smaller than a row", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  const bool lr = h->params.left_right_check != 0;
+  if (a.device_io && (!a.out_l || (lr && !a.out_r))) {
+    set_err(h, "%s: null output pointer", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  if (!a.device_io && a.out_l && lr && !a.out_r) {
+    set_err(h, "%s: disp_r required when left_right_check is set", what);
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = pipe_init(h)) return rc;
+  if (h->pipe_count == h->max_batch) {
+    set_err(h, "%s: %d pairs in flight (the plan's max_batch); collect one first", what, h->pipe_count);
+    return PM_ERR_BUSY;
+  }
+  if (h->pipe_count > 0) {
+    const pm_handle::PipeSlot& first = h->pipe[(size_t)h->pipe_head];
+    if (first.rows != rows || first.cols != cols) {  // the frames in flight share the noise table and the slot layout
+      set_err(h, "%s: image size changed with pairs in flight; collect them first", what);
+      return PM_ERR_BUSY;
+    }
+  } else if (h->params.mode == PM_MODE_SCALAR) {
+    if (int rc = ensure_noise(h, rows, cols)) return rc;
+  }
+  const int slot = (h->pipe_head + h->pipe_count) % h->max_batch;
+  pm_handle::PipeSlot& sl = h->pipe[(size_t)slot];
+  const size_t px = (size_t)rows * cols;
+  sl.tag = a.tag;
+  sl.rows = rows;
+  sl.cols = cols;
+  sl.has_sl = a.seed_l != nullptr;
+  sl.has_sr = a.seed_r != nullptr;
+  sl.device_io = a.device_io;
+  sl.direct_l = sl.direct_r = false;
+  if (a.device_io) {
+    sl.d_left = a.left;
+    sl.d_right = a.right;
+    sl.d_seed_l = a.seed_l;
+    sl.d_seed_r = a.seed_r;
+    sl.d_out_l = a.out_l;
+    sl.d_out_r = a.out_r;
+    sl.out_l = sl.out_r = nullptr;
+    sl.out_step = 0;
+  } else {
+    // ring slot k keeps its inputs and outputs at offset k * px of the staging arrays: frames in flight share one size
+    uint8_t* dl8 = h->st_left + (size_t)slot * px;
+    uint8_t* dr8 = h->st_right + (size_t)slot * px;
+    float* dsl = h->st_seed_l + (size_t)slot * px;
+    float* dsr = h->st_seed_r + (size_t)slot * px;
+    const PinnedSlot ps = pinned_slot(h, slot, px);
+    if (int rc = upload_plane(h, dl8, a.left, image_step, (size_t)cols, rows, ps.l, h->s_in)) return rc;
+    if (int rc = upload_plane(h, dr8, a.right, image_step, (size_t)cols, rows, ps.r, h->s_in)) return rc;
+    if (a.seed_l)
+      if (int rc = upload_plane(h, dsl, a.seed_l, seed_step, frow, rows, ps.sl, h->s_in)) return rc;
+    if (a.seed_r)
+      if (int rc = upload_plane(h, dsr, a.seed_r, seed_step, frow, rows, ps.sr, h->s_in)) return rc;
+    PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
+    sl.d_left = dl8;
+    sl.d_right = dr8;
+    sl.d_seed_l = a.seed_l ? dsl : nullptr;
+    sl.d_seed_r = a.seed_r ? dsr : nullptr;
+    sl.d_out_l = h->st_disp_l + (size_t)slot * px;
+    sl.d_out_r = h->st_disp_r + (size_t)slot * px;
+    sl.out_l = a.out_l;
+    sl.out_r = a.out_r;
+    sl.out_step = a.out_l ? out_step : 0;
+  }
+  sl.state = 1;
+  ++h->pipe_count;
+  // Chunks: a frame that is being held takes this one as its partner if the two are neighbours in memory, and goes alone
+  // otherwise.  This frame is held in turn while the device is busy with earlier chunks anyway and a neighbour slot
+  // exists for a partner; with an idle device it starts at once.
+  const int held = held_slot(h) == slot ? -1 : held_slot(h);
+  if (held >= 0) {
+    if (can_gang(h, h->pipe[(size_t)held], sl, held, slot)) return enqueue_frames(h, held, 2);
+    if (int rc = enqueue_frames(h, held, 1)) return rc;
+  }
+  const bool hold = seq_pipelined(h) && seq_chunk_pairs() >= 2 && slot + 1 < h->max_batch && device_busy(h);
+  if (hold) return PM_OK;
+  return enqueue_frames(h, slot, 1);
+}
+
+}  // namespace
+
 extern "C" {
 
+int pm_host_alloc(pm_handle* h, size_t bytes, void** ptr) {
+  if (!h || !ptr || bytes == 0) return PM_ERR_INVALID_ARG;
+  *ptr = nullptr;
+  PM_HIP(h, hipSetDevice(h->device));
+  void* p = nullptr;
+  PM_HIP(h, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) dp = nullptr;
+  (void)hipGetLastError();
+  h->host_ranges.push_back({(char*)p, bytes, true, (char*)dp});
+  *ptr = p;
+  return PM_OK;
+}
+
+int pm_host_register(pm_handle* h, void* ptr, size_t bytes) {
+  if (!h || !ptr || bytes == 0) return PM_ERR_INVALID_ARG;
+  PM_HIP(h, hipSetDevice(h->device));
+  PM_HIP(h, hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, ptr, 0) != hipSuccess) dp = nullptr;
+  (void)hipGetLastError();
+  h->host_ranges.push_back({(char*)ptr, bytes, false, (char*)dp});
+  return PM_OK;
+}
+
+static int host_release(pm_handle* h, void* ptr, bool owned, const char* what) {
+  if (!h || !ptr) return PM_ERR_INVALID_ARG;
+  if (h->pipe_count > 0) {
+    set_err(h, "%s: pairs are in flight (they may be reading or writing this memory); collect them first", what);
+    return PM_ERR_BUSY;
+  }
+  for (size_t i = 0; i < h->host_ranges.size(); ++i) {
+    if (h->host_ranges[i].base != (char*)ptr || h->host_ranges[i].owned != owned) continue;
+    PM_HIP(h, hipSetDevice(h->device));
+    // a synchronous entry point may have left a DMA into this range running only if it returned an error; be safe
+    PM_HIP(h, hipStreamSynchronize(h->stream));
+    h->host_ranges.erase(h->host_ranges.begin() + (long)i);
+    if (owned)
+      PM_HIP(h, hipHostFree(ptr));
+    else
+      PM_HIP(h, hipHostUnregister(ptr));
+    return PM_OK;
+  }
+  set_err(h, "%s: %p is not the start of a range this handle %s", what, ptr, owned ? "allocated" : "registered");
+  return PM_ERR_INVALID_ARG;
+}
+int pm_host_free(pm_handle* h, void* ptr) { return host_release(h, ptr, true, "pm_host_free"); }
+int pm_host_unregister(pm_handle* h, void* ptr) { return host_release(h, ptr, false, "pm_host_unregister"); }
+
+// n pairs per call as chunks of the frame sequence: the uploads of pair i + 1 run while pair i is matched, the maps of
+// finished chunks come back (and are unpacked by this thread) while later chunks are matched.
 int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uint8_t* const* right, int rows,
                       int cols, const float* const* seed_l, const float* const* seed_r, float* const* disp_l,
                       float* const* disp_r) {
@@ -26,81 +336,110 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
     set_err(h, "pm_match_batch_u8: disp_r required when left_right_check is set");
     return PM_ERR_INVALID_ARG;
   }
-  PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = ensure_noise(h, rows, cols)) return rc;  // uses the pinned buffer: before staging inputs
-  const size_t px = (size_t)rows * cols;
-  float* psl = (float*)h->pinned;  // floats first so every sub-buffer stays 4-byte aligned
-  float* psr = psl + n * px;
-  float* pdl = psr + n * px;
-  float* pdr = pdl + n * px;
-  uint8_t* pl = (uint8_t*)(pdr + n * px);
-  uint8_t* pr = pl + n * px;
-  bool any_sl = false, any_sr = false;
-  // With sparse_init a missing seed map means "seed this view on the device", which is decided per call, not per
-  // pair: a batch must give the seed map of a view for every pair or for none.
-  if (h->params.sparse_init) {
-    int nl = 0, nr = 0;
-    for (int i = 0; i < n; ++i) {
-      nl += (seed_l && seed_l[i]) ? 1 : 0;
-      nr += (seed_r && seed_r[i]) ? 1 : 0;
-    }
-    if ((nl != 0 && nl != n) || (nr != 0 && nr != n)) {
-      set_err(h, "pm_match_batch_u8: with sparse_init a view's seed maps must be given for all pairs or for none");
-      return PM_ERR_INVALID_ARG;
-    }
+  if (h->pipe_count > 0) {
+    set_err(h, "pm_match_batch_u8: pairs are in flight (pm_collect them first)");
+    return PM_ERR_BUSY;
   }
-  // every pair is packed into the pinned buffer by a few host threads (pm_hostcopy.hpp) and its upload enqueued at
-  // once: the DMA of pair i runs while the host packs pair i + 1
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  const size_t frow = sizeof(float) * (size_t)cols;
+  int nl = 0, nr = 0;
   for (int i = 0; i < n; ++i) {
     if (!left[i] || !right[i] || !disp_l[i] || (lr && !disp_r[i])) {
       set_err(h, "pm_match_batch_u8: null pointer for pair %d", i);
       return PM_ERR_INVALID_ARG;
     }
-    h->copy_pool->Copy2D(pl + i * px, (size_t)cols, left[i], (size_t)cols, (size_t)cols, rows);
-    PM_HIP(h, hipMemcpyAsync(h->st_left + i * px, pl + i * px, px, hipMemcpyHostToDevice, h->stream));
-    h->copy_pool->Copy2D(pr + i * px, (size_t)cols, right[i], (size_t)cols, (size_t)cols, rows);
-    PM_HIP(h, hipMemcpyAsync(h->st_right + i * px, pr + i * px, px, hipMemcpyHostToDevice, h->stream));
-    if (seed_l && seed_l[i]) {
-      h->copy_pool->Copy2D(psl + i * px, frow, seed_l[i], frow, frow, rows);
-      PM_HIP(h, hipMemcpyAsync(h->st_seed_l + i * px, psl + i * px, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-      any_sl = true;
+    nl += (seed_l && seed_l[i]) ? 1 : 0;
+    nr += (seed_r && seed_r[i]) ? 1 : 0;
+  }
+  // With sparse_init a missing seed map means "seed this view on the device", which is decided per call, not per
+  // pair: a batch must give the seed map of a view for every pair or for none.
+  if (h->params.sparse_init && ((nl != 0 && nl != n) || (nr != 0 && nr != n))) {
+    set_err(h, "pm_match_batch_u8: with sparse_init a view's seed maps must be given for all pairs or for none");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  if (int rc = pipe_init(h)) return rc;
+  if (h->params.mode == PM_MODE_SCALAR)
+    if (int rc = ensure_noise(h, rows, cols)) return rc;
+  const size_t px = (size_t)rows * cols;
+  const size_t frow = sizeof(float) * (size_t)cols;
+  const bool any_sl = nl > 0, any_sr = nr > 0;
+  const bool chunks = seq_pipelined(h);
+  const int chunk = chunks ? seq_chunk_pairs() : n;
+  h->pipe_head = 0;
+  for (int b = 0; b < n; b += chunk) {
+    const int c = n - b < chunk ? n - b : chunk;
+    for (int i = b; i < b + c; ++i) {
+      pm_handle::PipeSlot& sl = h->pipe[(size_t)i];
+      const PinnedSlot ps = pinned_slot(h, i, px);
+      uint8_t* dl8 = h->st_left + (size_t)i * px;
+      uint8_t* dr8 = h->st_right + (size_t)i * px;
+      float* dsl = h->st_seed_l + (size_t)i * px;
+      float* dsr = h->st_seed_r + (size_t)i * px;
+      if (int rc = upload_plane(h, dl8, left[i], (size_t)cols, (size_t)cols, rows, ps.l, h->s_in)) return rc;
+      if (int rc = upload_plane(h, dr8, right[i], (size_t)cols, (size_t)cols, rows, ps.r, h->s_in)) return rc;
+      // a view whose maps were given for some pairs only (allowed without sparse_init): the others start from zeros
+      if (seed_l && seed_l[i]) {
+        if (int rc = upload_plane(h, dsl, seed_l[i], frow, frow, rows, ps.sl, h->s_in)) return rc;
+      } else if (any_sl) {
+        PM_HIP(h, hipMemsetAsync(dsl, 0, sizeof(float) * px, h->s_in));
+      }
+      if (seed_r && seed_r[i]) {
+        if (int rc = upload_plane(h, dsr, seed_r[i], frow, frow, rows, ps.sr, h->s_in)) return rc;
+      } else if (any_sr) {
+        PM_HIP(h, hipMemsetAsync(dsr, 0, sizeof(float) * px, h->s_in));
+      }
+      PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
+      sl.tag = 0;
+      sl.rows = rows;
+      sl.cols = cols;
+      sl.has_sl = any_sl;
+      sl.has_sr = any_sr;
+      sl.device_io = false;
+      sl.d_left = dl8;
+      sl.d_right = dr8;
+      sl.d_seed_l = any_sl ? dsl : nullptr;
+      sl.d_seed_r = any_sr ? dsr : nullptr;
+      sl.d_out_l = h->st_disp_l + (size_t)i * px;
+      sl.d_out_r = h->st_disp_r + (size_t)i * px;
+      sl.out_l = disp_l[i];
+      sl.out_r = lr ? disp_r[i] : nullptr;
+      sl.out_step = frow;
+      sl.state = 1;
     }
-    if (seed_r && seed_r[i]) {
-      h->copy_pool->Copy2D(psr + i * px, frow, seed_r[i], frow, frow, rows);
-      PM_HIP(h, hipMemcpyAsync(h->st_seed_r + i * px, psr + i * px, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-      any_sr = true;
+    if (chunks) {
+      if (int rc = enqueue_frames(h, b, c)) return rc;
+    } else {
+      // all pairs through every launch together on the handle's stream (plane mode, single view)
+      PM_HIP(h, hipStreamWaitEvent(h->stream, h->pipe[(size_t)(n - 1)].in_done, 0));
+      if (int rc = match_device_impl(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
+                                     any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
+        return rc;
+      PM_HIP(h, hipEventRecord(h->pipe[0].v_done[0], h->stream));
+      PM_HIP(h, hipStreamWaitEvent(h->s_out, h->pipe[0].v_done[0], 0));
+      for (int i = 0; i < n; ++i) {
+        pm_handle::PipeSlot& f = h->pipe[(size_t)i];
+        const PinnedSlot ps = pinned_slot(h, i, px);
+        if (int rc = download_plane(h, f.out_l, frow, f.d_out_l, frow, rows, ps.dl, h->s_out, &f.direct_l)) return rc;
+        if (lr)
+          if (int rc = download_plane(h, f.out_r, frow, f.d_out_r, frow, rows, ps.dr, h->s_out, &f.direct_r)) return rc;
+        PM_HIP(h, hipEventRecord(f.out_done, h->s_out));
+      }
     }
   }
-  // a view whose maps were given for some pairs only (allowed without sparse_init): the others start from zeros
+  int rc_all = PM_OK;
   for (int i = 0; i < n; ++i) {
-    if (any_sl && !(seed_l && seed_l[i])) PM_HIP(h, hipMemsetAsync(h->st_seed_l + i * px, 0, sizeof(float) * px, h->stream));
-    if (any_sr && !(seed_r && seed_r[i])) PM_HIP(h, hipMemsetAsync(h->st_seed_r + i * px, 0, sizeof(float) * px, h->stream));
+    pm_handle::PipeSlot& f = h->pipe[(size_t)i];
+    f.state = 0;
+    if (hipEventSynchronize(f.out_done) != hipSuccess) {
+      set_err(h, "pm_match_batch_u8: waiting for pair %d failed", i);
+      rc_all = PM_ERR_HIP;
+      continue;
+    }
+    const PinnedSlot ps = pinned_slot(h, i, px);
+    if (!f.direct_l) h->copy_pool->Copy2D(disp_l[i], frow, ps.dl, frow, frow, rows);
+    if (lr && !f.direct_r) h->copy_pool->Copy2D(disp_r[i], frow, ps.dr, frow, frow, rows);
   }
-  if (int rc = match_device_impl(h, n, h->st_left, h->st_right, rows, cols, any_sl ? h->st_seed_l : nullptr,
-                               any_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
-    return rc;
-  // the left maps are unpacked into the caller's buffers while the right ones are still on the bus
-  if (!h->left_out) {
-    PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&h->right_out, hipEventDisableTiming));
-  }
-  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-  PM_HIP(h, hipEventRecord(h->left_out, h->stream));
-  if (lr) {
-    PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * n * px, hipMemcpyDeviceToHost, h->stream));
-    PM_HIP(h, hipEventRecord(h->right_out, h->stream));
-  }
-  PM_HIP(h, hipEventSynchronize(h->left_out));
-  for (int i = 0; i < n; ++i)
-    h->copy_pool->Copy2D(disp_l[i], frow, pdl + i * px, frow, frow, rows);
-  if (lr) {
-    PM_HIP(h, hipEventSynchronize(h->right_out));
-    for (int i = 0; i < n; ++i)
-      h->copy_pool->Copy2D(disp_r[i], frow, pdr + i * px, frow, frow, rows);
-  }
-  return PM_OK;
+  h->seq_last = -1;
+  return rc_all;
 }
 
 int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
@@ -118,41 +457,31 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
     set_err(h, "pm_match_u8: disp_r required when left_right_check is set");
     return PM_ERR_INVALID_ARG;
   }
+  if (h->pipe_count > 0) {
+    set_err(h, "pm_match_u8: pairs are in flight (pm_collect them first)");
+    return PM_ERR_BUSY;
+  }
+  const size_t frow = sizeof(float) * (size_t)cols;
   if (image_step == 0) image_step = (size_t)cols;
-  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
-  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
-  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols ||
-      disp_step < sizeof(float) * (size_t)cols) {
+  if (seed_step == 0) seed_step = frow;
+  if (disp_step == 0) disp_step = frow;
+  if (image_step < (size_t)cols || seed_step < frow || disp_step < frow) {
     set_err(h, "pm_match_u8: a row step is smaller than a row");
     return PM_ERR_INVALID_ARG;
   }
   PM_HIP(h, hipSetDevice(h->device));
   if (int rc = ensure_noise(h, rows, cols)) return rc;
   const size_t px = (size_t)rows * cols;
-  float* psl = (float*)h->pinned;
-  float* psr = psl + px;
-  float* pdl = psr + px;
-  float* pdr = pdl + px;
-  uint8_t* pl = (uint8_t*)(pdr + px);
-  uint8_t* pr = pl + px;
-  // every plane is packed into the pinned buffer (a few host threads share each copy, pm_hostcopy.hpp) and its upload
-  // enqueued at once: the DMA of one plane runs while the host packs the next
+  const PinnedSlot ps = pinned_slot(h, 0, px);
+  // every plane goes up as soon as it is ready -- by DMA from the caller's buffer if that is page-locked, else packed
+  // into the pinned slab by a few host threads (pm_hostcopy.hpp): the DMA of one plane runs while the host packs the next
   if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  auto pack = [&](void* dst, const void* src, size_t step, size_t row_bytes) {
-    h->copy_pool->Copy2D(dst, row_bytes, src, step, row_bytes, rows);
-  };
-  pack(pl, left, image_step, (size_t)cols);
-  PM_HIP(h, hipMemcpyAsync(h->st_left, pl, px, hipMemcpyHostToDevice, h->stream));
-  pack(pr, right, image_step, (size_t)cols);
-  PM_HIP(h, hipMemcpyAsync(h->st_right, pr, px, hipMemcpyHostToDevice, h->stream));
-  if (seed_l) {
-    pack(psl, seed_l, seed_step, sizeof(float) * (size_t)cols);
-    PM_HIP(h, hipMemcpyAsync(h->st_seed_l, psl, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  }
-  if (seed_r) {
-    pack(psr, seed_r, seed_step, sizeof(float) * (size_t)cols);
-    PM_HIP(h, hipMemcpyAsync(h->st_seed_r, psr, sizeof(float) * px, hipMemcpyHostToDevice, h->stream));
-  }
+  if (int rc = upload_plane(h, h->st_left, left, image_step, (size_t)cols, rows, ps.l, h->stream)) return rc;
+  if (int rc = upload_plane(h, h->st_right, right, image_step, (size_t)cols, rows, ps.r, h->stream)) return rc;
+  if (seed_l)
+    if (int rc = upload_plane(h, h->st_seed_l, seed_l, seed_step, frow, rows, ps.sl, h->stream)) return rc;
+  if (seed_r)
+    if (int rc = upload_plane(h, h->st_seed_r, seed_r, seed_step, frow, rows, ps.sr, h->stream)) return rc;
   if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
                                seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
@@ -161,132 +490,59 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
     PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
     PM_HIP(h, hipEventCreateWithFlags(&h->right_out, hipEventDisableTiming));
   }
-  PM_HIP(h, hipMemcpyAsync(pdl, h->st_disp_l, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+  bool direct_l = false, direct_r = false;
+  if (int rc = download_plane(h, disp_l, disp_step, h->st_disp_l, frow, rows, ps.dl, h->stream, &direct_l)) return rc;
   PM_HIP(h, hipEventRecord(h->left_out, h->stream));
   if (lr) {
-    PM_HIP(h, hipMemcpyAsync(pdr, h->st_disp_r, sizeof(float) * px, hipMemcpyDeviceToHost, h->stream));
+    if (int rc = download_plane(h, disp_r, disp_step, h->st_disp_r, frow, rows, ps.dr, h->stream, &direct_r)) return rc;
     PM_HIP(h, hipEventRecord(h->right_out, h->stream));
   }
-  const size_t row_bytes = sizeof(float) * (size_t)cols;
   PM_HIP(h, hipEventSynchronize(h->left_out));
-  h->copy_pool->Copy2D(disp_l, disp_step, pdl, row_bytes, row_bytes, rows);
+  if (!direct_l) h->copy_pool->Copy2D(disp_l, disp_step, ps.dl, frow, frow, rows);
   if (lr) {
     PM_HIP(h, hipEventSynchronize(h->right_out));
-    h->copy_pool->Copy2D(disp_r, disp_step, pdr, row_bytes, row_bytes, rows);
+    if (!direct_r) h->copy_pool->Copy2D(disp_r, disp_step, ps.dr, frow, frow, rows);
   }
   return PM_OK;
 }
 
-// ---- pipelined host-buffer path ---------------------------------------------------------------------
-// What the Sequence caller of the reference does frame by frame (patchmatch_gpu_test.cpp:118-128) with
-// the copies taken off the critical path: while pair k is matched, pair k+1 is packed and uploaded and
-// pair k-1 is downloaded.  Depth = max_batch of the plan.
-}  // extern "C"
-
-namespace {
-
-int pipe_init(pm_handle* h) {
-  if (!h->pipe.empty()) return PM_OK;
-  PM_HIP(h, create_stream(&h->s_in, kStreamCopy));
-  PM_HIP(h, create_stream(&h->s_out, kStreamCopy));
-  h->pipe.resize((size_t)h->max_batch);
-  for (auto& sl : h->pipe) {
-    PM_HIP(h, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&sl.compute_done, hipEventDisableTiming));
-    PM_HIP(h, hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
-  }
-  return PM_OK;
-}
-
-struct PinnedSlot {
-  float *sl, *sr, *dl, *dr;
-  uint8_t *l, *r;
-};
-PinnedSlot pinned_slot(pm_handle* h, int slot, size_t px) {
-  const size_t tight = (size_t)h->max_rows * h->max_cols;
-  char* base = (char*)h->pinned + (size_t)slot * tight * (2 + 4 * sizeof(float));
-  PinnedSlot p;
-  p.sl = (float*)base;
-  p.sr = p.sl + px;
-  p.dl = p.sr + px;
-  p.dr = p.dl + px;
-  p.l = (uint8_t*)(p.dr + px);
-  p.r = p.l + px;
-  return p;
-}
-
-}  // namespace
-
-extern "C" {
+// ---- the frame sequence -------------------------------------------------------------------------------------------
+// What the Sequence caller of the reference does frame by frame (patchmatch_gpu_test.cpp:118-128), with the copies off
+// the critical path and consecutive frames overlapping on the device (pm_handle::PipeSlot, seq_enqueue_chunk).
 
 int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
                  const float* seed_l, const float* seed_r, size_t seed_step, uint64_t tag) {
   if (!h) return PM_ERR_INVALID_ARG;
-  if (int rc = refuse_while_capturing(h, "pm_submit_u8")) return rc;
-  if (!left || !right) {
-    set_err(h, "pm_submit_u8: null image pointer");
+  const SubmitArgs a{left, right, rows, cols, image_step, seed_l, seed_r, seed_step, nullptr, nullptr, 0, tag, false};
+  return submit_impl(h, a, "pm_submit_u8");
+}
+
+int pm_submit_bound_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
+                       const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
+                       size_t disp_step, uint64_t tag) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (!disp_l) {
+    set_err(h, "pm_submit_bound_u8: null output pointer");
     return PM_ERR_INVALID_ARG;
   }
-  if (int rc = check_size(h, rows, cols, 1)) return rc;
-  if (image_step == 0) image_step = (size_t)cols;
-  if (seed_step == 0) seed_step = sizeof(float) * (size_t)cols;
-  if (image_step < (size_t)cols || seed_step < sizeof(float) * (size_t)cols) {
-    set_err(h, "pm_submit_u8: a row step is smaller than a row");
-    return PM_ERR_INVALID_ARG;
-  }
+  const SubmitArgs a{left, right, rows, cols, image_step, seed_l, seed_r, seed_step, disp_l, disp_r, disp_step, tag, false};
+  return submit_impl(h, a, "pm_submit_bound_u8");
+}
+
+int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                     const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  const SubmitArgs a{d_left, d_right, rows, cols, 0, d_seed_l, d_seed_r, 0, d_disp_l, d_disp_r, 0, tag, true};
+  return submit_impl(h, a, "pm_submit_device");
+}
+
+int pm_flush(pm_handle* h) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_flush")) return rc;
+  const int held = held_slot(h);
+  if (held < 0) return PM_OK;
   PM_HIP(h, hipSetDevice(h->device));
-  if (int rc = pipe_init(h)) return rc;
-  if (h->pipe_count == h->max_batch) {
-    set_err(h, "pm_submit_u8: %d pairs in flight (the plan's max_batch); collect one first", h->pipe_count);
-    return PM_ERR_BUSY;
-  }
-  if (h->noise_rows != rows || h->noise_cols != cols) {
-    // the noise table is staged through the pinned buffer the slots live in
-    if (h->pipe_count > 0) {
-      set_err(h, "pm_submit_u8: image size changed with pairs in flight; collect them first");
-      return PM_ERR_BUSY;
-    }
-    if (int rc = ensure_noise(h, rows, cols)) return rc;
-    PM_HIP(h, hipStreamSynchronize(h->stream));
-  }
-  const int slot = (h->pipe_head + h->pipe_count) % h->max_batch;
-  pm_handle::PipeSlot& sl = h->pipe[(size_t)slot];
-  const size_t px = (size_t)rows * cols;
-  const size_t tight = (size_t)h->max_rows * h->max_cols;
-  const PinnedSlot ps = pinned_slot(h, slot, px);
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  h->copy_pool->Copy2D(ps.l, (size_t)cols, left, image_step, (size_t)cols, rows);
-  h->copy_pool->Copy2D(ps.r, (size_t)cols, right, image_step, (size_t)cols, rows);
-  if (seed_l) h->copy_pool->Copy2D(ps.sl, sizeof(float) * cols, seed_l, seed_step, sizeof(float) * cols, rows);
-  if (seed_r) h->copy_pool->Copy2D(ps.sr, sizeof(float) * cols, seed_r, seed_step, sizeof(float) * cols, rows);
-  uint8_t* dl8 = h->st_left + slot * tight;
-  uint8_t* dr8 = h->st_right + slot * tight;
-  float* dsl = h->st_seed_l + slot * tight;
-  float* dsr = h->st_seed_r + slot * tight;
-  float* ddl = h->st_disp_l + slot * tight;
-  float* ddr = h->st_disp_r + slot * tight;
-  const bool lr = h->params.left_right_check != 0;
-  PM_HIP(h, hipMemcpyAsync(dl8, ps.l, px, hipMemcpyHostToDevice, h->s_in));
-  PM_HIP(h, hipMemcpyAsync(dr8, ps.r, px, hipMemcpyHostToDevice, h->s_in));
-  if (seed_l) PM_HIP(h, hipMemcpyAsync(dsl, ps.sl, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
-  if (seed_r) PM_HIP(h, hipMemcpyAsync(dsr, ps.sr, sizeof(float) * px, hipMemcpyHostToDevice, h->s_in));
-  PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
-  // Every frame computes on the handle's stream.  (Frames on lanes of their own -- what helps device-resident callers,
-  // tools/multi_handle.py -- lose here: 368 -> 350 pairs/s with one to three lanes, tools/pipe_timing.py.)
-  PM_HIP(h, hipStreamWaitEvent(h->stream, sl.in_done, 0));
-  if (int rc = match_device_impl(h, 1, dl8, dr8, rows, cols, seed_l ? dsl : nullptr, seed_r ? dsr : nullptr, ddl,
-                               lr ? ddr : nullptr))
-    return rc;
-  PM_HIP(h, hipEventRecord(sl.compute_done, h->stream));
-  PM_HIP(h, hipStreamWaitEvent(h->s_out, sl.compute_done, 0));
-  PM_HIP(h, hipMemcpyAsync(ps.dl, ddl, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
-  if (lr) PM_HIP(h, hipMemcpyAsync(ps.dr, ddr, sizeof(float) * px, hipMemcpyDeviceToHost, h->s_out));
-  PM_HIP(h, hipEventRecord(sl.out_done, h->s_out));
-  sl.tag = tag;
-  sl.rows = rows;
-  sl.cols = cols;
-  ++h->pipe_count;
-  return PM_OK;
+  return enqueue_frames(h, held, 1);
 }
 
 int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag) {
@@ -297,26 +553,41 @@ int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uin
     return PM_ERR_BUSY;
   }
   const bool lr = h->params.left_right_check != 0;
-  if (!disp_l || (lr && !disp_r)) {
-    set_err(h, "pm_collect: null output pointer");
-    return PM_ERR_INVALID_ARG;
-  }
   pm_handle::PipeSlot& sl = h->pipe[(size_t)h->pipe_head];
   const int rows = sl.rows, cols = sl.cols;
-  if (disp_step == 0) disp_step = sizeof(float) * (size_t)cols;
-  if (disp_step < sizeof(float) * (size_t)cols) {
-    set_err(h, "pm_collect: disp_step is smaller than a row");
-    return PM_ERR_INVALID_ARG;
+  const size_t frow = sizeof(float) * (size_t)cols;
+  // where the maps go: the buffers bound at submit, else the ones given here (a device-resident frame has neither)
+  float* out_l = sl.out_l ? sl.out_l : disp_l;
+  float* out_r = sl.out_l ? sl.out_r : disp_r;
+  size_t out_step = sl.out_l ? sl.out_step : (disp_step ? disp_step : frow);
+  if (!sl.device_io) {
+    if (!out_l || (lr && !out_r)) {
+      set_err(h, "pm_collect: null output pointer (no maps were bound when the pair was submitted)");
+      return PM_ERR_INVALID_ARG;
+    }
+    if (sl.out_l && ((disp_l && disp_l != sl.out_l) || (disp_r && disp_r != sl.out_r))) {
+      set_err(h, "pm_collect: other maps than the ones bound when the pair was submitted");
+      return PM_ERR_INVALID_ARG;
+    }
+    if (out_step < frow) {
+      set_err(h, "pm_collect: disp_step is smaller than a row");
+      return PM_ERR_INVALID_ARG;
+    }
   }
   PM_HIP(h, hipSetDevice(h->device));
+  if (sl.state == 1)  // still held for a partner that never came
+    if (int rc = enqueue_frames(h, h->pipe_head, 1)) return rc;
   PM_HIP(h, hipEventSynchronize(sl.out_done));
-  const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
-  if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
-  h->copy_pool->Copy2D(disp_l, disp_step, ps.dl, sizeof(float) * cols, sizeof(float) * cols, rows);
-  if (lr) h->copy_pool->Copy2D(disp_r, disp_step, ps.dr, sizeof(float) * cols, sizeof(float) * cols, rows);
+  if (!sl.device_io) {
+    const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
+    if (!sl.direct_l) h->copy_pool->Copy2D(out_l, out_step, ps.dl, frow, frow, rows);
+    if (lr && !sl.direct_r) h->copy_pool->Copy2D(out_r, out_step, ps.dr, frow, frow, rows);
+  }
   if (tag) *tag = sl.tag;
+  sl.state = 0;
   h->pipe_head = (h->pipe_head + 1) % h->max_batch;
   --h->pipe_count;
+  if (h->pipe_count == 0) h->seq_last = -1;
   return PM_OK;
 }
 

@@ -13,6 +13,7 @@
 #include "pm_enhance.hpp"
 #include "pm_imaging.hpp"
 #include "pm_internal.hpp"
+#include "pm_tune.hpp"
 
 using namespace pm;
 
@@ -333,17 +334,17 @@ int run_gaussian_batch(pm_handle* h, const void* const* d_src, float* const* d_d
   int W = 0, T = 0, NT = 256;
   {
     static const int forced[3] = {[] {
-      const char* e = getenv("PM_BLUR_COL");  // "W,T,threads" (experiments)
+      const char* e = pm::tune_env("PM_BLUR_COL");  // "W,T,threads" (experiments)
       int w = 0, t = 0, n = 0;
       if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return w;
       return 0;
     }(), [] {
-      const char* e = getenv("PM_BLUR_COL");
+      const char* e = pm::tune_env("PM_BLUR_COL");
       int w = 0, t = 0, n = 0;
       if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return t;
       return 0;
     }(), [] {
-      const char* e = getenv("PM_BLUR_COL");
+      const char* e = pm::tune_env("PM_BLUR_COL");
       int w = 0, t = 0, n = 0;
       if (e && sscanf(e, "%d,%d,%d", &w, &t, &n) == 3) return n;
       return 0;

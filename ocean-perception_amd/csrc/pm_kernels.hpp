@@ -753,6 +753,31 @@ __global__ void __launch_bounds__(256) k_copy_disp_strided(PlaneSet ps, float* _
   if (to_caller) buf[(size_t)y * stride + x] = ps.disp[(size_t)y * ps.pitch + x];
   else ps.disp[(size_t)y * ps.pitch + x] = buf[(size_t)y * stride + x];
 }
+// Disparity maps out of device memory into page-locked HOST memory, by a few wavefronts.  The runtime performs a
+// device-to-host hipMemcpyAsync on a busy stream with a blit kernel of its own, one per map, whose waves wait on the
+// bus for 71 us while they hold CU slots the sweeps of the next frames want (rocprofv3 kernel trace of a frame sequence:
+// 2 x __amd_rocclr_copyBuffer per frame; the sequence ran 6 % below the same frames without downloads).  PCIe takes
+// ~55 GB/s whatever the number of waves behind it, so this copy runs on kDownloadBlocks workgroups: a grid-stride loop,
+// 16 bytes per lane and step.  rows x cols floats, source tight, destination row stride dst_step floats.
+constexpr int kDownloadBlocks = 16;
+__global__ void __launch_bounds__(256) k_download(float* __restrict__ dst, size_t dst_step, const float* __restrict__ src,
+                                                  int rows, int cols) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+  if (dst_step == (size_t)cols && (((size_t)dst | (size_t)src) & 15) == 0) {
+    const size_t total = (size_t)rows * cols, n4 = total / 4;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* s4 = (const v4f*)src;
+    v4f* d4 = (v4f*)dst;
+    for (size_t i = tid; i < n4; i += nthreads) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+    for (size_t i = n4 * 4 + tid; i < total; i += nthreads) dst[i] = src[i];
+    return;
+  }
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = tid; i < total; i += nthreads) {
+    const size_t y = i / (size_t)cols, x = i - y * (size_t)cols;
+    dst[y * dst_step + x] = src[i];
+  }
+}
 __global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict__ dst, int which) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;

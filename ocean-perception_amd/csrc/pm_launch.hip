@@ -149,6 +149,11 @@ void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_dis
                      snap_cost, d_mask);
 }
 
+void launch_download(pm_handle* h, float* dst_dev, size_t dst_step_floats, const float* d_src, int rows, int cols,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(k_download, dim3(kDownloadBlocks), dim3(256), 0, stream, dst_dev, dst_step_floats, d_src, rows, cols);
+}
+
 void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src) {
   hipLaunchKernelGGL(k_copy_in, pixel_grid(ps.cols, ps.rows, 1), dim3(256), 0, h->stream, ps, d_src);
 }

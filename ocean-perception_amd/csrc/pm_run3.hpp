@@ -30,6 +30,7 @@
 #pragma once
 
 #include "pm_run2.hpp"
+#include "pm_tune.hpp"
 
 namespace pm {
 
@@ -109,14 +110,14 @@ inline size_t run3_lref_bytes(const PlaneSet& ps) {
 // PM_RUN2_LREF: bit 0 = row sweeps, bit 1 = column sweeps (default 2); PM_RUN2_LREF_KB: LDS budget per workgroup (A/B knobs)
 inline bool run3_lref_enabled(int axis) {
   static const int v = [] {
-    const char* e = getenv("PM_RUN2_LREF");
+    const char* e = pm::tune_env("PM_RUN2_LREF");
     return e ? atoi(e) : 2;
   }();
   return (v >> axis) & 1;
 }
 inline size_t run3_lref_limit() {
   static const size_t v = [] {
-    const char* e = getenv("PM_RUN2_LREF_KB");
+    const char* e = pm::tune_env("PM_RUN2_LREF_KB");
     return (size_t)(e ? atoi(e) : 40) * 1024;
   }();
   return v;

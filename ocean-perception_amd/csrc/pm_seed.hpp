@@ -26,6 +26,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "pm_device.hpp"
+#include "pm_tune.hpp"
 #include "pm_seed_api.hpp"
 
 namespace pm {
@@ -51,8 +52,8 @@ __device__ __forceinline__ int reflect101n(int p, int len) {
 constexpr int kEigTileW = 64, kEigTileH = 32, kEigRowsPerThread = kEigTileH / 4;
 template <int BLOCK>
 __global__ void __launch_bounds__(256) k_seed_response(const uint8_t* __restrict__ im, int rows, int cols, int pitch,
-                                                       int block_rt, float* __restrict__ eig,
-                                                       unsigned* __restrict__ counters) {
+                                                       int block_rt, int use_harris, double harris_k,
+                                                       float* __restrict__ eig, unsigned* __restrict__ counters) {
   extern __shared__ unsigned s_d[];  // [kEigTileH + 2h][kEigTileW + 2h]
   const int block = BLOCK ? BLOCK : block_rt;
   const int h = block / 2;
@@ -76,11 +77,24 @@ __global__ void __launch_bounds__(256) k_seed_response(const uint8_t* __restrict
   float m = 0.f;
   auto finish = [&](int y, int sxx, int sxy, int syy) {
     if (x < cols && y < rows) {
-      const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-      const float t = a - c;
-      const float tt = t * t, bb = b * b;
-      const float s = a + c;
-      const float e = s - sqrtf(tt + bb);
+      float e;
+      if (use_harris) {
+        // calcHarris (OpenCV 3.4 imgproc/corner.cpp): (float)(a*c - b*b - k*(a + c)*(a + c)) with float a, b, c and a
+        // double k -- the products and the difference round to binary32, the trace term is formed in binary64
+        const float a = (float)sxx, b = (float)sxy, c = (float)syy;
+        const float ac = a * c, bb = b * b;
+        const float det = ac - bb;
+        const float tr = a + c;
+        const double kt = harris_k * (double)tr;
+        const double ktt = kt * (double)tr;
+        e = (float)((double)det - ktt);
+      } else {
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        const float t = a - c;
+        const float tt = t * t, bb = b * b;
+        const float s = a + c;
+        e = s - sqrtf(tt + bb);
+      }
       eig[(size_t)y * pitch + x] = e;
       m = fmaxf(m, e);  // m starts at 0: only positive responses count
     }
@@ -702,7 +716,7 @@ __global__ void __launch_bounds__(256) k_seed_resize_nearest(const float* __rest
 // PM_SEED_FUSED=0 keeps the radix sort + separate selection (A/B and the fallback's own test); read once.
 inline bool seed_fused_enabled() {
   static const bool on = [] {
-    const char* v = getenv("PM_SEED_FUSED");
+    const char* v = pm::tune_env("PM_SEED_FUSED");
     return !(v && v[0] == '0');
   }();
   return on;
@@ -735,7 +749,8 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                 : sp.block_size == 5 ? k_seed_response<5>
                 : sp.block_size == 7 ? k_seed_response<7>
                                      : k_seed_response<0>;
-    hipLaunchKernelGGL(kern, tiles, block, lds, stream, left, rows, cols, pitch, sp.block_size, sc.eig, sc.counters);
+    hipLaunchKernelGGL(kern, tiles, block, lds, stream, left, rows, cols, pitch, sp.block_size, sp.use_harris,
+                       sp.harris_k, sc.eig, sc.counters);
   }
   hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
                      rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);

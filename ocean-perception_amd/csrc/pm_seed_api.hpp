@@ -13,6 +13,8 @@ struct SeedParams {
   int max_features, min_distance, block_size;
   int templ_cols, templ_rows, max_disp;
   double quality_level, max_matching_cost;
+  int use_harris;   // corner response det(M) - k trace(M)^2 (cv::cornerHarris) instead of the smaller eigenvalue
+  double harris_k;
 };
 
 constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list

@@ -10,6 +10,7 @@
 #include "pm_wave.hpp"
 #include "pm_run2.hpp"
 #include "pm_run3.hpp"
+#include "pm_tune.hpp"
 
 namespace pm {
 namespace {
@@ -22,11 +23,11 @@ int runblk_waves(int chain_len, int axis, int group = 32) {
     Knobs() {
       const char* names[2][2] = {{"PM_RUNBLK_WAVES_ROW", "PM_RUNBLK_WAVES_ROW16"},
                                  {"PM_RUNBLK_WAVES_COL", "PM_RUNBLK_WAVES_COL16"}};
-      const char* both = getenv("PM_RUNBLK_WAVES");
+      const char* both = pm::tune_env("PM_RUNBLK_WAVES");
       for (int a = 0; a < 2; ++a)
         for (int g = 0; g < 2; ++g) {
-          const char* e = getenv(names[a][g]);
-          if (!e && g == 1) e = getenv(names[a][0]);
+          const char* e = pm::tune_env(names[a][g]);
+          if (!e && g == 1) e = pm::tune_env(names[a][0]);
           if (!e) e = both;
           const int x = e ? atoi(e) : 0;
           v[a][g] = x < 1 ? 0 : (x > kMaxSegWaves ? kMaxSegWaves : x);
@@ -53,7 +54,7 @@ int runblk_waves(int chain_len, int axis, int group = 32) {
 // profiles/r02f_sweep_group_thresholds.txt).
 int runblk_group(int semantics, int axis, float amp, int win, int dir = 1) {
   static int v = [] {
-    const char* e = getenv("PM_RUNBLK_GROUP");
+    const char* e = pm::tune_env("PM_RUNBLK_GROUP");
     const int g = e ? atoi(e) : 0;
     return (g == 8 || g == 16 || g == 32) ? g : 0;
   }();
@@ -63,10 +64,10 @@ int runblk_group(int semantics, int axis, float amp, int win, int dir = 1) {
   struct Thr {
     float t[2], tn[2];  // forward sweeps, backward sweeps (PM_G16_*_AMP_NEG)
     Thr() {
-      const char* er = getenv("PM_G16_ROW_AMP");
-      const char* ec = getenv("PM_G16_COL_AMP");
-      const char* ern = getenv("PM_G16_ROW_AMP_NEG");
-      const char* ecn = getenv("PM_G16_COL_AMP_NEG");
+      const char* er = pm::tune_env("PM_G16_ROW_AMP");
+      const char* ec = pm::tune_env("PM_G16_COL_AMP");
+      const char* ern = pm::tune_env("PM_G16_ROW_AMP_NEG");
+      const char* ecn = pm::tune_env("PM_G16_COL_AMP_NEG");
       t[0] = er ? (float)atof(er) : 0.5f;
       t[1] = ec ? (float)atof(ec) : 4.0f;
       tn[0] = ern ? (float)atof(ern) : 8.0f;

@@ -30,6 +30,13 @@ pm_params PatchmatchGpu::Params::ToC() const {
   p.min_distance_btw_features = detector_params.min_distance_btw_tracked_and_detected_features;
   p.gftt_block_size = detector_params.gftt_block_size;
   p.gftt_quality_level = detector_params.gftt_quality_level;
+  p.gftt_use_harris = detector_params.gftt_use_harris_corner_detector ? 1 : 0;
+  p.gftt_k = detector_params.gftt_k;
+  // cv::cornerSubPix is not built: pm_create refuses these two instead of ignoring them (the constructor / the first
+  // Match() then throws).  subpix_winsize / _zerozone / _maxiters / _epsilon only matter with subpixel_corners, and
+  // StereoMatcher::Params::bidirectional is never read by the reference either (stereo_matcher.cpp:11-116).
+  p.subpixel_corners = detector_params.subpixel_corners ? 1 : 0;
+  p.subpixel_refinement = matcher_params.subpixel_refinement ? 1 : 0;
   p.templ_cols = matcher_params.templ_cols;
   p.templ_rows = matcher_params.templ_rows;
   p.max_disp = matcher_params.max_disp;
@@ -74,6 +81,24 @@ void PatchmatchGpu::EnsurePlan(int rows, int cols) {
   }
   plan_rows_ = rows;
   plan_cols_ = cols;
+  for (const auto& r : registered_)  // registrations belong to the handle: renew them on the new one
+    Check(pm_host_register(handle_, r.first, r.second), "pm_host_register");
+}
+
+void PatchmatchGpu::RegisterRange(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) throw std::invalid_argument("PatchmatchGpu::Register: empty image");
+  if (handle_) Check(pm_host_register(handle_, ptr, bytes), "pm_host_register");
+  registered_.emplace_back(ptr, bytes);
+}
+
+void PatchmatchGpu::UnregisterRange(void* ptr) {
+  for (size_t i = 0; i < registered_.size(); ++i) {
+    if (registered_[i].first != ptr) continue;
+    if (handle_) Check(pm_host_unregister(handle_, ptr), "pm_host_unregister");
+    registered_.erase(registered_.begin() + (long)i);
+    return;
+  }
+  throw std::invalid_argument("PatchmatchGpu::Unregister: this image was not registered");
 }
 
 void PatchmatchGpu::SetSeeds(const Image1f& seed_l, const Image1f& seed_r) {
@@ -142,6 +167,30 @@ bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, uint64_t tag)
   if (rc == PM_ERR_BUSY) return false;
   Check(rc, "pm_submit_u8");
   in_flight_sizes_.emplace_back(iml.rows, iml.cols);
+  return true;
+}
+
+bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, uint64_t tag) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
+    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size");
+  if (disp.rows != iml.rows || disp.cols != iml.cols || dispr.rows != iml.rows || dispr.cols != iml.cols)
+    throw std::invalid_argument("PatchmatchGpu::Submit: bound maps must already have the image size");
+  if (InFlight() == 0) EnsurePlan(iml.rows, iml.cols);
+  const bool seeded_l = !seed_l_.empty() && seed_l_.rows == iml.rows && seed_l_.cols == iml.cols;
+  const bool seeded_r = !seed_r_.empty() && seed_r_.rows == iml.rows && seed_r_.cols == iml.cols;
+  const int rc = pm_submit_bound_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
+                                    seeded_l ? seed_l_.data() : nullptr, seeded_r ? seed_r_.data() : nullptr, 0,
+                                    disp.data(), dispr.data(), disp.step, tag);
+  if (rc == PM_ERR_BUSY) return false;
+  Check(rc, "pm_submit_bound_u8");
+  in_flight_sizes_.emplace_back(iml.rows, iml.cols);
+  return true;
+}
+
+bool PatchmatchGpu::Collect(uint64_t* tag) {
+  if (in_flight_sizes_.empty()) return false;
+  Check(pm_collect(handle_, nullptr, nullptr, 0, tag), "pm_collect");
+  in_flight_sizes_.erase(in_flight_sizes_.begin());
   return true;
 }
 

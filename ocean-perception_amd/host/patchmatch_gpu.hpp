@@ -170,6 +170,22 @@ class PatchmatchGpu final {
   // when full).  Results equal Match()'s.
   bool Submit(const Image1b& iml, const Image1b& imr, uint64_t tag = 0);
   bool Collect(Image1f& disp, Image1f& dispr, uint64_t* tag = nullptr);
+  // The same with the output maps bound at submission (they must have the image size and stay alive until the frame is
+  // collected): Collect(tag) then only waits.  With images and maps that were Register()ed nothing is staged on either
+  // side of the frame: the DMA engines read the images and write the maps in place.
+  bool Submit(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, uint64_t tag = 0);
+  bool Collect(uint64_t* tag = nullptr);
+  // Page-locks the storage of an image (pm_host_register): the host-buffer entry points then move it by DMA without
+  // the staging copy through the handle's pinned slab.  Register buffers that are reused from frame to frame (the
+  // capture loop's images, the output maps); Unregister() before an image is resized or destroyed.
+  template <typename T>
+  void Register(core::Image<T>& im) {
+    RegisterRange(im.data(), sizeof(T) * (size_t)im.rows * (size_t)im.cols);
+  }
+  template <typename T>
+  void Unregister(core::Image<T>& im) {
+    UnregisterRange(im.data());
+  }
   int InFlight() const { return handle_ ? pm_in_flight(handle_) : 0; }
 
   // The sparse-init maps Match() starts from (what SparseInit returns, patchmatch_gpu.cu:414-442):
@@ -195,6 +211,9 @@ class PatchmatchGpu final {
  private:
   void EnsurePlan(int rows, int cols);
   void Check(int status, const char* what) const;
+  void RegisterRange(void* ptr, size_t bytes);
+  void UnregisterRange(void* ptr);
+  std::vector<std::pair<void*, size_t>> registered_;
 
   Params params_;
   pm_handle* handle_ = nullptr;

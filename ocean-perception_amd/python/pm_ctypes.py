@@ -9,13 +9,13 @@ import os
 
 import numpy as np
 
-PM_ABI_VERSION = 4
+PM_ABI_VERSION = 5
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
 PM_ENGINE_AUTO, PM_ENGINE_SERIAL, PM_ENGINE_WAVE, PM_ENGINE_RUNBLK2 = 0, 1, 2, 5
 PM_OK = 0
-PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY = -1, -2, -3, -4, -5, -6
+PM_ERR_INVALID_ARG, PM_ERR_SIZE, PM_ERR_HIP, PM_ERR_NO_DEVICE, PM_ERR_NOMEM, PM_ERR_BUSY, PM_ERR_STATE = -1, -2, -3, -4, -5, -6, -7
 PM_K_COUNT = 12
 PM_MODE_SCALAR, PM_MODE_PLANES = 0, 1
 PM_STATE_F32, PM_STATE_F16 = 0, 1
@@ -29,7 +29,9 @@ LIB_PATH = os.environ.get("PM_LIB") or os.path.normpath(os.path.join(_HERE, ".."
 EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
-    "pm_submit_u8", "pm_collect", "pm_in_flight", "pm_capture_begin", "pm_capture_end", "pm_replay",
+    "pm_submit_u8", "pm_submit_bound_u8", "pm_submit_device", "pm_collect", "pm_flush", "pm_in_flight",
+    "pm_host_alloc", "pm_host_free", "pm_host_register", "pm_host_unregister",
+    "pm_capture_begin", "pm_capture_end", "pm_replay", "pm_debug_capture_fork",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
     "pm_normalize_color_illuminant", "pm_match_bgr_device", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
@@ -75,6 +77,10 @@ class PmParams(C.Structure):
         ("templ_rows", C.c_int),
         ("max_disp", C.c_int),
         ("max_matching_cost", C.c_double),
+        ("gftt_use_harris", C.c_int),
+        ("gftt_k", C.c_double),
+        ("subpixel_corners", C.c_int),
+        ("subpixel_refinement", C.c_int),
         ("cpu_initialize_factor", C.c_int),
         ("mode", C.c_int),
         ("state_dtype", C.c_int),
@@ -143,8 +149,25 @@ def load():
     lib.pm_match_device.restype = C.c_int
     lib.pm_submit_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t, f32p, f32p, C.c_size_t, C.c_uint64]
     lib.pm_submit_u8.restype = C.c_int
+    lib.pm_submit_bound_u8.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t, f32p, f32p, C.c_size_t, f32p, f32p,
+                                       C.c_size_t, C.c_uint64]
+    lib.pm_submit_bound_u8.restype = C.c_int
+    lib.pm_submit_device.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.c_uint64]
+    lib.pm_submit_device.restype = C.c_int
     lib.pm_collect.argtypes = [vp, f32p, f32p, C.c_size_t, C.POINTER(C.c_uint64)]
     lib.pm_collect.restype = C.c_int
+    lib.pm_flush.argtypes = [vp]
+    lib.pm_flush.restype = C.c_int
+    lib.pm_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.pm_host_alloc.restype = C.c_int
+    lib.pm_host_free.argtypes = [vp, vp]
+    lib.pm_host_free.restype = C.c_int
+    lib.pm_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.pm_host_register.restype = C.c_int
+    lib.pm_host_unregister.argtypes = [vp, vp]
+    lib.pm_host_unregister.restype = C.c_int
+    lib.pm_debug_capture_fork.argtypes = [vp]
+    lib.pm_debug_capture_fork.restype = C.c_int
     lib.pm_in_flight.argtypes = [vp]
     lib.pm_in_flight.restype = C.c_int
     # pm/imaging.h: raw device addresses
@@ -342,35 +365,42 @@ class Engine:
                                          dr.ctypes.data_as(C.c_void_p) if lr else None, 0), "pm_match_u8")
         return (dl, dr) if lr else (dl, None)
 
-    def match_batch(self, lefts, rights, seeds_l=None, seeds_r=None):
+    def match_batch(self, lefts, rights, seeds_l=None, seeds_r=None, out=None):
+        """out = (list of left maps, list of right maps) to write into (e.g. views of pm_host_alloc memory)."""
         n = len(lefts)
         keep = []
 
         def arr(items, conv):
-            out = (C.c_void_p * n)()
+            out_ = (C.c_void_p * n)()
             for i, it in enumerate(items):
                 if it is None:
-                    out[i] = None
+                    out_[i] = None
                 else:
                     a, p = conv(it)
                     keep.append(a)
-                    out[i] = p
-            return out
+                    out_[i] = p
+            return out_
 
         rows, cols = np.asarray(lefts[0]).shape
         pl, pr = arr(lefts, _u8), arr(rights, _u8)
         psl = arr(seeds_l, _f32) if seeds_l is not None else None
         psr = arr(seeds_r, _f32) if seeds_r is not None else None
-        dls = [np.empty((rows, cols), np.float32) for _ in range(n)]
-        drs = [np.empty((rows, cols), np.float32) for _ in range(n)]
-        pdl, pdr = arr(dls, _f32), arr(drs, _f32)
+        if out is not None:
+            dls, drs = out
+        else:
+            dls = [np.empty((rows, cols), np.float32) for _ in range(n)]
+            drs = [np.empty((rows, cols), np.float32) for _ in range(n)]
+        raw = lambda maps: (C.c_void_p * n)(*[m.ctypes.data for m in maps])
+        pdl, pdr = raw(dls), raw(drs)
         lr = bool(self.params.left_right_check)
         self._check(self.lib.pm_match_batch_u8(self.h, n, pl, pr, rows, cols, psl, psr, pdl, pdr if lr else None),
                     "pm_match_batch_u8")
         return dls, (drs if lr else None)
 
     # --- pipelined sequence: submit without waiting, collect the oldest --------------------------------
-    def submit(self, left, right, seed_l=None, seed_r=None, tag=0):
+    def submit(self, left, right, seed_l=None, seed_r=None, tag=0, out=None):
+        """out = (disp_l, disp_r): maps bound at submission (pm_submit_bound_u8); collect() may then be called without
+        buffers.  Arrays are passed as they are (no copy): a caller that hands in pm_host_alloc views gets the DMA path."""
         left, pl = _u8(left)
         right, pr = _u8(right)
         rows, cols = left.shape
@@ -381,19 +411,80 @@ class Engine:
         if seed_r is not None:
             sr, psr = _f32(seed_r)
         self._shape_q = getattr(self, "_shape_q", [])
-        self._check(self.lib.pm_submit_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, tag), "pm_submit_u8")
-        self._shape_q.append((rows, cols))
+        if out is None:
+            self._check(self.lib.pm_submit_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, tag), "pm_submit_u8")
+        else:
+            lr = bool(self.params.left_right_check)
+            self._check(self.lib.pm_submit_bound_u8(self.h, pl, pr, rows, cols, 0, psl, psr, 0, out[0].ctypes.data,
+                                                    out[1].ctypes.data if lr else None, 0, tag), "pm_submit_bound_u8")
+        self._shape_q.append((rows, cols, out))
+
+    def submit_device(self, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r, tag=0):
+        """Raw device addresses; nothing is copied.  collect_device() waits for the frame."""
+        self._shape_q = getattr(self, "_shape_q", [])
+        self._check(self.lib.pm_submit_device(self.h, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
+                                              d_disp_r, tag), "pm_submit_device")
+        self._shape_q.append((rows, cols, "device"))
+
+    def collect_device(self):
+        tag = C.c_uint64(0)
+        self._check(self.lib.pm_collect(self.h, None, None, 0, C.byref(tag)), "pm_collect")
+        self._shape_q.pop(0)
+        return int(tag.value)
 
     def collect(self, out=None):
-        rows, cols = self._shape_q[0] if getattr(self, "_shape_q", None) else (1, 1)
-        dl, dr = out if out is not None else (np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32))
+        rows, cols, bound = self._shape_q[0] if getattr(self, "_shape_q", None) else (1, 1, None)
         tag = C.c_uint64(0)
         lr = bool(self.params.left_right_check)
-        self._check(self.lib.pm_collect(self.h, dl.ctypes.data_as(C.POINTER(C.c_float)),
-                                        dr.ctypes.data_as(C.POINTER(C.c_float)) if lr else None, 0, C.byref(tag)),
-                    "pm_collect")
+        if bound is not None and out is None:
+            dl, dr = bound
+            self._check(self.lib.pm_collect(self.h, None, None, 0, C.byref(tag)), "pm_collect")
+        else:
+            dl, dr = out if out is not None else (np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32))
+            self._check(self.lib.pm_collect(self.h, dl.ctypes.data_as(C.POINTER(C.c_float)),
+                                            dr.ctypes.data_as(C.POINTER(C.c_float)) if lr else None, 0, C.byref(tag)),
+                        "pm_collect")
         self._shape_q.pop(0)
         return dl, (dr if lr else None), int(tag.value)
+
+    def flush(self):
+        self._check(self.lib.pm_flush(self.h), "pm_flush")
+
+    # --- page-locked caller memory (pm_host_alloc / pm_host_register) ----------------------------------
+    def host_alloc(self, shape, dtype, owned=False):
+        """A numpy array over page-locked memory: images, seed maps and output maps kept in such arrays are transferred
+        by DMA without a staging copy.  Default: numpy's own memory, page-locked in place (pm_host_register) -- the
+        array stays valid after close().  owned=True: memory handed out by pm_host_alloc, which pm_host_free /
+        pm_destroy give back: the array must not be touched after host_free(array) / close()."""
+        dtype = np.dtype(dtype)
+        if not owned:
+            a = np.empty(shape, dtype)
+            self.host_register(a)
+            return a
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        ptr = C.c_void_p()
+        self._check(self.lib.pm_host_alloc(self.h, nbytes, C.byref(ptr)), "pm_host_alloc")
+        buf = (C.c_char * nbytes).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._host = getattr(self, "_host", {})
+        self._host[a.ctypes.data] = ptr.value
+        return a
+
+    def host_free(self, a):
+        if a.ctypes.data in getattr(self, "_host", {}):
+            ptr = self._host.pop(a.ctypes.data)
+            self._check(self.lib.pm_host_free(self.h, ptr), "pm_host_free")
+        else:
+            self.host_unregister(a)
+
+    def host_register(self, a):
+        self._check(self.lib.pm_host_register(self.h, a.ctypes.data, a.nbytes), "pm_host_register")
+
+    def host_unregister(self, a):
+        self._check(self.lib.pm_host_unregister(self.h, a.ctypes.data), "pm_host_unregister")
+
+    def debug_capture_fork(self):
+        self._check(self.lib.pm_debug_capture_fork(self.h), "pm_debug_capture_fork")
 
     def in_flight(self):
         return int(self.lib.pm_in_flight(self.h))

@@ -168,12 +168,18 @@ typedef struct pmo_seed_params {
   int templ_rows;           /* 11    :22 */
   int max_disp;             /* 128   :23 */
   double max_matching_cost; /* 0.15  :24 */
+  int use_harris;           /* 0     feature_detector.hpp:34 gftt_use_harris_corner_detector */
+  double harris_k;          /* 0.04  :35 gftt_k */
 } pmo_seed_params;
 
 void pmo_seed_params_default(pmo_seed_params* p);
 /* min-eigenvalue response (cv::cornerMinEigenVal, unscaled): eig = (a+c) - sqrt((a-c)^2 + b^2) in binary32 with
  * a = Sxx/2, b = Sxy, c = Syy/2, S** = block_size^2 box sums (REFLECT_101) of the Sobel products. */
 void pmo_min_eig_map(const uint8_t* img, int rows, int cols, int block_size, float* eig);
+/* the same with the Harris response (cv::cornerHarris, unscaled): (float)(a*c - b*b - k*(a+c)*(a+c)) with
+ * a = Sxx, b = Sxy, c = Syy as binary32 values and a binary64 k, as calcHarris computes it */
+void pmo_corner_response_map(const uint8_t* img, int rows, int cols, int block_size, int use_harris, double harris_k,
+                             float* eig);
 /* goodFeaturesToTrack as FeatureDetector::Detect configures it (feature_detector.cpp:44-57,89-122);
  * returns the number of corners written to xs/ys (strongest first). */
 int pmo_gftt_detect(const uint8_t* img, int rows, int cols, const pmo_seed_params* p, int* xs, int* ys, int cap);

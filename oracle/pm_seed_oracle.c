@@ -19,6 +19,8 @@ void pmo_seed_params_default(pmo_seed_params* p) {
   p->templ_rows = 11;
   p->max_disp = 128;
   p->max_matching_cost = 0.15;
+  p->use_harris = 0;
+  p->harris_k = 0.04;
 }
 
 static inline int refl101(int p, int len) {
@@ -41,7 +43,10 @@ static void sobel_xy(const uint8_t* im, int rows, int cols, int* dx, int* dy) {
   }
 }
 
-void pmo_min_eig_map(const uint8_t* img, int rows, int cols, int block_size, float* eig) {
+/* Corner response of cv::goodFeaturesToTrack: cornerMinEigenVal, or cornerHarris when use_harris is set
+ * (feature_detector.cpp:44-57 hands gftt_use_harris_corner_detector / gftt_k to cv::GFTTDetector::create). */
+void pmo_corner_response_map(const uint8_t* img, int rows, int cols, int block_size, int use_harris, double harris_k,
+                             float* eig) {
   const size_t n = (size_t)rows * cols;
   int* dx = (int*)malloc(sizeof(int) * n);
   int* dy = (int*)malloc(sizeof(int) * n);
@@ -60,15 +65,32 @@ void pmo_min_eig_map(const uint8_t* img, int rows, int cols, int block_size, flo
           syy += gy * gy;
         }
       }
-      /* calcMinEigenVal: a = cov0*0.5, b = cov1, c = cov2*0.5; (a+c) - sqrt((a-c)^2 + b^2) */
-      const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-      const float t = a - c;
-      const float tt = t * t, bb = b * b;
-      const float s = a + c;
-      eig[(size_t)y * cols + x] = s - sqrtf(tt + bb);
+      if (use_harris) {
+        /* calcHarris (OpenCV 3.4 imgproc/corner.cpp): float a = cov0, b = cov1, c = cov2;
+         * dst = (float)(a*c - b*b - k*(a + c)*(a + c)) -- a*c, b*b and their difference are binary32 operations,
+         * k is a double, so the trace term and the final difference are binary64 */
+        const float a = (float)sxx, b = (float)sxy, c = (float)syy;
+        const float ac = a * c, bb = b * b;
+        const float det = ac - bb;
+        const float tr = a + c;
+        const double kt = harris_k * (double)tr;
+        const double ktt = kt * (double)tr;
+        eig[(size_t)y * cols + x] = (float)((double)det - ktt);
+      } else {
+        /* calcMinEigenVal: a = cov0*0.5, b = cov1, c = cov2*0.5; (a+c) - sqrt((a-c)^2 + b^2) */
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        const float t = a - c;
+        const float tt = t * t, bb = b * b;
+        const float s = a + c;
+        eig[(size_t)y * cols + x] = s - sqrtf(tt + bb);
+      }
     }
   free(dx);
   free(dy);
+}
+
+void pmo_min_eig_map(const uint8_t* img, int rows, int cols, int block_size, float* eig) {
+  pmo_corner_response_map(img, rows, cols, block_size, 0, 0.0, eig);
 }
 
 typedef struct { float v; int idx; } cand_t;
@@ -84,7 +106,7 @@ static int cand_cmp(const void* pa, const void* pb) {
 int pmo_gftt_detect(const uint8_t* img, int rows, int cols, const pmo_seed_params* p, int* xs, int* ys, int cap) {
   const size_t n = (size_t)rows * cols;
   float* eig = (float*)malloc(sizeof(float) * n);
-  pmo_min_eig_map(img, rows, cols, p->block_size, eig);
+  pmo_corner_response_map(img, rows, cols, p->block_size, p->use_harris, p->harris_k, eig);
   float maxv = 0.f; /* the response is >= 0 up to rounding; a non-positive maximum means "no corners" */
   for (size_t i = 0; i < n; ++i)
     if (eig[i] > maxv) maxv = eig[i];

@@ -46,6 +46,24 @@ int main(int argc, char** argv) {
   params.patchmatch_iters = atoi(argv[6]);
   params.max_rows = rows;  // plan in the constructor (the reference allocates lazily in the first Match)
   params.max_cols = cols;
+  // An option of the nested seeder parameters that this engine does not build (cv::cornerSubPix,
+  // feature_detector.cpp:110-120 / stereo_matcher.cpp:94-103) must be REFUSED, not ignored: the constructor throws.
+  // The parameter check comes before the device check, so this holds on a box without a GPU too.
+  if (argc > 7 && std::string(argv[7]) == "refused") {
+    int refused = 0;
+    for (int which = 0; which < 2; ++which) {
+      PatchmatchGpu::Params bad = params;
+      if (which == 0) bad.detector_params.subpixel_corners = true;
+      else bad.matcher_params.subpixel_refinement = true;
+      try {
+        PatchmatchGpu pm(bad);
+      } catch (const std::runtime_error& e) {
+        if (std::string(e.what()).find("cornerSubPix") != std::string::npos) ++refused;
+      }
+    }
+    std::cout << "refused " << refused << "\n";
+    return refused == 2 ? 0 : 14;
+  }
   try {
     PatchmatchGpu pm(params);
     Image1b il(rows, cols), ir(rows, cols);
@@ -89,6 +107,48 @@ int main(int argc, char** argv) {
         if (std::memcmp(qr.data(), dispr.data(), sizeof(float) * (size_t)rows * cols) != 0) return 5;
       }
       if (collected != 7) return 6;
+    }
+    // the same loop on page-locked images with the maps bound at submission: nothing is staged, the DMA engines read
+    // the images and write the maps in place
+    {
+      PatchmatchGpu::Params p4 = params;
+      p4.max_batch = 4;
+      PatchmatchGpu seq(p4);
+      seq.SetSeeds(sl, sr);
+      Image1b pl = il, pr = ir;
+      std::vector<Image1f> outs_l(4, Image1f(rows, cols)), outs_r(4, Image1f(rows, cols));
+      seq.Register(pl);
+      seq.Register(pr);
+      for (int k = 0; k < 4; ++k) {
+        seq.Register(outs_l[(size_t)k]);
+        seq.Register(outs_r[(size_t)k]);
+      }
+      int submitted = 0, collected = 0;
+      uint64_t tag = 0;
+      const size_t bytes = sizeof(float) * (size_t)rows * cols;
+      while (collected < 9) {
+        while (submitted < 9 && seq.Submit(pl, pr, outs_l[(size_t)(submitted % 4)], outs_r[(size_t)(submitted % 4)], 2000 + submitted))
+          ++submitted;
+        if (!seq.Collect(&tag) || tag != (uint64_t)(2000 + collected)) return 15;
+        if (std::memcmp(outs_l[(size_t)(collected % 4)].data(), disp.data(), bytes) != 0 ||
+            std::memcmp(outs_r[(size_t)(collected % 4)].data(), dispr.data(), bytes) != 0)
+          return 16;
+        ++collected;
+      }
+      for (int k = 0; k < 4; ++k) {
+        seq.Unregister(outs_l[(size_t)k]);
+        seq.Unregister(outs_r[(size_t)k]);
+      }
+      seq.Unregister(pl);
+      seq.Unregister(pr);
+    }
+    // the Harris response instead of the smaller eigenvalue (feature_detector.hpp:34-35)
+    {
+      PatchmatchGpu::Params ph = params;
+      ph.detector_params.gftt_use_harris_corner_detector = true;
+      ph.detector_params.gftt_k = 0.06;
+      PatchmatchGpu harris(ph);
+      write_raw(dir + "/sparse_init_harris.f32", harris.SparseInit(il, ir, 4));
     }
     // a batch in one call: three pairs (the pair, the pair with left and right swapped, the pair again), every map
     // equal to what Match() returns for that pair alone

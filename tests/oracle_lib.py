@@ -24,7 +24,7 @@ class Functor(C.Structure):
 class SeedParams(C.Structure):
     _fields_ = [("max_features", C.c_int), ("min_distance", C.c_int), ("quality_level", C.c_double),
                 ("block_size", C.c_int), ("templ_cols", C.c_int), ("templ_rows", C.c_int), ("max_disp", C.c_int),
-                ("max_matching_cost", C.c_double)]
+                ("max_matching_cost", C.c_double), ("use_harris", C.c_int), ("harris_k", C.c_double)]
 
 
 class Params(C.Structure):
@@ -311,6 +311,16 @@ def min_eig_map(img, block_size=5):
     img = c_u8(img)
     out = np.empty(img.shape, np.float32)
     load().pmo_min_eig_map(_p(img), img.shape[0], img.shape[1], block_size, _p(out))
+    return out
+
+
+def corner_response_map(img, block_size=5, use_harris=0, harris_k=0.04):
+    img = c_u8(img)
+    out = np.empty(img.shape, np.float32)
+    lib = load()
+    lib.pmo_corner_response_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    lib.pmo_corner_response_map.restype = None
+    lib.pmo_corner_response_map(_p(img), img.shape[0], img.shape[1], block_size, use_harris, harris_k, _p(out))
     return out
 
 

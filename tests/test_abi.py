@@ -66,6 +66,39 @@ def test_create_rejects_bad_arguments_without_touching_a_device(pm):
     lib.pm_destroy(h)
 
 
+def test_create_refuses_seeder_options_that_are_not_built(pm):
+    """feature_detector.hpp:34-44 / stereo_matcher.hpp:25-26: the Harris response is honoured (parameters checked),
+    cv::cornerSubPix on corners or matches is not built and must be refused, never silently dropped."""
+    lib = pm.load()
+    h = C.c_void_p()
+    for field in ("subpixel_corners", "subpixel_refinement"):
+        p = pm.default_params(pm.PM_SEM_GPU, **{field: 1})
+        rc = lib.pm_create(C.byref(p), 0, 64, 64, 1, C.byref(h))
+        assert rc == pm.PM_ERR_INVALID_ARG and b"cornerSubPix" in lib.pm_last_error(h), field
+        lib.pm_destroy(h)
+    for kw in (dict(gftt_use_harris=2), dict(gftt_use_harris=1, gftt_k=-0.1), dict(gftt_k=float("nan"))):
+        p = pm.default_params(pm.PM_SEM_GPU, **kw)
+        rc = lib.pm_create(C.byref(p), 0, 64, 64, 1, C.byref(h))
+        assert rc == pm.PM_ERR_INVALID_ARG and b"gftt" in lib.pm_last_error(h), kw
+        lib.pm_destroy(h)
+    d = pm.default_params(pm.PM_SEM_GPU)
+    assert d.gftt_use_harris == 0 and abs(d.gftt_k - 0.04) < 1e-12 and d.subpixel_corners == 0
+
+
+def test_the_shipped_library_carries_no_tuning_knob():
+    """The A/B knobs of the tuning build (pm_tune.hpp: PM_STREAM_PRIO, PM_PAIR_CHUNK, PM_RUNBLK_*, PM_G16_*, ...) are
+    compiled out of the product: none of their names is left in the binary, so no schedule or LDS budget can depend
+    on the host's environment."""
+    import subprocess
+    so = os.path.join(ROOT, "ocean-perception_amd", "lib", "libvehicle_pm_gpu.so")
+    names = re.findall(r"^PM_[A-Z0-9_]+$", subprocess.run(["strings", so], capture_output=True, text=True).stdout, re.M)
+    assert names == [], names
+    src = os.path.join(ROOT, "ocean-perception_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f != "pm_tune.hpp":
+            assert "getenv" not in open(os.path.join(src, f)).read().replace("tune_env", ""), f
+
+
 def _has_gpu():
     try:
         import torch

@@ -317,6 +317,102 @@ def test_pipelined_sequence_equals_single_matches(pm, oracle, synth, depth):
         assert_same(dr, wr, f"pair {i} right")
 
 
+@pytest.mark.parametrize("sem,patch,mode", [(0, 5, 0), (1, 3, 0), (0, 5, 1)])
+def test_sequence_on_page_locked_memory_with_bound_maps(pm, oracle, synth, sem, patch, mode):
+    """pm_host_alloc + pm_submit_bound_u8: images read and maps written in place by DMA, frames overlapping on the
+    device as chunks of one or two (held frames, pm_flush), results those of pm_match_u8 in submission order; a mix of
+    page-locked and pageable buffers; the plane mode takes the one-frame-after-the-other route."""
+    rows, cols = 60, 100
+    pairs = [small_pair(synth, 140 + i, rows, cols, n_points=25, dilate_factor=2) for i in range(9)]
+    kw = dict(mode=pm.PM_MODE_PLANES, max_disp=48) if mode else {}
+    params = pm.default_params(sem, patch=patch, patchmatch_iters=2, **kw)
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=1) as e:
+        want = [e.match(l, r, sl, sr) for (l, r, sl, sr, _) in pairs]
+    with pm.Engine(params, max_rows=rows + 4, max_cols=cols + 8, max_batch=4) as e:
+        ins = []
+        for i, (l, r, sl, sr, _) in enumerate(pairs):
+            row = []
+            for a in (l, r, sl, sr):
+                if i % 4 == 3:          # every fourth frame comes from pageable memory
+                    row.append(a)
+                else:
+                    b = e.host_alloc(a.shape, a.dtype)
+                    np.copyto(b, a)
+                    row.append(b)
+            ins.append(row)
+        outs = [(e.host_alloc((rows, cols), np.float32), e.host_alloc((rows, cols), np.float32)) for _ in range(3)]
+        outs.append((np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32)))  # pageable maps
+        got, tags, done = [], [], 0
+        for i in range(len(pairs)):
+            if e.in_flight() == 4:
+                dl, dr, tag = e.collect()
+                assert dl is outs[done % 4][0]
+                got.append((dl.copy(), dr.copy())); tags.append(tag); done += 1
+            e.submit(*ins[i], tag=500 + i, out=outs[i % 4])
+            if i == 5:
+                e.flush()
+        with pytest.raises(pm.PmError) as err:   # other maps than the bound ones
+            e.collect(out=(np.empty((rows, cols), np.float32), np.empty((rows, cols), np.float32)))
+        assert err.value.status == pm.PM_ERR_INVALID_ARG
+        with pytest.raises(pm.PmError) as err:   # the memory may be the target of a DMA
+            e.host_free(outs[0][0])
+        assert err.value.status == pm.PM_ERR_BUSY
+        with pytest.raises(pm.PmError) as err:   # frames in flight live in the plane slots a device match would use
+            e.match(pairs[0][0], pairs[0][1])
+        assert err.value.status == pm.PM_ERR_BUSY
+        while e.in_flight():
+            dl, dr, tag = e.collect()
+            got.append((dl.copy(), dr.copy())); tags.append(tag); done += 1
+        e.host_free(outs[0][0])
+        # a registered range: plain numpy memory, page-locked in place
+        reg = np.empty((rows, cols), np.float32)
+        regr = np.empty((rows, cols), np.float32)
+        e.host_register(reg); e.host_register(regr)
+        l, r, sl, sr, _ = pairs[2]
+        e.submit(l, r, sl, sr, tag=7, out=(reg, regr))
+        e.collect()
+        assert_same(reg, want[2][0], "registered map, left")
+        assert_same(regr, want[2][1], "registered map, right")
+        e.host_unregister(reg); e.host_unregister(regr)
+        with pytest.raises(pm.PmError):
+            e.host_unregister(reg)
+    assert tags == [500 + i for i in range(len(pairs))]
+    for i, ((dl, dr), (wl, wr)) in enumerate(zip(got, want)):
+        assert_same(dl, wl, f"pair {i} left")
+        assert_same(dr, wr, f"pair {i} right")
+
+
+def test_device_resident_sequence_and_self_seeded_frames(pm, oracle, synth):
+    """pm_submit_device: nothing is copied, frames that lie next to each other in device memory run as one chunk;
+    with sparse_init every frame seeds itself on the view streams' seeder scratch."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 96, 160
+    dev = torch.device("cuda:0")
+    n = 6
+    pairs = [small_pair(synth, 160 + i, rows, cols, n_points=25, dilate_factor=2) for i in range(n)]
+    params = pm.default_params(0, patch=5, patchmatch_iters=2, sparse_init=1)
+    with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
+        want = [e.match(p[0], p[1]) for p in pairs]
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    DL = torch.full((n, rows, cols), -1.0, dtype=torch.float32, device=dev)
+    DR = torch.full_like(DL, -1.0)
+    torch.cuda.synchronize()
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=4) as e:
+        tags = []
+        for i in range(n):
+            if e.in_flight() == 4:
+                tags.append(e.collect_device())
+            e.submit_device(L[i].data_ptr(), R[i].data_ptr(), rows, cols, None, None, DL[i].data_ptr(), DR[i].data_ptr(),
+                            tag=i)
+        while e.in_flight():
+            tags.append(e.collect_device())
+    assert tags == list(range(n))
+    for i in range(n):
+        assert_same(DL[i].cpu().numpy(), want[i][0], f"frame {i} left")
+        assert_same(DR[i].cpu().numpy(), want[i][1], f"frame {i} right")
+
+
 def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
     rows, cols = 33, 47
     l, r, sl, sr, _ = small_pair(synth, 50, rows, cols, n_points=12, dilate_factor=2)
@@ -491,6 +587,35 @@ def test_capture_error_paths_leave_the_handle_usable(pm, oracle, synth):
         assert ei.value.status == pm.PM_ERR_SIZE
         run()
         e.synchronize()
+    # 4) A capture whose recorded calls forked work onto another stream and never joined it back: ending such a capture
+    # faults inside the runtime (gpurun_out/r03/crash.log) -- pm_capture_end joins, discards and says PM_ERR_STATE.
+    with mk(pm, 0, patch=5, iters=2, rows=rows, cols=cols) as e:
+        run2 = lambda: e.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(),
+                                      DL.data_ptr(), DR.data_ptr())
+        with pytest.raises(pm.PmError) as ei:
+            e.debug_capture_fork()   # not capturing
+        assert ei.value.status == pm.PM_ERR_STATE
+        run2()
+        e.synchronize()
+        e.capture_begin()
+        run2()
+        e.debug_capture_fork()
+        with pytest.raises(pm.PmError) as ei:
+            e.capture_end()
+        assert ei.value.status == pm.PM_ERR_STATE and "never joined" in str(ei.value)
+        with pytest.raises(pm.PmError):
+            e.replay()               # nothing was kept
+        DL.zero_()
+        run2()                       # the handle works, and captures, as before
+        e.synchronize()
+        assert_same(DL.cpu().numpy(), el, "after a discarded capture")
+        e.capture_begin()
+        run2()
+        e.capture_end()
+        DL.zero_()
+        e.replay()
+        e.synchronize()
+        assert_same(DL.cpu().numpy(), el, "capture after a discarded capture")
     # destroying a handle in the middle of a capture must not hang or crash
     e2 = mk(pm, 0, patch=5, iters=1, rows=rows, cols=cols)
     e2.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, SL.data_ptr(), SR.data_ptr(), DL.data_ptr(),

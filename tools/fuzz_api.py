@@ -46,7 +46,7 @@ for case in range(a.cases):
     R = [p["right"] for p in pairs]
     SL = [p["seed_l"] if s else None for p, s in zip(pairs, seeded)]
     SR = [p["seed_r"] if s else None for p, s in zip(pairs, seeded)]
-    what = int(rng.integers(0, 5))
+    what = int(rng.integers(0, 7))
     with pm.Engine(params, max_rows=max_rows, max_cols=max_cols, max_batch=n) as e:
         want = [e.match(L[i], R[i], SL[i], SR[i]) for i in range(n)]
         if what == 0:    # batch
@@ -64,6 +64,61 @@ for case in range(a.cases):
                 dl, dr, tag = e.collect()
                 got.append((dl, dr))
             name = f"submit/collect depth {depth}"
+        elif what == 5:  # the sequence on page-locked caller memory: DMA in place, maps bound at submission
+            depth = int(rng.integers(1, n + 1))
+            pin = lambda a_: None if a_ is None else np.copyto(e.host_alloc(a_.shape, a_.dtype), a_) or None
+            bufs, got = [], []
+            for i in range(n):
+                b = {}
+                for k, src in (("l", L[i]), ("r", R[i]), ("sl", SL[i]), ("sr", SR[i])):
+                    if src is None or rng.random() < 0.25:   # a quarter of the planes stay in pageable memory
+                        b[k] = src
+                    else:
+                        b[k] = e.host_alloc(src.shape, src.dtype)
+                        np.copyto(b[k], src)
+                b["dl"] = e.host_alloc((rows, cols), np.float32) if rng.random() < 0.8 else np.empty((rows, cols), np.float32)
+                b["dr"] = e.host_alloc((rows, cols), np.float32) if rng.random() < 0.8 else np.empty((rows, cols), np.float32)
+                b["dl"][:] = -3
+                b["dr"][:] = -3
+                bufs.append(b)
+            done = 0
+            for i in range(n):
+                if e.in_flight() >= depth:
+                    e.collect()
+                    got.append((bufs[done]["dl"].copy(), bufs[done]["dr"].copy()))
+                    done += 1
+                b = bufs[i]
+                e.submit(b["l"], b["r"], b["sl"], b["sr"], tag=i, out=(b["dl"], b["dr"]))
+                if rng.random() < 0.3:
+                    e.flush()
+            while e.in_flight():
+                e.collect()
+                got.append((bufs[done]["dl"].copy(), bufs[done]["dr"].copy()))
+                done += 1
+            name = f"submit_bound on pm_host_alloc memory, depth {depth}"
+        elif what == 6:  # device-resident sequence
+            depth = int(rng.integers(1, n + 1))
+            zero = np.zeros((rows, cols), np.float32)
+            tl = torch.from_numpy(np.stack(L)).to(dev)
+            tr = torch.from_numpy(np.stack(R)).to(dev)
+            tsl = torch.from_numpy(np.stack([s if s is not None else zero for s in SL])).to(dev)
+            tsr = torch.from_numpy(np.stack([s if s is not None else zero for s in SR])).to(dev)
+            want = [e.match(L[i], R[i], SL[i] if SL[i] is not None else zero, SR[i] if SR[i] is not None else zero)
+                    for i in range(n)]
+            dl = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
+            dr = torch.empty_like(dl)
+            torch.cuda.synchronize()
+            tags = []
+            for i in range(n):
+                if e.in_flight() >= depth:
+                    tags.append(e.collect_device())
+                e.submit_device(tl[i].data_ptr(), tr[i].data_ptr(), rows, cols, tsl[i].data_ptr(), tsr[i].data_ptr(),
+                                dl[i].data_ptr(), dr[i].data_ptr(), tag=i)
+            while e.in_flight():
+                tags.append(e.collect_device())
+            assert tags == list(range(n)), tags
+            got = [(dl[i].cpu().numpy(), dr[i].cpu().numpy()) for i in range(n)]
+            name = f"submit_device depth {depth}"
         elif what == 2:  # device-resident batch
             tl = torch.from_numpy(np.stack(L)).to(dev)
             tr = torch.from_numpy(np.stack(R)).to(dev)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 4 stream policy, final: four streams per handle created together (rotated roles), all in the high class
+mkdir -p gpurun_out/r04
+out=gpurun_out/r04/streams3.txt
+: > $out
+run() { echo "## $*" >> $out; timeout -k 10 400 python tools/stream_matrix.py "$@" 2>&1 | grep -v amdgpu.ids >> $out; }
+run --alive || exit 1
+run --alive --dummies 3 --legs tiled,batch_u8_pinned,sync,pipe_dev,pipe_pinned,pipe,batch,single || exit 1
+run --alive --legs batch,single,tiled,pipe_dev,sync || exit 1
+for leg in single batch pipe pipe_pinned pipe_dev sync batch_u8 batch_u8_pinned tiled; do run --legs $leg || exit 1; done
+cat $out
+bash tools/r04_qtrace.sh > gpurun_out/r04/qtrace3.txt 2>&1; tail -16 gpurun_out/r04/qtrace3.txt
