@@ -28,7 +28,9 @@ PlanesParams planes_params(const pm_params& p) {
   pp.one_minus_alpha = 1.f - p.functor_alpha;
   pp.tau_color = p.functor_tau_color;
   pp.tau_grad = p.functor_tau_grad;
-  pp.inv_n = 1.0f / (float)(pp.patch * pp.patch);
+  pp.window = p.plane_window;
+  // taps that count: all of them, or those with i + j even (the centre and every other tap: (P * P + 1) / 2)
+  pp.inv_n = 1.0f / (float)(pp.window == PM_PL_WINDOW_CHECKER ? (pp.patch * pp.patch + 1) / 2 : pp.patch * pp.patch);
   pp.lr_tol = p.plane_lr_tol;
   pp.seed = p.noise_seed;
   pp.n_views = p.left_right_check ? 2 : 1;

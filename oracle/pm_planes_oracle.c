@@ -36,6 +36,7 @@ void pmo_planes_params_default(pmo_planes_params* p) {
   p->lr_tol = 1.0f;
   p->state_f16 = 0;
   p->nthreads = 1;
+  p->window = PMO_PL_WINDOW_CHECKER;
 }
 
 /* One random 32-bit word per (stage, iteration, step, view, draw, pixel): a 64-bit counter key, mixed
@@ -107,6 +108,18 @@ static inline float slope_bound(const pmo_planes_params* p) { return quant(p, p-
 static inline float clamp_slope(float v, float smax) { return fminf(fmaxf(v, -smax), smax); }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+int pmo_planes_tap(int window, int i, int j) {
+  if (window == PMO_PL_WINDOW_CHECKER) return ((i + j) & 1) == 0;
+  if (window == PMO_PL_WINDOW_EVEN_COLS) return (j & 1) == 0;
+  return 1;
+}
+int pmo_planes_taps(int window, int P) {
+  int n = 0;
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) n += pmo_planes_tap(window, i, j);
+  return n;
+}
+
 float pmo_planes_cost(const pmo_planes_params* p, const pmo_planes_view* im, int x, int y, float a, float b, float z) {
   const int P = p->patch, h = P / 2, rows = im->rows, cols = im->cols;
   const int Z = (int)rintf(z * 65536.0f), A = (int)rintf(a * 65536.0f), B = (int)rintf(b * 65536.0f);
@@ -114,6 +127,7 @@ float pmo_planes_cost(const pmo_planes_params* p, const pmo_planes_view* im, int
   for (int i = 0; i < P; ++i) {
     const size_t row = (size_t)clampi(y + i - h, 0, rows - 1) * cols;
     for (int j = 0; j < P; ++j) {
+      if (!pmo_planes_tap(p->window, i, j)) continue;
       const int D = Z + A * (j - h) + B * (i - h);
       const int X = (x + j - h) * 65536 - D;
       const int c0 = X >> 16; /* floor: gcc shifts negative ints arithmetically */
@@ -127,7 +141,7 @@ float pmo_planes_cost(const pmo_planes_params* p, const pmo_planes_view* im, int
       sg += abs((int)im->refg8[ro] - (int)(s >> 24));
     }
   }
-  const float inv_n = 1.0f / (float)(P * P);
+  const float inv_n = 1.0f / (float)pmo_planes_taps(p->window, P);
   const float mc = (float)sc * inv_n, mg = (float)sg * inv_n;
   const float t0 = p->alpha * fminf(mc, p->tau_color);
   const float t1 = (1.0f - p->alpha) * fminf(mg, p->tau_grad);

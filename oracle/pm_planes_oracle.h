@@ -59,7 +59,15 @@ typedef struct pmo_planes_params {
   float lr_tol;                          /* |dl - dr| above which the left disparity is zeroed (1.0)     */
   int state_f16;                         /* 0: f32 state, 1: f16 state                                   */
   int nthreads;
+  int window;                            /* which taps of the P x P window count (PMO_PL_WINDOW_*)        */
 } pmo_planes_params;
+
+/* The window's taps.  FULL: all P*P.  CHECKER (the default since round 4): tap (i, j) counts iff i + j is even -- the
+ * centre, and every other tap in both directions: 61 of 121 for 11 x 11.  EVEN_COLS: columns j = 0, 2, 4 ... of every
+ * row (66 of 121).  The cost divides by the number of taps that count. */
+enum { PMO_PL_WINDOW_FULL = 0, PMO_PL_WINDOW_CHECKER = 1, PMO_PL_WINDOW_EVEN_COLS = 2 };
+int pmo_planes_tap(int window, int i, int j);
+int pmo_planes_taps(int window, int P);
 
 void pmo_planes_params_default(pmo_planes_params* p);
 

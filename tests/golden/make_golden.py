@@ -54,11 +54,13 @@ def planes():
     # (oracle/pm_planes_oracle.c) against regressions, for f32 and f16 state
     p = synth.make_pair(102, rows=64, cols=96, d_max=20.0)
     out = dict(left=p["left"], right=p["right"], patch=7, iters=3, max_disp=24)
+    # both windows of the definition: the checkerboard (default since round 4) and the full one ("full_" keys)
     for f16 in (0, 1):
-        prm = O.planes_params(n_iters=3, nthreads=8, state_f16=f16, patch=7, max_disp=24)
-        dl, dr = O.planes_match(prm, p["left"], p["right"])
-        out[f"disp_l_f{16 if f16 else 32}"] = dl
-        out[f"disp_r_f{16 if f16 else 32}"] = dr
+        for window, tag in ((O.PL_WINDOW_CHECKER, ""), (O.PL_WINDOW_FULL, "full_")):
+            prm = O.planes_params(n_iters=3, nthreads=8, state_f16=f16, patch=7, max_disp=24, window=window)
+            dl, dr = O.planes_match(prm, p["left"], p["right"])
+            out[f"{tag}disp_l_f{16 if f16 else 32}"] = dl
+            out[f"{tag}disp_r_f{16 if f16 else 32}"] = dr
     save("planes_64x96", **out)
 
 

@@ -25,7 +25,8 @@ def okw(pm_params):
                 slope_per_disp=pm_params.plane_slope_per_disp, alpha=pm_params.functor_alpha,
                 tau_color=pm_params.functor_tau_color, tau_grad=pm_params.functor_tau_grad,
                 seed=pm_params.noise_seed, left_right_check=pm_params.left_right_check,
-                lr_tol=pm_params.plane_lr_tol, state_f16=pm_params.state_dtype, nthreads=8)
+                lr_tol=pm_params.plane_lr_tol, state_f16=pm_params.state_dtype, window=pm_params.plane_window,
+                nthreads=8)
 
 
 def pparams(pm, patch=11, iters=2, f16=0, **kw):
@@ -118,10 +119,11 @@ def test_golden_planes_fixture(oracle):
     from conftest import GOLDEN
     g = np.load(os.path.join(GOLDEN, "planes_64x96.npz"))
     for f16 in (0, 1):
-        prm = oracle.planes_params(n_iters=3, nthreads=4, state_f16=f16, patch=7, max_disp=24)
-        dl, dr = oracle.planes_match(prm, g["left"], g["right"])
-        assert_same(dl, g[f"disp_l_f{16 if f16 else 32}"], "golden left")
-        assert_same(dr, g[f"disp_r_f{16 if f16 else 32}"], "golden right")
+        for window, tag in ((oracle.PL_WINDOW_CHECKER, ""), (oracle.PL_WINDOW_FULL, "full_")):
+            prm = oracle.planes_params(n_iters=3, nthreads=4, state_f16=f16, patch=7, max_disp=24, window=window)
+            dl, dr = oracle.planes_match(prm, g["left"], g["right"])
+            assert_same(dl, g[f"{tag}disp_l_f{16 if f16 else 32}"], f"golden left {tag}")
+            assert_same(dr, g[f"{tag}disp_r_f{16 if f16 else 32}"], f"golden right {tag}")
 
 
 # ---- HIP vs definition --------------------------------------------------------------------------------------------
@@ -136,13 +138,15 @@ def dev_pair(pair_list):
 
 
 @gpu
+@pytest.mark.parametrize("window", [1, 0])
 @pytest.mark.parametrize("f16", [0, 1])
 @pytest.mark.parametrize("seeded", [False, True])
-def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded):
-    """NS-1 random plane initialisation, NS-2 red-black propagation, NS-3 view propagation, NS-4 refinement."""
+def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded, window):
+    """NS-1 random plane initialisation, NS-2 red-black propagation, NS-3 view propagation, NS-4 refinement -- on the
+    checkerboard window (the mode's default) and on the full one."""
     import torch
     p = synth.make_pair(11, ROWS, COLS, n_points=30, dilate_factor=2)
-    prm = pparams(pm, iters=2, f16=f16, max_disp=48)
+    prm = pparams(pm, iters=2, f16=f16, max_disp=48, plane_window=window)
     op = oracle.planes_params(**okw(prm))
     L, R, SL, SR = dev_pair([p])
     ov = oracle.PlanesViews(p["left"], p["right"])
@@ -233,11 +237,12 @@ def test_stages_on_injected_adversarial_planes(pm, oracle, synth):
 
 
 @gpu
+@pytest.mark.parametrize("window", [1, 0])  # PM_PL_WINDOW_CHECKER (the default), PM_PL_WINDOW_FULL
 @pytest.mark.parametrize("f16", [0, 1])
 @pytest.mark.parametrize("patch,max_disp", [(11, 64), (7, 32), (5, 128), (3, 16), (15, 40), (11, 300)])  # 300: > 64 KB of LDS
-def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp):
+def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp, window):
     p = synth.make_pair(20 + patch, ROWS, COLS)
-    prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp)
+    prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp, plane_window=window)
     want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"])
     with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
         got = e.match(p["left"], p["right"])
@@ -310,11 +315,12 @@ def test_golden_planes_fixture_on_device(pm):
     from conftest import GOLDEN
     g = np.load(os.path.join(GOLDEN, "planes_64x96.npz"))
     for f16 in (0, 1):
-        prm = pparams(pm, patch=7, iters=3, f16=f16, max_disp=24)
-        with pm.Engine(prm, max_rows=64, max_cols=96) as e:
-            dl, dr = e.match(g["left"], g["right"])
-        assert_same(dl, g[f"disp_l_f{16 if f16 else 32}"], "golden left")
-        assert_same(dr, g[f"disp_r_f{16 if f16 else 32}"], "golden right")
+        for window, tag in ((pm.PM_PL_WINDOW_CHECKER, ""), (pm.PM_PL_WINDOW_FULL, "full_")):
+            prm = pparams(pm, patch=7, iters=3, f16=f16, max_disp=24, plane_window=window)
+            with pm.Engine(prm, max_rows=64, max_cols=96) as e:
+                dl, dr = e.match(g["left"], g["right"])
+            assert_same(dl, g[f"{tag}disp_l_f{16 if f16 else 32}"], f"golden left {tag}")
+            assert_same(dr, g[f"{tag}disp_r_f{16 if f16 else 32}"], f"golden right {tag}")
 
 
 @gpu
