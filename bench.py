@@ -16,10 +16,15 @@ pairs/s (max elapsed over ranks), the roofline of the dominant kernel (per-launc
 recorded by the engine on its own stream during the timed steps) and the CPU baseline (the oracle -- a port of
 the reference CPU path -- timed on this host, rank 0, N=1).
 
-Side legs in the same line (rank 0, N=1, never `value`):
+Side legs in the same line (rank 0, N=1, never `value`; all measured in THIS process, beside the headline's handle):
     planes            the slanted-plane mode (north_star kernels) at the same shape: fp32 state (configs[1] shape) and
                       fp16 state behind the on-device stereo-ready enhancement (configs[4] shape)
-    host_buffers      PCIe-inclusive rates of the host-buffer entry points
+    host_buffers      PCIe-inclusive rates of the host-buffer entry points (pageable and page-locked caller memory,
+                      seeded and self-seeded): synchronous, the frame sequence, batches of 32
+    sequence_device   the frame sequence on device-resident pairs (pm_submit_device)
+    batch             4 and 32 pairs per pm_match_device call (configs[2]'s per-GPU share)
+    reference_test_shape  the reference's own timed call pattern (patchmatch_gpu_test.cpp:68-88) with its CPU side
+    tiled_4096x2160   configs[3]: untiled, and through the C-ABI driver in 8 bands on this device
 Other workloads: --mode planes [--state f16] [--enhance] makes the plane mode the timed one; --pairs-per-gpu 32 is
 configs[2]'s per-GPU share; --tiled runs configs[3] (one 4096x2160 pair row-tiled over the ranks).
 """
@@ -72,7 +77,7 @@ def parse():
                          "fully timed step cost 6 %% of the step; 1 = every step)")
     ap.add_argument("--no-profile", action="store_true",
                     help="experiment: no per-kernel HIP events in the timed region (the roofline object is then empty)")
-    ap.add_argument("--host-pairs", type=int, default=48,
+    ap.add_argument("--host-pairs", type=int, default=64,
                     help="pairs of the untimed host-buffer leg (PCIe-inclusive rates, reported beside `value`); 0 = skip")
     ap.add_argument("--semantics", type=int, default=0,
                     help="0 = PM_SEM_CPU (the benchmark configuration), 1 = PM_SEM_GPU (side measurement)")
@@ -173,6 +178,24 @@ def pmc_valu(kernel_class, prof=None, n_prof=0):
         return None
 
 
+ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs, a wave64 op holds its SIMD 4 cycles
+
+
+def binding_roof(kernel_class, prof, n_prof, ms_per_step):
+    """What actually bounds the step, computed from THIS run's ms_per_step: the chip-level vector-issue fraction -- vector
+    instructions of one step (per-launch counts of the committed PMC passes x this run's launches per step) x 4 cycles
+    over (1024 SIMDs x clock x the step's wall time) -- beside the texture address / data unit occupancy of the dominant
+    kernel (committed PMC passes: kernels alone on the chip; with both views' kernels running the units are shared)."""
+    v = pmc_valu(kernel_class, prof, n_prof)
+    if not v or not v.get("insts_per_step") or not ms_per_step:
+        return None
+    issue = v["insts_per_step"] * 4.0 / (1024.0 * ENGINE_CLOCK_GHZ * 1e9 * ms_per_step * 1e-3)
+    return {"issue_frac_chip": issue, "ta_busy": v.get("ta_busy_frac"), "td_busy": v.get("td_busy_frac"),
+            "insts_valu_per_step": v["insts_per_step"], "clock_ghz": ENGINE_CLOCK_GHZ,
+            "formula": "insts_valu_per_step * 4 / (1024 SIMDs * clock * ms_per_step); ta / td: the dominant kernel "
+                       "alone on the chip (profiles/valu.json)"}
+
+
 def shard(rank, world, steps, nb):
     """Pair indices matched by `rank` at each step: independent pairs, contiguous by rank; the steps rotate over
     N_ROTATE distinct pairs of the rank's share."""
@@ -234,53 +257,185 @@ def cpu_baseline_planes(args, f16):
                       f"code) on the whole {args.cols}x{args.rows} frame, {nthr} OpenMP threads: {t:.2f} s"}
 
 
-def host_buffer_leg(pm, params, args, pair, device):
-    """PCIe-inclusive rates (never `value`): pageable host images in, host maps out.  `synchronous` is
-    pm_match_u8 call by call (what the reference's Match() does); `pipelined` keeps 3 pairs in flight with
-    pm_submit_u8 / pm_collect, so packing, upload and download overlap the matching of the neighbours."""
-    n = args.host_pairs
-    seeds = (None, None) if args.self_seed else (pair["seed_l"], pair["seed_r"])
-    out = {"pairs": n, "depth": 3, "unit": "pairs/s",
-           "note": "the caller re-uses its output arrays (fresh 3.7 MB arrays per call cost more in page faults than the copies)"}
+def host_buffer_leg(pm, args, pairs, device):
+    """PCIe-inclusive rates (never `value`): host images in, host maps out, seeded (seed maps uploaded) and self-seeded
+    (SparseInit on the device, as the reference's Match() does).  Every way in exists for PAGEABLE caller memory (the
+    engine packs into its pinned slab and unpacks) and for memory made known through pm_host_alloc / pm_host_register
+    (DMA in place, nothing staged):
+      synchronous   pm_match_u8 call by call -- what the reference's host Match() does (patchmatch_gpu.cu:331-376)
+      pipelined     the frame sequence pm_submit_u8 / pm_submit_bound_u8 + pm_collect, `depth` frames in flight
+      batch         pm_match_batch_u8: `batch_pairs` pairs per call (BASELINE configs[2]'s per-GPU share incl. H2D / D2H)
+      sequence_device  pm_submit_device: the same frame sequence on device-resident pairs (no copies at all)"""
     import numpy as np
-    bufs = [(np.zeros((args.rows, args.cols), np.float32), np.zeros((args.rows, args.cols), np.float32)) for _ in range(4)]
-    with pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=3) as e:
-        e.match(pair["left"], pair["right"], *seeds, out=bufs[0])
-        t0 = time.perf_counter()
-        for i in range(n):
-            e.match(pair["left"], pair["right"], *seeds, out=bufs[i & 3])
-        out["synchronous"] = n / (time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        k = 0
-        for i in range(n):
-            if e.in_flight() == 3:
-                e.collect(out=bufs[k & 3])
-                k += 1
-            e.submit(pair["left"], pair["right"], *seeds, tag=i)
-        while e.in_flight():
-            e.collect(out=bufs[k & 3])
-            k += 1
-        out["pipelined"] = n / (time.perf_counter() - t0)
-    # two handles, pairs alternating between them: two matches (four view streams) share the chip
-    with pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=2) as e0, \
-            pm.Engine(params, device=device, max_rows=args.rows, max_cols=args.cols, max_batch=2) as e1:
-        engs = (e0, e1)
-        for e in engs:
-            e.match(pair["left"], pair["right"], *seeds, out=bufs[0])
-        t0 = time.perf_counter()
-        k = 0
-        for i in range(n):
-            e = engs[i & 1]
-            if e.in_flight() == 2:
-                e.collect(out=bufs[k & 3])
-                k += 1
-            e.submit(pair["left"], pair["right"], *seeds, tag=i)
-        for e in engs:
-            while e.in_flight():
-                e.collect(out=bufs[k & 3])
-                k += 1
-        out["pipelined_two_handles"] = n / (time.perf_counter() - t0)
+    n, depth, nbatch = args.host_pairs, 4, 32
+    rows, cols = args.rows, args.cols
+    out = {"pairs": n, "depth": depth, "batch_pairs": nbatch, "unit": "pairs/s",
+           "note": "the caller re-uses its buffers from frame to frame; `pinned` = buffers of pm_host_alloc / "
+                   "pm_host_register memory (DMA in place), `pageable` = plain numpy arrays (staged through the "
+                   "engine's pinned slab by four host threads)"}
+    fmaps = lambda k: [(np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32)) for _ in range(k)]
+    for self_seed in (False, True):
+        params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine,
+                                   sparse_init=1 if self_seed else 0)
+        seeds = (lambda p: (None, None)) if self_seed else (lambda p: (p["seed_l"], p["seed_r"]))
+        res = {}
+        with pm.Engine(params, device=device, max_rows=rows, max_cols=cols, max_batch=depth) as e:
+            bufs = fmaps(depth)
+            pin = lambda a_: (lambda b_: (np.copyto(b_, a_), b_)[1])(e.host_alloc(a_.shape, a_.dtype))
+            pinned = [{k: pin(p[k]) for k in ("left", "right", "seed_l", "seed_r")} for p in pairs]
+            pbufs = [(e.host_alloc((rows, cols), np.float32), e.host_alloc((rows, cols), np.float32)) for _ in range(depth)]
+            for tag, src, dst in (("pageable", pairs, bufs), ("pinned", pinned, pbufs)):
+                e.match(src[0]["left"], src[0]["right"], *seeds(src[0]), out=dst[0])
+                t0 = time.perf_counter()
+                for i in range(n):
+                    p = src[i % len(src)]
+                    e.match(p["left"], p["right"], *seeds(p), out=dst[i % depth])
+                res["synchronous_" + tag] = n / (time.perf_counter() - t0)
+                for rep in range(2):  # the first pass warms the ring (first-use allocations of the view streams' scratch)
+                    k = 2 * depth if rep == 0 else n
+                    t0 = time.perf_counter()
+                    for i in range(k):
+                        if e.in_flight() == depth:
+                            e.collect() if tag == "pinned" else e.collect(out=dst[(i - depth) % depth])
+                        p = src[i % len(src)]
+                        e.submit(p["left"], p["right"], *seeds(p), tag=i, out=dst[i % depth] if tag == "pinned" else None)
+                    j = k - e.in_flight()
+                    while e.in_flight():
+                        e.collect() if tag == "pinned" else e.collect(out=dst[j % depth])
+                        j += 1
+                    res["pipelined_" + tag] = k / (time.perf_counter() - t0)
+        with pm.Engine(params, device=device, max_rows=rows, max_cols=cols, max_batch=nbatch) as e:
+            pin = lambda a_: (lambda b_: (np.copyto(b_, a_), b_)[1])(e.host_alloc(a_.shape, a_.dtype))
+            pinned = [{k: pin(p[k]) for k in ("left", "right", "seed_l", "seed_r")} for p in pairs]
+            for tag, src in (("pageable", pairs), ("pinned", pinned)):
+                ls = [src[i % len(src)]["left"] for i in range(nbatch)]
+                rs = [src[i % len(src)]["right"] for i in range(nbatch)]
+                sl = None if self_seed else [src[i % len(src)]["seed_l"] for i in range(nbatch)]
+                sr = None if self_seed else [src[i % len(src)]["seed_r"] for i in range(nbatch)]
+                if tag == "pinned":
+                    outs = ([e.host_alloc((rows, cols), np.float32) for _ in range(nbatch)],
+                            [e.host_alloc((rows, cols), np.float32) for _ in range(nbatch)])
+                else:
+                    outs = ([np.zeros((rows, cols), np.float32) for _ in range(nbatch)],
+                            [np.zeros((rows, cols), np.float32) for _ in range(nbatch)])
+                e.match_batch(ls[:4], rs[:4], sl[:4] if sl else None, sr[:4] if sr else None, out=(outs[0][:4], outs[1][:4]))
+                calls = max(1, n // nbatch)
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    e.match_batch(ls, rs, sl, sr, out=outs)
+                res["batch_" + tag] = calls * nbatch / (time.perf_counter() - t0)
+        out["self_seeded" if self_seed else "seeded"] = res
     return out
+
+
+def sequence_device_leg(pm, torch, w, args, device, depth=4, frames=96):
+    """pm_submit_device / pm_collect on the headline's resident pairs: one pair per call as in the headline, but the engine
+    may overlap consecutive frames (two frames advanced through every launch together while the device is busy)."""
+    a = args
+    with pm.Engine(w.params, device=device, max_rows=a.rows, max_cols=a.cols, max_batch=depth) as e:
+        DL = torch.empty((depth, a.rows, a.cols), dtype=torch.float32, device=w.DL.device)
+        DR = torch.empty_like(DL)
+        seeded = not a.self_seed
+        L = torch.cat([w.L[g][:1] for g in range(N_ROTATE)]).contiguous()
+        R = torch.cat([w.R[g][:1] for g in range(N_ROTATE)]).contiguous()
+        SL = torch.cat([w.SL[g][:1] for g in range(N_ROTATE)]).contiguous()
+        SR = torch.cat([w.SR[g][:1] for g in range(N_ROTATE)]).contiguous()
+        torch.cuda.synchronize()
+
+        def run(k):
+            for i in range(k):
+                if e.in_flight() == depth:
+                    e.collect_device()
+                q = i % N_ROTATE
+                e.submit_device(L[q].data_ptr(), R[q].data_ptr(), a.rows, a.cols, SL[q].data_ptr() if seeded else None,
+                                SR[q].data_ptr() if seeded else None, DL[i % depth].data_ptr(), DR[i % depth].data_ptr(), tag=i)
+            while e.in_flight():
+                e.collect_device()
+        run(2 * depth)
+        t0 = time.perf_counter()
+        run(frames)
+        dt = time.perf_counter() - t0
+        # the map of the last frame of pair 0 equals the headline's (same pair, same parameters)
+        last0 = ((frames - 1) // N_ROTATE) * N_ROTATE
+        w.step(0)
+        w.eng.synchronize()
+        same = bool(torch.equal(DL[last0 % depth], w.DL[0]))
+    return {"value": frames / dt, "unit": "pairs/s", "ms_per_frame": 1e3 * dt / frames, "frames": frames, "depth": depth,
+            "equals_the_headline_maps": same,
+            "note": "one device-resident pair per pm_submit_device call, up to `depth` in flight: frames run back to "
+                    "back on the handle's two view streams (no fork / join per frame), two of them through every "
+                    "launch together while the device is busy"}
+
+
+def batch_leg(pm, torch, np, synth, args, dev, device, nb, steps):
+    """The headline workload as a batch -- `nb` pairs per pm_match_device call, BASELINE configs[2]'s per-GPU shape --
+    in THIS process, beside the other handles (round 3 needed a process of its own for it: tools/stream_matrix.py)."""
+    class A:
+        pass
+    a2 = A()
+    a2.__dict__.update(vars(args))
+    a2.pairs_per_gpu = nb
+    w = Workload(a2, pm, torch, np, synth, dev, device, 0, "scalar", "f32", False)
+    for s_ in range(2):
+        w.step(s_)
+    w.eng.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        w.step(s_)
+    w.eng.synchronize()
+    dt = time.perf_counter() - t0
+    q = w.quality()
+    w.eng.close()
+    return {"pairs_per_call": nb, "calls": steps, "value": nb * steps / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / steps / nb,
+            "check": q, "note": "one pm_match_device call per batch: chunks of two pairs one after the other on the "
+                                 "handle's two view streams, every chunk's cross-check on a third"}
+
+
+def reference_test_shape_leg(pm, args, device):
+    """The only timing the reference itself does (test/stereo_matching/patchmatch_gpu_test.cpp:68-88): its farmsim test pair
+    halved to 376x240, PatchmatchGpu with cost_alpha 0.9 and 3 iterations, `Match(iml, imr, disp, dispr)` five times under
+    a Timer -- host images in, host maps out, self-seeded by SparseInit(4) inside the call.  The pair comes from
+    tests/golden/farmsim_fs1_376x240.npz (decoded and halved by tests/golden/make_golden.py; the reference tree itself is
+    not read here).  CPU side: the oracle's restatement of the same call on one thread, the whole frame, unscaled."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "farmsim_fs1_376x240.npz"))
+    l, r = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+    rows, cols = l.shape
+    prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=3, sparse_init=1)
+    calls = []
+    with pm.Engine(prm, device=device, max_rows=rows, max_cols=cols) as e:
+        out = (np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32))
+        for i in range(5):
+            t0 = time.perf_counter()
+            e.match(l, r, out=out)
+            calls.append(1e3 * (time.perf_counter() - t0))
+        steady = []
+        for i in range(40):
+            t0 = time.perf_counter()
+            e.match(l, r, out=out)
+            steady.append(1e3 * (time.perf_counter() - t0))
+        rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)  # as tests/test_golden.py pins them
+        same = bool(np.array_equal(rowsum(out[0]), g["gpu_test_rows_l"]) and np.array_equal(rowsum(out[1]), g["gpu_test_rows_r"]))
+    res = {"workload": f"{cols}x{rows} farmsim test pair, PM_SEM_GPU (the CUDA module's own 5-tap semantics), cost_alpha "
+                       "0.9, 3 iterations, self-seeded, host images in / host maps out, Match x 5 "
+                       "(patchmatch_gpu_test.cpp:68-88)",
+           "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": float(np.median(steady)),
+           "pairs_per_s_steady": 1e3 / float(np.median(steady)),
+           "equals_the_golden_row_checksums": same}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        t0 = time.perf_counter()
+        sp = O.seed_params()
+        sl = O.sparse_init(l, r, 4, sp)
+        sr = np.ascontiguousarray(O.sparse_init(np.ascontiguousarray(r[:, ::-1]), np.ascontiguousarray(l[:, ::-1]), 4, sp)[:, ::-1])
+        op = O.default_params(O.SEM_GPU, n_iters=3, nthreads=1, cost_alpha=0.9)
+        O.match(op, l, r, sl, sr)
+        t = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": 1.0 / t, "unit": "pairs/s", "cores": 1, "kind": "port", "ms_per_call": 1e3 * t,
+                               "sample": "oracle (SparseInit on both views + the 5-tap Match), one thread, the whole "
+                                         "376x240 frame, unscaled"}
+    return res
 
 
 class Workload:
@@ -339,7 +494,7 @@ class Workload:
                 "foreground_within_1px_of_truth": float((err[ok] < 1.0).float().mean().item()) if fg > 0 else 0.0}
 
 
-def roofline_of(args, prof, n_prof, nb, mode, state):
+def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None):
     px_views = args.rows * args.cols * 2 * nb
     if mode == "planes":
         dom = max(PLANE_LAUNCH_BYTES, key=lambda k: prof.get(k, (0, 0.0))[1])
@@ -352,6 +507,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (nb == 1 and state == "f32") else None,
                 "traffic_source": "profiles/traffic.json" if (nb == 1 and state == "f32") else None,
                 "valu": pmc_valu(dom, prof, n_prof) if (nb == 1 and state == "f32") else None,
+                "binding": binding_roof(dom, prof, n_prof, ms_per_step) if (nb == 1 and state == "f32") else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
                 "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48 (two "
@@ -374,6 +530,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state):
             "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command, not measured in this run)" if nb == 1 else None,
             "valu": pmc_valu(dom, prof, n_prof) if nb == 1 else None,
+            "binding": binding_roof(dom, prof, n_prof, ms_per_step) if nb == 1 else None,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
             "launches": n_launch, "profiled_steps": n_prof, "concurrent_launches": concurrency,
             "achieved_all_concurrent": achieved * concurrency,
@@ -446,79 +603,11 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
            "step_ms": step_stats,
            "dtype": "u8 window cost, " + state + " state",
-           "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state),
+           "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state, 1e3 * elapsed / steps),
            "kernels_ms_per_step": {k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
            "check": w.quality()}
     w.eng.close()
     return out
-
-
-def batch_child(args, nb=4, steps=8):
-    """The headline workload as a batch -- `nb` pairs per pm_match_device call, BASELINE configs[2]'s per-GPU shape in
-    small -- measured by a CHILD process started before this process touches the GPU.  The engine runs a batch as
-    pipelines of two pairs over two lanes of view streams; four in-order chains side by side need the process's four
-    hardware queues to themselves (with any other queue-owning stream in the process two chains share a queue and the
-    rate falls back to the lockstep schedule's: 418 -> 362 pairs/s, tools/batch_after.py), hence the clean process.
-    Whole-job throughput of pairs that are at hand together; a pair's latency is not improved.  Never `value`."""
-    import subprocess
-    env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
-              "TORCHELASTIC_USE_AGENT_STORE"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.abspath(__file__), "--pairs-per-gpu", str(nb), "--steps", str(steps), "--warmup", "2",
-           "--rows", str(args.rows), "--cols", str(args.cols), "--iters", str(args.iters), "--patch", str(args.patch),
-           "--semantics", str(args.semantics), "--no-cpu-baseline", "--host-pairs", "0", "--no-side-legs", "--no-profile"]
-
-    def child(extra_env):
-        e2 = dict(env)
-        e2.update(extra_env)
-        try:
-            r = subprocess.run(cmd, env=e2, capture_output=True, text=True, timeout=300)
-        except (OSError, subprocess.TimeoutExpired) as e:
-            return {"error": "batch leg: %r" % (e,)}
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                try:
-                    return json.loads(line)
-                except ValueError:
-                    break
-        return {"error": "batch leg exited with code %d" % r.returncode, "stderr_tail": r.stderr[-300:]}
-
-    j = child({})
-    if "error" in j:
-        return j
-    out = {"pairs_per_call": nb, "calls": steps, "value": j["value"], "unit": "pairs/s", "ms_per_pair": j["ms_per_frame"],
-           "check": j.get("check"),
-           "note": "one pm_match_device call per batch, measured in a process of its own (`bench.py --pairs-per-gpu %d`).  "
-                   "Pipelines of two pairs, one after the other on two view streams of the high priority class (hardware "
-                   "queues of their own whatever else the process holds)" % nb}
-    return out
-
-
-def eight_bands_child(args):
-    """One 4096x2160 pair through the C-ABI driver with 8 bands on ONE device -- the protocol (boundary rows, masked
-    re-sweeps, flag) at work, its cost beside the untiled frame -- in a process of its own, started before this one
-    touches the GPU: eight band streams beside the priority stream a single-pair handle creates run 2.2x slower
-    (any stream of another priority in the process does that to them), and a real caller has one band per GPU."""
-    import subprocess
-    env = dict(os.environ)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
-              "TORCHELASTIC_USE_AGENT_STORE"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py"), "--rows", "2160", "--cols",
-           "4096", "--iters", str(args.iters), "--patch", str(args.patch), "--steps", "2", "--single-process", "1",
-           "--bands", "8"]
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.tiled_timeout)
-    except (OSError, subprocess.TimeoutExpired) as e:
-        return {"error": "eight-band leg: %r" % (e,)}
-    for line in reversed(r.stdout.strip().splitlines()):
-        if line.startswith("{"):
-            try:
-                return json.loads(line)
-            except ValueError:
-                break
-    return {"error": "eight-band leg exited with code %d" % r.returncode, "stderr_tail": r.stderr[-300:]}
 
 
 def run_tiled(args, d):
@@ -654,11 +743,6 @@ def main():
             and max(1, args.pairs_per_gpu) == 1 and (not args.dry_run or args.rehearse_tiled_leg)):
         import torch  # noqa: F401 -- pages the libraries in before the children import them
         tiled_result = tiled_children(args)
-    batch_result = eight_bands_result = None
-    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not planes and not args.no_side_legs and not args.tiled
-            and max(1, args.pairs_per_gpu) == 1 and not args.self_seed and not args.dry_run):
-        batch_result = batch_child(args)
-        eight_bands_result = eight_bands_child(args)
     if os.environ.get("PM_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):  # fault injection of tests/test_dist.py
         sys.exit(7)
     d = Dist(args)
@@ -742,17 +826,26 @@ def main():
             value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
             ms_per_frame=1e3 * elapsed / steps / nb,
             step_ms=step_stats,
-            roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state) if n_prof else None,
+            roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state, 1e3 * elapsed / steps) if n_prof else None,
             kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
             gpu_busy_ms_per_step=gpu_ms / max(n_prof, 1),
             check=check,
         )
         if counters is not None:
             result["run_engine_counters_per_step"] = counters
+        side = d.world == 1 and not planes and nb == 1 and not args.no_side_legs
         if d.world == 1 and not planes and args.host_pairs > 0:
-            result["host_buffers"] = host_buffer_leg(pm, w.params, args, w.pairs[0], d.local_rank)
-        if batch_result is not None:
-            result["batch"] = batch_result
+            # every leg below runs in THIS process, beside the headline's handle (one stream policy: DESIGN.md 6)
+            result["host_buffers"] = host_buffer_leg(pm, args, w.pairs[:N_ROTATE], d.local_rank)
+            result["sequence_device"] = sequence_device_leg(pm, torch, w, args, d.local_rank)
+        if side and not args.self_seed:
+            result["batch"] = {"4": batch_leg(pm, torch, np, synth, args, dev, d.local_rank, 4, 8),
+                               "32": batch_leg(pm, torch, np, synth, args, dev, d.local_rank, 32, 2)}
+        if side and args.semantics == 0:
+            try:
+                result["reference_test_shape"] = reference_test_shape_leg(pm, args, d.local_rank)
+            except Exception as e:  # noqa: BLE001 -- report, never lose the headline
+                result["reference_test_shape"] = {"error": repr(e)}
     eng.close()
     del w
     if not planes and not args.no_side_legs and nb == 1:
@@ -763,8 +856,9 @@ def main():
             import tiled
             try:
                 tiled_result = tiled.bench(args, d, steps=2, quiet=True)
-                if eight_bands_result is not None:
-                    tiled_result["eight_bands_on_this_device"] = eight_bands_result
+                # the C-ABI driver with 8 bands on THIS device: the protocol (boundary rows, masked re-sweeps, flag) at
+                # work, its cost beside the untiled frame; a real caller has one band per GPU
+                tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:

@@ -475,7 +475,7 @@ int join_stream(pm_handle* h, hipStream_t from, hipEvent_t ev, hipStream_t onto)
 // a process of its own and at 400-435 beside other handles, depending on whether a view stream ended up behind the
 // download stream's waits: profiles/r04_stream_matrix.txt).  This creates the events the view streams fork and join on.
 int view_streams_create(pm_handle* h) {
-  if (h->view_fork && h->view1_join && h->out_join) return PM_OK;
+  if (h->view_fork && h->view1_join && h->out_join && h->in_join) return PM_OK;
   if (h->capturing) {
     set_err(h, "the view events do not exist yet: run this call once before capturing it");
     return PM_ERR_BUSY;
@@ -483,6 +483,7 @@ int view_streams_create(pm_handle* h) {
   if (!h->view_fork) PM_HIP(h, hipEventCreateWithFlags(&h->view_fork, hipEventDisableTiming));
   if (!h->view1_join) PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
   if (!h->out_join) PM_HIP(h, hipEventCreateWithFlags(&h->out_join, hipEventDisableTiming));
+  if (!h->in_join) PM_HIP(h, hipEventCreateWithFlags(&h->in_join, hipEventDisableTiming));
   return PM_OK;
 }
 
@@ -495,7 +496,7 @@ int seq_events_create(pm_handle* h) {
   }
   std::vector<pm_handle::PipeSlot> slots((size_t)h->max_batch);
   for (auto& sl : slots) {
-    hipEvent_t* evs[] = {&sl.in_done, &sl.v_done[0], &sl.v_done[1], &sl.fin_done, &sl.out_done};
+    hipEvent_t* evs[] = {&sl.in_done, &sl.head_done, &sl.v_done[0], &sl.v_done[1], &sl.fin_done, &sl.out_done};
     for (hipEvent_t* e : evs) PM_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   h->pipe.swap(slots);
@@ -595,25 +596,69 @@ bool seq_pipelined(const pm_handle* h) {
   return h->params.mode == PM_MODE_SCALAR && h->params.left_right_check != 0 && view_streams_enabled() && !h->bgr;
 }
 
-// One CHUNK of a batch or of a frame sequence: pairs [b, b + c) of the plan, the first view on the handle's stream, the
-// second on view1_stream, both behind the non-null events `ready` (the chunk's inputs are in device memory) and
-// `slot_free` (whoever last used these plane slots is done with them); then, on s_out behind both views (events
-// v_done[0 / 1]), the cross-check / un-mirror into d_disp_l / d_disp_r ([c][rows][cols]).  Chunks enqueued one after the
-// other run back to back on the two view streams -- the head and the tail of one (a dozen small launches) beside the
-// sweeps of its neighbour, nothing forks or joins in between.  Enqueue only; the caller orders what follows behind s_out.
+// One CHUNK of a batch or of a frame sequence: pairs [b, b + c) of the plan.
+//   the HEAD of the chunk, behind the non-null events `ready` (the chunk's inputs are in device memory) and `slot_free`
+//                 (whoever last used these plane slots is done with them): images, gradients, transposes and line
+//                 planes of both views, and the device seeder where a view seeds itself (a chain of latency-bound
+//                 launches, 0.11 ms per view and pair).  A chunk that seeds itself runs its head on s_in -- the stream
+//                 the uploads ran on -- BESIDE the sweeps of the chunk in front instead of between two chunks on the
+//                 view streams; the others keep it at the head of their view streams (see below);
+//   the handle's stream / view1_stream   the iterations of the first / second view (behind event head_done);
+//   s_out         behind both views (events v_done[0 / 1]): the cross-check / un-mirror into d_disp_l / d_disp_r
+//                 ([c][rows][cols]).
+// Chunks enqueued one after the other run back to back on the two view streams, nothing forks or joins in between.
+// Enqueue only; the caller orders what follows behind s_out.
 int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                       const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, hipEvent_t ready,
-                      hipEvent_t slot_free, hipEvent_t v_done[2]) {
+                      hipEvent_t slot_free, hipEvent_t v_done[2], hipEvent_t head_done) {
   if (int rc = view_streams_create(h)) return rc;
   const PlaneSet ps = plane_set(h, rows, cols, 2);
   const PlaneSet pb = plane_set_of_pair(ps, b);
   h->need_seed[0] = h->params.sparse_init && !d_seed_l;
   h->need_seed[1] = h->params.sparse_init && !d_seed_r;
-  const ViewSetup sb{d_left, d_right, d_seed_l, d_seed_r, c};
   hipStream_t keep = h->stream;
+  struct Restore {
+    pm_handle* h;
+    hipStream_t s;
+    ~Restore() { h->stream = s; }
+  } restore{h, keep};
+  // ---- head: on s_in when a view seeds itself (measured, frame sequence at 720p: self-seeded 396 -> 401 pairs/s with the
+  // head aside, seeded 410 -> 402 -- without the seeder the head is too short to pay for one more cross-queue wait)
+  const bool head_aside = h->need_seed[0] || h->need_seed[1];
   hipStream_t vs[2] = {keep, h->view1_stream};
-  const hipEvent_t waits[2] = {ready, slot_free};
-  if (int rc = run_views_on(h, pb, 2 * c, &sb, vs, waits, 2, true)) return rc;
+  if (head_aside) {
+    if (ready) PM_HIP(h, hipStreamWaitEvent(h->s_in, ready, 0));
+    if (slot_free) PM_HIP(h, hipStreamWaitEvent(h->s_in, slot_free, 0));
+    mark_forked(h, h->s_in);
+    prof_break(h, h->s_in);
+    h->stream = h->s_in;
+    for (int v = 0; v < 2; ++v) {
+      {
+        Launch l(h, PM_K_PREP);
+        const PrepSeedMaps seeds{d_seed_l, d_seed_r};  // the seed copy rides along (one launch less)
+        launch_prep(h, pb, d_left, d_right, c, (size_t)cols, v, &seeds);
+        if (int rc = launch_check(h, "prep")) return rc;
+      }
+      {
+        Launch l(h, PM_K_PREP);
+        if (int rc = run_transpose(h, pb, c, v)) return rc;
+      }
+    }
+    for (int v = 0; v < 2; ++v) {
+      PlaneSet pv = pb;
+      pv.view_fixed = v;
+      if (int rc = seed_views(h, pv, c, v, v)) return rc;
+    }
+    PM_HIP(h, hipEventRecord(head_done, h->s_in));
+    h->stream = keep;
+    h->need_seed[0] = h->need_seed[1] = false;  // done in the head: the view streams start with the first noise + cost
+    if (int rc = run_views_on(h, pb, 2 * c, nullptr, vs, &head_done, 1, true)) return rc;
+  } else {
+    const ViewSetup sb{d_left, d_right, d_seed_l, d_seed_r, c};
+    const hipEvent_t waits[2] = {ready, slot_free};
+    if (int rc = run_views_on(h, pb, 2 * c, &sb, vs, waits, 2, true)) return rc;
+  }
+  mark_joined(h, h->s_in);
   for (int v = 0; v < 2; ++v) {
     PM_HIP(h, hipEventRecord(v_done[v], vs[v]));
     PM_HIP(h, hipStreamWaitEvent(h->s_out, v_done[v], 0));
@@ -622,14 +667,12 @@ int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const u
   mark_forked(h, h->s_out);
   prof_break(h, h->s_out);
   h->stream = h->s_out;
-  int rc;
   {
     Launch l(h, PM_K_FINALIZE);
     launch_finalize(h, pb, d_disp_l, d_disp_r, c);
-    rc = launch_check(h, "finalize");
+    if (int rc = launch_check(h, "finalize")) return rc;
   }
-  h->stream = keep;
-  return rc;
+  return PM_OK;
 }
 
 namespace {
@@ -648,7 +691,7 @@ int run_pairs_as_chunks(pm_handle* h, int n, const ViewSetup& vs, int rows, int 
                                    vs.d_seed_l ? vs.d_seed_l + b * px : nullptr,
                                    vs.d_seed_r ? vs.d_seed_r + b * px : nullptr, d_disp_l + b * px,
                                    d_disp_r ? d_disp_r + b * px : nullptr, b == 0 ? h->view_fork : nullptr, nullptr,
-                                   h->pipe[(size_t)b].v_done))
+                                   h->pipe[(size_t)b].v_done, h->pipe[(size_t)b].head_done))
       return rc;
   }
   return join_stream(h, h->s_out, h->out_join, h->stream);
@@ -740,7 +783,7 @@ int validate_params(pm_handle* h, const pm_params& p) {
 void abort_capture(pm_handle* h) {
   if (!h->capturing) return;
   for (hipStream_t st : h->cap_unjoined) {  // see pm_capture_end: an unjoined fork must not reach hipStreamEndCapture
-    hipEvent_t ev = st == h->s_out ? h->out_join : h->view1_join;
+    hipEvent_t ev = st == h->s_out ? h->out_join : (st == h->s_in ? h->in_join : h->view1_join);
     if (ev && hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
   }
   h->cap_unjoined.clear();
@@ -901,7 +944,7 @@ void pm_destroy(pm_handle* h) {
   for (hipStream_t st : streams)
     if (st) (void)hipStreamSynchronize(st);
   pm_internal::release_imaging(h);
-  hipEvent_t events[] = {h->ext_fork, h->ext_join, h->left_out, h->right_out, h->view1_join, h->out_join, h->view_fork};
+  hipEvent_t events[] = {h->ext_fork, h->ext_join, h->left_out, h->right_out, h->view1_join, h->out_join, h->in_join, h->view_fork};
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -910,7 +953,7 @@ void pm_destroy(pm_handle* h) {
     (void)hipEventDestroy(r.stop);
   }
   for (auto& sl : h->pipe) {
-    hipEvent_t evs[] = {sl.in_done, sl.v_done[0], sl.v_done[1], sl.fin_done, sl.out_done};
+    hipEvent_t evs[] = {sl.in_done, sl.head_done, sl.v_done[0], sl.v_done[1], sl.fin_done, sl.out_done};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -1083,7 +1126,7 @@ int pm_capture_end(pm_handle* h) {
   if (unjoined) {
     std::vector<hipStream_t> open_streams = h->cap_unjoined;
     for (hipStream_t st : open_streams) {
-      hipEvent_t ev = st == h->s_out ? h->out_join : h->view1_join;
+      hipEvent_t ev = st == h->s_out ? h->out_join : (st == h->s_in ? h->in_join : h->view1_join);
       if (hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
       mark_joined(h, st);
     }

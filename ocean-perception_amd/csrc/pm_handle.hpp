@@ -102,6 +102,7 @@ struct pm_handle {
   // forks per frame.
   struct PipeSlot {
     hipEvent_t in_done = nullptr;   // s_in: the slot's inputs are in device memory
+    hipEvent_t head_done = nullptr; // s_in: images, gradients, line planes and seeds of the chunk that STARTS here are ready
     hipEvent_t v_done[2] = {nullptr, nullptr};  // view stream v: the chunk that STARTS at this slot has run
     hipEvent_t fin_done = nullptr;  // s_out: cross-check done, the slot's planes and input staging are free again
     hipEvent_t out_done = nullptr;  // s_out: the slot's maps have arrived on the host
@@ -136,6 +137,7 @@ struct pm_handle {
   hipStream_t view1_stream = nullptr;
   hipEvent_t view1_join = nullptr;
   hipEvent_t out_join = nullptr;  // s_out -> the handle's stream at the end of a batch
+  hipEvent_t in_join = nullptr;   // s_in -> the handle's stream (only when a capture is ended with the head stream unjoined)
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
@@ -279,7 +281,7 @@ int seq_chunk_pairs();
 bool seq_pipelined(const pm_handle* h);
 int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                       const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, hipEvent_t ready,
-                      hipEvent_t slot_free, hipEvent_t v_done[2]);
+                      hipEvent_t slot_free, hipEvent_t v_done[2], hipEvent_t head_done);
 SeedParams seed_params(const pm_params& p);
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc);
 // SparseInit (or Patchmatch::Initialize(.., 1)) for view `view` of pair `b` straight into its disparity plane

@@ -101,7 +101,7 @@ int enqueue_frames(pm_handle* h, int b, int c) {
   hipEvent_t ready = f0.device_io ? nullptr : h->pipe[(size_t)(b + c - 1)].in_done;  // s_in runs in order
   if (seq_pipelined(h)) {
     if (int rc = seq_enqueue_chunk(h, b, c, f0.d_left, f0.d_right, rows, cols, f0.d_seed_l, f0.d_seed_r, f0.d_out_l,
-                                   f0.d_out_r, ready, nullptr, f0.v_done))
+                                   f0.d_out_r, ready, nullptr, f0.v_done, f0.head_done))
       return rc;
   } else {
     if (ready) PM_HIP(h, hipStreamWaitEvent(h->stream, ready, 0));
