@@ -288,6 +288,14 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
  * 2^f (not f: SURVEY Q1).  `seed` holds (rows/f) * (cols/f) floats. */
 int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
                   float* seed);
+/* ForegroundTextureMask(gray, mask, ksize, min_grad, downsize) (src/vehicle/stereo_matching/patchmatch.hpp:11-16,
+ * patchmatch.cpp:19-49): 255 where the morphological gradient of the gray image over a (2 k + 1)^2 rectangle,
+ * k = ksize / downsize, exceeds min_grad; with downsize > 1 the gradient is taken on the image shrunk with
+ * cv::resize(INTER_LINEAR) and the thresholded mask is blown up again the same way (values between 0 and 255 at its
+ * edges, as in the reference).  DEVICE images, tightly packed, on the handle's stream.  Nothing in the reference calls
+ * this function; it completes stereo_matching/patchmatch.{hpp,cpp}. */
+int pm_foreground_texture_mask(pm_handle* h, const uint8_t* d_gray, int rows, int cols, int ksize, double min_grad,
+                               int downsize, uint8_t* d_mask);
 /* MaskOcclusions (patchmatch_gpu.cu:273-295). */
 int pm_mask_occlusions(pm_handle* h, float* disp_l, const float* disp_r, int rows, int cols);
 
@@ -368,6 +376,10 @@ int pm_tiled_upload_u8(pm_tiled_plan* plan, const uint8_t* left, const uint8_t* 
 int pm_tiled_run(pm_tiled_plan* plan, int rounds, pm_tiled_info* info);
 int pm_tiled_download(pm_tiled_plan* plan, float* disp_l, float* disp_r, size_t disp_step);
 const char* pm_tiled_last_error(const pm_tiled_plan* plan);
+/* How the bands are spread: neighbouring bands that live on different devices (their boundary rows cross devices), and how
+ * many of those boundaries got direct peer access (hipDeviceEnablePeerAccess both ways; the rest is staged by the
+ * runtime).  All bands on one device: 0 and 0 -- no peer access is requested at all. */
+int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* peer_links);
 
 /* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------
  * pm_match_u8 / pm_match_batch_u8 / pm_submit_u8 / pm_match_device run the whole schedule

@@ -960,7 +960,7 @@ void pm_destroy(pm_handle* h) {
   void* dev[] = {h->rpg,     h->rqk,      h->cpg,       h->img8,      h->g32,       h->g8,        h->timg8,
                  h->tg32,    h->tg8,      h->pk16,      h->tpk16,     h->disp,      h->cost,      h->noise,
                  h->counters, h->st_left, h->st_right,  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r,
-                 h->snap_disp, h->snap_cost, h->planes_state};
+                 h->snap_disp, h->snap_cost, h->planes_state, h->texmask_scratch};
   for (auto& sc : h->seeds) seed_scratch_free(sc);
   for (void* p : dev)
     if (p) (void)hipFree(p);

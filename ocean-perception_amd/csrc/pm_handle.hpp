@@ -139,6 +139,7 @@ struct pm_handle {
   hipEvent_t out_join = nullptr;  // s_out -> the handle's stream at the end of a batch
   hipEvent_t in_join = nullptr;   // s_in -> the handle's stream (only when a capture is ended with the head stream unjoined)
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
+  void* texmask_scratch = nullptr;  // pm_foreground_texture_mask: four byte planes, allocated on first use
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
   hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay

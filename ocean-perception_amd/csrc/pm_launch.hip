@@ -3,6 +3,7 @@
 #include "pm_handle.hpp"
 #include "pm_kernels.hpp"
 #include "pm_sweeps.hpp"
+#include "pm_texmask.hpp"
 
 namespace pm {
 namespace eng {
@@ -169,3 +170,48 @@ void launch_copy_disp_strided(pm_handle* h, const PlaneSet& ps, float* d_buf, si
 
 }  // namespace eng
 }  // namespace pm
+
+// ---- ForegroundTextureMask (src/vehicle/stereo_matching/patchmatch.cpp:19-49), device images ------------------------------
+extern "C" int pm_foreground_texture_mask(pm_handle* h, const uint8_t* d_gray, int rows, int cols, int ksize,
+                                          double min_grad, int downsize, uint8_t* d_mask) {
+  using namespace pm;
+  using namespace pm::eng;
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_foreground_texture_mask")) return rc;
+  if (!d_gray || !d_mask) {
+    set_err(h, "pm_foreground_texture_mask: null pointer");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (downsize < 1 || downsize > 8 || ksize / downsize <= 1) {  // the reference CHECKs both (patchmatch.cpp:25-27)
+    set_err(h, "pm_foreground_texture_mask: downsize must be within [1, 8] and ksize / downsize > 1");
+    return PM_ERR_INVALID_ARG;
+  }
+  if (int rc = check_size(h, rows, cols, 1)) return rc;
+  const int srows = rows / downsize, scols = cols / downsize;
+  if (srows < 1 || scols < 1) {
+    set_err(h, "pm_foreground_texture_mask: image smaller than downsize");
+    return PM_ERR_INVALID_ARG;
+  }
+  PM_HIP(h, hipSetDevice(h->device));
+  const size_t plane = (size_t)h->max_rows * h->max_cols;
+  if (!h->texmask_scratch) PM_HIP(h, hipMalloc(&h->texmask_scratch, 4 * plane));
+  uint8_t* small = (uint8_t*)h->texmask_scratch;
+  uint8_t* lo = small + plane;
+  uint8_t* hi = lo + plane;
+  uint8_t* bin = hi + plane;
+  const int k = ksize / downsize;
+  const dim3 block(256);
+  const dim3 sgrid((unsigned)((scols + 255) / 256), (unsigned)srows), fgrid((unsigned)((cols + 255) / 256), (unsigned)rows);
+  if (downsize > 1) {
+    hipLaunchKernelGGL(k_resize_linear_u8, sgrid, block, 0, h->stream, d_gray, rows, cols, small, srows, scols);
+    hipLaunchKernelGGL(k_morph_rows, sgrid, block, 0, h->stream, (const uint8_t*)small, srows, scols, k, lo, hi);
+    hipLaunchKernelGGL(k_morph_cols_threshold, sgrid, block, 0, h->stream, (const uint8_t*)lo, (const uint8_t*)hi, srows,
+                       scols, k, min_grad, bin);
+    hipLaunchKernelGGL(k_resize_linear_u8, fgrid, block, 0, h->stream, (const uint8_t*)bin, srows, scols, d_mask, rows, cols);
+  } else {
+    hipLaunchKernelGGL(k_morph_rows, fgrid, block, 0, h->stream, d_gray, rows, cols, k, lo, hi);
+    hipLaunchKernelGGL(k_morph_cols_threshold, fgrid, block, 0, h->stream, (const uint8_t*)lo, (const uint8_t*)hi, rows, cols,
+                       k, min_grad, d_mask);
+  }
+  return launch_check(h, "foreground texture mask");
+}

@@ -40,6 +40,7 @@ struct Band {
   hipEvent_t ev_sent[2] = {nullptr, nullptr};  // sent[i] is written (this band's stream)
   hipEvent_t ev_read[2] = {nullptr, nullptr};  // the successor has copied sent[i] (recorded on ITS stream)
   bool read_pending[2] = {false, false};
+  int last = 0;  // the buffer of `sent` that holds the row this band published last
 };
 
 }  // namespace
@@ -48,6 +49,8 @@ struct pm_tiled_plan {
   std::vector<Band> bands;
   int rows = 0, cols = 0, n_views = 1, halo = 0;
   bool resident = false, have_seed_l = false, have_seed_r = false;  // a pair has been uploaded (pm_tiled_upload_u8)
+  int device_boundaries = 0;  // neighbouring bands that live on DIFFERENT devices (their rows cross by peer copy)
+  int peer_links = 0;         // ... of which direct peer access could be enabled (the others are staged by the runtime)
   char err[512] = {0};
 };
 
@@ -155,6 +158,7 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
     }
     TL_PM(p, b, pm_tile_get_row(b.h, out_row, b.sent[cur]));
     TL_HIP(p, hipEventRecord(b.ev_sent[cur], b.stream));
+    b.last = cur;
     return PM_OK;
   };
   // band k copies its predecessor's published row into dst (on k's stream, behind the predecessor's event)
@@ -193,14 +197,23 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
         TL_PM(p, b, pm_tile_snapshot(b.h));
         TL_PM(p, b, pm_tile_sweep(b.h, it, k));
       }
+      // Round r hands band j the row its predecessor held after round r - 1.  The first band of the sweep direction has
+      // no predecessor: its row is final after the first sweep; its successor is final after round 0, and so on -- the
+      // band at position `pos` (0 = first in sweep direction) is final after round pos - 1.  From round pos on it
+      // would receive the row it already has, restore nothing and re-sweep nothing: it skips those rounds (and its
+      // predecessor does not publish for it).  n (n - 1) / 2 band-rounds instead of (n - 1)^2, same result.
+      auto pos_of = [&](int j) { return down ? j : n - 1 - j; };
       for (int r = 0; r < rounds; ++r) {
         cur ^= 1;
-        for (int j = 0; j < n; ++j)
+        for (int j = 0; j < n; ++j) {
+          const int succ = down ? j + 1 : j - 1;
+          if (succ < 0 || succ >= n || pos_of(succ) <= r) continue;  // nobody reads this band's row in this round
           if (int rc = publish(j, out_row(p->bands[(size_t)j]))) return rc;
+        }
         for (int j = 0; j < n; ++j) {
           Band& b = p->bands[(size_t)j];
           const int pr = pred_of(j);
-          if (pr < 0 || pr >= n) continue;
+          if (pr < 0 || pr >= n || pos_of(j) <= r) continue;  // no predecessor, or final since round pos - 1
           if (int rc = fetch(j, pr, b.incoming)) return rc;
           hipLaunchKernelGGL(k_row_changed, rgrid, rblock, 0, b.stream, b.mask, b.incoming, b.used, row_n);
           TL_PM(p, b, pm_tile_restore_cols(b.h, b.mask));
@@ -218,7 +231,7 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
         if (succ < 0 || succ >= n) continue;
         TL_HIP(p, hipSetDevice(b.dev));
         TL_PM(p, b, pm_tile_get_row(b.h, out_row(b), b.probe));
-        hipLaunchKernelGGL(k_row_moved, rgrid, rblock, 0, b.stream, b.flag, b.probe, b.sent[cur], row_n);
+        hipLaunchKernelGGL(k_row_moved, rgrid, rblock, 0, b.stream, b.flag, b.probe, b.sent[b.last], row_n);
       }
     }
   }
@@ -256,6 +269,13 @@ int pm_tiled_band_rows(const pm_params* params, int global_rows, int n_bands) {
 }
 
 const char* pm_tiled_last_error(const pm_tiled_plan* plan) { return plan ? plan->err : "null plan"; }
+
+int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* peer_links) {
+  if (!plan) return PM_ERR_INVALID_ARG;
+  if (device_boundaries) *device_boundaries = plan->device_boundaries;
+  if (peer_links) *peer_links = plan->peer_links;
+  return PM_OK;
+}
 
 void pm_tiled_destroy(pm_tiled_plan* plan) {
   if (!plan) return;
@@ -326,13 +346,16 @@ int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm
   // neighbouring bands on different devices: direct peer copies over xGMI where the platform allows them
   for (int k = 0; k + 1 < n_bands; ++k) {
     const int a = p->bands[(size_t)k].dev, c = p->bands[(size_t)k + 1].dev;
-    if (a == c) continue;
+    if (a == c) continue;  // bands sharing a device: hipMemcpyPeerAsync is then a plain device copy, nothing to enable
+    ++p->device_boundaries;
     int ok = 0;
     if (hipDeviceCanAccessPeer(&ok, a, c) == hipSuccess && ok) {
       (void)hipSetDevice(a);
-      (void)hipDeviceEnablePeerAccess(c, 0);  // "already enabled" is fine
+      const hipError_t e1 = hipDeviceEnablePeerAccess(c, 0);
       (void)hipSetDevice(c);
-      (void)hipDeviceEnablePeerAccess(a, 0);
+      const hipError_t e2 = hipDeviceEnablePeerAccess(a, 0);
+      const auto fine = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+      if (fine(e1) && fine(e2)) ++p->peer_links;
     }
     (void)hipGetLastError();
   }

@@ -238,6 +238,12 @@ class TiledPatchmatchGpu final {
   // rounds: boundary exchange rounds per vertical sweep; -1 = bands - 1, always exact without a repeat (pm_tiled_run)
   void Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds = -1);
   const pm_tiled_info& LastInfo() const { return info_; }
+  // neighbouring bands on different devices, and how many of those boundaries have direct peer access (pm_tiled_topology)
+  std::pair<int, int> Topology() const {
+    int a = 0, b = 0;
+    pm_tiled_topology(plan_, &a, &b);
+    return {a, b};
+  }
 
  private:
   int rows_, cols_;

@@ -37,14 +37,14 @@ EXPORTS = [
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
     "pm_normalize_color_illuminant", "pm_match_bgr_device", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
-    "pm_remove_background", "pm_mask_occlusions", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
+    "pm_remove_background", "pm_mask_occlusions", "pm_foreground_texture_mask", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
     "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
-    "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download",
+    "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download", "pm_tiled_topology",
 ]
 
 
@@ -215,6 +215,8 @@ def load():
     lib.pm_remove_background.restype = C.c_int
     lib.pm_mask_occlusions.argtypes = [vp, f32p, f32p, C.c_int, C.c_int]
     lib.pm_mask_occlusions.restype = C.c_int
+    lib.pm_foreground_texture_mask.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    lib.pm_foreground_texture_mask.restype = C.c_int
     lib.pm_sparse_init.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
     lib.pm_sparse_init.restype = C.c_int
     lib.pm_initialize.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
@@ -245,6 +247,8 @@ def load():
     lib.pm_tiled_download.restype = C.c_int
     lib.pm_tiled_last_error.argtypes = [vp]
     lib.pm_tiled_last_error.restype = C.c_char_p
+    lib.pm_tiled_topology.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pm_tiled_topology.restype = C.c_int
     lib.pm_tile_restore_cols.argtypes = [vp, vp]
     lib.pm_tile_sweep_masked.argtypes = [vp, C.c_int, C.c_int, vp]
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
@@ -621,6 +625,11 @@ class Engine:
                                            seed.ctypes.data_as(C.c_void_p)), "pm_initialize")
         return seed
 
+    def foreground_texture_mask(self, d_gray, rows, cols, ksize, min_grad, downsize, d_mask):
+        """Raw device addresses (u8 planes)."""
+        self._check(self.lib.pm_foreground_texture_mask(self.h, d_gray, rows, cols, ksize, min_grad, downsize, d_mask),
+                    "pm_foreground_texture_mask")
+
     def mask_occlusions(self, disp_l, disp_r):
         dl = np.array(disp_l, dtype=np.float32, order="C", copy=True)
         dr, pdr = _f32(disp_r)
@@ -725,6 +734,12 @@ class TiledEngine:
             msg = self.lib.pm_tiled_last_error(self.plan).decode() if self.plan else ""
             self.close()
             raise PmError(rc, "pm_tiled_create", msg)
+
+    def topology(self):
+        """(neighbouring bands on different devices, of which with direct peer access)"""
+        a, b = C.c_int(-1), C.c_int(-1)
+        self._tcheck(self.lib.pm_tiled_topology(self.plan, C.byref(a), C.byref(b)), "pm_tiled_topology")
+        return a.value, b.value
 
     def match(self, left, right, seed_l=None, seed_r=None, rounds=-1):
         self.upload(left, right, seed_l, seed_r)

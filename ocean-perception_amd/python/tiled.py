@@ -62,15 +62,19 @@ class DistComm:
         self.timed = False   # bench: bracket every exchange with events on the current (= the engine's) stream
         self._events = []
 
-    def shift(self, row, down):
-        """Send `row` to the next rank in sweep direction, return the row of the previous one (or None)."""
+    def shift(self, row, down, send=True, recv=True):
+        """Send `row` to the next rank in sweep direction, return the row of the previous one (or None).  send / recv =
+        False: this rank's side of the exchange is known to be redundant in this round (match_band) -- both ends of a
+        transfer derive that from their positions, so every send still meets its receive."""
         dist = self.dist
         dst = self.rank + 1 if down else self.rank - 1
         src = self.rank - 1 if down else self.rank + 1
-        ops, recv = [], None
-        if 0 <= dst < self.world:
+        ops, recv_buf = [], None
+        want_recv = recv
+        recv = None
+        if send and 0 <= dst < self.world:
             ops.append(dist.P2POp(dist.isend, row, dst))
-        if 0 <= src < self.world:
+        if want_recv and 0 <= src < self.world:
             recv = torch.empty_like(row)
             ops.append(dist.P2POp(dist.irecv, recv, src))
         if ops:
@@ -116,11 +120,11 @@ class LocalComm:
         self.s, self.rank, self.world = shared, rank, shared.world
         self.exchanges = 0
 
-    def shift(self, row, down):
+    def shift(self, row, down, send=True, recv=True):
         s = self.s
         d = 0 if down else 1
         ev = None
-        if row.is_cuda:
+        if row.is_cuda and send:
             # the row handed over last time stays referenced by the slot until now; its reader recorded an event after
             # copying it, and this stream waits for that event before the slot lets go of the tensor -- so whatever
             # this stream's allocator does with the block next is ordered behind the reader's copy.  (record_stream()
@@ -130,11 +134,12 @@ class LocalComm:
                 s.done[self.rank][d] = None
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-        s.slots[self.rank][d] = (row, ev)
+        if send:
+            s.slots[self.rank][d] = (row, ev)
         s.barrier.wait()
         src = self.rank - 1 if down else self.rank + 1
         got = None
-        if 0 <= src < self.world:
+        if recv and 0 <= src < self.world:
             src_row, src_ev = s.slots[src][d]
             if src_ev is not None:
                 torch.cuda.current_stream().wait_event(src_ev)
@@ -194,9 +199,16 @@ def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_
                     engine.tile_set_row(pred_row, used.data_ptr())
                 engine.tile_snapshot()
                 engine.tile_sweep(it, k)
-                for _ in range(rounds):
-                    sent = get_row(out_row)
-                    new_in = comm.shift(sent, down)
+                # The band at position pos of the sweep direction (0 = the band without a predecessor) is final after
+                # round pos - 1: from round pos on it would receive the row it already has.  It skips those rounds and
+                # its predecessor does not send: world (world - 1) / 2 band-rounds instead of (world - 1)^2.
+                pos = comm.rank if down else comm.world - 1 - comm.rank
+                for r in range(rounds):
+                    recv = pos > r            # my predecessor's row can still have changed
+                    send = pos + 1 > r and 0 <= (comm.rank + 1 if down else comm.rank - 1) < comm.world
+                    if send:
+                        sent = get_row(out_row)
+                    new_in = comm.shift(sent, down, send=send, recv=recv)
                     if new_in is not None:
                         mask = (new_in != used).to(torch.int32).contiguous()  # columns whose incoming value changed
                         engine.tile_restore_cols(mask.data_ptr())

@@ -177,6 +177,45 @@ void pmo_resize_linear_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, 
   free(hbuf[1]);
 }
 
+/* ForegroundTextureMask (src/vehicle/stereo_matching/patchmatch.cpp:19-49).  cv::morphologyEx(MORPH_GRADIENT) with a
+ * (2k+1)^2 rectangle = dilate - erode; the default border value never wins a min or a max, i.e. the window is clipped at
+ * the image border.  `gradient > min_grad` compares the 8-bit gradient with a double and gives 255 / 0. */
+static void morph_gradient_u8(const uint8_t* src, int rows, int cols, int k, uint8_t* grad) {
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      int mn = 255, mx = 0;
+      for (int yy = y - k < 0 ? 0 : y - k; yy <= (y + k > rows - 1 ? rows - 1 : y + k); ++yy)
+        for (int xx = x - k < 0 ? 0 : x - k; xx <= (x + k > cols - 1 ? cols - 1 : x + k); ++xx) {
+          const int v = src[(size_t)yy * cols + xx];
+          if (v < mn) mn = v;
+          if (v > mx) mx = v;
+        }
+      grad[(size_t)y * cols + x] = (uint8_t)(mx - mn);
+    }
+}
+int pmo_foreground_texture_mask(const uint8_t* gray, int rows, int cols, int ksize, double min_grad, int downsize,
+                                uint8_t* mask) {
+  if (downsize < 1 || downsize > 8) return -1; /* CHECK at patchmatch.cpp:25 */
+  const int k = ksize / downsize;
+  if (k <= 1) return -1;                       /* CHECK_GT(scaled_ksize, 1) at :27 */
+  if (downsize > 1) {
+    const int srows = rows / downsize, scols = cols / downsize; /* gray.size() / downsize: integer division */
+    const size_t n = (size_t)srows * scols;
+    uint8_t* small = (uint8_t*)malloc(n);
+    uint8_t* grad = (uint8_t*)malloc(n);
+    pmo_resize_linear_u8(gray, rows, cols, small, srows, scols);
+    morph_gradient_u8(small, srows, scols, k, grad);
+    for (size_t i = 0; i < n; ++i) grad[i] = (double)grad[i] > min_grad ? 255 : 0;
+    pmo_resize_linear_u8(grad, srows, scols, mask, rows, cols);
+    free(small);
+    free(grad);
+  } else {
+    morph_gradient_u8(gray, rows, cols, k, mask);
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) mask[i] = (double)mask[i] > min_grad ? 255 : 0;
+  }
+  return 0;
+}
+
 void pmo_flip_h_u8(const uint8_t* src, uint8_t* dst, int rows, int cols) {
   for (int y = 0; y < rows; ++y)
     for (int x = 0; x < cols; ++x) dst[(size_t)y * cols + x] = src[(size_t)y * cols + (cols - 1 - x)];

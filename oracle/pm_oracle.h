@@ -100,6 +100,9 @@ void pmo_get_rect_subpix_f32(const float* src, int rows, int cols, int pw, int p
  *   - otherwise: source coordinate fx = (dx + 0.5) * scale - 0.5, clamped at the borders, 11-bit fixed-point weights
  *     cvRound(w * 2048), horizontal pass in int, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2. */
 void pmo_resize_linear_u8(const uint8_t* src, int rows, int cols, uint8_t* dst, int drows, int dcols);
+/* ForegroundTextureMask (stereo_matching/patchmatch.cpp:19-49); 0, or -1 where the reference CHECK-fails. */
+int pmo_foreground_texture_mask(const uint8_t* gray, int rows, int cols, int ksize, double min_grad, int downsize,
+                                uint8_t* mask);
 void pmo_flip_h_u8(const uint8_t* src, uint8_t* dst, int rows, int cols);
 void pmo_flip_h_f32(const float* src, float* dst, int rows, int cols);
 

@@ -3,6 +3,8 @@
 // bm::pm::PatchmatchGpu::Match -- the construct-and-Match() calls of patchmatch_gpu.h:94-102.  Writes both results for
 // tests/test_cpp_tiled.py to compare bit for bit.
 // usage: tiled_main <dir> <rows> <cols> <semantics> <patch> <iters> <bands> <rounds>
+//        tiled_main devices <d0,d1,...>   only construct the row-tiled matcher with band k on device dk (64x96 image)
+//                                          and print its topology, or the exception: the multi-device constructor path
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -30,6 +32,25 @@ static void write_raw(const std::string& path, const bm::core::Image<T>& im) {
 }
 
 int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "devices") {
+    std::vector<int> devices;
+    for (const char* q = argv[2]; *q;) {
+      devices.push_back(atoi(q));
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+    PatchmatchGpu::Params params;
+    params.semantics = PM_SEM_CPU;
+    try {
+      TiledPatchmatchGpu tiled(params, 64, 96, devices);
+      const auto t = tiled.Topology();
+      std::printf("bands %zu device_boundaries %d peer_links %d\n", devices.size(), t.first, t.second);
+      return 0;
+    } catch (const std::exception& e) {
+      std::printf("exception: %s\n", e.what());
+      return 10;
+    }
+  }
   if (argc < 9) return 2;
   const std::string dir = argv[1];
   const int rows = atoi(argv[2]), cols = atoi(argv[3]), bands = atoi(argv[7]), rounds = atoi(argv[8]);

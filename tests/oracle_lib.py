@@ -172,6 +172,18 @@ def resize_linear_u8(src, drows, dcols):
     return dst
 
 
+def foreground_texture_mask(gray, ksize, min_grad, downsize):
+    gray = c_u8(gray)
+    out = np.empty(gray.shape, np.uint8)
+    lib = load()
+    lib.pmo_foreground_texture_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    lib.pmo_foreground_texture_mask.restype = C.c_int
+    rc = lib.pmo_foreground_texture_mask(_p(gray), gray.shape[0], gray.shape[1], ksize, min_grad, downsize, _p(out))
+    if rc != 0:
+        raise ValueError("the reference CHECK-fails on these arguments")
+    return out
+
+
 def dilate_rect(src, k):
     src = c_f32(src)
     dst = np.empty_like(src)

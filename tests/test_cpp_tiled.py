@@ -41,6 +41,38 @@ def test_tiled_driver_builds_with_gxx(tiled_exe):
     assert os.path.exists(tiled_exe)
 
 
+def _gpus():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def test_bands_on_devices_that_do_not_exist_fail_loudly(tiled_exe):
+    """The multi-device constructor path (pm_tiled_create over band handles of DISTINCT devices) on a box that does not
+    have those devices: no band is silently moved to another device, nothing falls back to the CPU -- the constructor
+    throws what pm_create said.  Without a GPU device 0 fails the same way; with one GPU device 1 does."""
+    n = _gpus()
+    res = subprocess.run([tiled_exe, "devices", f"{n},{n + 1}"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 10 and "exception" in res.stdout, res.stdout + res.stderr
+    assert ("no HIP device" in res.stdout) or ("out of range" in res.stdout), res.stdout
+    if n >= 1:  # the first band can be created, the second cannot: the constructor cleans up and still throws
+        res = subprocess.run([tiled_exe, "devices", f"0,{n}"], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 10 and "out of range" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_bands_sharing_a_device_request_no_peer_access(tiled_exe):
+    """All bands on device 0: no device boundary, hipDeviceEnablePeerAccess is never called (pm_tiled_topology says so);
+    on a box with two or more GPUs the same call over distinct devices reports one boundary per neighbouring pair."""
+    res = subprocess.run([tiled_exe, "devices", "0,0,0"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "bands 3 device_boundaries 0 peer_links 0" in res.stdout, res.stdout + res.stderr
+    if _gpus() >= 2:
+        res = subprocess.run([tiled_exe, "devices", "0,1"], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "bands 2 device_boundaries 1" in res.stdout, res.stdout + res.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sem,patch,bands,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 0), (0, 5, 2, 2)])
 def test_cpp_tiled_equals_untiled_and_oracle(tiled_exe, tmp_path, oracle, synth, sem, patch, bands, rounds):

@@ -86,8 +86,13 @@ def _comm_worker(rank, world, port, q):
     row = torch.full((2, 5), float(rank))
     down = comm.shift(row, True)    # from rank-1
     up = comm.shift(row, False)     # from rank+1
+    # a later round of a downward sweep (r = 1): bands already final neither send nor receive -- only rank 1 -> rank 2
+    # is left, and both ends derive that from their positions (match_band)
+    r, pos = 1, rank
+    late = comm.shift(row + 10.0, True, send=pos + 1 > r and rank + 1 < world, recv=pos > r)
     res = (None if down is None else float(down[0, 0]), None if up is None else float(up[0, 0]),
-           comm.any(torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)), comm.any(torch.zeros(1, dtype=torch.int32)))
+           comm.any(torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)), comm.any(torch.zeros(1, dtype=torch.int32)),
+           None if late is None else float(late[0, 0]))
     q.put((rank, res))
     dist.destroy_process_group()
 
@@ -111,9 +116,9 @@ def test_dist_comm_protocol_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out[0] == (None, 1.0, True, False)
-    assert out[1] == (0.0, 2.0, True, False)
-    assert out[2] == (1.0, None, True, False)
+    assert out[0] == (None, 1.0, True, False, None)
+    assert out[1] == (0.0, 2.0, True, False, None)
+    assert out[2] == (1.0, None, True, False, 11.0)
 
 
 @pytest.mark.gpu

@@ -58,6 +58,15 @@ class Leg:
         n = self.name
         if n == "single":
             self.e = pm.Engine(prm, max_rows=ROWS, max_cols=COLS)
+        elif n == "replay":
+            self.e = pm.Engine(prm, max_rows=ROWS, max_cols=COLS)
+            a = (1, L.data_ptr(), R.data_ptr(), ROWS, COLS, None if args.self_seed else SL.data_ptr(),
+                 None if args.self_seed else SR.data_ptr(), DL.data_ptr(), DR.data_ptr())
+            self.e.match_device(*a)
+            self.e.synchronize()
+            self.e.capture_begin()
+            self.e.match_device(*a)
+            self.e.capture_end()
         elif n == "batch":
             self.e = pm.Engine(prm, max_rows=ROWS, max_cols=COLS, max_batch=NB)
         elif n in ("pipe", "pipe_pinned", "pipe_dev"):
@@ -104,6 +113,16 @@ class Leg:
             t0 = time.perf_counter()
             for _ in range(k):
                 e.match_device(*a)
+            t1 = time.perf_counter()
+            e.synchronize()
+            extra["enqueue_ms_per_pair"] = round(1e3 * (t1 - t0) / k, 3)
+            return k, time.perf_counter() - t0, extra
+        if n == "replay":
+            k = 3 if warm else 40
+            e.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                e.replay()
             t1 = time.perf_counter()
             e.synchronize()
             extra["enqueue_ms_per_pair"] = round(1e3 * (t1 - t0) / k, 3)
