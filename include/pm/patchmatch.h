@@ -129,9 +129,13 @@ typedef struct pm_params {
   int gftt_use_harris;            /* 0     gftt_use_harris_corner_detector (feature_detector.hpp:34): corner response
                                            det(M) - k trace(M)^2 instead of the smaller eigenvalue               */
   double gftt_k;                  /* 0.04  gftt_k (:35), used with gftt_use_harris only                          */
-  int subpixel_corners;           /* 0     cv::cornerSubPix on the detected corners (feature_detector.cpp:110-120) and */
-  int subpixel_refinement;        /* 0     on the matches (stereo_matcher.cpp:94-103): NOT BUILT -- pm_create refuses
-                                           a non-zero value with PM_ERR_INVALID_ARG rather than ignoring it        */
+  int subpixel_corners;           /* 0     cv::cornerSubPix on the detected corners (feature_detector.cpp:110-120)    */
+  int subpix_winsize;             /* 10    half window of that refinement (feature_detector.hpp:40), <= 15            */
+  int subpix_zerozone;            /* -1    half size of its dead zone, -1 = none (:41)                                */
+  int subpix_maxiters;            /* 10    (:42)                                                                      */
+  float subpix_epsilon;           /* 0.01  (:43)                                                                      */
+  int subpixel_refinement;        /* 0     cv::cornerSubPix on the match in the right image, window 10, 40 steps, 0.001
+                                           (stereo_matcher.cpp:94-103): the seed disparities become fractional        */
   int cpu_initialize_factor;      /* 0: a self-seeded Match() seeds with SparseInit (patchmatch_gpu.cu:414-442);
                                      1: with Patchmatch::Initialize(il, ir, 1) as the CPU recipe does
                                         (patchmatch.cpp:52-87 called at patchmatch_test.cpp:149-150): dilation
@@ -283,6 +287,9 @@ int pm_remove_background(pm_handle* h, const uint8_t* left, const uint8_t* right
  * GFTT corners, rectified template matching, scatter, (2*(2^f+1)+1)^2 dilation -- all on the device. */
 int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
                    float* seed);
+/* cv::cornerSubPix as FeatureDetector::Detect applies it (feature_detector.cpp:110-120): n <= 1024 points of an 8-bit
+ * image refined in place with the handle's subpix_winsize / subpix_zerozone / subpix_maxiters / subpix_epsilon. */
+int pm_corner_subpix(pm_handle* h, const uint8_t* image, int rows, int cols, float* xs, float* ys, int n);
 /* Patchmatch::Initialize(iml, imr, downsample_factor) (stereo_matching/patchmatch.hpp:24, patchmatch.cpp:52-87):
  * as SparseInit with dilation 2*(2^(f-1)+1)+1, then cv::resize(INTER_NEAREST) to (rows/f) x (cols/f) and division by
  * 2^f (not f: SURVEY Q1).  `seed` holds (rows/f) * (cols/f) floats. */

@@ -275,11 +275,18 @@ SeedParams seed_params(const pm_params& p) {
   sp.max_matching_cost = p.max_matching_cost;
   sp.use_harris = p.gftt_use_harris;
   sp.harris_k = p.gftt_k;
+  sp.subpixel_corners = p.subpixel_corners;
+  sp.subpix_winsize = p.subpix_winsize;
+  sp.subpix_zerozone = p.subpix_zerozone;
+  sp.subpix_maxiters = p.subpix_maxiters;
+  sp.subpix_epsilon = p.subpix_epsilon;
+  sp.subpixel_refinement = p.subpixel_refinement;
   return sp;
 }
 
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
   PM_HIP(h, seed_scratch_alloc(sc, (size_t)h->max_rows * h->max_pitch, h->stream));
+  PM_HIP(h, seed_subpix_prepare(sc, seed_params(h->params), h->stream));
   return PM_OK;
 }
 
@@ -739,9 +746,10 @@ int validate_params(pm_handle* h, const pm_params& p) {
     set_err(h, "gftt_use_harris must be 0 or 1 and gftt_k within [0, 1]");
     return PM_ERR_INVALID_ARG;
   }
-  if (p.subpixel_corners != 0 || p.subpixel_refinement != 0) {
-    // cv::cornerSubPix (feature_detector.cpp:110-120, stereo_matcher.cpp:94-103) is not built: refuse, never ignore
-    set_err(h, "subpixel_corners / subpixel_refinement (cv::cornerSubPix) are not supported by this engine");
+  if ((p.subpixel_corners != 0 && p.subpixel_corners != 1) || (p.subpixel_refinement != 0 && p.subpixel_refinement != 1) ||
+      p.subpix_winsize < 1 || p.subpix_winsize > kSubpixMaxWin || p.subpix_maxiters < 1 || !(p.subpix_epsilon >= 0.f)) {
+    set_err(h, "cv::cornerSubPix parameters out of range (subpixel_corners / subpixel_refinement 0 or 1, subpix_winsize "
+               "within [1, %d], subpix_maxiters >= 1, subpix_epsilon >= 0)", kSubpixMaxWin);
     return PM_ERR_INVALID_ARG;
   }
   for (int i = 0; i < p.patchmatch_iters; ++i)
@@ -900,6 +908,10 @@ void pm_params_default(pm_params* p, int semantics) {
   p->gftt_use_harris = 0;            // feature_detector.hpp:34
   p->gftt_k = 0.04;                  // :35
   p->subpixel_corners = 0;           // :39
+  p->subpix_winsize = 10;            // :40
+  p->subpix_zerozone = -1;           // :41
+  p->subpix_maxiters = 10;           // :42
+  p->subpix_epsilon = 0.01f;         // :43
   p->subpixel_refinement = 0;        // stereo_matcher.hpp:26
   p->cpu_initialize_factor = 0;
   p->mode = PM_MODE_SCALAR;

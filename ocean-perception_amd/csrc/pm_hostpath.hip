@@ -736,6 +736,29 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
   return stage_out(h, ps, seed, 0);
 }
 
+int pm_corner_subpix(pm_handle* h, const uint8_t* image, int rows, int cols, float* xs, float* ys, int n) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  if (int rc = refuse_while_capturing(h, "pm_corner_subpix")) return rc;
+  if (!image || !xs || !ys || n < 0 || n > kSeedMaxFeatures) {
+    set_err(h, "pm_corner_subpix: null pointer, or more than %d points", kSeedMaxFeatures);
+    return PM_ERR_INVALID_ARG;
+  }
+  PlaneSet ps;
+  if (int rc = stage_prep(h, image, nullptr, rows, cols, &ps)) return rc;
+  SeedParams sp = seed_params(h->params);
+  sp.subpixel_corners = 1;  // the stage always needs the masks and the neighbourhood buffer
+  PM_HIP(h, seed_subpix_prepare(h->seeds[0], sp, h->stream));
+  float* d_x = h->st_disp_l;
+  float* d_y = h->st_disp_l + kSeedMaxFeatures;
+  PM_HIP(h, hipMemcpyAsync(d_x, xs, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, hipMemcpyAsync(d_y, ys, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  PM_HIP(h, seed_corner_subpix(h->seeds[0], sp, ps.img8, rows, cols, ps.pitch, d_x, d_y, n, h->stream));
+  PM_HIP(h, hipMemcpyAsync(xs, d_x, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipMemcpyAsync(ys, d_y, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  PM_HIP(h, hipStreamSynchronize(h->stream));
+  return PM_OK;
+}
+
 int pm_initialize(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, int downsample_factor,
                   float* seed) {
   if (!h) return PM_ERR_INVALID_ARG;

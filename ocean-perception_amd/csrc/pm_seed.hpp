@@ -580,15 +580,160 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
   if (tid == 0) counters[2] = (unsigned)count;
 }
 
+// ---- cv::cornerSubPix on the device (oracle: pm_seed_oracle.c::pmo_corner_subpix, which cites the OpenCV source it
+// restates).  One LANE per point, strictly sequential: the 2 x 2 normal equations are accumulated in double in raster
+// order, so that the result is the oracle's bit for bit.  `buf` = the lane's neighbourhood, element e at buf[e * bs]
+// (corner-major interleave: the lanes of a wavefront read and write neighbouring words).
+__device__ inline int sp_floor(float v) {
+  const int i = (int)v;
+  return i - (v < (float)i ? 1 : 0);
+}
+// getRectSubPix 8u -> 32f (samplers.cpp: getRectSubPix_8u32f inside the image, getRectSubPix_Cn_ + adjustRect at the border)
+__device__ inline void sp_get_rect_8u32f(const uint8_t* src, int rows, int cols, int pitch, int ww, int wh, float cx,
+                                         float cy, float* dst, int bs) {
+  cx -= (float)(ww - 1) * 0.5f;
+  cy -= (float)(wh - 1) * 0.5f;
+  const int ipx = sp_floor(cx), ipy = sp_floor(cy);
+  if (0 <= ipx && ipx + ww < cols && 0 <= ipy && ipy + wh < rows && ww > 0 && wh > 0) {
+    float a = cx - (float)ipx;
+    const float b = cy - (float)ipy;
+    a = a > 0.0001f ? a : 0.0001f;
+    const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+    const double s = (1. - (double)a) / (double)a;
+    const uint8_t* r = src + (size_t)ipy * pitch + ipx;
+    for (int i = 0; i < wh; ++i, r += pitch) {
+      const float t0 = b1 * (float)r[0], t1 = b2 * (float)r[pitch];
+      float prev = (1.f - a) * (t0 + t1);
+      float* d = dst + (size_t)i * ww * bs;
+      for (int j = 0; j < ww; ++j) {
+        const float u0 = a12 * (float)r[j + 1], u1 = a22 * (float)r[j + 1 + pitch];
+        const float t = u0 + u1;
+        d[(size_t)j * bs] = prev + t;
+        prev = (float)((double)t * s);
+      }
+    }
+    return;
+  }
+  const float a = cx - (float)ipx, b = cy - (float)ipy;
+  const float ia = 1.f - a, ib = 1.f - b;
+  const float a11 = ia * ib, a12 = a * ib, a21 = ia * b, a22 = a * b, b1 = ib, b2 = b;
+  int rx, ry, rw, rh;
+  long off = 0;
+  if (ipx >= 0) { off += ipx; rx = 0; } else { rx = -ipx; if (rx > ww) rx = ww; }
+  if (ipx < cols - ww) rw = ww; else { rw = cols - ipx - 1; if (rw < 0) { off += rw; rw = 0; } }
+  if (ipy >= 0) { off += (long)ipy * pitch; ry = 0; } else ry = -ipy;
+  if (ipy < rows - wh) rh = wh; else { rh = rows - ipy - 1; if (rh < 0) { off += (long)rh * pitch; rh = 0; } }
+  const uint8_t* r = src + (off - rx);
+  for (int i = 0; i < wh; ++i) {
+    const uint8_t* r2 = r + pitch;
+    if (i < ry || i >= rh) r2 -= pitch;
+    float* d = dst + (size_t)i * ww * bs;
+    float s0 = (float)r[rx] * b1 + (float)r2[rx] * b2;
+    for (int j = 0; j < rx; ++j) d[(size_t)j * bs] = s0;
+    s0 = (float)r[rw] * b1 + (float)r2[rw] * b2;
+    for (int j = rw; j < ww; ++j) d[(size_t)j * bs] = s0;
+    for (int j = rx; j < rw; ++j) {
+      float v = (float)r[j] * a11;
+      v = v + (float)r[j + 1] * a12;
+      v = v + (float)r2[j] * a21;
+      v = v + (float)r2[j + 1] * a22;
+      d[(size_t)j * bs] = v;
+    }
+    if (i < rh) r = r2;
+  }
+}
+__device__ inline void sp_corner_subpix(const uint8_t* img, int rows, int cols, int pitch, float& x, float& y, int win,
+                                        const float* __restrict__ mask, int max_iters, double eps, float* buf, int bs) {
+  const int ww = 2 * win + 1, bw = ww + 2;
+  max_iters = max_iters < 1 ? 1 : (max_iters > 100 ? 100 : max_iters);
+  eps = eps > 0. ? eps : 0.;
+  eps *= eps;
+  const float tx = x, ty = y;
+  float ix = tx, iy = ty;
+  int iter = 0;
+  double err = 0.;
+  do {
+    double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+    sp_get_rect_8u32f(img, rows, cols, pitch, bw, bw, ix, iy, buf, bs);
+    for (int i = 0, k = 0; i < ww; ++i) {
+      const float* sp = buf + (size_t)((i + 1) * bw + 1) * bs;
+      const double py = i - win;
+      for (int j = 0; j < ww; ++j, ++k) {
+        const double m = mask[k];
+        const float fgx = sp[(size_t)(j + 1) * bs] - sp[(long)(j - 1) * bs];
+        const float fgy = sp[(size_t)(j + bw) * bs] - sp[(long)(j - bw) * bs];
+        const double tgx = fgx, tgy = fgy;
+        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+        const double px = j - win;
+        a += gxx;
+        b += gxy;
+        c += gyy;
+        bb1 += gxx * px + gxy * py;
+        bb2 += gxy * px + gyy * py;
+      }
+    }
+    const double det = a * c - b * b;
+    if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+    const double scale = 1.0 / det;
+    const float nx = (float)((double)ix + c * scale * bb1 - b * scale * bb2);
+    const float ny = (float)((double)iy - b * scale * bb1 + a * scale * bb2);
+    const float dxs = nx - ix, dys = ny - iy;
+    const float e0 = dxs * dxs, e1 = dys * dys;
+    err = (double)(e0 + e1);
+    ix = nx;
+    iy = ny;
+    if (ix < 0 || ix >= (float)cols || iy < 0 || iy >= (float)rows) break;
+  } while (++iter < max_iters && err > eps);
+  if (fabsf(ix - tx) > (float)win || fabsf(iy - ty) > (float)win) {
+    ix = tx;
+    iy = ty;
+  }
+  x = ix;
+  y = iy;
+}
+// FeatureDetector::Detect's refinement (feature_detector.cpp:110-120): corner i of the selection -> its sub-pixel
+// position (kp_f) and the rounded position the matcher and the scatter use (std::round, back into kp_xy)
+__global__ void __launch_bounds__(64) k_seed_subpix_corners(const uint8_t* __restrict__ img, int rows, int cols, int pitch,
+                                                            int* __restrict__ kp_xy, float* __restrict__ kp_f,
+                                                            const unsigned* __restrict__ counters, SeedParams sp,
+                                                            const float* __restrict__ mask, float* __restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int)counters[2]) return;
+  float x = (float)kp_xy[2 * i], y = (float)kp_xy[2 * i + 1];
+  sp_corner_subpix(img, rows, cols, pitch, x, y, sp.subpix_winsize, mask, sp.subpix_maxiters, (double)sp.subpix_epsilon,
+                   buf + i, kSeedMaxFeatures);
+  kp_f[2 * i] = x;
+  kp_f[2 * i + 1] = y;
+  kp_xy[2 * i] = (int)roundf(x);
+  kp_xy[2 * i + 1] = (int)roundf(y);
+}
+
+// cv::cornerSubPix as a stage of its own (pm_corner_subpix): n points, xs / ys in and out
+__global__ void __launch_bounds__(64) k_seed_subpix_points(const uint8_t* __restrict__ img, int rows, int cols, int pitch,
+                                                           float* __restrict__ xs, float* __restrict__ ys, int n, int win,
+                                                           int max_iters, double eps, const float* __restrict__ mask,
+                                                           float* __restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = xs[i], y = ys[i];
+  sp_corner_subpix(img, rows, cols, pitch, x, y, win, mask, max_iters, eps, buf + i, kSeedMaxFeatures);
+  xs[i] = x;
+  ys[i] = y;
+}
+
 // One workgroup per accepted corner (StereoMatcher::MatchRectified).  Writes the corner's disparity (>= 0) or -1.
 __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                     int rows, int cols, int pitch, const int* __restrict__ kp_xy,
+                                                    const float* __restrict__ kp_f,
                                                     const unsigned* __restrict__ counters, SeedParams sp,
-                                                    float* __restrict__ kp_d) {
+                                                    float* __restrict__ kp_d, const float* __restrict__ sp_mask,
+                                                    float* __restrict__ sp_buf) {
   const int kp = blockIdx.x;
   if (kp >= (int)counters[2]) return;
   if (threadIdx.x == 0) kp_d[kp] = -1.f;  // every early exit below means "no match"; thread 0 also writes the result
-  const int rx = kp_xy[2 * kp], ry = kp_xy[2 * kp + 1];  // integer corners: round() is the identity
+  // the rounded corner (an integer corner is its own rounding; sub-pixel corners were rounded by k_seed_subpix_corners)
+  const int rx = kp_xy[2 * kp], ry = kp_xy[2 * kp + 1];
+  const float kx = kp_f ? kp_f[2 * kp] : (float)rx;  // left_keypoint.x
   const int tc = sp.templ_cols, tr = sp.templ_rows, md = sp.max_disp;
   const int stripe_rows = tr + 2;
   int ty = ry - (tr - 1) / 2;
@@ -671,9 +816,15 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = s_best[w] < best ? s_best[w] : best;
     const float minv = __builtin_bit_cast(float, (unsigned)(best >> 32));
     const int pos = (int)(best & 0xffffffffull);
-    const int bx = pos % rw;
+    const int bx = pos % rw, by = pos / rw;
     const int mx = bx + sx + (tc - 1) / 2 + offset_x;
-    if ((double)minv < sp.max_matching_cost && rx >= mx) kp_d[kp] = (float)(rx - mx);
+    float mpx = (float)mx;
+    if (sp.subpixel_refinement) {  // stereo_matcher.cpp:94-103: cornerSubPix on the right image, 10 x 10, 40 steps, 0.001
+      float mpy = (float)(by + sy + (tr - 1) / 2);
+      sp_corner_subpix(right, rows, cols, pitch, mpx, mpy, kSubpixMatchWin, sp_mask + kSubpixMaskStride, 40, 0.001,
+                       sp_buf + kp, kSeedMaxFeatures);
+    }
+    if ((double)minv < sp.max_matching_cost && kx >= mpx) kp_d[kp] = kx - mpx;
   }
 }
 
@@ -684,15 +835,26 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
 // order; a maximum does not depend on the order of the updates: deterministic) into a zeroed map.  `inv_scale`
 // (1, or 2^-f for Initialize, patchmatch.cpp:81) is applied to the corner value first: scaling by a power of two
 // is exact and monotone, so it commutes with the maximum.
+// `dedup` (sub-pixel corners only): two corners may have been refined onto the same pixel; the scatter
+// `disps.at(round(kp.y), round(kp.x)) = d` (patchmatch_gpu.cu:426-432) is sequential, so the LAST corner with a valid
+// match (d >= 0, even 0) owns the pixel -- a corner with such a successor does not count.
 __global__ void __launch_bounds__(256) k_seed_splat(const int* __restrict__ kp_xy, const float* __restrict__ kp_d,
                                                     const unsigned* __restrict__ counters, int rows, int cols, int k,
-                                                    float inv_scale, float* __restrict__ out, int out_pitch) {
+                                                    float inv_scale, float* __restrict__ out, int out_pitch, int dedup) {
   const int kp = blockIdx.x;
-  if (kp >= (int)counters[2]) return;
+  const int count = (int)counters[2];
+  if (kp >= count) return;
   const float d = kp_d[kp];
   if (!(d > 0.f)) return;  // no match (-1) or disparity 0: nothing to raise above the zero background
   const unsigned bits = __builtin_bit_cast(unsigned, d * inv_scale);
   const int kx = kp_xy[2 * kp], ky = kp_xy[2 * kp + 1];
+  if (kx < 0 || kx >= cols || ky < 0 || ky >= rows) return;  // a sub-pixel corner rounded out of the image: no pixel to set
+  if (dedup) {
+    int later = 0;
+    for (int j = kp + 1 + (int)threadIdx.x; j < count; j += (int)blockDim.x)
+      later |= (kp_xy[2 * j] == kx && kp_xy[2 * j + 1] == ky && kp_d[j] >= 0.f) ? 1 : 0;
+    if (__syncthreads_or(later)) return;
+  }
   const int x0 = max(kx - k, 0), x1 = min(kx + k, cols - 1), y0 = max(ky - k, 0), y1 = min(ky + k, rows - 1);
   const int w = x1 - x0 + 1, n = w * (y1 - y0 + 1);
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
@@ -780,8 +942,13 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   {
     const size_t px_bytes = 4 * ((size_t)sp.templ_rows * ((sp.templ_cols + 3) / 4) +
                                  (size_t)(sp.templ_rows + 2) * ((sp.max_disp + 3) / 4 + 1));
+    if (sp.subpixel_corners)
+      hipLaunchKernelGGL(k_seed_subpix_corners, dim3((unsigned)((maxf + 63) / 64 > 0 ? (maxf + 63) / 64 : 1)), dim3(64), 0,
+                         stream, left, rows, cols, pitch, sc.kp_xy, sc.kp_f, (const unsigned*)sc.counters, sp,
+                         (const float*)sc.sp_mask, sc.sp_buf);
     hipLaunchKernelGGL(k_seed_match, dim3((unsigned)(maxf > 0 ? maxf : 1)), dim3(256), px_bytes, stream, left, right,
-                       rows, cols, pitch, sc.kp_xy, sc.counters, sp, sc.kp_d);
+                       rows, cols, pitch, sc.kp_xy, sp.subpixel_corners ? (const float*)sc.kp_f : (const float*)nullptr,
+                       sc.counters, sp, sc.kp_d, (const float*)sc.sp_mask, sc.sp_buf);
   }
   const bool resized = out_rows != rows || out_cols != cols;
   // full-size splat target: the output itself, or the (idle by now) response plane when a resize follows
@@ -789,10 +956,20 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   const int full_pitch = resized ? pitch : out_pitch;
   if ((e = hipMemsetAsync(full, 0, sizeof(float) * (size_t)rows * full_pitch, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)(maxf > 0 ? maxf : 1)), block, 0, stream, (const int*)sc.kp_xy,
-                     (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, inv_scale, full, full_pitch);
+                     (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, inv_scale, full, full_pitch,
+                     sp.subpixel_corners);
   if (resized)
     hipLaunchKernelGGL(k_seed_resize_nearest, dim3((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block, 0,
                        stream, (const float*)full, rows, cols, full_pitch, out, out_rows, out_cols, out_pitch);
+  return hipGetLastError();
+}
+// pm_corner_subpix: the detector's window of `sp` (sc.sp_mask) on n <= kSeedMaxFeatures device points
+hipError_t seed_corner_subpix(const SeedScratch& sc, const SeedParams& sp, const uint8_t* img, int rows, int cols, int pitch,
+                              float* d_xs, float* d_ys, int n, hipStream_t stream) {
+  if (n < 1) return hipSuccess;
+  hipLaunchKernelGGL(k_seed_subpix_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, img, rows, cols, pitch, d_xs,
+                     d_ys, n, sp.subpix_winsize, sp.subpix_maxiters, (double)sp.subpix_epsilon, (const float*)sc.sp_mask,
+                     sc.sp_buf);
   return hipGetLastError();
 }
 hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,

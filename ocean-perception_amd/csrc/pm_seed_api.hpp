@@ -15,10 +15,17 @@ struct SeedParams {
   double quality_level, max_matching_cost;
   int use_harris;   // corner response det(M) - k trace(M)^2 (cv::cornerHarris) instead of the smaller eigenvalue
   double harris_k;
+  // cv::cornerSubPix on the detected corners (feature_detector.cpp:110-120) / on the match (stereo_matcher.cpp:94-103)
+  int subpixel_corners, subpix_winsize, subpix_zerozone, subpix_maxiters;
+  float subpix_epsilon;
+  int subpixel_refinement;
 };
+constexpr int kSubpixMaxWin = 15;       // largest half window of cornerSubPix the scratch is sized for
+constexpr int kSubpixMatchWin = 10;     // StereoMatcher's fixed window (stereo_matcher.cpp:97)
 
 constexpr int kSeedMaxFeatures = 1024;  // capacity of the accepted-corner list
 constexpr int kSeedCounters = 8;        // SeedScratch::counters
+constexpr int kSubpixMaskStride = 1024;  // floats between the two masks of SeedScratch::sp_mask (31 * 31 = 961)
 
 // Scratch owned by the handle (sized for max_rows x max_cols).
 struct SeedScratch {
@@ -29,6 +36,10 @@ struct SeedScratch {
                              // count, [3] = grid overflow flag
   int* kp_xy;                // [kSeedMaxFeatures][2]
   float* kp_d;               // [kSeedMaxFeatures] matched disparity of a corner, < 0 = no match
+  float* kp_f;               // [kSeedMaxFeatures][2] sub-pixel corner positions (subpixel_corners)
+  float* sp_buf;             // cornerSubPix neighbourhoods, [(2 * kSubpixMaxWin + 3)^2][kSeedMaxFeatures]
+  float* sp_mask;            // window masks: detector's [(2 w + 1)^2] at 0, matcher's [21 * 21] at kSubpixMaskStride
+  int sp_mask_win, sp_mask_zero;  // what the detector's mask was built for
   void* sort_tmp;
   size_t sort_tmp_bytes;
   int cap;
@@ -39,7 +50,13 @@ struct SeedScratch {
 // pixels dropped candidates there in whatever order the atomics fell.
 hipError_t seed_scratch_alloc(SeedScratch& sc, size_t plane_elems, hipStream_t stream);
 void seed_scratch_free(SeedScratch& sc);
+// the masks and the neighbourhood buffer of cv::cornerSubPix, for handles whose parameters ask for it (synchronises
+// the stream when it has to upload the masks: call outside captures)
+hipError_t seed_subpix_prepare(SeedScratch& sc, const SeedParams& sp, hipStream_t stream);
 
+// cv::cornerSubPix with the detector's window parameters of `sp` on n device points (needs seed_subpix_prepare)
+hipError_t seed_corner_subpix(const SeedScratch& sc, const SeedParams& sp, const uint8_t* img, int rows, int cols, int pitch,
+                              float* d_xs, float* d_ys, int n, hipStream_t stream);
 // PatchmatchGpu::SparseInit(iml, imr, f)  (patchmatch_gpu.cu:414-442): dilation half-width 2^f + 1, map at image size
 hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                             int rows, int cols, int pitch, int dilate_factor, float* out, int out_pitch,

@@ -32,10 +32,13 @@ pm_params PatchmatchGpu::Params::ToC() const {
   p.gftt_quality_level = detector_params.gftt_quality_level;
   p.gftt_use_harris = detector_params.gftt_use_harris_corner_detector ? 1 : 0;
   p.gftt_k = detector_params.gftt_k;
-  // cv::cornerSubPix is not built: pm_create refuses these two instead of ignoring them (the constructor / the first
-  // Match() then throws).  subpix_winsize / _zerozone / _maxiters / _epsilon only matter with subpixel_corners, and
+  // cv::cornerSubPix on the corners (feature_detector.cpp:110-120) and on the matches (stereo_matcher.cpp:94-103).
   // StereoMatcher::Params::bidirectional is never read by the reference either (stereo_matcher.cpp:11-116).
   p.subpixel_corners = detector_params.subpixel_corners ? 1 : 0;
+  p.subpix_winsize = detector_params.subpix_winsize;
+  p.subpix_zerozone = detector_params.subpix_zerozone;
+  p.subpix_maxiters = detector_params.subpix_maxiters;
+  p.subpix_epsilon = detector_params.subpix_epsilon;
   p.subpixel_refinement = matcher_params.subpixel_refinement ? 1 : 0;
   p.templ_cols = matcher_params.templ_cols;
   p.templ_rows = matcher_params.templ_rows;

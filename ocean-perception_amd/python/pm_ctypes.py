@@ -37,7 +37,7 @@ EXPORTS = [
     "pm_compute_intensity", "pm_find_dark", "pm_stereo_ready", "pm_gaussian_blur", "pm_normalize",
     "pm_normalize_color_illuminant", "pm_match_bgr_device", "pm_device_malloc", "pm_device_free", "pm_upload", "pm_download",
     "pm_gradient_magnitude", "pm_unit_noise", "pm_add_noise", "pm_propagate",
-    "pm_remove_background", "pm_mask_occlusions", "pm_foreground_texture_mask", "pm_sparse_init", "pm_profile_enable", "pm_profile_read",
+    "pm_remove_background", "pm_mask_occlusions", "pm_foreground_texture_mask", "pm_sparse_init", "pm_corner_subpix", "pm_profile_enable", "pm_profile_read",
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
@@ -81,6 +81,10 @@ class PmParams(C.Structure):
         ("gftt_use_harris", C.c_int),
         ("gftt_k", C.c_double),
         ("subpixel_corners", C.c_int),
+        ("subpix_winsize", C.c_int),
+        ("subpix_zerozone", C.c_int),
+        ("subpix_maxiters", C.c_int),
+        ("subpix_epsilon", C.c_float),
         ("subpixel_refinement", C.c_int),
         ("cpu_initialize_factor", C.c_int),
         ("mode", C.c_int),
@@ -217,6 +221,8 @@ def load():
     lib.pm_mask_occlusions.restype = C.c_int
     lib.pm_foreground_texture_mask.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     lib.pm_foreground_texture_mask.restype = C.c_int
+    lib.pm_corner_subpix.argtypes = [vp, u8p, C.c_int, C.c_int, f32p, f32p, C.c_int]
+    lib.pm_corner_subpix.restype = C.c_int
     lib.pm_sparse_init.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
     lib.pm_sparse_init.restype = C.c_int
     lib.pm_initialize.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, C.c_int, f32p]
@@ -615,6 +621,14 @@ class Engine:
         self._check(self.lib.pm_sparse_init(self.h, pl, pr, left.shape[0], left.shape[1], dilate_factor,
                                             seed.ctypes.data_as(C.c_void_p)), "pm_sparse_init")
         return seed
+
+    def corner_subpix(self, image, xs, ys):
+        image, p = _u8(image)
+        xs = np.array(xs, dtype=np.float32, copy=True)
+        ys = np.array(ys, dtype=np.float32, copy=True)
+        self._check(self.lib.pm_corner_subpix(self.h, p, image.shape[0], image.shape[1], xs.ctypes.data_as(C.c_void_p),
+                                              ys.ctypes.data_as(C.c_void_p), len(xs)), "pm_corner_subpix")
+        return xs, ys
 
     def initialize(self, left, right, downsample_factor=1):
         left, pl = _u8(left)

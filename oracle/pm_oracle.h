@@ -173,7 +173,18 @@ typedef struct pmo_seed_params {
   double max_matching_cost; /* 0.15  :24 */
   int use_harris;           /* 0     feature_detector.hpp:34 gftt_use_harris_corner_detector */
   double harris_k;          /* 0.04  :35 gftt_k */
+  int subpixel_corners;     /* 0     :39 cv::cornerSubPix on the detected corners (feature_detector.cpp:110-120) */
+  int subpix_winsize;       /* 10    :40 */
+  int subpix_zerozone;      /* -1    :41 */
+  int subpix_maxiters;      /* 10    :42 */
+  float subpix_epsilon;     /* 0.01  :43 */
+  int subpixel_refinement;  /* 0     stereo_matcher.hpp:26 cornerSubPix on the match (stereo_matcher.cpp:94-103) */
 } pmo_seed_params;
+/* cv::cornerSubPix on an 8-bit image (pm_seed_oracle.c); xs / ys in and out */
+void pmo_corner_subpix(const uint8_t* img, int rows, int cols, float* xs, float* ys, int n, int win, int zero_zone,
+                       int max_iters, double eps);
+/* its window mask, (2 win + 1)^2 floats */
+void pmo_subpix_mask(int win, int zero_zone, float* mask);
 
 void pmo_seed_params_default(pmo_seed_params* p);
 /* min-eigenvalue response (cv::cornerMinEigenVal, unscaled): eig = (a+c) - sqrt((a-c)^2 + b^2) in binary32 with

@@ -21,6 +21,12 @@ void pmo_seed_params_default(pmo_seed_params* p) {
   p->max_matching_cost = 0.15;
   p->use_harris = 0;
   p->harris_k = 0.04;
+  p->subpixel_corners = 0;
+  p->subpix_winsize = 10;
+  p->subpix_zerozone = -1;
+  p->subpix_maxiters = 10;
+  p->subpix_epsilon = 0.01f;
+  p->subpixel_refinement = 0;
 }
 
 static inline int refl101(int p, int len) {
@@ -158,6 +164,140 @@ int pmo_gftt_detect(const uint8_t* img, int rows, int cols, const pmo_seed_param
   return count;
 }
 
+/* ---- cv::cornerSubPix (OpenCV 3.4 modules/imgproc/src/cornersubpix.cpp) on an 8-bit image ----------------------------
+ * FeatureDetector::Detect refines the detected corners with it when subpixel_corners is set
+ * (feature_detector.cpp:110-120), StereoMatcher::MatchRectified the match when subpixel_refinement is
+ * (stereo_matcher.cpp:94-103).  Restated from the published algorithm like the other OpenCV primitives (parity
+ * unpinned): Gaussian-like window mask in float, the (2 win + 3)^2 neighbourhood sampled by getRectSubPix 8u -> 32f,
+ * central differences in float, the 2 x 2 normal equations accumulated in double in raster order, at most max_iters
+ * steps, stop when the step is below eps; a corner that moved further than the window keeps its start. */
+static inline int sp_floor(float v) {
+  int i = (int)v;
+  return i - (v < (float)i);
+}
+/* getRectSubPix 8u -> 32f: getRectSubPix_8u32f of samplers.cpp (window inside the image: the running form with
+ * a = max(a, 0.0001) and prev = t * ((1 - a) / a)), else getRectSubPix_Cn_<uchar, float, float> with adjustRect. */
+static void sp_get_rect_8u32f(const uint8_t* src, int rows, int cols, int ww, int wh, float cx, float cy, float* dst) {
+  cx -= (float)(ww - 1) * 0.5f;
+  cy -= (float)(wh - 1) * 0.5f;
+  const int ipx = sp_floor(cx), ipy = sp_floor(cy);
+  if (0 <= ipx && ipx + ww < cols && 0 <= ipy && ipy + wh < rows && ww > 0 && wh > 0) {
+    float a = cx - (float)ipx;
+    const float b = cy - (float)ipy;
+    a = a > 0.0001f ? a : 0.0001f;
+    const float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+    const double s = (1. - (double)a) / (double)a;
+    const uint8_t* r = src + (size_t)ipy * cols + ipx;
+    for (int i = 0; i < wh; ++i, r += cols, dst += ww) {
+      const float t0 = b1 * (float)r[0], t1 = b2 * (float)r[cols];
+      float prev = (1.f - a) * (t0 + t1);
+      for (int j = 0; j < ww; ++j) {
+        const float u0 = a12 * (float)r[j + 1], u1 = a22 * (float)r[j + 1 + cols];
+        const float t = u0 + u1;
+        dst[j] = prev + t;
+        prev = (float)((double)t * s);
+      }
+    }
+    return;
+  }
+  const float a = cx - (float)ipx, b = cy - (float)ipy;
+  const float ia = 1.f - a, ib = 1.f - b;
+  const float a11 = ia * ib, a12 = a * ib, a21 = ia * b, a22 = a * b, b1 = ib, b2 = b;
+  /* adjustRect (samplers.cpp): clip the window, replicate the border */
+  int rx, ry, rw, rh;
+  ptrdiff_t off = 0;
+  if (ipx >= 0) { off += ipx; rx = 0; } else { rx = -ipx; if (rx > ww) rx = ww; }
+  if (ipx < cols - ww) rw = ww; else { rw = cols - ipx - 1; if (rw < 0) { off += rw; rw = 0; } }
+  if (ipy >= 0) { off += (ptrdiff_t)ipy * cols; ry = 0; } else ry = -ipy;
+  if (ipy < rows - wh) rh = wh; else { rh = rows - ipy - 1; if (rh < 0) { off += (ptrdiff_t)rh * cols; rh = 0; } }
+  const uint8_t* r = src + (off - rx);
+  for (int i = 0; i < wh; ++i, dst += ww) {
+    const uint8_t* r2 = r + cols;
+    if (i < ry || i >= rh) r2 -= cols;
+    float s0 = (float)r[rx] * b1 + (float)r2[rx] * b2;
+    for (int j = 0; j < rx; ++j) dst[j] = s0;
+    s0 = (float)r[rw] * b1 + (float)r2[rw] * b2;
+    for (int j = rw; j < ww; ++j) dst[j] = s0;
+    for (int j = rx; j < rw; ++j) {
+      float v = (float)r[j] * a11;
+      v = v + (float)r[j + 1] * a12;
+      v = v + (float)r2[j] * a21;
+      v = v + (float)r2[j + 1] * a22;
+      dst[j] = v;
+    }
+    if (i < rh) r = r2;
+  }
+}
+void pmo_subpix_mask(int win, int zero_zone, float* mask) {
+  const int ww = 2 * win + 1;
+  for (int i = 0; i < ww; ++i) {
+    const float y = (float)(i - win) / (float)win;
+    const float vy = expf(-y * y);
+    for (int j = 0; j < ww; ++j) {
+      const float x = (float)(j - win) / (float)win;
+      mask[i * ww + j] = (float)(vy * expf(-x * x));
+    }
+  }
+  if (zero_zone >= 0 && zero_zone * 2 + 1 < ww)
+    for (int i = win - zero_zone; i <= win + zero_zone; ++i)
+      for (int j = win - zero_zone; j <= win + zero_zone; ++j) mask[i * ww + j] = 0.f;
+}
+void pmo_corner_subpix(const uint8_t* img, int rows, int cols, float* xs, float* ys, int n, int win, int zero_zone,
+                       int max_iters, double eps) {
+  const int ww = 2 * win + 1, bw = ww + 2;
+  max_iters = max_iters < 1 ? 1 : (max_iters > 100 ? 100 : max_iters);
+  eps = eps > 0. ? eps : 0.;
+  eps *= eps;
+  float* mask = (float*)malloc(sizeof(float) * (size_t)ww * ww);
+  float* buf = (float*)malloc(sizeof(float) * (size_t)bw * bw);
+  pmo_subpix_mask(win, zero_zone, mask);
+  for (int p = 0; p < n; ++p) {
+    const float tx = xs[p], ty = ys[p];
+    float ix = tx, iy = ty;
+    int iter = 0;
+    double err = 0.;
+    do {
+      double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+      sp_get_rect_8u32f(img, rows, cols, bw, bw, ix, iy, buf);
+      const float* sp = buf + bw + 1;
+      for (int i = 0, k = 0; i < ww; ++i, sp += bw) {
+        const double py = i - win;
+        for (int j = 0; j < ww; ++j, ++k) {
+          const double m = mask[k];
+          const float fgx = sp[j + 1] - sp[j - 1], fgy = sp[j + bw] - sp[j - bw];
+          const double tgx = fgx, tgy = fgy;
+          const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+          const double px = j - win;
+          a += gxx;
+          b += gxy;
+          c += gyy;
+          bb1 += gxx * px + gxy * py;
+          bb2 += gxy * px + gyy * py;
+        }
+      }
+      const double det = a * c - b * b;
+      if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+      const double scale = 1.0 / det;
+      const float nx = (float)((double)ix + c * scale * bb1 - b * scale * bb2);
+      const float ny = (float)((double)iy - b * scale * bb1 + a * scale * bb2);
+      const float dxs = nx - ix, dys = ny - iy;
+      const float e0 = dxs * dxs, e1 = dys * dys;
+      err = (double)(e0 + e1);
+      ix = nx;
+      iy = ny;
+      if (ix < 0 || ix >= (float)cols || iy < 0 || iy >= (float)rows) break;
+    } while (++iter < max_iters && err > eps);
+    if (fabsf(ix - tx) > (float)win || fabsf(iy - ty) > (float)win) {
+      ix = tx;
+      iy = ty;
+    }
+    xs[p] = ix;
+    ys[p] = iy;
+  }
+  free(mask);
+  free(buf);
+}
+
 double pmo_match_rectified(const uint8_t* left, const uint8_t* right, int rows, int cols, float kx, float ky,
                            const pmo_seed_params* p) {
   const int tc = p->templ_cols, tr = p->templ_rows, md = p->max_disp;
@@ -213,22 +353,46 @@ double pmo_match_rectified(const uint8_t* left, const uint8_t* right, int rows, 
         have = 1;
       }
     }
-  (void)by;
   const int mx = bx + sx + (tc - 1) / 2 + offset_x;
-  if ((double)best < p->max_matching_cost && kx >= (float)mx) return (double)(float)(kx - (float)mx);
+  float mpx = (float)mx;
+  if (p->subpixel_refinement) { /* stereo_matcher.cpp:94-103: cornerSubPix on the right image, 10 x 10, 40 steps, 0.001 */
+    float mpy = (float)(by + sy + (tr - 1) / 2);
+    pmo_corner_subpix(right, rows, cols, &mpx, &mpy, 1, 10, -1, 40, 0.001);
+  }
+  if ((double)best < p->max_matching_cost && kx >= mpx) return (double)(float)(kx - mpx);
   return -1.0;
+}
+
+/* FeatureDetector::Detect (feature_detector.cpp:89-122): GFTT corners, optionally refined by cornerSubPix. */
+static int detect_corners(const uint8_t* img, int rows, int cols, const pmo_seed_params* p, float* fx, float* fy) {
+  const int cap = p->max_features > 0 ? p->max_features : 1;
+  int* xs = (int*)malloc(sizeof(int) * (size_t)cap);
+  int* ys = (int*)malloc(sizeof(int) * (size_t)cap);
+  const int cnt = pmo_gftt_detect(img, rows, cols, p, xs, ys, p->max_features);
+  for (int i = 0; i < cnt; ++i) {
+    fx[i] = (float)xs[i];
+    fy[i] = (float)ys[i];
+  }
+  if (p->subpixel_corners)
+    pmo_corner_subpix(img, rows, cols, fx, fy, cnt, p->subpix_winsize, p->subpix_zerozone, p->subpix_maxiters,
+                      (double)p->subpix_epsilon);
+  free(xs);
+  free(ys);
+  return cnt;
 }
 
 void pmo_sparse_init(const uint8_t* left, const uint8_t* right, int rows, int cols, int dilate_factor,
                      const pmo_seed_params* p, float* seed) {
   const size_t n = (size_t)rows * cols;
-  int* xs = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
-  int* ys = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
-  const int cnt = pmo_gftt_detect(left, rows, cols, p, xs, ys, p->max_features);
+  float* xs = (float*)malloc(sizeof(float) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  float* ys = (float*)malloc(sizeof(float) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  const int cnt = detect_corners(left, rows, cols, p, xs, ys);
   float* sparse = (float*)calloc(n, sizeof(float));
   for (int i = 0; i < cnt; ++i) {
-    const float d = (float)pmo_match_rectified(left, right, rows, cols, (float)xs[i], (float)ys[i], p);
-    if (d >= 0) sparse[(size_t)ys[i] * cols + xs[i]] = d;
+    const float d = (float)pmo_match_rectified(left, right, rows, cols, xs[i], ys[i], p);
+    /* disps.at<float>(std::round(kp.y), std::round(kp.x)) = d (patchmatch_gpu.cu:431) */
+    const int ry = (int)roundf(ys[i]), rx = (int)roundf(xs[i]);
+    if (d >= 0 && ry >= 0 && ry < rows && rx >= 0 && rx < cols) sparse[(size_t)ry * cols + rx] = d;
   }
   const int k = (int)pow(2.0, (double)dilate_factor) + 1; /* patchmatch_gpu.cu:436 */
   pmo_dilate_rect(sparse, seed, rows, cols, k);
@@ -245,14 +409,15 @@ void pmo_cpu_initialize(const uint8_t* left, const uint8_t* right, int rows, int
                         const pmo_seed_params* p, float* out) {
   const size_t n = (size_t)rows * cols;
   const int f = downsample_factor;
-  int* xs = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
-  int* ys = (int*)malloc(sizeof(int) * (size_t)(p->max_features > 0 ? p->max_features : 1));
-  const int cnt = pmo_gftt_detect(left, rows, cols, p, xs, ys, p->max_features);
+  float* xs = (float*)malloc(sizeof(float) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  float* ys = (float*)malloc(sizeof(float) * (size_t)(p->max_features > 0 ? p->max_features : 1));
+  const int cnt = detect_corners(left, rows, cols, p, xs, ys);
   float* sparse = (float*)calloc(n, sizeof(float));
   float* dil = (float*)malloc(sizeof(float) * n);
   for (int i = 0; i < cnt; ++i) {
-    const float d = (float)pmo_match_rectified(left, right, rows, cols, (float)xs[i], (float)ys[i], p);
-    if (d >= 0) sparse[(size_t)ys[i] * cols + xs[i]] = d;
+    const float d = (float)pmo_match_rectified(left, right, rows, cols, xs[i], ys[i], p);
+    const int ry = (int)roundf(ys[i]), rx = (int)roundf(xs[i]); /* patchmatch.cpp:68-71 */
+    if (d >= 0 && ry >= 0 && ry < rows && rx >= 0 && rx < cols) sparse[(size_t)ry * cols + rx] = d;
   }
   const int k = (int)pow(2.0, (double)(f - 1)) + 1;
   pmo_dilate_rect(sparse, dil, rows, cols, k);

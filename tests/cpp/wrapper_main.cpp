@@ -46,19 +46,23 @@ int main(int argc, char** argv) {
   params.patchmatch_iters = atoi(argv[6]);
   params.max_rows = rows;  // plan in the constructor (the reference allocates lazily in the first Match)
   params.max_cols = cols;
-  // An option of the nested seeder parameters that this engine does not build (cv::cornerSubPix,
-  // feature_detector.cpp:110-120 / stereo_matcher.cpp:94-103) must be REFUSED, not ignored: the constructor throws.
-  // The parameter check comes before the device check, so this holds on a box without a GPU too.
+  // Seeder parameters outside their ranges are REFUSED, not replaced: the constructor throws what pm_create said.  The
+  // parameter check comes before the device check, so this holds on a box without a GPU too.
   if (argc > 7 && std::string(argv[7]) == "refused") {
     int refused = 0;
     for (int which = 0; which < 2; ++which) {
       PatchmatchGpu::Params bad = params;
-      if (which == 0) bad.detector_params.subpixel_corners = true;
-      else bad.matcher_params.subpixel_refinement = true;
+      if (which == 0) {
+        bad.detector_params.subpixel_corners = true;
+        bad.detector_params.subpix_winsize = 0;
+      } else {
+        bad.detector_params.gftt_k = -1.0;
+      }
       try {
         PatchmatchGpu pm(bad);
       } catch (const std::runtime_error& e) {
-        if (std::string(e.what()).find("cornerSubPix") != std::string::npos) ++refused;
+        const std::string w = e.what();
+        if (w.find(which == 0 ? "cornerSubPix" : "gftt") != std::string::npos) ++refused;
       }
     }
     std::cout << "refused " << refused << "\n";
@@ -149,6 +153,15 @@ int main(int argc, char** argv) {
       ph.detector_params.gftt_k = 0.06;
       PatchmatchGpu harris(ph);
       write_raw(dir + "/sparse_init_harris.f32", harris.SparseInit(il, ir, 4));
+    }
+    // cv::cornerSubPix on the corners and on the matches (feature_detector.hpp:39-44, stereo_matcher.hpp:26)
+    {
+      PatchmatchGpu::Params ps = params;
+      ps.detector_params.subpixel_corners = true;
+      ps.detector_params.subpix_winsize = 6;
+      ps.matcher_params.subpixel_refinement = true;
+      PatchmatchGpu subpix(ps);
+      write_raw(dir + "/sparse_init_subpix.f32", subpix.SparseInit(il, ir, 4));
     }
     // a batch in one call: three pairs (the pair, the pair with left and right swapped, the pair again), every map
     // equal to what Match() returns for that pair alone

@@ -24,7 +24,9 @@ class Functor(C.Structure):
 class SeedParams(C.Structure):
     _fields_ = [("max_features", C.c_int), ("min_distance", C.c_int), ("quality_level", C.c_double),
                 ("block_size", C.c_int), ("templ_cols", C.c_int), ("templ_rows", C.c_int), ("max_disp", C.c_int),
-                ("max_matching_cost", C.c_double), ("use_harris", C.c_int), ("harris_k", C.c_double)]
+                ("max_matching_cost", C.c_double), ("use_harris", C.c_int), ("harris_k", C.c_double),
+                ("subpixel_corners", C.c_int), ("subpix_winsize", C.c_int), ("subpix_zerozone", C.c_int),
+                ("subpix_maxiters", C.c_int), ("subpix_epsilon", C.c_float), ("subpixel_refinement", C.c_int)]
 
 
 class Params(C.Structure):
@@ -334,6 +336,18 @@ def corner_response_map(img, block_size=5, use_harris=0, harris_k=0.04):
     lib.pmo_corner_response_map.restype = None
     lib.pmo_corner_response_map(_p(img), img.shape[0], img.shape[1], block_size, use_harris, harris_k, _p(out))
     return out
+
+
+def corner_subpix(img, xs, ys, win=10, zero_zone=-1, max_iters=10, eps=0.01):
+    img = c_u8(img)
+    xs = np.ascontiguousarray(xs, dtype=np.float32).copy()
+    ys = np.ascontiguousarray(ys, dtype=np.float32).copy()
+    lib = load()
+    lib.pmo_corner_subpix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_double]
+    lib.pmo_corner_subpix.restype = None
+    lib.pmo_corner_subpix(_p(img), img.shape[0], img.shape[1], _p(xs), _p(ys), len(xs), win, zero_zone, max_iters, eps)
+    return xs, ys
 
 
 def gftt_detect(img, sp=None):

@@ -66,15 +66,18 @@ def test_create_rejects_bad_arguments_without_touching_a_device(pm):
     lib.pm_destroy(h)
 
 
-def test_create_refuses_seeder_options_that_are_not_built(pm):
-    """feature_detector.hpp:34-44 / stereo_matcher.hpp:25-26: the Harris response is honoured (parameters checked),
-    cv::cornerSubPix on corners or matches is not built and must be refused, never silently dropped."""
+def test_create_checks_the_seeder_options(pm):
+    """feature_detector.hpp:34-44 / stereo_matcher.hpp:25-26: the Harris response and cv::cornerSubPix on corners and
+    matches are honoured; values outside their ranges are refused by pm_create (before it looks for a device), never
+    silently replaced."""
     lib = pm.load()
     h = C.c_void_p()
-    for field in ("subpixel_corners", "subpixel_refinement"):
-        p = pm.default_params(pm.PM_SEM_GPU, **{field: 1})
+    bad = (dict(subpixel_corners=2), dict(subpixel_refinement=-1), dict(subpixel_corners=1, subpix_winsize=0),
+           dict(subpixel_corners=1, subpix_winsize=16), dict(subpix_maxiters=0), dict(subpix_epsilon=-1.0))
+    for kw in bad:
+        p = pm.default_params(pm.PM_SEM_GPU, **kw)
         rc = lib.pm_create(C.byref(p), 0, 64, 64, 1, C.byref(h))
-        assert rc == pm.PM_ERR_INVALID_ARG and b"cornerSubPix" in lib.pm_last_error(h), field
+        assert rc == pm.PM_ERR_INVALID_ARG and b"cornerSubPix" in lib.pm_last_error(h), kw
         lib.pm_destroy(h)
     for kw in (dict(gftt_use_harris=2), dict(gftt_use_harris=1, gftt_k=-0.1), dict(gftt_k=float("nan"))):
         p = pm.default_params(pm.PM_SEM_GPU, **kw)
@@ -83,6 +86,7 @@ def test_create_refuses_seeder_options_that_are_not_built(pm):
         lib.pm_destroy(h)
     d = pm.default_params(pm.PM_SEM_GPU)
     assert d.gftt_use_harris == 0 and abs(d.gftt_k - 0.04) < 1e-12 and d.subpixel_corners == 0
+    assert (d.subpix_winsize, d.subpix_zerozone, d.subpix_maxiters) == (10, -1, 10) and abs(d.subpix_epsilon - 0.01) < 1e-9
 
 
 def test_the_shipped_library_carries_no_tuning_knob():

@@ -58,6 +58,53 @@ def test_harris_response_known_answers(oracle, synth):
     assert len(xs) > 0 and (len(xs) != len(xe) or not (np.array_equal(xs, xe) and np.array_equal(ys, ye)))
 
 
+def _corner_image(cx, cy, rows=64, cols=64, ss=8):
+    """An ideal dark / bright corner at the sub-pixel position (cx, cy), rendered by ss x ss supersampling."""
+    yy, xx = np.mgrid[0:rows * ss, 0:cols * ss]
+    big = (((xx + 0.5) / ss - 0.5 >= cx) & ((yy + 0.5) / ss - 0.5 >= cy)).astype(np.float64) * 180 + 40
+    return np.rint(big.reshape(rows, ss, cols, ss).mean(axis=(1, 3))).astype(np.uint8)
+
+
+def test_corner_subpix_known_answers(oracle):
+    """cv::cornerSubPix as restated in oracle/pm_seed_oracle.c (feature_detector.cpp:110-120, stereo_matcher.cpp:94-103)."""
+    # an ideal corner is found to a fraction of a pixel from its rounded position
+    for cx, cy in ((30.3, 31.7), (25.0, 33.5), (32.25, 28.75)):
+        xs, ys = oracle.corner_subpix(_corner_image(cx, cy), [round(cx)], [round(cy)], 5, -1, 20, 0.001)
+        assert abs(xs[0] - cx) < 0.25 and abs(ys[0] - cy) < 0.25, (cx, cy, xs, ys)
+    # no gradient: the normal equations are singular, the point stays where it was
+    xs, ys = oracle.corner_subpix(np.full((40, 40), 99, np.uint8), [17.0], [21.0], 5)
+    assert (xs[0], ys[0]) == (17.0, 21.0)
+    # a result further from the start than the window is rejected (poor convergence): a straight edge far from a corner
+    im = np.zeros((60, 60), np.uint8)
+    im[:, 33:] = 200
+    xs, ys = oracle.corner_subpix(im, [30.0], [30.0], 4, -1, 50, 0.0)
+    assert abs(xs[0] - 30.0) <= 4 and abs(ys[0] - 30.0) <= 4
+    # window reaching over the image border: the replicated-border sampler, no crash, finite result
+    xs, ys = oracle.corner_subpix(_corner_image(3.4, 2.6), [3.0], [3.0], 5, -1, 10, 0.01)
+    assert np.isfinite(xs[0]) and np.isfinite(ys[0])
+    # several points at once are refined independently
+    im = _corner_image(30.3, 31.7)
+    a = oracle.corner_subpix(im, [30.0, 12.0], [32.0, 50.0], 5)
+    b = oracle.corner_subpix(im, [30.0], [32.0], 5)
+    assert a[0][0] == b[0][0] and a[1][0] == b[1][0]
+    # the dead zone changes the weights, hence the result
+    c = oracle.corner_subpix(im, [30.0], [32.0], 5, 1)
+    assert (c[0][0], c[1][0]) != (b[0][0], b[1][0])
+
+
+def test_sparse_init_with_subpixel_options(oracle, synth):
+    """With subpixel_refinement the seed disparities become fractional; with subpixel_corners the corners move by less
+    than a pixel, so the seeds stay where they were up to the rounding of the corner."""
+    p = synth.make_pair(7, rows=96, cols=200)
+    base = oracle.sparse_init(p["left"], p["right"], 2)
+    ref = oracle.sparse_init(p["left"], p["right"], 2, oracle.seed_params(subpixel_refinement=1))
+    assert (base > 0).any() and np.all(base == np.rint(base))
+    assert (ref > 0).any() and not np.all(ref == np.rint(ref))
+    cor = oracle.sparse_init(p["left"], p["right"], 2, oracle.seed_params(subpixel_corners=1, subpix_winsize=5))
+    assert (cor > 0).any() and not np.array_equal(cor, base)
+    assert abs(float((cor > 0).mean()) - float((base > 0).mean())) < 0.2
+
+
 def test_gftt_rules(oracle, synth):
     p = synth.make_pair(3, rows=200, cols=320)
     sp = oracle.seed_params()
@@ -260,6 +307,67 @@ def test_harris_response_on_the_device(pm, oracle, synth, block, k):
     with pm.Engine(pm.default_params(1, gftt_block_size=block), max_rows=rows, max_cols=cols) as e:
         plain = e.sparse_init(p["left"], p["right"], 4)
     assert not np.array_equal(got, plain)  # ... and it is a different seed map than the eigenvalue detector's
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,zero,iters,eps", [(10, -1, 10, 0.01), (5, 1, 30, 0.0), (15, -1, 3, 0.1), (2, 0, 100, 1e-4)])
+def test_corner_subpix_stage_equals_the_oracle(pm, oracle, synth, win, zero, iters, eps):
+    """pm_corner_subpix: points all over a textured image, incl. points whose window reaches over the border."""
+    rows, cols = 120, 171
+    p = synth.make_pair(9, rows=rows, cols=cols)
+    rng = np.random.default_rng(win)
+    xs = np.concatenate([rng.uniform(0, cols - 1, 150), [0.0, 1.5, cols - 1.0, cols - 2.5, 40.0, 41.0]]).astype(np.float32)
+    ys = np.concatenate([rng.uniform(0, rows - 1, 150), [0.0, rows - 1.0, 2.5, rows - 3.0, 60.0, 60.0]]).astype(np.float32)
+    prm = pm.default_params(1, subpix_winsize=win, subpix_zerozone=zero, subpix_maxiters=iters, subpix_epsilon=eps)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        gx, gy = e.corner_subpix(p["left"], xs, ys)
+    ox, oy = oracle.corner_subpix(p["left"], xs, ys, win, zero, iters, eps)
+    bad = np.flatnonzero((gx != ox) | (gy != oy))
+    assert bad.size == 0, f"{bad.size} of {len(xs)} points differ; first: start ({xs[bad[0]]}, {ys[bad[0]]}) device " \
+                          f"({gx[bad[0]]!r}, {gy[bad[0]]!r}) oracle ({ox[bad[0]]!r}, {oy[bad[0]]!r})"
+    assert np.any(gx != xs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(subpixel_corners=1), dict(subpixel_refinement=1),
+                                dict(subpixel_corners=1, subpixel_refinement=1, subpix_winsize=5, subpix_zerozone=1,
+                                     subpix_maxiters=25, subpix_epsilon=0.001),
+                                dict(subpixel_corners=1, subpix_winsize=15, gftt_use_harris=1)])
+def test_corner_subpix_on_the_device(pm, oracle, synth, kw):
+    """subpixel_corners / subpixel_refinement (feature_detector.cpp:110-120, stereo_matcher.cpp:94-103): the device
+    seeder refines corners and matches with cv::cornerSubPix exactly as the oracle does -- one lane per point, the normal
+    equations accumulated in double in raster order -- incl. windows that reach over the image border (corners near it)."""
+    rows, cols = 133, 259
+    p = synth.make_pair(3, rows=rows, cols=cols)
+    prm = pm.default_params(1, min_distance_btw_features=9, **kw)
+    okw = {("use_harris" if k == "gftt_use_harris" else k): v for k, v in kw.items()}
+    sp = oracle.seed_params(min_distance=9, **okw)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        got = e.sparse_init(p["left"], p["right"], 3)
+        got_r = e.sparse_init(p["right"][:, ::-1].copy(), p["left"][:, ::-1].copy(), 3)
+    assert_same(got, oracle.sparse_init(p["left"], p["right"], 3, sp), f"SparseInit {kw}")
+    assert_same(got_r, oracle.sparse_init(p["right"][:, ::-1].copy(), p["left"][:, ::-1].copy(), 3, sp), f"mirrored {kw}")
+    assert (got > 0).any()
+    if kw.get("subpixel_refinement"):
+        assert not np.all(got == np.rint(got))  # fractional seed disparities
+
+
+@pytest.mark.gpu
+def test_self_seeded_match_with_subpixel_seeds(pm, oracle, synth):
+    rows, cols = 96, 160
+    p = synth.make_pair(12, rows=rows, cols=cols)
+    prm = pm.default_params(0, patch=5, patchmatch_iters=2, sparse_init=1, subpixel_corners=1, subpixel_refinement=1)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=2) as e:
+        dl, dr = e.match(p["left"], p["right"])
+        bl, br = e.match_batch([p["left"], p["left"]], [p["right"], p["right"]])
+    sp = oracle.seed_params(subpixel_corners=1, subpixel_refinement=1)
+    sl = oracle.sparse_init(p["left"], p["right"], 4, sp)
+    sr = oracle.sparse_init(p["right"][:, ::-1], p["left"][:, ::-1], 4, sp)[:, ::-1]
+    el, er = oracle.match(oracle.default_params(0, patch=5, n_iters=2, nthreads=8), p["left"], p["right"], sl, sr)
+    assert_same(dl, el, "left")
+    assert_same(dr, er, "right")
+    assert_same(bl[1], el, "batch, left")
+    assert_same(br[1], er, "batch, right")
 
 
 @pytest.mark.gpu

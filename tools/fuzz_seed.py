@@ -53,10 +53,23 @@ for case in range(a.cases):
     tr = int(rng.choice([5, 11]))
     md = int(rng.choice([64, 100, 128]))
     f = int(rng.integers(1, 5))
+    # the detector / matcher options of round 4: Harris response, cv::cornerSubPix on corners and on matches
+    harris = int(rng.random() < 0.3)
+    hk = float(rng.choice([0.0, 0.04, 0.15]))
+    spc = int(rng.random() < 0.35)
+    spr = int(rng.random() < 0.25)
+    swin, szero = int(rng.choice([2, 5, 10, 15])), int(rng.choice([-1, -1, 0, 1]))
+    sit, seps = int(rng.choice([1, 5, 10, 40])), float(rng.choice([0.0, 0.001, 0.01, 0.1]))
+    if spc and maxf > 200:   # one lane per corner, strictly sequential: keep the fuzz cases short
+        maxf = 200
     prm = pm.default_params(1, max_features_per_frame=maxf, min_distance_btw_features=mind, gftt_quality_level=q,
-                            gftt_block_size=blk, templ_cols=tc, templ_rows=tr, max_disp=md)
+                            gftt_block_size=blk, templ_cols=tc, templ_rows=tr, max_disp=md, gftt_use_harris=harris,
+                            gftt_k=hk, subpixel_corners=spc, subpix_winsize=swin, subpix_zerozone=szero,
+                            subpix_maxiters=sit, subpix_epsilon=seps, subpixel_refinement=spr)
     sp = oracle.seed_params(max_features=maxf, min_distance=mind, quality_level=q, block_size=blk, templ_cols=tc,
-                            templ_rows=tr, max_disp=md)
+                            templ_rows=tr, max_disp=md, use_harris=harris, harris_k=hk, subpixel_corners=spc,
+                            subpix_winsize=swin, subpix_zerozone=szero, subpix_maxiters=sit, subpix_epsilon=seps,
+                            subpixel_refinement=spr)
     if a.only >= 0 and case != a.only:
         continue
     want = oracle.sparse_init(left, right, f, sp)
@@ -64,7 +77,7 @@ for case in range(a.cases):
         got = e.sparse_init(left, right, f)
     ok = np.array_equal(got, want)
     print(f"case {case:3d}: {cols}x{rows} kind {kind} maxf {maxf} mind {mind} q {q} block {blk} templ {tc}x{tr} "
-          f"max_disp {md} f {f} seeds {(want > 0).mean():.3f} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]",
+          f"max_disp {md} f {f} harris {harris} subpix {spc}{spr} win {swin} seeds {(want > 0).mean():.3f} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]",
           flush=True)
     if not ok:
         if a.dump:
