@@ -255,7 +255,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
       const float cap = __builtin_bit_cast(float, 0x4b00ffffu);  // 2^23 + 65535
       const unsigned cw = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, fminf(m_a, cap)),
                                                 __builtin_bit_cast(unsigned, fminf(m_ia, cap)), 0x05040100u);
-      const f32x2 ia2 = {ia_r, ia_r}, a2 = {a_r, a_r};
+      const f32x2 w2 = {ia_r, a_r};
       if constexpr (AXIS == 0) {
         // lane = image column X (its own position's column -+ half), window rows in the lane, three per load
         constexpr int NT = (TP + 2) / 3, NQR = (TP + 3) / 4;
@@ -282,11 +282,9 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         gv[3 * NT] = 0.f;
         float sgr[4 * NQR + 4];  // gradient lerp sums g0 * (1 - a) + g1 * a, g1 = the next line's g0
 #pragma unroll
-        for (int t = 0; t < TP; t += 2) {
-          const f32x2 gg = {gv[t], gv[t + 1]};
-          const f32x2 pa = gg * ia2, pb = gg * a2;
-          sgr[t] = pa.x + next_line_f<DIR>(pb.x);
-          if (t + 1 < TP) sgr[t + 1] = pa.y + next_line_f<DIR>(pb.y);
+        for (int t = 0; t < TP; ++t) {  // one packed multiply per sample: the sample splat against (1 - a, a)
+          const f32x2 p = f32x2{gv[t], gv[t]} * w2;
+          sgr[t] = p.x + next_line_f<DIR>(p.y);
         }
         unsigned rq_c[NQR], rq_g[NQR];  // reference bytes of four window rows per dword
         if constexpr (LREF) {  // staged by the kernel: [image column][kLref4Stride] dwords
@@ -391,14 +389,11 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
             tcol[t] = 0u;
           }
         }
-        constexpr int NP2 = (TP + 2) / 2;  // samples 0 .. TP in pairs
-        f32x2 pa[NP2], pb[NP2];
+        // samples 0 .. TP, one packed multiply each: the sample splat against (1 - a, a) takes its register wherever the
+        // load left it (pairs of samples would have to be moved into aligned register pairs first)
+        f32x2 pw2[TP + 1];
 #pragma unroll
-        for (int m = 0; m < NP2; ++m) {
-          const f32x2 gg = {gv[2 * m], gv[2 * m + 1]};
-          pa[m] = gg * ia2;
-          pb[m] = gg * a2;
-        }
+        for (int t = 0; t <= TP; ++t) pw2[t] = f32x2{gv[t], gv[t]} * w2;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {  // four window columns per v_sad_u8
           const int t0q = 4 * q;
@@ -413,7 +408,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int t = t0q + j;
-            if (t < TP) g4 = __builtin_amdgcn_cvt_pk_u8_f32(pa[t / 2][t % 2] + pb[(t + 1) / 2][(t + 1) % 2], j, g4);
+            if (t < TP) g4 = __builtin_amdgcn_cvt_pk_u8_f32(pw2[t].x + pw2[t + 1].y, j, g4);
           }
           sc = __builtin_amdgcn_sad_u8(rc4[q], s4, sc);
           sg = __builtin_amdgcn_sad_u8(rg4[q], g4, sg);
