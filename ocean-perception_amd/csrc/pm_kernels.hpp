@@ -410,11 +410,12 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
                                                           int keep_zero) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
+  constexpr int LWP = (LW + 3) & ~3;  // row stride of the reference tiles: a lane's byte shift is the same in every row
   // byte tiles as dword arrays: window bytes are fetched as ALIGNED dwords and shifted into place
   // (v_alignbyte_b32).  Unaligned ds_read_b96/b128 made this kernel LDS-bound: SQ_LDS_UNALIGNED_STALL was
   // 70 % of SQ_LDS_IDX_ACTIVE, which itself equalled the kernel's duration (profiles/r01f_pmc_lds.txt).
-  __shared__ unsigned s_l8w[(TR * LW + 3) / 4 + 4];
-  __shared__ unsigned s_lgw[(TR * LW + 3) / 4 + 4];
+  __shared__ unsigned s_l8w[TR * LWP / 4 + 4];
+  __shared__ unsigned s_lgw[TR * LWP / 4 + 4];
   __shared__ unsigned s_r8w[TR * kTileRW / 4 + 4];
   __shared__ float s_rg[TR * kTileRW];
   uint8_t* const s_l8 = (uint8_t*)s_l8w;
@@ -495,8 +496,8 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
       const float* grow = v.tgtg + (size_t)gy * pitch;
       for (int cc = fl; cc < LW; cc += 64) {
         const unsigned pk = prow[min(max(lx0 + cc, 0), cols - 1)];
-        s_l8[rr * LW + cc] = (uint8_t)(pk & 0xffu);
-        s_lg[rr * LW + cc] = (uint8_t)(pk >> 8);
+        s_l8[rr * LWP + cc] = (uint8_t)(pk & 0xffu);
+        s_lg[rr * LWP + cc] = (uint8_t)(pk >> 8);
       }
       for (int cc = fl; cc < rw; cc += 64) {
         const int gx = min(max(lo + cc, 0), cols - 1);
@@ -512,29 +513,48 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
       unsigned sc = 0, sg = 0;
       const int rc = l.ipx - lo;
       constexpr int NG = (PW + 3) / 4;  // groups of four taps; the last one may be partial
-#pragma unroll 1
-      for (int i = 0; i < PH; ++i) {
-        const float* rg = s_rg + (ty + i) * kTileRW + rc;
-        // 4 * NG reference bytes from flat byte offset fl, 4 * NR target bytes from fr
-        constexpr int NR = (PW + 4) / 4;  // dwords covering r[0 .. PW]
-        const int fl = (ty + i) * LW + tx, fr = (ty + i) * kTileRW + rc;
+      constexpr int NR = (PW + 4) / 4;  // dwords covering r[0 .. PW]
+      // 4 * NG reference bytes from flat byte offset fl0 (+ a row), 4 * NR target bytes from fr0 (+ a row): the row strides
+      // are multiples of four bytes, so dword index and byte shift of row i are those of row 0 plus a constant
+      const int fl0 = ty * LWP + tx, fr0 = ty * kTileRW + rc;
+      // LDS pointers the compiler cannot see through (an absolute LDS address does not fit a ds_read2 offset field: every
+      // pair of dwords would get its own address add); re-based where the row offset outgrows the 8-bit dword offset
+      typedef __attribute__((address_space(3))) const unsigned* LdsU32;
+      typedef __attribute__((address_space(3))) const float* LdsF32;
+      LdsU32 pl = (LdsU32)(s_l8w + (fl0 >> 2));
+      LdsU32 pg = (LdsU32)(s_lgw + (fl0 >> 2));
+      LdsU32 pr = (LdsU32)(s_r8w + (fr0 >> 2));
+      LdsF32 rg = (LdsF32)(s_rg + fr0);
+      asm volatile("" : "+v"(pl), "+v"(pg), "+v"(pr), "+v"(rg));
+      const unsigned shl = (unsigned)fl0 & 3u, shr = (unsigned)fr0 & 3u;
+      static_assert(LWP % 4 == 0 && kTileRW % 4 == 0, "row strides in whole dwords");
+      static_assert((PH - 1) * (LWP / 4) + NG < 256, "reference rows within one ds_read2 offset range");
+      constexpr int kRowsPerBase = 4;  // target byte rows per base: 4 * kTileRW / 4 + NR dwords < 256
+      static_assert((kRowsPerBase - 1) * (kTileRW / 4) + NR < 256, "target rows within one ds_read2 offset range");
+#pragma unroll
+      for (int i = 0; i < PH; ++i) {  // unrolled: every LDS address is a base register plus a constant
+        if (i > 0) {
+          rg += kTileRW;
+          asm volatile("" : "+v"(rg));
+          if (i % kRowsPerBase == 0) {
+            pr += kRowsPerBase * (kTileRW / 4);
+            asm volatile("" : "+v"(pr));
+          }
+        }
         unsigned lw[NG], lgw[NG], rw[NR];
         {
-          const unsigned* pl = s_l8w + (fl >> 2);
-          const unsigned* pg = s_lgw + (fl >> 2);
-          const unsigned* pr = s_r8w + (fr >> 2);
-          const unsigned shl = (unsigned)fl & 3u, shr = (unsigned)fr & 3u;
-          unsigned a0 = pl[0], b0 = pg[0], c0 = pr[0];
+          const LdsU32 pl_i = pl + i * (LWP / 4), pg_i = pg + i * (LWP / 4), pr_i = pr + (i % kRowsPerBase) * (kTileRW / 4);
+          unsigned a0 = pl_i[0], b0 = pg_i[0], c0 = pr_i[0];
 #pragma unroll
           for (int q = 0; q < NR; ++q) {
             if (q < NG) {
-              const unsigned a1 = pl[q + 1], b1 = pg[q + 1];
+              const unsigned a1 = pl_i[q + 1], b1 = pg_i[q + 1];
               lw[q] = __builtin_amdgcn_alignbyte(a1, a0, shl);
               lgw[q] = __builtin_amdgcn_alignbyte(b1, b0, shl);
               a0 = a1;
               b0 = b1;
             }
-            const unsigned c1 = pr[q + 1];
+            const unsigned c1 = pr_i[q + 1];
             rw[q] = __builtin_amdgcn_alignbyte(c1, c0, shr);
             c0 = c1;
           }
@@ -560,8 +580,11 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
         }
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
+          // bytes of the last group that lie beyond the window take the REFERENCE's byte on both sides of the SAD (their
+          // difference is 0): no masks
+          const int rem = PW - 4 * q;  // taps in this group
           unsigned t[4] = {0, 0, 0, 0};
-          unsigned pg = 0;
+          unsigned pg = lgw[q];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int j = 4 * q + k;
@@ -572,11 +595,18 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
             }
           }
           // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00
-          const unsigned pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | __builtin_amdgcn_perm(t[3], t[2], 0x06020c0cu);
-          const int rem = PW - 4 * q;  // taps in this group
-          const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
-          sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc & mask, sc);
-          sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg & mask, sg);
+          unsigned pc;
+          if (rem >= 4) {
+            pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | __builtin_amdgcn_perm(t[3], t[2], 0x06020c0cu);
+          } else if (rem == 3) {
+            pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | __builtin_amdgcn_perm(lw[q], t[2], 0x07020c0cu);
+          } else if (rem == 2) {
+            pc = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u) | (lw[q] & 0xffff0000u);
+          } else {
+            pc = __builtin_amdgcn_perm(lw[q], t[0], 0x07060502u);
+          }
+          sc = __builtin_amdgcn_sad_u8(lw[q], pc, sc);
+          sg = __builtin_amdgcn_sad_u8(lgw[q], pg, sg);
         }
       }
       c = cpu_cost_from_sums((int)sc, (int)sg, cp);
