@@ -410,19 +410,31 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
                                                           int keep_zero) {
   constexpr int PW = TPW, PH = TPH;
   constexpr int LW = kTileW + PW - 1, TR = kTileH + PH - 1;
-  constexpr int LWP = (LW + 3) & ~3;  // row stride of the reference tiles: a lane's byte shift is the same in every row
+  // The reference tile starts at an EVEN image column (x0 - PW / 2 - OFF): its rows are whole pixel pairs of the packed
+  // plane (one dword load = two pixels); the row stride is a multiple of four bytes, so a lane's byte shift is the
+  // same in every row.
+  constexpr int OFF = (PW / 2) & 1;
+  constexpr int NPAIR = (OFF + LW + 1) / 2;
+  constexpr int LWP = (2 * NPAIR + 3) & ~3;
+  constexpr int NREF = TR * NPAIR, NREFK = (NREF + 255) / 256;  // pixel pairs of the reference tile, per thread
+  constexpr int LPR = 256 / TR;                                 // threads per row of the target tile
+  constexpr int KMAX = (kTileRW / 4 + LPR - 1) / LPR;           // four-column groups per thread
   // byte tiles as dword arrays: window bytes are fetched as ALIGNED dwords and shifted into place
   // (v_alignbyte_b32).  Unaligned ds_read_b96/b128 made this kernel LDS-bound: SQ_LDS_UNALIGNED_STALL was
   // 70 % of SQ_LDS_IDX_ACTIVE, which itself equalled the kernel's duration (profiles/r01f_pmc_lds.txt).
   __shared__ unsigned s_l8w[TR * LWP / 4 + 4];
   __shared__ unsigned s_lgw[TR * LWP / 4 + 4];
   __shared__ unsigned s_r8w[TR * kTileRW / 4 + 4];
-  __shared__ float s_rg[TR * kTileRW];
+  __shared__ __attribute__((aligned(16))) float s_rg[TR * kTileRW];
   uint8_t* const s_l8 = (uint8_t*)s_l8w;
   uint8_t* const s_lg = (uint8_t*)s_lgw;
   uint8_t* const s_r8 = (uint8_t*)s_r8w;
   __shared__ int s_red[8];
 
+#ifdef PM_TUNING
+  const int dbg = keep_zero >> 8;  // timing experiments of the tuning build (bit 0: no window rows, bit 1: no fill)
+  keep_zero &= 0xff;
+#endif
   const int tid = threadIdx.x, tx = tid & (kTileW - 1), ty = tid / kTileW;
   const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
   const int x = x0 + tx, y = y0 + ty, slot = blockIdx.z;
@@ -460,6 +472,24 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     l = cpu_lerp(x, d, PW);
   }
 
+  // ---- reference tile: the loads go out now (they do not depend on the disparities) and land in LDS after the
+  // column range is known.  Fast form: whole pixel pairs, when the tile's columns lie inside the image ---------------
+  const int ry0 = y0 - PH / 2, ls = x0 - PW / 2 - OFF;
+  const bool ref_fast = ls >= 0 && ls + 2 * NPAIR <= cols && (reinterpret_cast<uintptr_t>(v.refpk) & 3u) == 0;  // uniform
+  unsigned refv[NREFK];
+  if (ref_fast) {
+#pragma unroll
+    for (int kk = 0; kk < NREFK; ++kk) {
+      const int e = tid + 256 * kk;
+      refv[kk] = 0u;
+      if (e < NREF) {
+        const int rr = e / NPAIR, pp = e - rr * NPAIR;
+        const int gy = min(max(ry0 + rr, 0), rows - 1);
+        refv[kk] = *reinterpret_cast<const unsigned*>(v.refpk + (size_t)gy * pitch + (ls + 2 * pp));
+      }
+    }
+  }
+
   // ---- column range of the target tile: min / max of ipx over the block's interior lanes --------------
   int lo = interior ? l.ipx : 0x7fffffff, hi_ = interior ? l.ipx : -0x7fffffff;
 #pragma unroll
@@ -478,45 +508,99 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     if (inimg) v.disp[o] = d;
     return;
   }
-  const int rw = hi_ + PW + 1 - lo;  // columns needed: [lo, hi_ + PW]
+  // columns needed: [lo, hi_ + PW]; the tile starts at the multiple of four below lo (16-byte loads of the gradients)
+  const int lo4 = lo & ~3;
+  const int rw = hi_ + PW + 1 - lo4;
   const bool tiled = rw <= kTileRW;  // uniform
 
   float c = 0.f;
   if (tiled) {
     // ---- fill: rows y0-PH/2 .. y0+kTileH-1+PH/2, clamped (clamped rows/columns are only ever read by
     // pixels that are not interior, or carry weight 0) -----------------------------------------------
-    const int ry0 = y0 - PH / 2, lx0 = x0 - PW / 2;
-    // wavefront w fills tile rows w, w + 4, ...; its lanes walk along the row: no division per element, coalesced
-    // reads (the packed reference plane gives colour and gradient byte with one u16 load)
-    const int fw = tid >> 6, fl = tid & 63;
-    for (int rr = fw; rr < TR; rr += 4) {
-      const int gy = min(max(ry0 + rr, 0), rows - 1);
-      const uint16_t* prow = v.refpk + (size_t)gy * pitch;
-      const uint8_t* trow = v.tgt8 + (size_t)gy * pitch;
-      const float* grow = v.tgtg + (size_t)gy * pitch;
-      for (int cc = fl; cc < LW; cc += 64) {
-        const unsigned pk = prow[min(max(lx0 + cc, 0), cols - 1)];
-        s_l8[rr * LWP + cc] = (uint8_t)(pk & 0xffu);
-        s_lg[rr * LWP + cc] = (uint8_t)(pk >> 8);
+#ifdef PM_TUNING
+    if (!(dbg & 2)) {
+#else
+    {
+#endif
+      if (ref_fast) {
+#pragma unroll
+        for (int kk = 0; kk < NREFK; ++kk) {
+          const int e = tid + 256 * kk;
+          if (e < NREF) {
+            const int rr = e / NPAIR, pp = e - rr * NPAIR;
+            // dword = colour, gradient, colour, gradient of two pixels -> two colour bytes, two gradient bytes
+            *reinterpret_cast<uint16_t*>(s_l8 + rr * LWP + 2 * pp) = (uint16_t)__builtin_amdgcn_perm(0u, refv[kk], 0x0c0c0200u);
+            *reinterpret_cast<uint16_t*>(s_lg + rr * LWP + 2 * pp) = (uint16_t)__builtin_amdgcn_perm(0u, refv[kk], 0x0c0c0301u);
+          }
+        }
+      } else {  // a tile at the image border: element by element, clamped columns
+        const int fw = tid >> 6, fl = tid & 63, lx0 = x0 - PW / 2;
+        for (int rr = fw; rr < TR; rr += 4) {
+          const int gy = min(max(ry0 + rr, 0), rows - 1);
+          const uint16_t* prow = v.refpk + (size_t)gy * pitch;
+          for (int cc = fl; cc < LW; cc += 64) {
+            const unsigned pk = prow[min(max(lx0 + cc, 0), cols - 1)];
+            s_l8[rr * LWP + cc + OFF] = (uint8_t)(pk & 0xffu);
+            s_lg[rr * LWP + cc + OFF] = (uint8_t)(pk >> 8);
+          }
+        }
       }
-      for (int cc = fl; cc < rw; cc += 64) {
-        const int gx = min(max(lo + cc, 0), cols - 1);
-        s_r8[rr * kTileRW + cc] = trow[gx];
-        s_rg[rr * kTileRW + cc] = grow[gx];
+      const int n4 = (rw + 3) >> 2;
+      const bool tgt_fast = lo4 >= 0 && lo4 + 4 * n4 <= cols && (reinterpret_cast<uintptr_t>(v.tgt8) & 3u) == 0 &&
+                            (reinterpret_cast<uintptr_t>(v.tgtg) & 15u) == 0;  // uniform
+      if (tgt_fast) {
+        // LPR threads per tile row, four columns each: one 16-byte load of gradients and one dword of colour bytes
+        const int rr = tid / LPR, q0 = tid - rr * LPR;
+        if (rr < TR) {
+          const int gy = min(max(ry0 + rr, 0), rows - 1);
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          const f32x4* g4 = reinterpret_cast<const f32x4*>(v.tgtg + (size_t)gy * pitch + lo4);
+          const unsigned* t4 = reinterpret_cast<const unsigned*>(v.tgt8 + (size_t)gy * pitch + lo4);
+          f32x4* const sg4 = reinterpret_cast<f32x4*>(s_rg + rr * kTileRW);
+          unsigned* const st4 = s_r8w + rr * (kTileRW / 4);
+          f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = gq0, gq2 = gq0, gq3 = gq0;
+          unsigned tq0 = 0u, tq1 = 0u, tq2 = 0u, tq3 = 0u;
+          static_assert(KMAX <= 4, "four-column groups per thread");
+          const int q1 = q0 + LPR, q2 = q0 + 2 * LPR, q3 = q0 + 3 * LPR;
+          if (q0 < n4) { gq0 = g4[q0]; tq0 = t4[q0]; }
+          if (KMAX > 1 && q1 < n4) { gq1 = g4[q1]; tq1 = t4[q1]; }
+          if (KMAX > 2 && q2 < n4) { gq2 = g4[q2]; tq2 = t4[q2]; }
+          if (KMAX > 3 && q3 < n4) { gq3 = g4[q3]; tq3 = t4[q3]; }
+          if (q0 < n4) { sg4[q0] = gq0; st4[q0] = tq0; }
+          if (KMAX > 1 && q1 < n4) { sg4[q1] = gq1; st4[q1] = tq1; }
+          if (KMAX > 2 && q2 < n4) { sg4[q2] = gq2; st4[q2] = tq2; }
+          if (KMAX > 3 && q3 < n4) { sg4[q3] = gq3; st4[q3] = tq3; }
+        }
+      } else {
+        const int fw = tid >> 6, fl = tid & 63;
+        for (int rr = fw; rr < TR; rr += 4) {
+          const int gy = min(max(ry0 + rr, 0), rows - 1);
+          const uint8_t* trow = v.tgt8 + (size_t)gy * pitch;
+          const float* grow = v.tgtg + (size_t)gy * pitch;
+          for (int cc = fl; cc < rw; cc += 64) {
+            const int gx = min(max(lo4 + cc, 0), cols - 1);
+            s_r8[rr * kTileRW + cc] = trow[gx];
+            s_rg[rr * kTileRW + cc] = grow[gx];
+          }
+        }
       }
     }
     __syncthreads();
+#ifdef PM_TUNING
+    if (interior && !(dbg & 1)) {
+#else
     if (interior) {
+#endif
       // Four taps per v_sad_u8: the window row's reference bytes are consecutive in LDS and are used as
       // loaded; the four colour samples (byte 2 of the 16.16 fixed-point value) are gathered with
       // v_perm_b32, the four gradient samples are rounded and packed by v_cvt_pk_u8_f32.
       unsigned sc = 0, sg = 0;
-      const int rc = l.ipx - lo;
+      const int rc = l.ipx - lo4;
       constexpr int NG = (PW + 3) / 4;  // groups of four taps; the last one may be partial
       constexpr int NR = (PW + 4) / 4;  // dwords covering r[0 .. PW]
       // 4 * NG reference bytes from flat byte offset fl0 (+ a row), 4 * NR target bytes from fr0 (+ a row): the row strides
       // are multiples of four bytes, so dword index and byte shift of row i are those of row 0 plus a constant
-      const int fl0 = ty * LWP + tx, fr0 = ty * kTileRW + rc;
+      const int fl0 = ty * LWP + tx + OFF, fr0 = ty * kTileRW + rc;
       // LDS pointers the compiler cannot see through (an absolute LDS address does not fit a ds_read2 offset field: every
       // pair of dwords would get its own address add); re-based where the row offset outgrows the 8-bit dword offset
       typedef __attribute__((address_space(3))) const unsigned* LdsU32;

@@ -4,6 +4,7 @@
 #include "pm_kernels.hpp"
 #include "pm_sweeps.hpp"
 #include "pm_texmask.hpp"
+#include "pm_tune.hpp"
 
 namespace pm {
 namespace eng {
@@ -84,6 +85,13 @@ void launch_noise_cost(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
   const bool tiled = cp.semantics == PM_SEM_CPU && cp.pw == cp.ph && !h->no_tiled;
   const dim3 tgrid((unsigned)((ps.cols + kTileW - 1) / kTileW), (unsigned)((ps.rows + kTileH - 1) / kTileH),
                    (unsigned)slots);
+#ifdef PM_TUNING
+  static const int dbg = [] {
+    const char* e = pm::tune_env("PM_NOISE_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  keep_zero |= dbg << 8;
+#endif
 #define PM_NC_CASE(W)                                                                                                 \
   case W:                                                                                                             \
     hipLaunchKernelGGL((k_noise_cost_tiled<W, W>), tgrid, dim3(256), 0, h->stream, ps, cp, in, amount, keep_zero);    \
