@@ -513,6 +513,13 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
   View v = make_view(ps, blockIdx.z);
+#ifdef PM_TUNING
+  const int dbg = seg_len >> 24;  // timing experiments (PM_RUN3_DBG): bit 0 no steps, bit 1 no reference staging
+  seg_len &= 0xffffff;
+  if (dbg & 2) {
+    v.lds_ref4 = (unsigned*)(lds + 4 * n1 + 2 * nseg + 3);
+  } else
+#endif
   if constexpr (LREF && AXIS == 0) {
     // row sweeps: the reference quads of the chain's window rows (quads_block lines y0, y0 + 4, y0 + 8), per image column
     // NQ colour dwords and NQ gradient dwords at stride kLref4Stride
@@ -537,8 +544,34 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
     const int len = ps.rows;
     unsigned* sref4 = (unsigned*)(s_changed + 2);
     const uint16_t* src = v.trefpk + (size_t)(chain - TP / 2) * ps.pitch_t;
-    for (int e = threadIdx.x; e < NQ * len; e += blockDim.x) {
-      const int q = e / len, row = e - q * len;
+    // eight rows per task: one 16-byte load per window column of the dword (4 * NQ loads in flight per thread), the
+    // bytes of a row gathered by four v_perm_b32
+    static_assert(NQ <= 3, "task index -> dword by two comparisons");
+    const bool wide = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (ps.pitch_t & 7) == 0;  // uniform
+    const int n8 = wide ? len >> 3 : 0;
+    for (int e = threadIdx.x; e < NQ * n8; e += blockDim.x) {
+      const int q = (e >= n8 ? 1 : 0) + (e >= 2 * n8 ? 1 : 0), r8 = e - q * n8;
+      u32x4 col[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * q + j;  // a column beyond the window stages zeros (the step compares whole dwords)
+        col[j] = u32x4{0u, 0u, 0u, 0u};
+        if (t < TP) col[j] = *reinterpret_cast<const u32x4*>(src + (size_t)t * ps.pitch_t + 8 * r8);
+      }
+      unsigned* dst = sref4 + (8 * r8) * kLref4Stride + q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // halfword i of every column = {colour, gradient} of row 8 * r8 + i
+        const unsigned sel = (i & 1) ? 0x07030602u : 0x05010400u;
+        const unsigned lo = __builtin_amdgcn_perm(col[1][i >> 1], col[0][i >> 1], sel);  // c0 c1 g0 g1
+        const unsigned hi = __builtin_amdgcn_perm(col[3][i >> 1], col[2][i >> 1], sel);  // c2 c3 g2 g3
+        dst[i * kLref4Stride] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        dst[i * kLref4Stride + NQ] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+      }
+    }
+    for (int e = threadIdx.x; e < NQ * (len - 8 * n8); e += blockDim.x) {  // the rows left over (all, if not `wide`)
+      const int nl = len - 8 * n8;
+      const int q = e / nl, row = 8 * n8 + (e - q * nl);
       unsigned cw = 0u, gw = 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -571,10 +604,29 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const ptrdiff_t first =
       AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
 
-  for (int j = threadIdx.x; j <= n; j += blockDim.x) {
-    const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
-    const float d = v.disp[o], c = j > 0 ? v.cost[o] : 0.f;
-    st4[j] = make_float4(d, c, d, c);
+  {
+    // the chain's state into LDS, four positions per thread in flight (a column chain reads every position from another
+    // cache line: the latency of one load, not of four in a row)
+    constexpr int U = 4;
+    const int bd = blockDim.x;
+    for (int j0 = threadIdx.x; j0 <= n; j0 += U * bd) {
+      float dd[U], cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * bd;
+        dd[u] = cc[u] = 0.f;
+        if (j <= n) {
+          const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
+          dd[u] = v.disp[o];
+          if (j > 0) cc[u] = v.cost[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * bd;
+        if (j <= n) st4[j] = make_float4(dd[u], cc[u], dd[u], cc[u]);
+      }
+    }
   }
   __syncthreads();
 
@@ -582,6 +634,9 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const int i1 = min(n, i0 + seg_len);
   const bool active = i0 < n;
   k.lim = (active && k.mpos >= 0 && k.mpos < nd) ? i1 : (int)0x80000000;
+#ifdef PM_TUNING
+  if (dbg & 1) k.lim = (int)0x80000000;
+#endif
   LdsSlot cand_slot = (LdsSlot)(s_cand + sidx);
   unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
   unsigned long long no_merge = 0ull;
@@ -687,6 +742,13 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   }
 }
 
+inline int run3_dbg() {
+  static const int v = [] {
+    const char* e = pm::tune_env("PM_RUN3_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
 inline size_t run3_lds_bytes(int n, int nseg) { return sizeof(float) * (4 * (size_t)(n + 1) + 2 * (size_t)nseg + 3); }
 
 template <int GS, int AXIS, int TP, int DIR, bool LREF>
@@ -702,7 +764,7 @@ inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepG
   if (LREF) lds_bytes += run3_lref_bytes<AXIS>(ps);
   allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
   hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
-                     dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len);
+                     dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len | (run3_dbg() << 24));
 }
 template <int GS, int AXIS, int TP>
 inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
