@@ -57,8 +57,12 @@ struct PlaneSet {
   uint32_t* rqk;       // [B][2][nrl][pitch][2]
   float* cpg;          // [B][2][ncl][pitch_t][4]  the same records on the transposed target planes
   int nrl, ncl;        // lines per view: rows + 2, cols + kTransPad + 2 (lines beyond the last repeat it)
-  float* disp;         // [B][2][rows][pitch]   view 0 = left, view 1 = right (mirrored coordinates)
-  float* cost;         // [B][2][rows][pitch]   cost of disp under the current window
+  // STATE planes: four image rows interleaved -- element (x, y) at state_at(x, y, pitch) = ((y >> 2) * pitch + x) * 4 +
+  // (y & 3), plane stride `splane` -- so that a column chain finds four of its positions in one 16-byte piece (180
+  // cache lines per plane for 720 rows instead of 720) while a row chain still reads every fourth word of a contiguous
+  // stretch (round 4: DESIGN.md 6, "what a launch costs besides its steps").  Every access goes through state_at() / chain_at().
+  float* disp;         // [B][2][rows4][pitch][4]   view 0 = left, view 1 = right (mirrored coordinates)
+  float* cost;         // [B][2][rows4][pitch][4]   cost of disp under the current window
   const float* noise;  // [rows][pitch]         cv::RNG(seed) uniform [-1,1), shared by all slots
   unsigned long long* counters;  // [8] work counters (see pm_debug_counters), one atomic per wavefront
   // Row-tiled mode: chains a sweep launch works on, [n_views][cols] (chain index = plane column), nullptr = all.
@@ -68,7 +72,17 @@ struct PlaneSet {
   int n_views;         // 1 or 2
   int view_fixed;      // -1: slot = pair * n_views + view; 0 / 1: slot = pair, this view only (per-view streams)
   size_t plane;        // rows * pitch
+  size_t splane;       // state planes: align_up(rows, 4) * pitch
 };
+
+// index of pixel (x, y) in a state plane (PlaneSet::disp / cost)
+__host__ __device__ __forceinline__ size_t state_at(int x, int y, int pitch) {
+  return (((size_t)(y >> 2) * (size_t)pitch + (size_t)x) << 2) + (size_t)(y & 3);
+}
+// position s of chain `chain`: a row chain (axis 0) runs along x, a column chain along y
+__host__ __device__ __forceinline__ size_t chain_at(int axis, int chain, int s, int pitch) {
+  return axis == 0 ? state_at(s, chain, pitch) : state_at(chain, s, pitch);
+}
 
 // The planes one view works on.  View 1 is "the same algorithm on the horizontally mirrored
 // (R, L) pair" (src/vehicle/patchmatch_gpu/patchmatch_gpu.cu:357-368): the mirrored copies are
@@ -129,7 +143,7 @@ __device__ __forceinline__ View make_view(const PlaneSet& ps, int slot) {
   w.rpg = ps.rpg + pv * (size_t)ps.nrl * ps.pitch * 4;
   w.rqk = ps.rqk + pv * (size_t)ps.nrl * ps.pitch * 2;
   w.cpg = ps.cpg + pv * (size_t)ps.ncl * ps.pitch_t * 4;
-  const size_t dofs = ((size_t)b * 2 + v) * ps.plane;
+  const size_t dofs = ((size_t)b * 2 + v) * ps.splane;
   w.disp = ps.disp + dofs;
   w.cost = ps.cost + dofs;
   return w;

@@ -168,6 +168,7 @@ PlaneSet plane_set(const pm_handle* h, int rows, int cols, int n_views) {
   ps.n_views = n_views;
   ps.view_fixed = -1;
   ps.plane = (size_t)rows * ps.pitch;
+  ps.splane = (size_t)align_up(rows, 4) * ps.pitch;
   return ps;
 }
 
@@ -303,13 +304,13 @@ int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scrat
   }
   const uint8_t* ref = ps.img8 + ((size_t)b * 4 + (view == 0 ? 0 : 3)) * ps.plane;
   const uint8_t* tgt = ps.img8 + ((size_t)b * 4 + (view == 0 ? 1 : 2)) * ps.plane;
-  float* out = ps.disp + ((size_t)b * 2 + view) * ps.plane;
+  float* out = ps.disp + ((size_t)b * 2 + view) * ps.splane;  // a state plane: rows interleaved (out_pitch < 0 below)
   if (h->params.cpu_initialize_factor == 1)  // Patchmatch::Initialize(il, ir, 1) (patchmatch_test.cpp:149-150): 5x5, / 2
-    PM_HIP(h, seed_initialize(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch, 1, out, ps.pitch,
+    PM_HIP(h, seed_initialize(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch, 1, out, -ps.pitch,
                               h->stream));
   else
     PM_HIP(h, seed_sparse_init(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
-                               h->params.init_dilate_factor, out, ps.pitch, h->stream));
+                               h->params.init_dilate_factor, out, -ps.pitch, h->stream));
   return PM_OK;
 }
 
@@ -578,8 +579,8 @@ PlaneSet plane_set_of_pair(const PlaneSet& ps, int b) {
   if (q.rpg) q.rpg += b2 * (size_t)ps.nrl * ps.pitch * 4;
   if (q.rqk) q.rqk += b2 * (size_t)ps.nrl * ps.pitch * 2;
   if (q.cpg) q.cpg += b2 * (size_t)ps.ncl * ps.pitch_t * 4;
-  q.disp += b2 * ps.plane;
-  q.cost += b2 * ps.plane;
+  q.disp += b2 * ps.splane;
+  q.cost += b2 * ps.splane;
   return q;
 }
 
@@ -1049,8 +1050,9 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   PM_HIP(h, hipMemsetAsync(h->tpk16, 0, sizeof(uint16_t) * (B * 4 * plane_t + 128), h->stream));
   if (pair_planes_wanted(h))
     if (int rc = pair_planes_alloc(h)) return rc;
-  PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * plane + 64)));
-  PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * plane + 64)));
+  const size_t splane = (size_t)align_up(max_rows, 4) * h->max_pitch;  // state planes: four rows interleaved (pm_device.hpp)
+  PM_HIP(h, hipMalloc((void**)&h->disp, sizeof(float) * (B * 2 * splane + 64)));
+  PM_HIP(h, hipMalloc((void**)&h->cost, sizeof(float) * (B * 2 * splane + 64)));
   PM_HIP(h, hipMalloc((void**)&h->noise, sizeof(float) * (plane + 64)));
   h->noise_capacity = plane;
   PM_HIP(h, hipMalloc((void**)&h->counters, sizeof(unsigned long long) * 16));  // [8..13]: timing builds only
@@ -1077,8 +1079,8 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   }
   // the cost planes are read only where the noise kernel wrote them; clear once so that tools that
   // scan whole planes never see uninitialised memory
-  PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
-  PM_HIP(h, hipMemsetAsync(h->disp, 0, sizeof(float) * (B * 2 * plane + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->cost, 0, sizeof(float) * (B * 2 * splane + 64), h->stream));
+  PM_HIP(h, hipMemsetAsync(h->disp, 0, sizeof(float) * (B * 2 * splane + 64), h->stream));
   PM_HIP(h, hipStreamSynchronize(h->stream));
   return PM_OK;
 }

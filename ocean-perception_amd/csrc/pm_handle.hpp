@@ -313,6 +313,7 @@ void launch_background(pm_handle* h, const PlaneSet& ps, const CostParams& cp, c
 int run_sweep(pm_handle* h, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, float amp = 1e30f);
 void launch_finalize(pm_handle* h, const PlaneSet& ps, float* d_disp_l, float* d_disp_r, int n);
 void launch_mask_occlusions(pm_handle* h, float* d_disp_l, const float* d_disp_r, int rows, int cols);
+void launch_state_row(pm_handle* h, const PlaneSet& ps, int r, float* d_buf, int to_buf);
 void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
                          const int* d_mask);
 // rows x cols floats from tight device memory into page-locked host memory (its DEVICE address), row stride in floats

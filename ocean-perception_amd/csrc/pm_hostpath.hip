@@ -732,7 +732,7 @@ int pm_sparse_init(pm_handle* h, const uint8_t* left, const uint8_t* right, int 
   PlaneSet ps;
   if (int rc = stage_prep(h, left, right, rows, cols, &ps)) return rc;
   PM_HIP(h, seed_sparse_init(h->seeds[0], seed_params(h->params), ps.img8, ps.img8 + ps.plane, rows, cols, ps.pitch,
-                             dilate_factor, ps.disp, ps.pitch, h->stream));
+                             dilate_factor, ps.disp, -ps.pitch, h->stream));  // into the state plane (rows interleaved)
   return stage_out(h, ps, seed, 0);
 }
 

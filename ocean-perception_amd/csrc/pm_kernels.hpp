@@ -46,10 +46,10 @@ __global__ void __launch_bounds__(256) k_prep(PlaneSet ps, const uint8_t* __rest
   if (x >= ps.cols) return;
   if (seeds.on) {
     const size_t sp = (size_t)ps.rows * ps.cols, so = (size_t)b * sp + (size_t)y * ps.cols;
-    const size_t o = (size_t)y * ps.pitch + x;
-    if (view_sel != 1) ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seeds.l ? seeds.l[so + x] : 0.f;
+    const size_t o = state_at(x, y, ps.pitch);
+    if (view_sel != 1) ps.disp[((size_t)b * 2 + 0) * ps.splane + o] = seeds.l ? seeds.l[so + x] : 0.f;
     if (ps.n_views > 1 && view_sel != 0)
-      ps.disp[((size_t)b * 2 + 1) * ps.plane + o] = seeds.r ? seeds.r[so + (ps.cols - 1 - x)] : 0.f;
+      ps.disp[((size_t)b * 2 + 1) * ps.splane + o] = seeds.r ? seeds.r[so + (ps.cols - 1 - x)] : 0.f;
   }
   const size_t in_plane = (size_t)ps.rows * in_stride;
   const uint8_t* srcs[2] = {in_left + (size_t)b * in_plane, in_right + (size_t)b * in_plane};
@@ -336,11 +336,11 @@ __global__ void __launch_bounds__(256) k_seed(PlaneSet ps, const float* __restri
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
   const size_t sp = (size_t)ps.rows * seed_stride;
-  const size_t o = (size_t)y * ps.pitch + x;
+  const size_t o = state_at(x, y, ps.pitch);
   if (view_sel != 1)
-    ps.disp[((size_t)b * 2 + 0) * ps.plane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
+    ps.disp[((size_t)b * 2 + 0) * ps.splane + o] = seed_l ? seed_l[(size_t)b * sp + (size_t)y * seed_stride + x] : 0.f;
   if (ps.n_views > 1 && view_sel != 0)
-    ps.disp[((size_t)b * 2 + 1) * ps.plane + o] =
+    ps.disp[((size_t)b * 2 + 1) * ps.splane + o] =
         seed_r ? seed_r[(size_t)b * sp + (size_t)y * seed_stride + (ps.cols - 1 - x)] : 0.f;
 }
 
@@ -361,11 +361,11 @@ __global__ void __launch_bounds__(256) k_noise_cost(PlaneSet ps, CostParams cp, 
   const int y = blockIdx.y, slot = blockIdx.z;
   if (x >= ps.cols) return;
   const View v = make_view(ps, slot);
-  const size_t o = (size_t)y * ps.pitch + x;
+  const size_t o = state_at(x, y, ps.pitch);
   float d = v.disp[o];
   if (amount >= 0.f) {
     if (d > 0.f) {
-      const float m = ps.noise[o] * amount;
+      const float m = ps.noise[(size_t)y * ps.pitch + x] * amount;
       const float s = m + d;
       d = s > 0.f ? s : 0.f;
     } else {
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
   const View v = make_view(ps, slot);
   const int cols = ps.cols, rows = ps.rows, pitch = ps.pitch;
   const bool inimg = x < cols && y < rows;
-  const size_t o = (size_t)y * pitch + x;
+  const size_t o = state_at(x, y, pitch);  // state planes
 
   float d = 0.f;
   bool was_zero = false;
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
     was_zero = !(d > 0.f);
     if (amount >= 0.f) {
       if (d > 0.f) {
-        const float m = ps.noise[o] * amount;
+        const float m = ps.noise[(size_t)y * pitch + x] * amount;
         const float s = m + d;
         d = s > 0.f ? s : 0.f;
       } else {
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256) k_background(PlaneSet ps, CostParams cp, 
   const int y = blockIdx.y, slot = blockIdx.z;
   if (x < in.x_lo || x > in.x_hi || y < in.y_lo || y > in.y_hi) return;
   const View v = make_view(ps, slot);
-  const size_t o = (size_t)y * ps.pitch + x;
+  const size_t o = state_at(x, y, ps.pitch);
   const float d = v.disp[o];
   if (cp.semantics == 0) {
     const float hi = (float)x - (float)(cp.pw / 2);
@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256) k_background_tiled(PlaneSet ps, CostParam
     }
   }
   const float c_bg = cpu_cost_from_sums((int)sc, (int)sg, cp);
-  const size_t o = (size_t)y * pitch + x;
+  const size_t o = state_at(x, y, pitch);
   const float d = v.disp[o];
   const float hi = (float)x - (float)(PW / 2);
   float dd = d > 0.f ? d : 0.f;
@@ -815,14 +815,14 @@ __global__ void __launch_bounds__(256) k_finalize(PlaneSet ps, float* __restrict
   const int y = blockIdx.y, b = blockIdx.z;
   if (x >= ps.cols) return;
   const size_t op = (size_t)ps.rows * out_stride;
-  const float* dl_plane = ps.disp + ((size_t)b * 2 + 0) * ps.plane + (size_t)y * ps.pitch;
-  float dl = dl_plane[x];
+  const float* dl_plane = ps.disp + ((size_t)b * 2 + 0) * ps.splane;
+  float dl = dl_plane[state_at(x, y, ps.pitch)];
   if (ps.n_views > 1) {
-    const float* dr_plane = ps.disp + ((size_t)b * 2 + 1) * ps.plane + (size_t)y * ps.pitch;
+    const float* dr_plane = ps.disp + ((size_t)b * 2 + 1) * ps.splane;
     const int xr = (int)fmaxf((float)x - dl, 0.f);
-    const float dr = dr_plane[ps.cols - 1 - xr];
+    const float dr = dr_plane[state_at(ps.cols - 1 - xr, y, ps.pitch)];
     if ((double)dr > 1.4 * (double)dl || (double)dr < 0.7 * (double)dl) dl = 0.f;
-    if (out_r) out_r[(size_t)b * op + (size_t)y * out_stride + x] = dr_plane[ps.cols - 1 - x];
+    if (out_r) out_r[(size_t)b * op + (size_t)y * out_stride + x] = dr_plane[state_at(ps.cols - 1 - x, y, ps.pitch)];
   }
   out_l[(size_t)b * op + (size_t)y * out_stride + x] = dl;
 }
@@ -846,9 +846,19 @@ __global__ void __launch_bounds__(256) k_restore_cols(PlaneSet ps, const float* 
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, v = blockIdx.z;
   if (x >= ps.cols || !mask[v * ps.cols + x]) return;
-  const size_t o = (size_t)v * ps.plane + (size_t)y * ps.pitch + x;
+  const size_t o = (size_t)v * ps.splane + state_at(x, y, ps.pitch);
   ps.disp[o] = snap_disp[o];
   ps.cost[o] = snap_cost[o];
+}
+
+// Row-tiled mode: image row r of every view between the disparity planes and a tight [n_views][cols] buffer.
+__global__ void __launch_bounds__(256) k_state_row(PlaneSet ps, int r, float* __restrict__ buf, int to_buf) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (x >= ps.cols) return;
+  float* p = ps.disp + (size_t)v * ps.splane + state_at(x, r, ps.pitch);
+  if (to_buf) buf[(size_t)v * ps.cols + x] = *p;
+  else *p = buf[(size_t)v * ps.cols + x];
 }
 
 // Plain copies between caller planes and the pitched disparity plane of view 0.
@@ -856,7 +866,7 @@ __global__ void __launch_bounds__(256) k_copy_in(PlaneSet ps, const float* __res
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  ps.disp[(size_t)y * ps.pitch + x] = src[(size_t)y * ps.cols + x];
+  ps.disp[state_at(x, y, ps.pitch)] = src[(size_t)y * ps.cols + x];
 }
 // caller plane with its own row stride (elements); to_caller != 0 copies the other way
 __global__ void __launch_bounds__(256) k_copy_disp_strided(PlaneSet ps, float* __restrict__ buf, size_t stride,
@@ -864,8 +874,8 @@ __global__ void __launch_bounds__(256) k_copy_disp_strided(PlaneSet ps, float* _
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
-  if (to_caller) buf[(size_t)y * stride + x] = ps.disp[(size_t)y * ps.pitch + x];
-  else ps.disp[(size_t)y * ps.pitch + x] = buf[(size_t)y * stride + x];
+  if (to_caller) buf[(size_t)y * stride + x] = ps.disp[state_at(x, y, ps.pitch)];
+  else ps.disp[state_at(x, y, ps.pitch)] = buf[(size_t)y * stride + x];
 }
 // Disparity maps out of device memory into page-locked HOST memory, by a few wavefronts.  The runtime performs a
 // device-to-host hipMemcpyAsync on a busy stream with a blit kernel of its own, one per map, whose waves wait on the
@@ -897,7 +907,7 @@ __global__ void __launch_bounds__(256) k_copy_out(PlaneSet ps, float* __restrict
   const int y = blockIdx.y;
   if (x >= ps.cols) return;
   const float* src = which == 0 ? ps.disp : (which == 1 ? ps.g32 : ps.noise);
-  dst[(size_t)y * ps.cols + x] = src[(size_t)y * ps.pitch + x];
+  dst[(size_t)y * ps.cols + x] = src[which == 0 ? state_at(x, y, ps.pitch) : (size_t)y * ps.pitch + x];
 }
 
 }  // namespace pm

@@ -152,6 +152,11 @@ void launch_mask_occlusions(pm_handle* h, float* d_disp_l, const float* d_disp_r
                      cols);
 }
 
+void launch_state_row(pm_handle* h, const PlaneSet& ps, int r, float* d_buf, int to_buf) {
+  hipLaunchKernelGGL(k_state_row, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.n_views), dim3(256), 0, h->stream, ps, r,
+                     d_buf, to_buf);
+}
+
 void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
                          const int* d_mask) {
   hipLaunchKernelGGL(k_restore_cols, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps, snap_disp,

@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
     const float* seed = view == 0 ? ar.seed_l : ar.seed_r;
     float s = 0.f;
     if (((ar.seed_in_disp >> view) & 1) && on) {
-      s = ps.disp[((size_t)pair * 2 + view) * ps.plane + (size_t)y * pitch + x];
+      s = ps.disp[((size_t)pair * 2 + view) * ps.splane + state_at(x, y, pitch)];
     } else if (seed && on) {
       // the right view's seed map is given in right-image coordinates: view 1 works on the mirrored pair
       const int sx = view == 0 ? x : cols - 1 - x;

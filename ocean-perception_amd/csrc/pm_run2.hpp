@@ -114,12 +114,8 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   const int nseg = kPerWave * nw;
   const int sidx = kPerWave * w + lane / GS;
   constexpr int nd = GS - 2;
-  const int stride = AXIS == 0 ? g.dir : g.dir * ps.pitch;
-  const ptrdiff_t first =
-      AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
-
   for (int k = threadIdx.x; k <= n; k += blockDim.x) {
-    const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+    const size_t o = chain_at(AXIS, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
     const float d = v.disp[o];
     const float cc = k > 0 ? v.cost[o] : 0.f;
     din[k] = d;
@@ -215,7 +211,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) {
     const float d = dout[k];
     if (d != din[k]) {
-      const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+      const size_t o = chain_at(AXIS, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
       v.disp[o] = d;
       v.cost[o] = cout[k];
     }

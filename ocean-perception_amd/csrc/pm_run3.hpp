@@ -600,13 +600,10 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   k.dmposf = (float)(DIR * k.mpos);
   k.rofs = DIR > 0 ? k.gl : pw - k.gl;
   const int sidx = kPerWave * w + lane / GS;
-  const int stride = AXIS == 0 ? DIR : DIR * ps.pitch;
-  const ptrdiff_t first =
-      AXIS == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
 
   {
-    // the chain's state into LDS, four positions per thread in flight (a column chain reads every position from another
-    // cache line: the latency of one load, not of four in a row)
+    // the chain's state into LDS, four positions per thread in flight (the latency of one load, not of four in a row;
+    // four consecutive positions of a column chain share a 16-byte piece of the state planes, pm_device.hpp::state_at)
     constexpr int U = 4;
     const int bd = blockDim.x;
     for (int j0 = threadIdx.x; j0 <= n; j0 += U * bd) {
@@ -616,7 +613,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
         const int j = j0 + u * bd;
         dd[u] = cc[u] = 0.f;
         if (j <= n) {
-          const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
+          const size_t o = chain_at(AXIS, chain, g.s_first + DIR * (j - 1), ps.pitch);
           dd[u] = v.disp[o];
           if (j > 0) cc[u] = v.cost[o];
         }
@@ -735,7 +732,7 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   for (int j = threadIdx.x + 1; j <= n; j += blockDim.x) {
     const float4 t = st4[j];
     if (t.z != t.x) {
-      const ptrdiff_t o = first + (ptrdiff_t)(j - 1) * stride;
+      const size_t o = chain_at(AXIS, chain, g.s_first + DIR * (j - 1), ps.pitch);
       v.disp[o] = t.z;
       v.cost[o] = t.w;
     }

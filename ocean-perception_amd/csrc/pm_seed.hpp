@@ -835,6 +835,11 @@ __global__ void __launch_bounds__(256) k_seed_match(const uint8_t* __restrict__ 
 // order; a maximum does not depend on the order of the updates: deterministic) into a zeroed map.  `inv_scale`
 // (1, or 2^-f for Initialize, patchmatch.cpp:81) is applied to the corner value first: scaling by a power of two
 // is exact and monotone, so it commutes with the maximum.
+// The output map is row-major with `out_pitch` elements per row, or -- out_pitch < 0 -- one of the engine's state
+// planes (four rows interleaved, pm_device.hpp::state_at, pitch -out_pitch).
+__host__ __device__ __forceinline__ size_t seed_out_at(int x, int y, int out_pitch) {
+  return out_pitch < 0 ? state_at(x, y, -out_pitch) : (size_t)y * (size_t)out_pitch + (size_t)x;
+}
 // `dedup` (sub-pixel corners only): two corners may have been refined onto the same pixel; the scatter
 // `disps.at(round(kp.y), round(kp.x)) = d` (patchmatch_gpu.cu:426-432) is sequential, so the LAST corner with a valid
 // match (d >= 0, even 0) owns the pixel -- a corner with such a successor does not count.
@@ -859,7 +864,7 @@ __global__ void __launch_bounds__(256) k_seed_splat(const int* __restrict__ kp_x
   const int w = x1 - x0 + 1, n = w * (y1 - y0 + 1);
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
     const int yy = e / w, xx = e - yy * w;
-    atomicMax((unsigned*)out + (size_t)(y0 + yy) * out_pitch + x0 + xx, bits);
+    atomicMax((unsigned*)out + seed_out_at(x0 + xx, y0 + yy, out_pitch), bits);
   }
 }
 // Initialize's down-sampled map: cv::resize(INTER_NEAREST) of the dilated full-size map (patchmatch.cpp:79):
@@ -872,7 +877,7 @@ __global__ void __launch_bounds__(256) k_seed_resize_nearest(const float* __rest
   const double ifx = 1.0 / ((double)out_cols / (double)cols), ify = 1.0 / ((double)out_rows / (double)rows);
   const int sx = min((int)floor((double)xo * ifx), cols - 1);
   const int sy = min((int)floor((double)yo * ify), rows - 1);
-  dst[(size_t)yo * dst_pitch + xo] = src[(size_t)sy * src_pitch + sx];
+  dst[seed_out_at(xo, yo, dst_pitch)] = src[(size_t)sy * src_pitch + sx];
 }
 
 // PM_SEED_FUSED=0 keeps the radix sort + separate selection (A/B and the fallback's own test); read once.
@@ -954,7 +959,8 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   // full-size splat target: the output itself, or the (idle by now) response plane when a resize follows
   float* full = resized ? sc.eig : out;
   const int full_pitch = resized ? pitch : out_pitch;
-  if ((e = hipMemsetAsync(full, 0, sizeof(float) * (size_t)rows * full_pitch, stream)) != hipSuccess) return e;
+  const size_t full_elems = full_pitch < 0 ? (size_t)((rows + 3) & ~3) * (size_t)(-full_pitch) : (size_t)rows * full_pitch;
+  if ((e = hipMemsetAsync(full, 0, sizeof(float) * full_elems, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)(maxf > 0 ? maxf : 1)), block, 0, stream, (const int*)sc.kp_xy,
                      (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, inv_scale, full, full_pitch,
                      sp.subpixel_corners);

@@ -57,6 +57,8 @@ hipError_t seed_subpix_prepare(SeedScratch& sc, const SeedParams& sp, hipStream_
 // cv::cornerSubPix with the detector's window parameters of `sp` on n device points (needs seed_subpix_prepare)
 hipError_t seed_corner_subpix(const SeedScratch& sc, const SeedParams& sp, const uint8_t* img, int rows, int cols, int pitch,
                               float* d_xs, float* d_ys, int n, hipStream_t stream);
+// `out`: a row-major map with out_pitch elements per row, or -- out_pitch < 0 -- one of the engine's state planes (four
+// rows interleaved, pm_device.hpp::state_at, pitch -out_pitch).
 // PatchmatchGpu::SparseInit(iml, imr, f)  (patchmatch_gpu.cu:414-442): dilation half-width 2^f + 1, map at image size
 hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                             int rows, int cols, int pitch, int dilate_factor, float* out, int out_pitch,

@@ -26,10 +26,10 @@ __global__ void __launch_bounds__(64) k_sweep_serial(PlaneSet ps, CostParams cp,
   if (n <= 0) return;
   int x = g.axis == 0 ? g.s_first - g.dir : chain;
   int y = g.axis == 0 ? chain : g.s_first - g.dir;
-  float prev = v.disp[(size_t)y * ps.pitch + x];
+  float prev = v.disp[state_at(x, y, ps.pitch)];
   for (int s = 0; s < n; ++s) {
     if (g.axis == 0) x += g.dir; else y += g.dir;
-    const size_t o = (size_t)y * ps.pitch + x;
+    const size_t o = state_at(x, y, ps.pitch);
     const float d0 = v.disp[o];
     const float c0 = v.cost[o];
     float nd = d0, nc = c0;

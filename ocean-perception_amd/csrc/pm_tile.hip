@@ -145,13 +145,13 @@ static int tile_sweep(pm_handle* h, int it, int k, const int* d_mask) {
 
 int pm_tile_snapshot(pm_handle* h) {
   if (int rc = tile_check(h, "pm_tile_snapshot")) return rc;
-  const size_t plane = (size_t)h->max_rows * h->max_pitch;
+  const size_t plane = (size_t)align_up(h->max_rows, 4) * h->max_pitch;  // state planes (pm_device.hpp::state_at)
   if (!h->snap_disp) {
     PM_HIP(h, hipMalloc((void**)&h->snap_disp, sizeof(float) * 2 * plane));
     PM_HIP(h, hipMalloc((void**)&h->snap_cost, sizeof(float) * 2 * plane));
   }
   const PlaneSet ps = tile_plane_set(h);
-  const size_t bytes = sizeof(float) * ps.plane * ps.n_views;
+  const size_t bytes = sizeof(float) * ps.splane * ps.n_views;
   PM_HIP(h, hipMemcpyAsync(h->snap_disp, h->disp, bytes, hipMemcpyDeviceToDevice, h->stream));
   PM_HIP(h, hipMemcpyAsync(h->snap_cost, h->cost, bytes, hipMemcpyDeviceToDevice, h->stream));
   return PM_OK;
@@ -164,7 +164,7 @@ int pm_tile_restore(pm_handle* h) {
     return PM_ERR_INVALID_ARG;
   }
   const PlaneSet ps = tile_plane_set(h);
-  const size_t bytes = sizeof(float) * ps.plane * ps.n_views;
+  const size_t bytes = sizeof(float) * ps.splane * ps.n_views;
   PM_HIP(h, hipMemcpyAsync(h->disp, h->snap_disp, bytes, hipMemcpyDeviceToDevice, h->stream));
   PM_HIP(h, hipMemcpyAsync(h->cost, h->snap_cost, bytes, hipMemcpyDeviceToDevice, h->stream));
   return PM_OK;
@@ -189,16 +189,9 @@ static int tile_row_copy(pm_handle* h, int image_row, float* d_dst, const float*
     return PM_ERR_INVALID_ARG;
   }
   const PlaneSet ps = tile_plane_set(h);
-  for (int v = 0; v < ps.n_views; ++v) {
-    float* plane_row = h->disp + (size_t)v * ps.plane + (size_t)r * ps.pitch;
-    if (d_dst)
-      PM_HIP(h, hipMemcpyAsync(d_dst + (size_t)v * ps.cols, plane_row, sizeof(float) * ps.cols,
-                               hipMemcpyDeviceToDevice, h->stream));
-    else
-      PM_HIP(h, hipMemcpyAsync(plane_row, d_src + (size_t)v * ps.cols, sizeof(float) * ps.cols,
-                               hipMemcpyDeviceToDevice, h->stream));
-  }
-  return PM_OK;
+  // (the state planes keep four rows interleaved: a row is every fourth word of a stretch -- a small kernel, not a copy)
+  launch_state_row(h, ps, r, d_dst ? d_dst : const_cast<float*>(d_src), d_dst ? 1 : 0);
+  return launch_check(h, what);
 }
 
 int pm_tile_get_row(pm_handle* h, int image_row, float* d_dst) {

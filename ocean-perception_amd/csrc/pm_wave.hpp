@@ -101,15 +101,13 @@ __global__ void __launch_bounds__(64) k_sweep_wave_cpu(PlaneSet ps, CostParams c
   {
     const int px = g.axis == 0 ? g.s_first - g.dir : chain;
     const int py = g.axis == 0 ? chain : g.s_first - g.dir;
-    prev = v.disp[(size_t)py * ps.pitch + px];
+    prev = v.disp[state_at(px, py, ps.pitch)];
   }
-  const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;  // element step along the chain
-  const size_t first = g.axis == 0 ? (size_t)chain * ps.pitch + g.s_first : (size_t)g.s_first * ps.pitch + chain;
 
   for (int base = 0; base < n; base += kWave) {
     const int cnt = min(kWave, n - base);
     const bool mine = lane < cnt;
-    const ptrdiff_t o = (ptrdiff_t)first + (ptrdiff_t)(base + lane) * stride;
+    const size_t o = chain_at(g.axis, chain, g.s_first + (base + (mine ? lane : 0)) * g.dir, ps.pitch);
     const float dreg = mine ? v.disp[o] : 0.f;
     const float creg = mine ? v.cost[o] : 0.f;
     float dnew = dreg, cnew = creg;
@@ -165,11 +163,8 @@ __global__ void __launch_bounds__(64) k_sweep_gpu_lanes(PlaneSet ps, CostParams 
   if (!chain_active(ps, blockIdx.z, chain)) return;
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x;
-  const int stride = g.axis == 0 ? g.dir : g.dir * ps.pitch;
-  const ptrdiff_t first =
-      g.axis == 0 ? (ptrdiff_t)chain * ps.pitch + g.s_first : (ptrdiff_t)g.s_first * ps.pitch + chain;
   for (int k = lane; k <= n; k += kWave) {
-    const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+    const size_t o = chain_at(g.axis, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
     const float d = v.disp[o];
     const float cc = k > 0 ? v.cost[o] : 0.f;
     din[k] = d;
@@ -243,7 +238,7 @@ __global__ void __launch_bounds__(64) k_sweep_gpu_lanes(PlaneSet ps, CostParams 
   for (int k = lane + 1; k <= n; k += kWave) {
     const float d = dout[k];
     if (d != din[k]) {
-      const ptrdiff_t o = first + (ptrdiff_t)(k - 1) * stride;
+      const size_t o = chain_at(g.axis, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
       v.disp[o] = d;
       v.cost[o] = cout[k];
     }
