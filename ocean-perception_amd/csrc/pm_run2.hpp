@@ -42,7 +42,7 @@
 namespace pm {
 
 constexpr int kMaxSegWaves = 16;
-constexpr int kLref4Stride = 7;  // dwords per image row of the column sweeps' staged reference bytes (odd)
+constexpr int kLref4Stride = 7;  // dwords per image row of the column sweeps' staged reference bytes (odd; 6 measures the same)
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its 4 MiB L2).
 // Adjacent chains read almost the same image rows, so chain k of the sweep goes to the block whose

@@ -351,12 +351,7 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         gv[3 * NTC] = 0.f;
         unsigned rc4[NQ], rg4[NQ];  // reference bytes of the lane's row, four window columns per dword
         if constexpr (LREF) {
-          unsigned y8 = (unsigned)Y << 3;  // Y * kLref4Stride (7) as a shift and a subtraction, opaque (no multiply)
-          asm volatile("" : "+v"(y8));
-          unsigned y7 = y8 - (unsigned)Y;
-          asm volatile("" : "+v"(y7));
-          const unsigned* rr = v.lds_ref4 + y7;
-          static_assert(kLref4Stride == 7, "row stride of the staged reference bytes");
+          const unsigned* rr = v.lds_ref4 + __umul24((unsigned)Y, (unsigned)kLref4Stride);  // (24-bit multiply: full rate)
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
             rc4[q] = rr[q];
@@ -759,6 +754,13 @@ inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepG
   if (len < 8) len = 8;
   size_t lds_bytes = run3_lds_bytes(n, nseg);
   if (LREF) lds_bytes += run3_lref_bytes<AXIS>(ps);
+  {  // tuning build: PM_RUN3_LDS_EXTRA_KB pads the allocation (how sensitive is the step to workgroups per CU?)
+    static const int extra = [] {
+      const char* e = pm::tune_env("PM_RUN3_LDS_EXTRA_KB");
+      return e ? atoi(e) : 0;
+    }();
+    lds_bytes += (size_t)extra * 1024;
+  }
   allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
   hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len | (run3_dbg() << 24));
