@@ -339,6 +339,7 @@ struct PlArgs {
   // INIT: bit v set = view v's seeds are in the scalar engine's disparity plane of (pair, v) (pitched, view 1
   // already mirrored): where the device SparseInit leaves them
   int seed_in_disp;
+  int dbg;  // tuning build only (PM_PLANES_DBG): bit 0 no window evaluation, bit 1 no tile fill -- timing experiments
 };
 
 // grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 512, dynamic LDS = pl_lds_bytes().
@@ -386,36 +387,139 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   const uint16_t* refpk = ps.pk16 + ((size_t)pair * 4 + iref) * ps.plane;
   const uint16_t* tgtpk = ps.pk16 + ((size_t)pair * 4 + itgt) * ps.plane;
 
-  // ---- fill: wavefront w takes tile rows w, w + 8, ...; lanes walk along the row (coalesced u16 reads) --------
+  // ---- fill: wavefront w takes tile rows w, w + 8, ...; lanes walk along the row (coalesced u16 reads).  Every load of
+  // a thread is issued before its first store: the fill is a chain of memory latencies, not of bytes (timed with the
+  // window evaluation switched off, it was 34 of a spatial launch's 96 us when each element waited for its own load) ---
   {
     uint8_t* rc8 = (uint8_t*)s_rc;
     uint8_t* rg8 = (uint8_t*)s_rg;
     const int ry0 = y0 - h, lx0 = x0 - h;
     const int xs_lo = x0 - h - pp.max_disp - pp.margin;
-    for (int rr = ty; rr < TR; rr += kPlThreads / 64) {
-      const int gy = min(max(ry0 + rr, 0), rows - 1);
-      const uint16_t* rrow = refpk + (size_t)gy * pitch;
-      const uint16_t* trw = tgtpk + (size_t)gy * pitch;
-      for (int cc = tx; cc < LW; cc += 64) {
-        const unsigned pk = rrow[min(max(lx0 + cc, 0), cols - 1)];
-        // byte cc of the row goes to byte cc - s of copy s (s = 0..3); checkerboard: byte cc >> 1 of its parity's half
-        const int par = WIN == 1 ? (cc & 1) : 0, ci = WIN == 1 ? (cc >> 1) : cc;
+    constexpr int NW = kPlThreads / 64;          // wavefronts
+    constexpr int NRR = (TR + NW - 1) / NW;      // tile rows per wavefront
+    constexpr int NCM = (LW + 63) / 64;          // reference columns per lane
+    const uint16_t* rrow[NRR];
+    const uint16_t* trw[NRR];
 #pragma unroll
-        for (int sft = 0; sft < 4; ++sft)
-          if (ci >= sft) {
-            const int o = 4 * ((par * 4 + sft) * COPYW + rr * LWW) + ci - sft;
-            rc8[o] = (uint8_t)(pk & 0xffu);
-            rg8[o] = (uint8_t)(pk >> 8);
+    for (int k = 0; k < NRR; ++k) {  // (a row beyond the tile reads the last image row: loaded, never stored)
+      const size_t gy = (size_t)min(max(ry0 + ty + NW * k, 0), rows - 1);
+      rrow[k] = refpk + gy * pitch;
+      trw[k] = tgtpk + gy * pitch;
+    }
+#ifdef PM_TUNING
+    if (!(ar.dbg & 2))
+#endif
+    {
+      unsigned rpk[NRR][NCM];
+#pragma unroll
+      for (int k = 0; k < NRR; ++k)
+#pragma unroll
+        for (int m = 0; m < NCM; ++m) rpk[k][m] = rrow[k][min(max(lx0 + tx + 64 * m, 0), cols - 1)];
+      // the first target columns are on their way while the reference bytes are stored
+      auto store_ref = [&]() {
+#ifdef PM_TUNING
+        if (ar.dbg & 4) return;  // timing: no reference stores
+#endif
+#pragma unroll
+        for (int k = 0; k < NRR; ++k) {
+          const int rr = ty + NW * k;
+#pragma unroll
+          for (int m = 0; m < NCM; ++m) {
+            const int rcc = tx + 64 * m;
+            if (rr < TR && rcc < LW) {
+              const unsigned pk = rpk[k][m];
+              // byte cc of the row goes to byte cc - s of copy s (s = 0..3); checkerboard: byte cc >> 1 of its parity's half
+              const int par = WIN == 1 ? (rcc & 1) : 0, ci = WIN == 1 ? (rcc >> 1) : rcc;
+#pragma unroll
+              for (int sft = 0; sft < 4; ++sft)
+                if (ci >= sft) {
+                  const int o = 4 * ((par * 4 + sft) * COPYW + rr * LWW) + ci - sft;
+                  rc8[o] = (uint8_t)(pk & 0xffu);
+                  rg8[o] = (uint8_t)(pk >> 8);
+                }
+            }
           }
-      }
-      pl_u2* trow = s_tgt + rr * rw;
-      for (int cc = tx; cc < rw; cc += 64) {
-        const unsigned pk0 = trw[min(max(xs_lo + cc, 0), cols - 1)];
-        const unsigned pk1 = trw[min(max(xs_lo + cc + 1, 0), cols - 1)];
-        pl_u2 v;
-        v.x = (pk0 & 0xffu) | ((pk0 & 0xff00u) << 8);
-        v.y = (pk1 & 0xffu) | ((pk1 & 0xff00u) << 8);
-        trow[cc] = v;
+        }
+      };
+      // target entry of column x = {pixel x, pixel x + 1}, each as colour | gradient << 16
+      const bool tfast = (cols & 1) == 0 && (reinterpret_cast<uintptr_t>(tgtpk) & 3u) == 0;  // uniform
+      constexpr int MAXT = 4;  // 128-column strips of the target tile whose loads are all in flight together
+      if (tfast && rw + 1 <= 128 * MAXT) {
+        // one dword (two pixels) per lane, row and strip: the entries of both its columns; the pixel behind them comes
+        // from the next lane (lane 63: one more u16).  Columns outside the image repeat the border pixel, as the clamp did.
+        const int xs_e = xs_lo & ~1, eoff = xs_lo - xs_e;  // even start column; entry index of column c = c - xs_lo
+        unsigned dw[MAXT][NRR], nx[MAXT][NRR];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int colA = xs_e + 128 * t + 2 * tx;
+          const int ce = min(max(colA, 0), cols - 2);
+#pragma unroll
+          for (int k = 0; k < NRR; ++k) {
+            dw[t][k] = 0u;
+            nx[t][k] = 0u;
+            if (128 * t < rw + eoff) {  // uniform
+              dw[t][k] = *reinterpret_cast<const unsigned*>(trw[k] + ce);
+              if (tx == 63) nx[t][k] = trw[k][min(max(colA + 2, 0), cols - 1)];
+            }
+          }
+        }
+        store_ref();
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          if (128 * t >= rw + eoff) break;  // uniform
+          const int colA = xs_e + 128 * t + 2 * tx;
+#pragma unroll
+          for (int k = 0; k < NRR; ++k) {
+            unsigned d = dw[t][k];
+            if (colA < 0) d = __builtin_amdgcn_perm(0u, d, 0x01000100u);            // pixel 0 twice
+            else if (colA > cols - 2) d = __builtin_amdgcn_perm(0u, d, 0x03020302u);  // pixel cols - 1 twice
+            const unsigned fromnext = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d, 0x130, 0xF, 0xF, true);  // lane + 1
+            const unsigned n = tx == 63 ? nx[t][k] : fromnext;
+            const unsigned ea = __builtin_amdgcn_perm(0u, d, 0x0c010c00u);  // pixel A: colour | gradient << 16
+            const unsigned eb = __builtin_amdgcn_perm(0u, d, 0x0c030c02u);  // pixel B
+            const unsigned en = __builtin_amdgcn_perm(0u, n, 0x0c010c00u);  // the pixel behind B
+            const int rr = ty + NW * k, ia = 128 * t + 2 * tx - eoff;
+#ifdef PM_TUNING
+            if (ar.dbg & 8) continue;  // timing: no target stores
+#endif
+            if (rr < TR) {
+              pl_u2* trow = s_tgt + rr * rw;
+              if (ia >= 0 && ia < rw) {
+                pl_u2 v;
+                v.x = ea;
+                v.y = eb;
+                trow[ia] = v;
+              }
+              if (ia + 1 < rw) {
+                pl_u2 v;
+                v.x = eb;
+                v.y = en;
+                trow[ia + 1] = v;
+              }
+            }
+          }
+        }
+      } else {
+        for (int c0 = 0; c0 < rw; c0 += 64) {
+          const int cc = c0 + tx;
+          unsigned p0[NRR], p1[NRR];
+#pragma unroll
+          for (int k = 0; k < NRR; ++k) {
+            p0[k] = trw[k][min(max(xs_lo + cc, 0), cols - 1)];
+            p1[k] = trw[k][min(max(xs_lo + cc + 1, 0), cols - 1)];
+          }
+          if (c0 == 0) store_ref();
+#pragma unroll
+          for (int k = 0; k < NRR; ++k) {
+            const int rr = ty + NW * k;
+            if (rr < TR && cc < rw) {
+              pl_u2 v;
+              v.x = (p0[k] & 0xffu) | ((p0[k] & 0xff00u) << 8);
+              v.y = (p1[k] & 0xffu) | ((p1[k] & 0xff00u) << 8);
+              s_tgt[rr * rw + cc] = v;
+            }
+          }
+        }
       }
     }
   }
@@ -425,16 +529,32 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   ST* const pc = st.arr(pair, view, 3);
   if constexpr (STAGE == PL_SPATIAL) {
     constexpr int PW2 = TW + 2, PH2 = kPlTileH + 2;
-    for (int e = tid; e < PW2 * PH2; e += kPlThreads) {
+    constexpr int NE = (PW2 * PH2 + kPlThreads - 1) / kPlThreads;
+    float va[NE], vb[NE], vz[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {  // (an element beyond the halo tile re-reads its last one: loaded, never stored)
+      const int e = min(tid + kPlThreads * u, PW2 * PH2 - 1);
       const int rr = e / PW2, cc = e - rr * PW2;
       const int gy = min(max(y0 - 1 + rr, 0), rows - 1), gx = min(max(x0 - 1 + cc, 0), cols - 1);
       const size_t o = st.idx(gx, gy);
-      s_pl[e] = pl_load(pa, o);
-      s_pl[PW2 * PH2 + e] = pl_load(pb, o);
-      s_pl[2 * PW2 * PH2 + e] = pl_load(pz, o);
+      va[u] = pl_load(pa, o);
+      vb[u] = pl_load(pb, o);
+      vz[u] = pl_load(pz, o);
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + kPlThreads * u;
+      if (e < PW2 * PH2) {
+        s_pl[e] = va[u];
+        s_pl[PW2 * PH2 + e] = vb[u];
+        s_pl[2 * PW2 * PH2 + e] = vz[u];
+      }
     }
   }
   __syncthreads();
+#ifdef PM_TUNING
+  if (ar.dbg & 1) return;
+#endif
 
   PlTile t;
   // absolute LDS address of the target tile in 8-byte units (the dynamic LDS block is 16-byte aligned)

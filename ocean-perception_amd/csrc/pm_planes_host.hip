@@ -5,6 +5,7 @@
 
 #include "pm_handle.hpp"
 #include "pm_planes.hpp"
+#include "pm_tune.hpp"
 
 using namespace pm;
 using namespace pm::eng;
@@ -40,6 +41,14 @@ PlanesParams planes_params(const pm_params& p) {
 }  // namespace
 
 namespace pm {
+// tuning build: PM_PLANES_DBG (timing switches of k_planes); 0 in the shipped library
+static int planes_dbg() {
+  static const int v = [] {
+    const char* e = pm::tune_env("PM_PLANES_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
 namespace eng {
 
 int planes_alloc(pm_handle* h) {
@@ -81,6 +90,7 @@ int planes_stage(pm_handle* h, const PlaneSet& ps, const PlArgs& ar, int slots, 
 int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
   const int nv = ps.n_views;
   PlArgs ar{};
+  ar.dbg = planes_dbg();
   ar.stage = stage;
   ar.arg = arg;
   ar.view_fixed = -1;
@@ -123,6 +133,7 @@ int planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
   const float* sl = d_seed_l;
   const float* sr = d_seed_r;
   PlArgs ar{};
+  ar.dbg = planes_dbg();
   if (h->params.sparse_init) {
     // SparseInit on the device (patchmatch_gpu.cu:414-442) into the scalar engine's disparity planes, from
     // which the initialisation kernel takes the seeds (view 1's plane is already in mirrored coordinates)
