@@ -457,7 +457,7 @@ def reference_test_shape_leg(pm, args, device):
 class Workload:
     """Device-resident inputs/outputs of one rank and the step function of the selected mode."""
 
-    def __init__(self, args, pm, torch, np, synth, dev, local_rank, rank, mode, state, enhance):
+    def __init__(self, args, pm, torch, np, synth, dev, local_rank, rank, mode, state, enhance, plane_neighbours=0):
         self.args, self.pm, self.torch, self.mode, self.enhance = args, pm, torch, mode, enhance
         nb = max(1, args.pairs_per_gpu)
         self.nb = nb
@@ -477,7 +477,7 @@ class Workload:
         if mode == "planes":
             self.params = pm.default_params(0, patch=args.patch, patchmatch_iters=args.iters, mode=pm.PM_MODE_PLANES,
                                             state_dtype=pm.PM_STATE_F16 if state == "f16" else pm.PM_STATE_F32,
-                                            sparse_init=1 if args.self_seed else 0)
+                                            sparse_init=1 if args.self_seed else 0, plane_neighbours=plane_neighbours)
         else:
             self.params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters,
                                             engine=args.engine, sparse_init=1 if args.self_seed else 0)
@@ -597,15 +597,16 @@ def timed_loop(w, d, steps, warmup, every, no_profile):
     return elapsed, prof, n_prof, stats
 
 
-def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
-    """One plane-mode measurement for the default run's JSON line (rank 0, N=1)."""
+def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbours=0):
+    """One plane-mode measurement for the default run's JSON line (rank 0, N=1).  plane_neighbours = 1: the spatial stage's
+    two-neighbour option (pm_params.plane_neighbours = PM_PL_NEIGH_TWO), an option, not the default."""
     class NoDist:
         def barrier(self):
             pass
 
         def max_over_ranks(self, v):
             return v
-    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance)
+    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance, plane_neighbours)
     steps = 12
     # (six warm-up steps: the engine's creation leaves the GPU idle for a few hundred ms and its clocks take ~20 ms of
     # work to come back; with two warm-up steps the leg read 3 % low)
@@ -615,7 +616,8 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance):
     out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
                        f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images fused into the "
                                                       "Match's load path (pm_match_bgr_device; BASELINE configs[4] per-GPU shape)" if enhance
-                                                      else " (BASELINE configs[1] shape)"),
+                                                      else " (BASELINE configs[1] shape)") +
+                       ("; spatial stage with TWO neighbours per pass (PM_PL_NEIGH_TWO: an option, not the default)" if plane_neighbours else ""),
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
            "step_ms": step_stats,
            "dtype": "u8 window cost, " + state + " state",
@@ -882,7 +884,8 @@ def main():
     if d.rank == 0:
         if d.world == 1 and not planes and not args.no_side_legs and nb == 1:
             result["planes"] = {"f32": side_leg(args, pm, torch, np, synth, dev, d, "f32", False),
-                                "f16_enhanced": side_leg(args, pm, torch, np, synth, dev, d, "f16", True)}
+                                "f16_enhanced": side_leg(args, pm, torch, np, synth, dev, d, "f16", True),
+                                "f32_two_neighbours": side_leg(args, pm, torch, np, synth, dev, d, "f32", False, 1)}
         if d.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_planes(args, args.state == "f16") if planes else cpu_baseline(args)
             if not planes and "planes" in result:

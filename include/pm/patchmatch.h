@@ -153,11 +153,17 @@ typedef struct pm_params {
   float plane_slope_per_disp;     /* 1/64  slope range of a refinement step = dz * this                   */
   float plane_lr_tol;             /* 1.0   |dl - dr| above which the left disparity is zeroed             */
   int plane_window;               /* 1     pm_plane_window: which taps of the window count                        */
+  int plane_neighbours;           /* 0     pm_plane_neighbours: the spatial stage's candidates                    */
 } pm_params;
 /* PM_MODE_PLANES window.  CHECKER (default since ABI 5): tap (i, j) counts iff i + j is even -- the centre and every other
  * tap in both directions, 61 of 121 for 11 x 11; the mean divides by the taps that count.  Half the arithmetic of the
  * full window at the same quality on the benchmark pairs (99.86 % of the valid pixels within 1 px either way). */
 typedef enum pm_plane_window { PM_PL_WINDOW_FULL = 0, PM_PL_WINDOW_CHECKER = 1 } pm_plane_window;
+/* PM_MODE_PLANES spatial stage.  FOUR (default): a pixel is offered the planes of its left, right, upper and lower
+ * neighbour.  TWO: the left and the upper one in the colour passes of an even iteration, the right and the lower one in
+ * those of an odd iteration -- half the evaluations of the stage (the whole mode ~20 % faster); on the benchmark pairs
+ * the same validity, 99.84-99.88 % of the valid pixels within 1 px (FOUR: 99.86-99.89 %), mean absolute error + 12-13 %. */
+typedef enum pm_plane_neighbours { PM_PL_NEIGH_FOUR = 0, PM_PL_NEIGH_TWO = 1 } pm_plane_neighbours;
 
 /* Fills *p with the reference defaults for the given semantics. */
 void pm_params_default(pm_params* p, int semantics);
@@ -397,7 +403,8 @@ enum { PM_PL_SPATIAL = 1, PM_PL_VIEW = 2, PM_PL_REFINE = 3, PM_PL_VIEW_REFINE = 
 /* prep + random plane initialisation (+ its cost) of n pairs; seeds as in pm_match_device */
 int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                     const float* d_seed_l, const float* d_seed_r);
-/* stage = PM_PL_SPATIAL: arg = colour (0 red: x + y even, 1 black), both views;
+/* stage = PM_PL_SPATIAL: arg = colour + 2 * iteration (colour 0 red: x + y even, 1 black), both views; the iteration
+ *                        only matters with PM_PL_NEIGH_TWO (which pair of neighbours);
  *         PM_PL_VIEW:    arg = the view that receives candidates from the other one;
  *         PM_PL_REFINE:  arg = iteration (selects noise_amp[arg] and the random numbers), both views;
  *         PM_PL_VIEW_REFINE: arg = iteration * 2 + view: PM_PL_VIEW for that view, then its PM_PL_REFINE, fused */

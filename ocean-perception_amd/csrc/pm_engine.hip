@@ -778,7 +778,8 @@ int validate_params(pm_handle* h, const pm_params& p) {
         p.plane_refine_steps > 16 || !(p.plane_slope_max > 0.f) || !(p.plane_slope_max <= 4.f) ||
         !(p.plane_slope_init >= 0.f) || !(p.plane_slope_init <= p.plane_slope_max) ||
         !(p.plane_slope_per_disp >= 0.f) || !(p.plane_lr_tol >= 0.f) || p.max_disp < 1 || p.max_disp > 1024 ||
-        (p.plane_window != PM_PL_WINDOW_FULL && p.plane_window != PM_PL_WINDOW_CHECKER)) {
+        (p.plane_window != PM_PL_WINDOW_FULL && p.plane_window != PM_PL_WINDOW_CHECKER) ||
+        (p.plane_neighbours != PM_PL_NEIGH_FOUR && p.plane_neighbours != PM_PL_NEIGH_TWO)) {
       set_err(h, "PM_MODE_PLANES: plane parameters out of range");
       return PM_ERR_INVALID_ARG;
     }
@@ -923,6 +924,7 @@ void pm_params_default(pm_params* p, int semantics) {
   p->plane_slope_per_disp = 1.0f / 64.0f;
   p->plane_lr_tol = 1.0f;
   p->plane_window = PM_PL_WINDOW_CHECKER;
+  p->plane_neighbours = PM_PL_NEIGH_FOUR;
 }
 
 const char* pm_status_string(int status) {

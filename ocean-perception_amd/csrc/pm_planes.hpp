@@ -42,6 +42,7 @@ struct PlanesParams {
   unsigned long long seed;
   int n_views;
   int window;  // PM_PL_WINDOW_FULL / PM_PL_WINDOW_CHECKER (pm/patchmatch.h): which taps of the P x P window count
+  int neighbours;  // PM_PL_NEIGH_FOUR / PM_PL_NEIGH_TWO: the spatial stage's candidates
 };
 
 // State of all slots: slot (pair, view) holds 4 arrays of `plane` elements: a, b, z, cost.
@@ -331,7 +332,7 @@ __device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xr
 
 struct PlArgs {
   int stage;
-  int arg;         // SPATIAL: parity; VIEW: the view; REFINE / VIEW_REFINE: iteration
+  int arg;         // SPATIAL: colour + 2 * iteration; VIEW: the view; REFINE / VIEW_REFINE: iteration
   int view_fixed;  // >= 0: blockIdx.z = pair, this view; -1: blockIdx.z = pair * n_views + view
   float refine_amp;
   const float* seed_l;  // INIT: tightly packed [n][rows][cols] seed maps in left / right image coordinates, or null
@@ -567,7 +568,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   const float smax = pp.slope_max;
 #pragma unroll 1
   for (int sub = 0; sub < SUBS; ++sub) {
-  const int lx = STAGE == PL_SPATIAL ? 2 * tx + ((y + ar.arg) & 1) : tx + 64 * sub;
+  const int lx = STAGE == PL_SPATIAL ? 2 * tx + ((y + (ar.arg & 1)) & 1) : tx + 64 * sub;
   const int x = x0 + lx;
   const bool on = x < cols && y < rows;
   const int xrel = lx + pp.max_disp + pp.margin;
@@ -610,20 +611,23 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
       const float* sb = s_pl + PW2 * PH2;
       const float* sz = s_pl + 2 * PW2 * PH2;
       const int c = (ty + 1) * PW2 + lx + 1;
-      // left, right, up, down: the neighbour's plane evaluated at this pixel
-      {
+      // left, right, up, down: the neighbour's plane evaluated at this pixel.  PM_PL_NEIGH_TWO: left + up in the passes of
+      // an even iteration, right + down in those of an odd one (uniform for the launch)
+      const bool two = pp.neighbours == 1, odd_it = ((ar.arg >> 1) & 1) != 0;
+      const bool lu = !two || !odd_it, rd = !two || odd_it;
+      if (lu) {
         const float na = sa[c - 1], nb = sb[c - 1], nz = sz[c - 1];
         pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp);
       }
-      {
+      if (rd) {
         const float na = sa[c + 1], nb = sb[c + 1], nz = sz[c + 1];
         pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && x < cols - 1, na, nb, nz - na, px, pp);
       }
-      {
+      if (lu) {
         const float na = sa[c - PW2], nb = sb[c - PW2], nz = sz[c - PW2];
         pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && y > 0, na, nb, nz + nb, px, pp);
       }
-      {
+      if (rd) {
         const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
         pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
       }

@@ -30,6 +30,7 @@ PlanesParams planes_params(const pm_params& p) {
   pp.tau_color = p.functor_tau_color;
   pp.tau_grad = p.functor_tau_grad;
   pp.window = p.plane_window;
+  pp.neighbours = p.plane_neighbours;
   // taps that count: all of them, or those with i + j even (the centre and every other tap: (P * P + 1) / 2)
   pp.inv_n = 1.0f / (float)(pp.window == PM_PL_WINDOW_CHECKER ? (pp.patch * pp.patch + 1) / 2 : pp.patch * pp.patch);
   pp.lr_tol = p.plane_lr_tol;
@@ -201,8 +202,8 @@ int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
   const int nv = h->params.left_right_check ? 2 : 1;
   const PlaneSet ps = plane_set(h, rows, cols, nv);
   for (int it = 0; it < h->params.patchmatch_iters; ++it) {
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 0)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 1)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 2 * it)) return rc;
+    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 2 * it + 1)) return rc;
     // per view: view propagation then refinement, fused in one launch (one tile fill for 1 + R candidates)
     for (int v = 0; v < nv; ++v)
       if (int rc = planes_step(h, ps, n, PM_PL_VIEW_REFINE, it * 2 + v)) return rc;
@@ -229,7 +230,7 @@ int pm_planes_begin(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d
 int pm_planes_step(pm_handle* h, int stage, int arg) {
   if (int rc = planes_check(h, "pm_planes_step", true)) return rc;
   const int nv = h->params.left_right_check ? 2 : 1;
-  const bool ok = (stage == PM_PL_SPATIAL && (arg == 0 || arg == 1)) ||
+  const bool ok = (stage == PM_PL_SPATIAL && arg >= 0 && arg < 2 * PM_MAX_ITERS) ||
                   (stage == PM_PL_VIEW && (arg == 0 || arg == 1)) ||
                   (stage == PM_PL_REFINE && arg >= 0 && arg < PM_MAX_ITERS) ||
                   (stage == PM_PL_VIEW_REFINE && arg >= 0 && arg < 2 * PM_MAX_ITERS);

@@ -21,6 +21,7 @@ PM_MODE_SCALAR, PM_MODE_PLANES = 0, 1
 PM_STATE_F32, PM_STATE_F16 = 0, 1
 PM_PL_SPATIAL, PM_PL_VIEW, PM_PL_REFINE, PM_PL_VIEW_REFINE = 1, 2, 3, 4
 PM_PL_WINDOW_FULL, PM_PL_WINDOW_CHECKER = 0, 1
+PM_PL_NEIGH_FOUR, PM_PL_NEIGH_TWO = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB: experiment knob to load another build of the same library (e.g. a different unroll factor)
@@ -95,6 +96,7 @@ class PmParams(C.Structure):
         ("plane_slope_per_disp", C.c_float),
         ("plane_lr_tol", C.c_float),
         ("plane_window", C.c_int),
+        ("plane_neighbours", C.c_int),
     ]
 
 

@@ -37,6 +37,7 @@ void pmo_planes_params_default(pmo_planes_params* p) {
   p->state_f16 = 0;
   p->nthreads = 1;
   p->window = PMO_PL_WINDOW_CHECKER;
+  p->neighbours = PMO_PL_NEIGH_FOUR;
 }
 
 /* One random 32-bit word per (stage, iteration, step, view, draw, pixel): a 64-bit counter key, mixed
@@ -195,18 +196,21 @@ void pmo_planes_init(const pmo_planes_params* p, const pmo_planes_view* im, int 
     }
 }
 
-void pmo_planes_spatial(const pmo_planes_params* p, const pmo_planes_view* im, pmo_planes_state* st, int parity) {
+void pmo_planes_spatial(const pmo_planes_params* p, const pmo_planes_view* im, pmo_planes_state* st, int arg) {
   const int rows = im->rows, cols = im->cols;
+  const int parity = arg & 1, odd_it = (arg >> 1) & 1;
+  const int two = p->neighbours == PMO_PL_NEIGH_TWO;
+  const int lu = !two || !odd_it, rd = !two || odd_it; /* left + up / right + down */
 #pragma omp parallel for schedule(dynamic, 4) num_threads(p->nthreads)
   for (int y = 0; y < rows; ++y)
     for (int x = (y + parity) & 1; x < cols; x += 2) {
       const size_t o = (size_t)y * cols + x;
       float a = st->a[o], b = st->b[o], z = st->z[o], c = st->cost[o];
       /* the neighbour's plane evaluated at this pixel: z_n + a_n*(x - x_n) + b_n*(y - y_n) */
-      if (x > 0) offer(p, im, x, y, st->a[o - 1], st->b[o - 1], st->z[o - 1] + st->a[o - 1], &a, &b, &z, &c);
-      if (x < cols - 1) offer(p, im, x, y, st->a[o + 1], st->b[o + 1], st->z[o + 1] - st->a[o + 1], &a, &b, &z, &c);
-      if (y > 0) offer(p, im, x, y, st->a[o - cols], st->b[o - cols], st->z[o - cols] + st->b[o - cols], &a, &b, &z, &c);
-      if (y < rows - 1)
+      if (lu && x > 0) offer(p, im, x, y, st->a[o - 1], st->b[o - 1], st->z[o - 1] + st->a[o - 1], &a, &b, &z, &c);
+      if (rd && x < cols - 1) offer(p, im, x, y, st->a[o + 1], st->b[o + 1], st->z[o + 1] - st->a[o + 1], &a, &b, &z, &c);
+      if (lu && y > 0) offer(p, im, x, y, st->a[o - cols], st->b[o - cols], st->z[o - cols] + st->b[o - cols], &a, &b, &z, &c);
+      if (rd && y < rows - 1)
         offer(p, im, x, y, st->a[o + cols], st->b[o + cols], st->z[o + cols] - st->b[o + cols], &a, &b, &z, &c);
       st->a[o] = a;
       st->b[o] = b;
@@ -330,7 +334,7 @@ void pmo_planes_match(const pmo_planes_params* p, const uint8_t* left, const uin
   for (int v = 0; v < nv; ++v) pmo_planes_init(p, &im[v], v, v == 0 ? seed_l : seed_rm, &st[v]);
   for (int it = 0; it < p->n_iters; ++it) {
     for (int par = 0; par < 2; ++par)
-      for (int v = 0; v < nv; ++v) pmo_planes_spatial(p, &im[v], &st[v], par);
+      for (int v = 0; v < nv; ++v) pmo_planes_spatial(p, &im[v], &st[v], par + 2 * it);
     /* per view: candidates from the other view, then the view's own random refinement */
     for (int v = 0; v < nv; ++v) {
       if (nv == 2) pmo_planes_view_prop(p, &im[v], &st[v], &st[1 - v]);

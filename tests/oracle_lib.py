@@ -511,11 +511,12 @@ class PlanesParams(C.Structure):
         ("slope_max", C.c_float), ("slope_init", C.c_float), ("slope_per_disp", C.c_float),
         ("alpha", C.c_float), ("tau_color", C.c_float), ("tau_grad", C.c_float),
         ("seed", C.c_uint64), ("left_right_check", C.c_int), ("lr_tol", C.c_float), ("state_f16", C.c_int),
-        ("nthreads", C.c_int), ("window", C.c_int),
+        ("nthreads", C.c_int), ("window", C.c_int), ("neighbours", C.c_int),
     ]
 
 
 PL_WINDOW_FULL, PL_WINDOW_CHECKER, PL_WINDOW_EVEN_COLS = 0, 1, 2
+PL_NEIGH_FOUR, PL_NEIGH_TWO = 0, 1
 
 
 class PlanesView(C.Structure):

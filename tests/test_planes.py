@@ -26,7 +26,7 @@ def okw(pm_params):
                 tau_color=pm_params.functor_tau_color, tau_grad=pm_params.functor_tau_grad,
                 seed=pm_params.noise_seed, left_right_check=pm_params.left_right_check,
                 lr_tol=pm_params.plane_lr_tol, state_f16=pm_params.state_dtype, window=pm_params.plane_window,
-                nthreads=8)
+                neighbours=pm_params.plane_neighbours, nthreads=8)
 
 
 def pparams(pm, patch=11, iters=2, f16=0, **kw):
@@ -114,6 +114,42 @@ def test_definition_recovers_the_synthetic_truth_and_f16_costs_little(oracle, sy
     assert_same(a[0], b[0], "threads")
 
 
+def test_two_neighbour_option_of_the_spatial_stage(oracle, synth):
+    """PMO_PL_NEIGH_TWO: the colour passes of an even iteration offer the left and the upper neighbour only, those of an odd
+    iteration the right and the lower one.  A zero-cost plane planted in ONE pixel of an otherwise bad field travels
+    accordingly; the whole Match keeps the quality bar of the definition (>= 97 % of the valid pixels within 1 px here)."""
+    rng = np.random.default_rng(5)
+    right = rng.integers(0, 256, (40, 120), dtype=np.uint8)
+    left = np.roll(right, 7, axis=1)  # the true plane everywhere: (0, 0, 7)
+    for neighbours in (oracle.PL_NEIGH_FOUR, oracle.PL_NEIGH_TWO):
+        for it in (0, 1):
+            v = oracle.PlanesViews(left, right)
+            prm = oracle.planes_params(patch=5, neighbours=neighbours, nthreads=1)
+            a, b, z, c = v.planes[0]
+            a[:], b[:] = 0.0, 0.0
+            z[:] = 3.0                        # a wrong plane everywhere ...
+            for y in range(40):
+                for x in range(120):
+                    c[y, x] = v.cost(prm, 0, x, y, 0.0, 0.0, 3.0)
+            y0, x0 = 20, 60                   # ... except one pixel (x0 + y0 even: colour 0)
+            z[y0, x0] = 7.0
+            c[y0, x0] = v.cost(prm, 0, x0, y0, 0.0, 0.0, 7.0)
+            assert c[y0, x0] == 0.0
+            v.spatial(prm, 0, 1 + 2 * it)     # the pass of the OTHER colour: the four neighbours of (x0, y0) may adopt
+            got = {(dx, dy): float(z[y0 + dy, x0 + dx]) == 7.0 for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1))}
+            if neighbours == oracle.PL_NEIGH_FOUR:
+                assert all(got.values()), (neighbours, it, got)
+            elif it == 0:  # left + up are offered: the pixels to the RIGHT of and BELOW the planted one see it
+                assert got == {(1, 0): True, (-1, 0): False, (0, 1): True, (0, -1): False}, got
+            else:
+                assert got == {(1, 0): False, (-1, 0): True, (0, 1): False, (0, -1): True}, got
+    p = synth.make_pair(3, 120, 240)
+    prm = oracle.planes_params(n_iters=6, nthreads=8, neighbours=oracle.PL_NEIGH_TWO)
+    dl, _ = oracle.planes_match(prm, p["left"], p["right"])
+    ok = dl > 0
+    assert ok.mean() > 0.5 and (np.abs(dl - p["gt"])[ok] < 1).mean() >= 0.97
+
+
 def test_golden_planes_fixture(oracle):
     import os
     from conftest import GOLDEN
@@ -138,15 +174,16 @@ def dev_pair(pair_list):
 
 
 @gpu
-@pytest.mark.parametrize("window", [1, 0])
+@pytest.mark.parametrize("window,neighbours", [(1, 0), (0, 0), (1, 1)])  # (1, 0) = the defaults
 @pytest.mark.parametrize("f16", [0, 1])
 @pytest.mark.parametrize("seeded", [False, True])
-def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded, window):
+def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded, window, neighbours):
     """NS-1 random plane initialisation, NS-2 red-black propagation, NS-3 view propagation, NS-4 refinement -- on the
-    checkerboard window (the mode's default) and on the full one."""
+    checkerboard window (the mode's default) and on the full one, and with the spatial stage's two-neighbour option
+    (left + up in the passes of an even iteration, right + down in those of an odd one)."""
     import torch
     p = synth.make_pair(11, ROWS, COLS, n_points=30, dilate_factor=2)
-    prm = pparams(pm, iters=2, f16=f16, max_disp=48, plane_window=window)
+    prm = pparams(pm, iters=2, f16=f16, max_disp=48, plane_window=window, plane_neighbours=neighbours)
     op = oracle.planes_params(**okw(prm))
     L, R, SL, SR = dev_pair([p])
     ov = oracle.PlanesViews(p["left"], p["right"])
@@ -170,9 +207,9 @@ def test_each_stage_matches_the_definition(pm, oracle, synth, f16, seeded, windo
         check(e, "init")
         for it in range(2):
             for par in (0, 1):
-                e.planes_step(pm.PM_PL_SPATIAL, par)
+                e.planes_step(pm.PM_PL_SPATIAL, par + 2 * it)
                 for v in range(2):
-                    ov.spatial(op, v, par)
+                    ov.spatial(op, v, par + 2 * it)
                 check(e, f"spatial it {it} colour {par}")
             if it == 0:  # the two stages on their own ...
                 for v in range(2):
@@ -237,12 +274,12 @@ def test_stages_on_injected_adversarial_planes(pm, oracle, synth):
 
 
 @gpu
-@pytest.mark.parametrize("window", [1, 0])  # PM_PL_WINDOW_CHECKER (the default), PM_PL_WINDOW_FULL
+@pytest.mark.parametrize("window,neighbours", [(1, 0), (0, 0), (1, 1)])  # checkerboard + four neighbours = the defaults
 @pytest.mark.parametrize("f16", [0, 1])
 @pytest.mark.parametrize("patch,max_disp", [(11, 64), (7, 32), (5, 128), (3, 16), (15, 40), (11, 300)])  # 300: > 64 KB of LDS
-def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp, window):
+def test_match_equals_the_definition(pm, oracle, synth, f16, patch, max_disp, window, neighbours):
     p = synth.make_pair(20 + patch, ROWS, COLS)
-    prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp, plane_window=window)
+    prm = pparams(pm, patch=patch, iters=3, f16=f16, max_disp=max_disp, plane_window=window, plane_neighbours=neighbours)
     want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"])
     with pm.Engine(prm, max_rows=ROWS, max_cols=COLS) as e:
         got = e.match(p["left"], p["right"])

@@ -35,7 +35,7 @@ for case in range(a.cases):
               plane_refine_steps=int(rng.integers(1, 6)), plane_slope_max=float(rng.choice([0.25, 0.5, 1.0])),
               plane_slope_init=float(rng.choice([0.0, 0.25, 0.5])), plane_slope_per_disp=float(rng.choice([1 / 64, 0.03])),
               plane_lr_tol=float(rng.choice([0.5, 1.0, 2.0])), noise_seed=int(rng.integers(1, 1 << 30)),
-              plane_window=int(rng.integers(0, 2)))
+              plane_window=int(rng.integers(0, 2)), plane_neighbours=int(rng.integers(0, 2)))
     kw["plane_slope_init"] = min(kw["plane_slope_init"], kw["plane_slope_max"])
     prm = pm.default_params(0, patch=patch, patchmatch_iters=iters, mode=pm.PM_MODE_PLANES, state_dtype=f16, **kw)
     p = synth.make_pair(int(rng.integers(0, 1000)), rows=rows, cols=cols, n_points=int(rng.integers(3, 40)),
@@ -46,7 +46,7 @@ for case in range(a.cases):
     with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
         got = e.match(p["left"], p["right"], sl, sr)
     ok = np.array_equal(got[0], want[0]) and (not lr or np.array_equal(got[1], want[1]))
-    print(f"case {case:3d}: {cols}x{rows} patch {patch} window {kw['plane_window']} iters {iters} max_disp {max_disp} f16 {f16} lr {lr} seeded {int(seeded)} "
+    print(f"case {case:3d}: {cols}x{rows} patch {patch} window {kw['plane_window']} neigh {kw['plane_neighbours']} iters {iters} max_disp {max_disp} f16 {f16} lr {lr} seeded {int(seeded)} "
           f"{'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
     if not ok:
         print("params:", kw)

@@ -13,7 +13,7 @@ print("host_buffers", json.dumps(j.get("host_buffers"), indent=None)[:1500])
 print("sequence_device", j.get("sequence_device"))
 print("batch", {k:(round(v["value"],1)) for k,v in j.get("batch",{}).items()})
 print("reference_test_shape", j.get("reference_test_shape"))
-print("planes", {k:(round(v["value"],1) if isinstance(v,dict) and "value" in v else None) for k,v in j.get("planes",{}).items()})
+print("planes", {k:((round(v["value"],1), v.get("check",{}).get("foreground_within_1px_of_truth")) if isinstance(v,dict) and "value" in v else None) for k,v in j.get("planes",{}).items()})
 t = j.get("tiled_4096x2160", {})
 print("tiled", t.get("ms_per_frame"), (t.get("eight_bands_on_this_device") or {}).get("ms_per_frame"), t.get("error"))
 print("cpu_baseline", j.get("cpu_baseline",{}).get("value"), j.get("cpu_baseline",{}).get("all_cores",{}).get("value"))
