@@ -22,6 +22,42 @@ def test_band_partition_cpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("band_rows", [37, 40, 41, 43])  # the state planes keep four rows interleaved: every remainder
+def test_boundary_row_get_and_set(pm, synth, band_rows):
+    """pm_tile_get_row / pm_tile_set_row: image row r of every view as a tight [n_views][cols] buffer -- after the
+    band's seeds went in, a row reads back as the seed maps' row (view 1 mirrored); a row written is the row read."""
+    import torch
+    cols = 150
+    l, r, sl, sr, _ = small_pair(synth, 90, band_rows, cols, n_points=40, dilate_factor=3)
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    L, R, SL, SR = up(l), up(r), up(sl), up(sr)
+    params = pm.default_params(0, patch=5, patchmatch_iters=1)
+    row0 = 0  # the top band of a taller image: its owned rows and the halo below them
+    tile = pm.PmTile(band_rows + 100, 0, 0, band_rows - 5 // 2 - 1)
+    with pm.Engine(params, max_rows=band_rows, max_cols=cols) as e:
+        e.tile_begin(tile, L.data_ptr(), R.data_ptr(), band_rows, cols, SL.data_ptr(), SR.data_ptr())
+        buf = torch.empty((2, cols), dtype=torch.float32, device=dev)
+        for rr in (0, 1, 2, 3, band_rows // 2, band_rows - 2, band_rows - 1):
+            e.tile_get_row(row0 + rr, buf.data_ptr())
+            e.synchronize()
+            got = buf.cpu().numpy()
+            assert_same(got[0], sl[rr], f"view 0 row {rr}")
+            assert_same(got[1], sr[rr, ::-1], f"view 1 row {rr} (mirrored)")
+        rng = np.random.default_rng(band_rows)
+        for rr in (1, band_rows - 1):
+            new = rng.uniform(0, 40, (2, cols)).astype(np.float32)
+            e.tile_set_row(row0 + rr, up(new).data_ptr())
+            e.tile_get_row(row0 + rr, buf.data_ptr())
+            e.synchronize()
+            assert_same(buf.cpu().numpy(), new, f"row {rr} written and read")
+            # the rows beside it are untouched
+            e.tile_get_row(row0 + rr - 1, buf.data_ptr())
+            e.synchronize()
+            assert_same(buf.cpu().numpy()[0], sl[rr - 1], f"row {rr - 1} beside a written row")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sem,patch,world,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 2), (0, 3, 7, 0),
                                                     (0, 5, 4, 1), (0, 5, 2, 2), (1, 3, 2, 2)])
 def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world, rounds):
