@@ -154,7 +154,7 @@ def test_remove_background_and_mask_occlusions(pm, oracle, synth):
 # ---- the whole path ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("sem", SEMS)
 @pytest.mark.parametrize("engine", ENGINES)
-@pytest.mark.parametrize("rows,cols", [(48, 80), (67, 131), (120, 188)])
+@pytest.mark.parametrize("rows,cols", [(48, 80), (67, 131), (120, 188), (61, 99), (62, 100)])  # rows: every remainder mod 4
 def test_match_both_views(pm, oracle, synth, sem, engine, rows, cols):
     l, r, sl, sr, _ = small_pair(synth, rows, rows, cols, n_points=40, dilate_factor=2)
     with mk(pm, sem, engine, patch=5, iters=3, rows=rows, cols=cols) as e:
