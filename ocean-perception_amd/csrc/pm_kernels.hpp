@@ -446,11 +446,13 @@ __global__ void __launch_bounds__(256) k_noise_cost_tiled(PlaneSet ps, CostParam
   float d = 0.f;
   bool was_zero = false;
   if (inimg) {
+    // (the unit noise is loaded beside the disparity, not behind it: one memory latency instead of two)
+    const float unit = amount >= 0.f ? ps.noise[(size_t)y * pitch + x] : 0.f;
     d = v.disp[o];
     was_zero = !(d > 0.f);
     if (amount >= 0.f) {
       if (d > 0.f) {
-        const float m = ps.noise[(size_t)y * pitch + x] * amount;
+        const float m = unit * amount;
         const float s = m + d;
         d = s > 0.f ? s : 0.f;
       } else {
