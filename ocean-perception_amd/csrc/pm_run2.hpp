@@ -114,14 +114,33 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   const int nseg = kPerWave * nw;
   const int sidx = kPerWave * w + lane / GS;
   constexpr int nd = GS - 2;
-  for (int k = threadIdx.x; k <= n; k += blockDim.x) {
-    const size_t o = chain_at(AXIS, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
-    const float d = v.disp[o];
-    const float cc = k > 0 ? v.cost[o] : 0.f;
-    din[k] = d;
-    cin[k] = cc;
-    dout[k] = d;
-    cout[k] = cc;
+  {
+    // the chain's state into LDS, four positions per thread in flight (one memory latency, not four in a row)
+    constexpr int U = 4;
+    const int bd = blockDim.x;
+    for (int k0 = threadIdx.x; k0 <= n; k0 += U * bd) {
+      float dd[U], cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * bd;
+        dd[u] = cc[u] = 0.f;
+        if (k <= n) {
+          const size_t o = chain_at(AXIS, chain, g.s_first + (k - 1) * g.dir, ps.pitch);
+          dd[u] = v.disp[o];
+          if (k > 0) cc[u] = v.cost[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * bd;
+        if (k <= n) {
+          din[k] = dd[u];
+          cin[k] = cc[u];
+          dout[k] = dd[u];
+          cout[k] = cc[u];
+        }
+      }
+    }
   }
   __syncthreads();
 
