@@ -190,52 +190,73 @@ __device__ __forceinline__ void transpose_block(const T* __restrict__ src, T* __
 }
 
 // Line-triple planes of the run engine (PlaneSet::rpg / cpg): built from the plain and the transposed planes once per
-// Match.  Block (bx, l, z) of a (ceil(len / 256), lines, B * 2) grid with z = b * 2 + view; `rows_mode` != 0: row triples (len = cols,
+// Match.  Block (bx, lg, z) of a (ceil(len / 256), ceil(lines / 4), B * 2) grid with z = b * 2 + view (a thread builds
+// the records of four consecutive lines from six loaded ones); `rows_mode` != 0: row triples (len = cols,
 // line = image row, source planes img8 / g32 with pitch), else column triples on the transposed planes (len = rows,
 // line = image column incl. the replicated pad columns, source timg8 / tg32 with pitch_t).
 // Lines beyond the last one repeat it (they are only ever the unused twelfth line of a window).
-__device__ __forceinline__ void triples_block(const PlaneSet& ps, int rows_mode, int bx, int l, int z) {
+constexpr int kLinesPerSetupThread = 4;  // a thread of the row-triple / quad sections builds this many consecutive lines
+__device__ __forceinline__ void triples_block(const PlaneSet& ps, int rows_mode, int bx, int lg, int z) {
   const int e = bx * blockDim.x + threadIdx.x;
   const int view = z & 1, b = z >> 1;
   const int itgt = view == 0 ? 1 : 2;
   const int len = rows_mode ? ps.cols : ps.rows, nl = rows_mode ? ps.nrl : ps.ncl;
-  if (e >= len || l >= nl) return;
+  const int l0 = lg * kLinesPerSetupThread;
+  if (e >= len || l0 >= nl) return;
   const int lmax = rows_mode ? ps.rows - 1 : ps.cols + kTransPad - 1;
   const size_t sp = rows_mode ? (size_t)ps.pitch : (size_t)ps.pitch_t;
   const size_t tp = ((size_t)b * 4 + itgt) * (rows_mode ? ps.plane : ps.plane_t);
   const float* g = (rows_mode ? ps.g32 : ps.tg32) + tp;
   const uint8_t* c = (rows_mode ? ps.img8 : ps.timg8) + tp;
-  const size_t s0 = (size_t)min(l, lmax) * sp + e, s1 = (size_t)min(l + 1, lmax) * sp + e,
-               s2 = (size_t)min(l + 2, lmax) * sp + e;
-  // one 16-byte record per element: three gradients and three colour bytes -- ONE aligned global_load_dwordx4 in the sweeps
-  float4 rec;
-  rec.x = g[s0];
-  rec.y = g[s1];
-  rec.z = g[s2];
-  rec.w = __builtin_bit_cast(float, (uint32_t)c[s0] | ((uint32_t)c[s1] << 8) | ((uint32_t)c[s2] << 16));
+  // lines l0 .. l0 + 5 once (a record holds three consecutive lines: four records share six lines)
+  float gv[kLinesPerSetupThread + 2];
+  uint32_t cv[kLinesPerSetupThread + 2];
+#pragma unroll
+  for (int k = 0; k < kLinesPerSetupThread + 2; ++k) {
+    const size_t so = (size_t)min(l0 + k, lmax) * sp + e;
+    gv[k] = g[so];
+    cv[k] = c[so];
+  }
   float4* dst = (float4*)(rows_mode ? ps.rpg : ps.cpg);
-  dst[((size_t)z * nl + l) * sp + e] = rec;
+#pragma unroll
+  for (int k = 0; k < kLinesPerSetupThread; ++k) {
+    if (l0 + k >= nl) break;
+    // one 16-byte record per element: three gradients and three colour bytes -- ONE aligned global_load_dwordx4 in the sweeps
+    float4 rec;
+    rec.x = gv[k];
+    rec.y = gv[k + 1];
+    rec.z = gv[k + 2];
+    rec.w = __builtin_bit_cast(float, cv[k] | (cv[k + 1] << 8) | (cv[k + 2] << 16));
+    dst[((size_t)z * nl + (l0 + k)) * sp + e] = rec;
+  }
 }
 
-// Reference quads of the row sweeps (PlaneSet::rqk).  Block (bx, l, z) of a (ceil(cols / 256), nrl, B * 2) grid, z = b * 2 + view.
-// Rows beyond the last one repeat it (only ever the unused twelfth row).
-__device__ __forceinline__ void quads_block(const PlaneSet& ps, int bx, int l, int z) {
+// Reference quads of the row sweeps (PlaneSet::rqk).  Block (bx, lg, z) of a (ceil(cols / 256), ceil(nrl / 4), B * 2) grid,
+// z = b * 2 + view: rows 4 lg .. 4 lg + 3.  Rows beyond the last one repeat it (only ever the unused twelfth row).
+__device__ __forceinline__ void quads_block(const PlaneSet& ps, int bx, int lg, int z) {
   const int e = bx * blockDim.x + threadIdx.x;
   const int view = z & 1, b = z >> 1;
-  if (e >= ps.cols || l >= ps.nrl) return;
+  const int l0 = lg * kLinesPerSetupThread;
+  if (e >= ps.cols || l0 >= ps.nrl) return;
   const int iref = view == 0 ? 0 : 3;
   const size_t rp = ((size_t)b * 4 + iref) * ps.plane;
-  uint32_t cw = 0u, gw = 0u;
+  uint32_t pk[kLinesPerSetupThread + 3];  // rows l0 .. l0 + 6 once (a quad holds four consecutive rows)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = min(l + j, ps.rows - 1);
-    const uint32_t pk = ps.pk16[rp + (size_t)row * ps.pitch + e];
-    cw |= (pk & 0xffu) << (8 * j);
-    gw |= (pk >> 8) << (8 * j);
+  for (int k = 0; k < kLinesPerSetupThread + 3; ++k)
+    pk[k] = ps.pk16[rp + (size_t)min(l0 + k, ps.rows - 1) * ps.pitch + e];
+#pragma unroll
+  for (int k = 0; k < kLinesPerSetupThread; ++k) {
+    if (l0 + k >= ps.nrl) break;
+    uint32_t cw = 0u, gw = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      cw |= (pk[k + j] & 0xffu) << (8 * j);
+      gw |= (pk[k + j] >> 8) << (8 * j);
+    }
+    const size_t dst = (((size_t)z * ps.nrl + (l0 + k)) * ps.pitch + e) * 2;
+    ps.rqk[dst] = cw;
+    ps.rqk[dst + 1] = gw;
   }
-  const size_t dst = (((size_t)z * ps.nrl + l) * ps.pitch + e) * 2;
-  ps.rqk[dst] = cw;
-  ps.rqk[dst + 1] = gw;
 }
 
 // Column triples (PlaneSet::cpg) straight from the ROW-MAJOR target planes, transposed through LDS: the same records
@@ -284,7 +305,7 @@ __device__ __forceinline__ void col_triples_tile(const PlaneSet& ps, int bx, int
 // k_prep's planes only.  One linear grid; a block finds its section and its (bx, by, bz) there from the section sizes.
 struct SetupGrid {
   unsigned tx, ty, tz;  // transpose sections: (ceil(cols/64), ceil(rows/64), B * 4) each
-  unsigned lx, ly, lz;  // row triples / quads: (ceil(cols/256), nrl, B * 2) each
+  unsigned lx, ly, lz;  // row triples / quads: (ceil(cols/256), ceil(nrl / kLinesPerSetupThread), B * 2) each
   unsigned cx, cy, cz;  // column triples: (ceil(ncl/32), ceil(rows/64), B * 2)
   int with_lines;       // 0: transposes only (PM_SEM_GPU, plane mode, anchor engines)
   int view;             // -1: both views (tz = B * 4, lz = cz = B * 2); 0 / 1: that view's planes only (tz = B * 2, lz = cz = B)

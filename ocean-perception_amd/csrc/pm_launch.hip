@@ -22,7 +22,7 @@ static SetupGrid setup_grid(pm_handle* h, const PlaneSet& ps, int n, int view) {
   sg.with_lines = pair_planes_wanted(h) ? 1 : 0;  // the line-triple / quad planes of the run engine (pm_run3.hpp)
   if (sg.with_lines) {
     sg.lx = (unsigned)((ps.cols + 255) / 256);
-    sg.ly = (unsigned)ps.nrl;
+    sg.ly = (unsigned)((ps.nrl + kLinesPerSetupThread - 1) / kLinesPerSetupThread);
     sg.lz = (unsigned)(n * (view < 0 ? 2 : 1));
     sg.cx = (unsigned)((ps.ncl + 31) / 32);
     sg.cy = (unsigned)((ps.rows + 63) / 64);
