@@ -778,17 +778,31 @@ __global__ void __launch_bounds__(256) k_background_tiled(PlaneSet ps, CostParam
   const int x = x0 + tx, y = y0 + ty, slot = blockIdx.z;
   const View v = make_view(ps, slot);
   const int cols = ps.cols, rows = ps.rows, pitch = ps.pitch;
-  const uint8_t* tgtg8 = v.refg8 + ((v.tgt8 - v.ref8));  // the g8 plane of the target image (same plane order as img8)
-
   const int ry0 = y0 - PH / 2, lx0 = x0 - PW / 2;
-  for (int e = tid; e < TR * LW; e += 256) {
-    const int rr = e / LW, cc = e - rr * LW;
-    const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
-    const size_t go = (size_t)gy * pitch + gx;
-    ((uint8_t*)s_w[0])[e] = v.ref8[go];
-    ((uint8_t*)s_w[1])[e] = v.refg8[go];
-    ((uint8_t*)s_w[2])[e] = v.tgt8[go];
-    ((uint8_t*)s_w[3])[e] = tgtg8[go];
+  {
+    // colour and gradient byte of a pixel in one u16 load (the packed planes), every load of a thread before its stores
+    const uint16_t* tgtpk = v.refpk + (v.tgt8 - v.ref8);  // the packed plane of the target image (same plane order)
+    constexpr int NE = (TR * LW + 255) / 256;
+    unsigned pr[NE], pt[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {  // (an element beyond the tile re-reads its last one: loaded, never stored)
+      const int e = min(tid + 256 * u, TR * LW - 1);
+      const int rr = e / LW, cc = e - rr * LW;
+      const int gy = min(max(ry0 + rr, 0), rows - 1), gx = min(max(lx0 + cc, 0), cols - 1);
+      const size_t go = (size_t)gy * pitch + gx;
+      pr[u] = v.refpk[go];
+      pt[u] = tgtpk[go];
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u;
+      if (e < TR * LW) {
+        ((uint8_t*)s_w[0])[e] = (uint8_t)(pr[u] & 0xffu);
+        ((uint8_t*)s_w[1])[e] = (uint8_t)(pr[u] >> 8);
+        ((uint8_t*)s_w[2])[e] = (uint8_t)(pt[u] & 0xffu);
+        ((uint8_t*)s_w[3])[e] = (uint8_t)(pt[u] >> 8);
+      }
+    }
   }
   __syncthreads();
   if (x < in.x_lo || x > in.x_hi || y < in.y_lo || y > in.y_hi) return;
