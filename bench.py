@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--enhance", action="store_true",
                     help="--mode planes: inputs are BGR images, the stereo-ready enhancement (pm_stereo_ready) of both "
                          "runs on the device in front of every Match (BASELINE configs[4])")
+    ap.add_argument("--plane-neighbours", type=int, choices=(0, 1), default=0,
+                    help="--mode planes: 1 = the spatial stage's two-neighbour option (PM_PL_NEIGH_TWO)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the plane-mode side legs of the default run")
     ap.add_argument("--tiled", action="store_true",
                     help="BASELINE configs[3]: one 4096x2160 pair row-tiled over the ranks (see python/tiled.py)")
@@ -159,16 +161,24 @@ def pmc_traffic(kernel_class):
         return None
 
 
-def pmc_valu(kernel_class, prof=None, n_prof=0):
+def pmc_valu(kernel_class, prof=None, n_prof=0, variant=""):
     """The issue-side roofs of the window kernels beside the HBM figure BASELINE.json asks for, from the committed
     rocprofv3 --pmc passes of this same command (profiles/valu.json, written by tools/make_valu.py from separate SQ /
     TA / TD runs; rocprofv3 serialises the launches, so the fractions are those of a kernel ALONE on the chip):
     issue_frac = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); ta / td_busy_frac = texture address / data
     unit busy cycles over 256 CUs x kernel cycles.  insts_per_step = vector instructions of one timed step: per-launch
-    counts of the profiled classes x this run's launches per step.  None if the file is missing."""
+    counts of the profiled classes x this run's launches per step.  `variant`: suffix of a kernel variant that has a PMC
+    pass of its OWN in the file (e.g. "@two_neighbours": the same kernel name executes about half the instructions);
+    classes the variant's pass did not cover, or a variant without a pass, give None -- counts measured on another
+    variant are never applied.  None if the file is missing."""
     try:
         with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
             t = json.load(f)
+        if variant:
+            have = {c[:-len(variant)]: v for c, v in t["kernels"].items() if c.endswith(variant)}
+            if prof and any(n and c.startswith("planes_") and c not in have for c, (n, _) in prof.items()):
+                return None
+            t = {"kernels": have}
         k = t["kernels"][kernel_class]
         out = {"issue_frac": k["valu_issue_frac"], "ta_busy_frac": k.get("ta_busy_frac"),
                "td_busy_frac": k.get("td_busy_frac"), "insts_valu_per_launch": k.get("insts_valu_per_launch"),
@@ -184,12 +194,12 @@ def pmc_valu(kernel_class, prof=None, n_prof=0):
 ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs, a wave64 op holds its SIMD 4 cycles
 
 
-def binding_roof(kernel_class, prof, n_prof, ms_per_step):
+def binding_roof(kernel_class, prof, n_prof, ms_per_step, variant=""):
     """What actually bounds the step, computed from THIS run's ms_per_step: the chip-level vector-issue fraction -- vector
     instructions of one step (per-launch counts of the committed PMC passes x this run's launches per step) x 4 cycles
     over (1024 SIMDs x clock x the step's wall time) -- beside the texture address / data unit occupancy of the dominant
     kernel (committed PMC passes: kernels alone on the chip; with both views' kernels running the units are shared)."""
-    v = pmc_valu(kernel_class, prof, n_prof)
+    v = pmc_valu(kernel_class, prof, n_prof, variant)
     if not v or not v.get("insts_per_step") or not ms_per_step:
         return None
     issue = v["insts_per_step"] * 4.0 / (1024.0 * ENGINE_CLOCK_GHZ * 1e9 * ms_per_step * 1e-3)
@@ -237,7 +247,7 @@ def cpu_baseline(args):
     prm_all = O.default_params(O.SEM_CPU, patch=args.patch, n_iters=args.iters, nthreads=nthr, literal=1,
                                left_right_check=1)
     t0 = time.perf_counter()
-    O.match(prm_all, p["left"], p["right"], p["seed_l"], p["seed_r"])
+    maps_all = O.match(prm_all, p["left"], p["right"], p["seed_l"], p["seed_r"])
     t_all = time.perf_counter() - t0
     what = (f"oracle (literal getRectSubPix+functor port, 1 thread: the reference CPU path has no threading), pair 0, both "
             f"views, {args.iters} iterations, {args.patch}x{args.patch}")
@@ -254,23 +264,41 @@ def cpu_baseline(args):
                                 f"(rows / columns of a sweep in parallel; the box's CPU share for one GPU is 16 cores "
                                 f"of {ncpu}): {t_all:.2f} s, unscaled"},
         "host_cores": ncpu,
+        # pair 0's maps of the all-cores run (whole frame): the checker of `check.equals_oracle_full_frame`; popped by
+        # main() before the line is printed
+        "_maps": maps_all,
     }
 
 
-def cpu_baseline_planes(args, f16):
-    """The plane mode's CPU definition (oracle/pm_planes_oracle.c) on all host cores, whole frame."""
+def cpu_baseline_planes(args, f16, neighbours=0):
+    """The plane mode's CPU definition (oracle/pm_planes_oracle.c) on all host cores, whole frame.  `_maps` = pair 0's
+    maps (the checker of `check.equals_oracle_full_frame`; popped before the line is printed)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     import synth
     p = synth.make_pair(0, args.rows, args.cols)
+    import pm_ctypes as pm
     nthr = min(os.cpu_count() or 1, 16)
-    prm = O.planes_params(n_iters=args.iters, patch=args.patch, nthreads=nthr, state_f16=1 if f16 else 0)
+    # the parameter struct the engine's plane legs run with (Workload), translated field by field
+    prm = O.planes_params(**O.planes_kwargs_of(pm.default_params(
+        0, patch=args.patch, patchmatch_iters=args.iters, mode=pm.PM_MODE_PLANES,
+        state_dtype=pm.PM_STATE_F16 if f16 else pm.PM_STATE_F32, plane_neighbours=neighbours), nthreads=nthr))
     t0 = time.perf_counter()
-    O.planes_match(prm, p["left"], p["right"])
+    maps = O.planes_match(prm, p["left"], p["right"])
     t = time.perf_counter() - t0
-    return {"value": 1.0 / t, "unit": "pairs/s", "cores": nthr, "kind": "port",
+    return {"_maps": maps, "value": 1.0 / t, "unit": "pairs/s", "cores": nthr, "kind": "port",
             "sample": f"oracle/pm_planes_oracle.c (this mode's own CPU definition; the reference has no slanted-plane "
                       f"code) on the whole {args.cols}x{args.rows} frame, {nthr} OpenMP threads: {t:.2f} s"}
+
+
+def equals_oracle(mine, theirs, what):
+    """Whole-frame comparison of the engine's maps of pair 0 with the oracle's (value equality of the float32 maps,
+    tolerance 0, as tests/conftest.py::assert_same); the reference pattern it stands in for is the whole-image recipe of
+    test/stereo_matching/patchmatch_test.cpp:149-183 (which asserts nothing)."""
+    import numpy as np
+    nl, nr = int((mine[0] != theirs[0]).sum()), int((mine[1] != theirs[1]).sum())
+    return {"left": nl == 0, "right": nr == 0, "differing_pixels": nl + nr, "pixels_compared": int(mine[0].size + mine[1].size),
+            "tolerance": 0, "checker": what}
 
 
 def host_buffer_leg(pm, args, pairs, device):
@@ -401,6 +429,10 @@ def batch_leg(pm, torch, np, synth, args, dev, device, nb, steps):
     w.eng.synchronize()
     dt = time.perf_counter() - t0
     q = w.quality()
+    # every slot holds ITS pair's map: slots repeat the group's distinct pairs with period min(nb, 4)
+    per = min(nb, 4)
+    q["slots_equal_their_pairs_first_slot"] = bool(all(torch.equal(w.DL[i], w.DL[i % per]) for i in range(nb)))
+    q["passes"] = bool(q["foreground_within_1px_of_truth"] >= 0.95 and q["slots_equal_their_pairs_first_slot"])
     w.eng.close()
     return {"pairs_per_call": nb, "calls": steps, "value": nb * steps / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / steps / nb,
             "check": q, "note": "one pm_match_device call per batch: chunks of two pairs one after the other on the "
@@ -471,7 +503,8 @@ class Workload:
         self.R = [stack(g, "right") for g in groups]
         self.SL = [stack(g, "seed_l") for g in groups]
         self.SR = [stack(g, "seed_r") for g in groups]
-        self.gt0 = torch.from_numpy(groups[0][0]["gt"]).to(dev)
+        self.gt = [torch.from_numpy(g[0]["gt"]).to(dev) for g in groups]  # truth of slot 0 of every group
+        self.last_g = 0
         self.DL = torch.empty((nb, args.rows, args.cols), dtype=torch.float32, device=dev)
         self.DR = torch.empty_like(self.DL)
         if mode == "planes":
@@ -490,6 +523,7 @@ class Workload:
 
     def step(self, s):
         a, e, g = self.args, self.eng, s % N_ROTATE
+        self.last_g = g
         seeded = self.mode == "scalar" and not a.self_seed
         if self.enhance:
             # BGR inputs: pm_match_bgr_device -- per image the two Gaussian passes and two small min / max passes, the
@@ -502,15 +536,22 @@ class Workload:
                        self.SR[g].data_ptr() if seeded else None, self.DL.data_ptr(), self.DR.data_ptr())
 
     def quality(self):
+        """Slot 0 of the group the LAST step matched, against that pair's own synthetic truth."""
+        self.eng.synchronize()
         d = self.DL[0]
         ok = d > 0
         fg = float(ok.float().mean().item())
-        err = (d - self.gt0).abs()
-        return {"foreground_fraction": fg,
+        err = (d - self.gt[self.last_g]).abs()
+        return {"foreground_fraction": fg, "pair": "slot 0 of group %d (the last step's)" % self.last_g,
                 "foreground_within_1px_of_truth": float((err[ok] < 1.0).float().mean().item()) if fg > 0 else 0.0}
 
+    def maps0(self):
+        """Host copies of slot 0's maps (call after step(0): pair 0 of this rank)."""
+        self.eng.synchronize()
+        return self.DL[0].cpu().numpy(), self.DR[0].cpu().numpy()
 
-def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None):
+
+def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None, variant=""):
     px_views = args.rows * args.cols * 2 * nb
     if mode == "planes":
         dom = max(PLANE_LAUNCH_BYTES, key=lambda k: prof.get(k, (0, 0.0))[1])
@@ -520,10 +561,11 @@ def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None):
         bytes_per_launch = PLANE_LAUNCH_BYTES[dom] * scale * args.rows * args.cols * nb * PLANE_LAUNCH_VIEWS[dom]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (nb == 1 and state == "f32") else None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom + variant) if (nb == 1 and state == "f32") else None,
                 "traffic_source": "profiles/traffic.json" if (nb == 1 and state == "f32") else None,
-                "valu": pmc_valu(dom, prof, n_prof) if (nb == 1 and state == "f32") else None,
-                "binding": binding_roof(dom, prof, n_prof, ms_per_step) if (nb == 1 and state == "f32") else None,
+                "valu": pmc_valu(dom, prof, n_prof, variant) if (nb == 1 and state == "f32") else None,
+                "binding": binding_roof(dom, prof, n_prof, ms_per_step, variant) if (nb == 1 and state == "f32") else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "profiled_steps": n_prof,
                 "formula": "N * (74 + 320 * I) B per pair, plane state; stage bytes per px and view: spatial 48 (two "
@@ -613,7 +655,8 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
     elapsed, prof, n_prof, step_stats = timed_loop(w, NoDist(), steps, 6, 4, False)
     w.step(0)
     w.eng.synchronize()
-    out = {"workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
+    variant = "@two_neighbours" if plane_neighbours else ""
+    out = {"_maps": None if enhance else w.maps0(), "workload": f"PM_MODE_PLANES, {args.cols}x{args.rows}, {args.iters} iterations, {args.patch}x{args.patch}, "
                        f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images fused into the "
                                                       "Match's load path (pm_match_bgr_device; BASELINE configs[4] per-GPU shape)" if enhance
                                                       else " (BASELINE configs[1] shape)") +
@@ -621,7 +664,7 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
            "step_ms": step_stats,
            "dtype": "u8 window cost, " + state + " state",
-           "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state, 1e3 * elapsed / steps),
+           "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state, 1e3 * elapsed / steps, variant),
            "kernels_ms_per_step": {k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
            "check": w.quality()}
     w.eng.close()
@@ -815,7 +858,8 @@ def main():
 
     torch.cuda.set_device(d.local_rank)
     dev = torch.device(f"cuda:{d.local_rank}")
-    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, args.mode, args.state, args.enhance)
+    w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, args.mode, args.state, args.enhance,
+                 args.plane_neighbours if planes else 0)
     eng = w.eng
     elapsed, prof, n_prof, step_stats = timed_loop(w, d, steps, warmup, max(1, args.profile_every), args.no_profile)
 
@@ -837,6 +881,8 @@ def main():
     deterministic = bool(torch.equal(ref, w.DL[0]))
     check = w.quality()
     check["deterministic_across_steps"] = deterministic
+    # pair 0's maps (rank 0: synth pair 0, the pair the CPU baselines run) for the whole-frame comparison below
+    maps0 = w.maps0() if (d.rank == 0 and not args.enhance and not args.self_seed) else None
 
     if d.rank == 0:
         gpu_ms = sum(v[1] for v in prof.values())
@@ -844,7 +890,8 @@ def main():
             value=d.world * nb * steps / elapsed, ms_per_step=1e3 * elapsed / steps,
             ms_per_frame=1e3 * elapsed / steps / nb,
             step_ms=step_stats,
-            roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state, 1e3 * elapsed / steps) if n_prof else None,
+            roofline=roofline_of(args, prof, n_prof, nb, args.mode, args.state, 1e3 * elapsed / steps,
+                                 "@two_neighbours" if planes and args.plane_neighbours else "") if n_prof else None,
             kernels_ms_per_step={k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
             gpu_busy_ms_per_step=gpu_ms / max(n_prof, 1),
             check=check,
@@ -886,10 +933,31 @@ def main():
             result["planes"] = {"f32": side_leg(args, pm, torch, np, synth, dev, d, "f32", False),
                                 "f16_enhanced": side_leg(args, pm, torch, np, synth, dev, d, "f16", True),
                                 "f32_two_neighbours": side_leg(args, pm, torch, np, synth, dev, d, "f32", False, 1)}
+        plane_maps = {k: v.pop("_maps", None) for k, v in result.get("planes", {}).items()}
         if d.world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_planes(args, args.state == "f16") if planes else cpu_baseline(args)
+            # the CPU baselines run the oracle on the WHOLE frame of pair 0 anyway: their maps are the checker of the
+            # engine's maps of the same pair (tolerance 0) -- the whole-image recipe of patchmatch_test.cpp:149-183
+            if planes:
+                cb = cpu_baseline_planes(args, args.state == "f16", args.plane_neighbours)
+                if maps0 is not None:
+                    result["check"]["equals_oracle_full_frame"] = equals_oracle(
+                        maps0, cb["_maps"], "oracle/pm_planes_oracle.c (this mode's CPU definition), whole frame")
+            else:
+                cb = cpu_baseline(args)
+                if maps0 is not None and args.semantics == 0:
+                    result["check"]["equals_oracle_full_frame"] = equals_oracle(
+                        maps0, cb["_maps"], "oracle/pm_oracle.c (PM_SEM_CPU, literal getRectSubPix + functor form, "
+                                            "%d threads), whole frame" % cb["all_cores"]["cores"])
+            cb.pop("_maps", None)
+            result["cpu_baseline"] = cb
             if not planes and "planes" in result:
-                result["planes"]["cpu_baseline"] = cpu_baseline_planes(args, False)
+                for leg, neigh in (("f32", 0), ("f32_two_neighbours", 1)):
+                    pb = cpu_baseline_planes(args, False, neigh)
+                    if plane_maps.get(leg) is not None:
+                        result["planes"][leg]["check"]["equals_oracle_full_frame"] = equals_oracle(
+                            plane_maps[leg], pb["_maps"], "oracle/pm_planes_oracle.c (this mode's CPU definition), whole frame")
+                    pb.pop("_maps", None)
+                    result["planes"]["cpu_baseline" if neigh == 0 else "cpu_baseline_two_neighbours"] = pb
         print(json.dumps(result), flush=True)
     d.close()
 

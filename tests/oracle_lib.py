@@ -568,6 +568,18 @@ def planes_params(**kw):
     return p
 
 
+def planes_kwargs_of(pm_params, nthreads=8):
+    """The engine's parameter struct (pm_params of include/pm/patchmatch.h, ctypes) -> keyword arguments of
+    planes_params(): the SAME plane-mode configuration for the CPU definition."""
+    q = pm_params
+    return dict(n_iters=q.patchmatch_iters, patch=q.patch_w[0], max_disp=q.max_disp, refine_steps=q.plane_refine_steps,
+                refine_amp=[q.noise_amp[i] for i in range(16)], slope_max=q.plane_slope_max,
+                slope_init=q.plane_slope_init, slope_per_disp=q.plane_slope_per_disp, alpha=q.functor_alpha,
+                tau_color=q.functor_tau_color, tau_grad=q.functor_tau_grad, seed=q.noise_seed,
+                left_right_check=q.left_right_check, lr_tol=q.plane_lr_tol, state_f16=q.state_dtype,
+                window=q.plane_window, neighbours=q.plane_neighbours, nthreads=nthreads)
+
+
 def planes_rand(seed, stage, it, k, view, draw, x, y):
     return int(_planes_lib().pmo_planes_rand(seed, stage, it, k, view, draw, x, y))
 

@@ -773,6 +773,25 @@ def test_full_size_baseline_config_properties(pm, oracle, synth):
     assert_same(bdr, er, "64-row band at full width, right")
 
 
+def test_full_size_headline_whole_frame_equals_oracle(pm, oracle, synth):
+    """BASELINE.json configs[1], the benchmarked configuration, WHOLE frame against the oracle: 1280x720, 8 iterations,
+    11x11, PM_SEM_CPU, both views + cross-check, tolerance 0.  The oracle runs its literal form (getRectSubPix patches +
+    the test's functor, patchmatch.cpp:158-196 / patchmatch_test.cpp:30-45) on all host cores: rows / columns of a sweep
+    are independent chains, so the thread count does not change the result (test_oracle_algorithm.py).  The reference
+    pattern: the whole-image recipe of patchmatch_test.cpp:149-183."""
+    import os
+    rows, cols, patch, iters = 720, 1280, 11, 8
+    p = synth.make_pair(0, rows, cols)
+    l, r, sl, sr = p["left"], p["right"], p["seed_l"], p["seed_r"]
+    with mk(pm, 0, 0, patch=patch, iters=iters, rows=rows, cols=cols) as e:   # the engine bench.py runs
+        dl, dr = e.match(l, r, sl, sr)
+    op = oracle.default_params(0, patch=patch, n_iters=iters, left_right_check=1, literal=1,
+                               nthreads=min(os.cpu_count() or 1, 16))
+    el, er = oracle.match(op, l, r, sl, sr)
+    assert_same(dl, el, "whole 1280x720 frame, left")
+    assert_same(dr, er, "whole 1280x720 frame, right")
+
+
 def test_full_size_batch_of_32_pairs(pm, oracle, synth):
     """BASELINE configs[2]'s per-GPU share: 32 slots of 1280x720 (8 iterations, 11x11) in ONE pm_match_device call.
     Every slot of the default engine must equal the serial anchor's map of its pair, and a 64-row band of one of the

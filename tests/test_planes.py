@@ -18,15 +18,8 @@ ROWS, COLS = 72, 200  # not multiples of the 8 x 32 / 8 x 64 tiles
 
 def okw(pm_params):
     """pm_params (ctypes) -> keyword arguments of the oracle's parameter struct."""
-    it = pm_params.patchmatch_iters
-    return dict(n_iters=it, patch=pm_params.patch_w[0], max_disp=pm_params.max_disp,
-                refine_steps=pm_params.plane_refine_steps, refine_amp=[pm_params.noise_amp[i] for i in range(16)],
-                slope_max=pm_params.plane_slope_max, slope_init=pm_params.plane_slope_init,
-                slope_per_disp=pm_params.plane_slope_per_disp, alpha=pm_params.functor_alpha,
-                tau_color=pm_params.functor_tau_color, tau_grad=pm_params.functor_tau_grad,
-                seed=pm_params.noise_seed, left_right_check=pm_params.left_right_check,
-                lr_tol=pm_params.plane_lr_tol, state_f16=pm_params.state_dtype, window=pm_params.plane_window,
-                neighbours=pm_params.plane_neighbours, nthreads=8)
+    import oracle_lib
+    return oracle_lib.planes_kwargs_of(pm_params, nthreads=8)
 
 
 def pparams(pm, patch=11, iters=2, f16=0, **kw):
@@ -425,6 +418,30 @@ def test_full_size_properties(pm, oracle, synth, f16):
     drs = np.take_along_axis(dr, xt, axis=1)
     keep = np.abs(z0 - drs) <= 1.0
     assert_same(dl, np.where(keep, z0, 0).astype(np.float32), "consistency mask")
+
+
+@gpu
+@pytest.mark.parametrize("f16", [0, 1])
+def test_full_size_whole_frame_equals_the_definition(pm, oracle, synth, f16):
+    """1280x720, 8 iterations, 11x11 (the shape of bench.py's plane legs), WHOLE frame, both maps, tolerance 0 against
+    oracle/pm_planes_oracle.c on all host cores (the definition is per-pixel parallel by construction: its result does
+    not depend on the thread count, tested above)."""
+    import os
+    import torch
+    rows, cols = 720, 1280
+    p = synth.make_pair(0, rows, cols)
+    prm = pparams(pm, iters=8, f16=f16)
+    L, R, _, _ = dev_pair([p])
+    DL = torch.empty((1, rows, cols), dtype=torch.float32, device=L.device)
+    DR = torch.empty_like(DL)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
+        e.match_device(1, L.data_ptr(), R.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+        e.synchronize()
+    kw = okw(prm)
+    kw["nthreads"] = min(os.cpu_count() or 1, 16)
+    el, er = oracle.planes_match(oracle.planes_params(**kw), p["left"], p["right"])
+    assert_same(DL[0].cpu().numpy(), el, "whole frame, left map")
+    assert_same(DR[0].cpu().numpy(), er, "whole frame, right map")
 
 
 @gpu
