@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 5
+#define PM_ABI_VERSION 6
 #define PM_MAX_ITERS 16
 #define PM_MAX_PATCH 15 /* largest supported window side (odd) */
 
@@ -154,7 +154,22 @@ typedef struct pm_params {
   float plane_lr_tol;             /* 1.0   |dl - dr| above which the left disparity is zeroed             */
   int plane_window;               /* 1     pm_plane_window: which taps of the window count                        */
   int plane_neighbours;           /* 0     pm_plane_neighbours: the spatial stage's candidates                    */
+
+  /* --- how the handle sits in the host process (ABI 6; no reference counterpart: the reference runs everything on the
+   * default stream with device-wide synchronisation, patchmatch_gpu.cu:396-410) ---------------------------------- */
+  int stream_priority;            /* 1     pm_stream_priority: the class of the handle's four streams              */
+  int small_image_graph;          /* 1     pm_match_u8 replays a recorded HIP graph for images up to 384 Ki pixels
+                                           (the reference's own 376x240 test shape is bound by launch submission);
+                                           0 = always launch kernel by kernel                                      */
 } pm_params;
+/* The priority class ALL streams of a handle are created in.  HIGH (default): not for the priority but because streams
+ * of different classes never share a hardware queue, which keeps the matcher's two view streams off the queues of
+ * whatever else the process creates (a framework's side streams, RCCL) -- measured 384 -> 275 pairs/s when both views
+ * land on one queue.  The price: the matcher's kernels are scheduled AHEAD of the host application's default-class work.
+ * An application that must keep its own kernels in front picks DEFAULT (the matcher then shares the default class's four
+ * queues with the application's streams; its rate depends on what else owns queues) or LOW (a class of its own again,
+ * behind everything else). */
+typedef enum pm_stream_priority { PM_STREAM_PRIO_LOW = -1, PM_STREAM_PRIO_DEFAULT = 0, PM_STREAM_PRIO_HIGH = 1 } pm_stream_priority;
 /* PM_MODE_PLANES window.  CHECKER (default since ABI 5): tap (i, j) counts iff i + j is even -- the centre and every other
  * tap in both directions, 61 of 121 for 11 x 11; the mean divides by the taps that count.  Half the arithmetic of the
  * full window at the same quality on the benchmark pairs (99.86 % of the valid pixels within 1 px either way). */
@@ -202,8 +217,10 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
  * through pm_host_alloc / pm_host_register (below): such buffers are read by DMA and must stay untouched until the
  * frame has been collected.  While the device is busy with earlier frames a submitted frame may be HELD until the
  * next pm_submit (two frames advanced through every launch together run 10 % faster than one after the other);
- * pm_collect and pm_flush enqueue a held frame at once.  The other host-buffer entry points must not be called while
- * pairs are in flight (they share the staging buffers). */
+ * pm_flush enqueues a held frame at once; pm_collect enqueues the frame it is asked for at once, and a LATER held
+ * frame as soon as the device has nothing else to do (before its wait, or right after it when the frame being
+ * collected was what kept the device busy -- the loop submit(k + 1); collect(k) never leaves the device idle).  The
+ * other host-buffer entry points must not be called while pairs are in flight (they share the staging buffers). */
 int pm_submit_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols,
                  size_t image_step, const float* seed_l, const float* seed_r, size_t seed_step,
                  uint64_t tag);
@@ -215,7 +232,10 @@ int pm_submit_bound_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, 
                        float* disp_l, float* disp_r, size_t disp_step, uint64_t tag);
 /* The same sequence for callers whose frames are DEVICE resident (tightly packed rows x cols planes, as for
  * pm_match_device): nothing is copied; inputs must stay untouched and outputs unread until the frame is collected
- * (pm_collect with NULL maps waits for it). */
+ * (pm_collect with NULL maps waits for it).  Ordering is that of pm_match_device: the frame -- both views and a
+ * self-seeding head, whatever internal streams they run on -- starts behind everything pm_stream(h) held when
+ * pm_submit_device was called, so inputs produced by work enqueued on that stream (pm_stereo_ready, a framework's
+ * kernels on an external-stream wrapper) need no host synchronisation. */
 int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag);
 int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag);
@@ -266,9 +286,6 @@ int pm_synchronize(pm_handle* h);
 int pm_capture_begin(pm_handle* h);
 int pm_capture_end(pm_handle* h);
 int pm_replay(pm_handle* h);
-/* test hook: forks an empty dependency onto an internal stream of an open capture and leaves it unjoined, so that the
- * guard in pm_capture_end (PM_ERR_STATE instead of a fault inside the runtime) can be exercised */
-int pm_debug_capture_fork(pm_handle* h);
 /* The hipStream_t the handle enqueues on (as void*), for event timing by the caller. */
 void* pm_stream(pm_handle* h);
 

@@ -6,6 +6,7 @@
 // There is deliberately NO CPU fallback in this library: without a usable HIP device pm_create fails with
 // PM_ERR_NO_DEVICE.  `file:line` citations are relative to the reference tree.
 #include "pm/patchmatch.h"
+#include "pm/testing.h"
 
 #include <hip/hip_runtime.h>
 
@@ -35,7 +36,7 @@ void set_err(pm_handle* h, const char* fmt, ...) {
   va_end(ap);
 }
 
-hipError_t create_stream(hipStream_t* s, int kind) {
+hipError_t create_stream(hipStream_t* s, int kind, int prio_class) {
   // ONE class for every stream of the engine: high priority -- not for the priority, but because streams of different
   // classes never share a hardware queue, so a class of their own keeps the engine's streams off the queues of whatever
   // else the process creates (torch's side streams, RCCL), and the engine's own streams do not slow each other down
@@ -58,7 +59,8 @@ hipError_t create_stream(hipStream_t* s, int kind) {
       }
     }
   } prio;
-  const int p = prio.v[kind & 3];
+  // pm_params.stream_priority selects the class of a handle's streams; the tuning build's PM_STREAM_PRIO overrides it
+  const int p = pm::tune_env("PM_STREAM_PRIO") ? prio.v[kind & 3] : prio_class;
   if (p == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
   if (p == 2) {
     // a stream with a CU mask never shares its hardware queue (the runtime keeps such queues out of the shared pools);
@@ -95,17 +97,20 @@ int create_handle_streams(pm_handle* h) {
   hipStream_t grp[4] = {nullptr, nullptr, nullptr, nullptr};
   const int kinds[4] = {kStreamMain, kStreamView, kStreamCopy, kStreamCopy};
   hipStream_t* roles[4] = {&h->stream, &h->view1_stream, &h->s_out, &h->s_in};
+  int role_at[4];
   for (int pos = 0; pos < 4; ++pos) {
-    const int role = (int)((pos + 4u - (k & 3u)) & 3u);  // the role created at this position: (role + k) % 4 == pos
-    const hipError_t e = create_stream(&grp[pos], kinds[role]);
+    role_at[pos] = (int)((pos + 4u - (k & 3u)) & 3u);  // the role created at this position: (role + k) % 4 == pos
+    const hipError_t e = create_stream(&grp[pos], kinds[role_at[pos]], h->params.stream_priority);
     if (e != hipSuccess) {
+      // the handle's fields are assigned only once all four streams exist: pm_destroy (which the caller must still
+      // run on the handle pm_create hands back with the error) never sees a destroyed stream
       for (hipStream_t st : grp)
         if (st) (void)hipStreamDestroy(st);
       set_err(h, "stream creation failed: %s", hipGetErrorString(e));
       return PM_ERR_HIP;
     }
-    *roles[role] = grp[pos];
   }
+  for (int pos = 0; pos < 4; ++pos) *roles[role_at[pos]] = grp[pos];
   return PM_OK;
 }
 
@@ -784,6 +789,11 @@ int validate_params(pm_handle* h, const pm_params& p) {
       return PM_ERR_INVALID_ARG;
     }
   }
+  if (p.stream_priority < PM_STREAM_PRIO_LOW || p.stream_priority > PM_STREAM_PRIO_HIGH ||
+      (p.small_image_graph != 0 && p.small_image_graph != 1)) {
+    set_err(h, "stream_priority must be one of pm_stream_priority (-1, 0, 1) and small_image_graph 0 or 1");
+    return PM_ERR_INVALID_ARG;
+  }
   return PM_OK;
 }
 
@@ -807,6 +817,57 @@ int refuse_while_capturing(pm_handle* h, const char* what) {
   if (!h->capturing) return PM_OK;
   set_err(h, "%s: not allowed between pm_capture_begin and pm_capture_end", what);
   return PM_ERR_BUSY;
+}
+
+// Opens a capture on the handle's stream (thread-local mode).  Lazily created resources must exist before it starts:
+// creating streams, events or device memory is not capturable.
+int capture_open(pm_handle* h) {
+  if (h->params.left_right_check && h->params.mode == PM_MODE_SCALAR) {
+    if (int rc = view_streams_create(h)) return rc;
+    if (int rc = seq_events_create(h)) return rc;
+  }
+  if (h->params.sparse_init)
+    for (int i = 1; i < 2; ++i)
+      if (!h->seeds[i].eig)
+        if (int rc = alloc_seed_scratch(h, h->seeds[i])) return rc;
+  h->cap_unjoined.clear();
+  PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  h->capturing = true;
+  return PM_OK;
+}
+
+// Ends the capture and instantiates what was recorded.  Every stream the recorded calls forked work onto must have
+// been joined back into the handle's stream: ending a capture with an unjoined fork is an error the runtime answers with
+// a fault, not a status (gpurun_out/r03/crash.log: a schedule experiment that left a side stream forked).  The forks are
+// joined here so that the capture can be ended at all, the graph is thrown away, and the caller gets PM_ERR_STATE.
+int capture_close(pm_handle* h, hipGraphExec_t* exec, const char* what) {
+  *exec = nullptr;
+  const size_t unjoined = h->cap_unjoined.size();
+  if (unjoined) {
+    std::vector<hipStream_t> open_streams = h->cap_unjoined;
+    for (hipStream_t st : open_streams) {
+      hipEvent_t ev = st == h->s_out ? h->out_join : (st == h->s_in ? h->in_join : h->view1_join);
+      if (hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
+      mark_joined(h, st);
+    }
+  }
+  h->capturing = false;
+  hipGraph_t graph = nullptr;
+  PM_HIP(h, hipStreamEndCapture(h->stream, &graph));
+  if (unjoined) {
+    if (graph) (void)hipGraphDestroy(graph);
+    set_err(h, "%s: %zu stream(s) the recorded calls forked work onto were never joined back; the capture "
+               "was discarded", what, unjoined);
+    return PM_ERR_STATE;
+  }
+  const hipError_t e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    *exec = nullptr;
+    set_err(h, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return PM_ERR_HIP;
+  }
+  return PM_OK;
 }
 
 int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
@@ -925,6 +986,8 @@ void pm_params_default(pm_params* p, int semantics) {
   p->plane_lr_tol = 1.0f;
   p->plane_window = PM_PL_WINDOW_CHECKER;
   p->plane_neighbours = PM_PL_NEIGH_FOUR;
+  p->stream_priority = PM_STREAM_PRIO_HIGH;
+  p->small_image_graph = 1;
 }
 
 const char* pm_status_string(int status) {
@@ -1117,55 +1180,15 @@ int pm_capture_begin(pm_handle* h) {
   }
   PM_HIP(h, hipSetDevice(h->device));
   PM_HIP(h, hipStreamSynchronize(h->stream));
-  // lazily created resources must exist before the capture starts (creating them is not capturable)
-  if (h->params.left_right_check && h->params.mode == PM_MODE_SCALAR) {
-    if (int rc = view_streams_create(h)) return rc;
-    if (int rc = seq_events_create(h)) return rc;
-  }
-  if (h->params.sparse_init)
-    for (int i = 1; i < 2; ++i)
-      if (!h->seeds[i].eig)
-        if (int rc = alloc_seed_scratch(h, h->seeds[i])) return rc;
-  h->cap_unjoined.clear();
-  PM_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  h->capturing = true;
-  return PM_OK;
+  return pm::eng::capture_open(h);
 }
 
 int pm_capture_end(pm_handle* h) {
   if (!h || !h->capturing) return PM_ERR_INVALID_ARG;
-  // Every stream the recorded calls forked work onto must have been joined back into the handle's stream: ending a
-  // capture with an unjoined fork is an error the runtime answers with a fault, not a status (gpurun_out/r03/crash.log:
-  // a schedule experiment that left a side stream forked).  The forks are joined here so that the capture can be ended
-  // at all, the graph is thrown away, and the caller gets PM_ERR_STATE.
-  const size_t unjoined = h->cap_unjoined.size();
-  if (unjoined) {
-    std::vector<hipStream_t> open_streams = h->cap_unjoined;
-    for (hipStream_t st : open_streams) {
-      hipEvent_t ev = st == h->s_out ? h->out_join : (st == h->s_in ? h->in_join : h->view1_join);
-      if (hipEventRecord(ev, st) == hipSuccess) (void)hipStreamWaitEvent(h->stream, ev, 0);
-      mark_joined(h, st);
-    }
-  }
-  h->capturing = false;
-  hipGraph_t graph = nullptr;
-  PM_HIP(h, hipStreamEndCapture(h->stream, &graph));
-  if (unjoined) {
-    if (graph) (void)hipGraphDestroy(graph);
-    set_err(h, "pm_capture_end: %zu stream(s) the recorded calls forked work onto were never joined back; the capture "
-               "was discarded", unjoined);
-    return PM_ERR_STATE;
-  }
-  if (h->graph_exec) {
-    (void)hipGraphExecDestroy(h->graph_exec);
-    h->graph_exec = nullptr;
-  }
-  const hipError_t e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) {
-    set_err(h, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    return PM_ERR_HIP;
-  }
+  hipGraphExec_t exec = nullptr;
+  if (int rc = pm::eng::capture_close(h, &exec, "pm_capture_end")) return rc;
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  h->graph_exec = exec;
   return PM_OK;
 }
 

@@ -143,6 +143,15 @@ struct pm_handle {
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
   hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
+  // pm_match_u8 on small images (pm_hostpath.hip::match_small): the device part of the call -- staging in, staging out,
+  // fixed addresses -- recorded once per (size, which seed maps exist, noise table) and replayed with one graph launch:
+  // below ~0.3 Mpx the call is bound by the ~55 launch submissions, not by the device
+  struct SmallGraph {
+    hipGraphExec_t exec = nullptr;
+    int rows = 0, cols = 0, calls = 0;
+    bool sl = false, sr = false, failed = false;
+    const float* noise = nullptr;
+  } small_graph;
   bool capturing = false;
   bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
   hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream
@@ -199,7 +208,7 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 // (pm_submit_u8's upload / download streams beside the compute stream: 343 -> 280-300 pairs/s; eight band handles on
 // one device 49 -> 117 ms); "0" restores one class for everything (tools/multi_handle.py, batch_after.py, pipe_timing.py).
 enum StreamKind { kStreamMain = 0, kStreamView = 1, kStreamCopy = 2, kStreamLane = 3 };
-hipError_t create_stream(hipStream_t* s, int kind);
+hipError_t create_stream(hipStream_t* s, int kind, int prio_class);
 int create_handle_streams(pm_handle* h);  // the handle's four streams, together (pm_engine.hip)
 
 // Brackets the launches of one kernel class with a pair of events while the handle is profiling.
@@ -270,6 +279,8 @@ int launch_check(pm_handle* h, const char* what);
 int ensure_noise(pm_handle* h, int rows, int cols);
 void abort_capture(pm_handle* h);
 int refuse_while_capturing(pm_handle* h, const char* what);
+int capture_open(pm_handle* h);                                             // pm_engine.hip
+int capture_close(pm_handle* h, hipGraphExec_t* exec, const char* what);
 bool pair_planes_wanted(const pm_handle* h);
 int pair_planes_alloc(pm_handle* h);
 int run_one_view_set(pm_handle* h, const PlaneSet& ps, int slots);

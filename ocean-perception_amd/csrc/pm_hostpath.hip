@@ -65,6 +65,59 @@ int download_plane(pm_handle* h, void* dst, size_t step, const void* d_src, size
   return PM_OK;
 }
 
+// ---- pm_match_u8 on small images: one graph launch instead of ~55 kernel launches --------------------------------
+// The reference's own timed call (patchmatch_gpu_test.cpp:68-88) is a 376x240 pair: ~0.5 ms of device work behind 55
+// launch submissions that take the host about as long.  The device part of pm_match_u8 runs between FIXED addresses
+// (staging slot 0 in, staging slot 0 out), so it is recorded once per (size, which seed maps exist, noise table) and
+// replayed.  The first call of a key runs directly (it performs every lazy allocation), the second records, later
+// ones replay.  Larger images are bound by the device, not by submission (1280x720: 377.0 vs 377.5 pairs/s).
+constexpr size_t kSmallGraphMaxPx = 384u * 1024u;
+
+void small_graph_drop(pm_handle* h) {
+  if (h->small_graph.exec) (void)hipGraphExecDestroy(h->small_graph.exec);
+  h->small_graph.exec = nullptr;
+  h->small_graph.calls = 0;
+}
+
+int match_small(pm_handle* h, int rows, int cols, bool has_sl, bool has_sr) {
+  const bool lr = h->params.left_right_check != 0;
+  auto direct = [&]() {
+    return match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, has_sl ? h->st_seed_l : nullptr,
+                             has_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr);
+  };
+  pm_handle::SmallGraph& g = h->small_graph;
+  const bool eligible = (size_t)rows * cols <= kSmallGraphMaxPx && h->params.mode == PM_MODE_SCALAR && !h->profiling &&
+                        !h->counters_on && !h->tile_on && !g.failed && h->params.small_image_graph != 0;
+  if (!eligible) return direct();
+  if (g.rows != rows || g.cols != cols || g.sl != has_sl || g.sr != has_sr || g.noise != h->noise) {
+    small_graph_drop(h);
+    g.rows = rows;
+    g.cols = cols;
+    g.sl = has_sl;
+    g.sr = has_sr;
+    g.noise = h->noise;
+  }
+  if (g.calls++ == 0) return direct();
+  if (!g.exec) {
+    int rc = capture_open(h);
+    if (rc == PM_OK) {
+      rc = direct();
+      hipGraphExec_t exec = nullptr;
+      const int rc2 = capture_close(h, &exec, "pm_match_u8 (small-image graph)");
+      if (rc == PM_OK) rc = rc2;
+      if (rc == PM_OK) g.exec = exec;
+      else if (exec) (void)hipGraphExecDestroy(exec);
+    }
+    if (rc != PM_OK) {  // never an error of the call: this handle keeps to direct launches from now on
+      g.failed = true;
+      (void)hipGetLastError();
+      return direct();
+    }
+  }
+  PM_HIP(h, hipGraphLaunch(g.exec, h->stream));
+  return PM_OK;
+}
+
 struct PinnedSlot {
   float *sl, *sr, *dl, *dr;
   uint8_t *l, *r;
@@ -98,7 +151,10 @@ int enqueue_frames(pm_handle* h, int b, int c) {
   const int rows = f0.rows, cols = f0.cols;
   const size_t px = (size_t)rows * cols;
   const bool lr = h->params.left_right_check != 0;
-  hipEvent_t ready = f0.device_io ? nullptr : h->pipe[(size_t)(b + c - 1)].in_done;  // s_in runs in order
+  // host frames: the later frame's upload (s_in runs in order); device-resident frames: the point of the handle's stream
+  // at which the later frame was submitted -- whatever the caller enqueued on pm_stream(h) to produce the inputs is
+  // ordered in front of BOTH views and the self-seeding head, as pm_match_device orders it
+  hipEvent_t ready = h->pipe[(size_t)(b + c - 1)].in_done;
   if (seq_pipelined(h)) {
     if (int rc = seq_enqueue_chunk(h, b, c, f0.d_left, f0.d_right, rows, cols, f0.d_seed_l, f0.d_seed_r, f0.d_out_l,
                                    f0.d_out_r, ready, nullptr, f0.v_done, f0.head_done))
@@ -149,11 +205,20 @@ int held_slot(const pm_handle* h) {
 
 // two frames can be advanced through every launch together if they are neighbours in device memory
 bool can_gang(const pm_handle* h, const pm_handle::PipeSlot& a, const pm_handle::PipeSlot& b, int sa, int sb) {
-  if (sb != sa + 1 || a.rows != b.rows || a.cols != b.cols || a.has_sl != b.has_sl || a.has_sr != b.has_sr) return false;
+  if (sb != sa + 1 || a.rows != b.rows || a.cols != b.cols || a.has_sl != b.has_sl || a.has_sr != b.has_sr ||
+      a.device_io != b.device_io)
+    return false;
   const size_t px = (size_t)a.rows * a.cols;
   return b.d_left == a.d_left + px && b.d_right == a.d_right + px && (!a.has_sl || b.d_seed_l == a.d_seed_l + px) &&
          (!a.has_sr || b.d_seed_r == a.d_seed_r + px) && b.d_out_l == a.d_out_l + px &&
          (!h->params.left_right_check || b.d_out_r == a.d_out_r + px);
+}
+
+// a new frame starts at once on an idle device and is held for a partner while the device is busy with earlier chunks
+// anyway and a neighbour slot exists
+int enqueue_or_hold(pm_handle* h, int slot) {
+  const bool hold = seq_pipelined(h) && seq_chunk_pairs() >= 2 && slot + 1 < h->max_batch && device_busy(h);
+  return hold ? PM_OK : enqueue_frames(h, slot, 1);
 }
 
 struct SubmitArgs {
@@ -227,6 +292,7 @@ int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
     sl.d_out_r = a.out_r;
     sl.out_l = sl.out_r = nullptr;
     sl.out_step = 0;
+    PM_HIP(h, hipEventRecord(sl.in_done, h->stream));  // stream-ordered behind the producer of the inputs
   } else {
     // ring slot k keeps its inputs and outputs at offset k * px of the staging arrays: frames in flight share one size
     uint8_t* dl8 = h->st_left + (size_t)slot * px;
@@ -257,13 +323,22 @@ int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
   // otherwise.  This frame is held in turn while the device is busy with earlier chunks anyway and a neighbour slot
   // exists for a partner; with an idle device it starts at once.
   const int held = held_slot(h) == slot ? -1 : held_slot(h);
+  int rc = PM_OK;
   if (held >= 0) {
-    if (can_gang(h, h->pipe[(size_t)held], sl, held, slot)) return enqueue_frames(h, held, 2);
-    if (int rc = enqueue_frames(h, held, 1)) return rc;
+    if (can_gang(h, h->pipe[(size_t)held], sl, held, slot))
+      rc = enqueue_frames(h, held, 2);
+    else if ((rc = enqueue_frames(h, held, 1)) == PM_OK)
+      rc = enqueue_or_hold(h, slot);
+  } else {
+    rc = enqueue_or_hold(h, slot);
   }
-  const bool hold = seq_pipelined(h) && seq_chunk_pairs() >= 2 && slot + 1 < h->max_batch && device_busy(h);
-  if (hold) return PM_OK;
-  return enqueue_frames(h, slot, 1);
+  if (rc != PM_OK && sl.state == 1) {
+    // the frame never reached the device: it leaves the ring again, so that the caller's count of frames in flight
+    // (an error return = nothing submitted) stays right
+    sl.state = 0;
+    --h->pipe_count;
+  }
+  return rc;
 }
 
 }  // namespace
@@ -482,9 +557,7 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
     if (int rc = upload_plane(h, h->st_seed_l, seed_l, seed_step, frow, rows, ps.sl, h->stream)) return rc;
   if (seed_r)
     if (int rc = upload_plane(h, h->st_seed_r, seed_r, seed_step, frow, rows, ps.sr, h->stream)) return rc;
-  if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
-                               seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
-    return rc;
+  if (int rc = match_small(h, rows, cols, seed_l != nullptr, seed_r != nullptr)) return rc;
   // the left map is unpacked into the caller's buffer while the right one is still on the bus
   if (!h->left_out) {
     PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
@@ -577,7 +650,15 @@ int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uin
   PM_HIP(h, hipSetDevice(h->device));
   if (sl.state == 1)  // still held for a partner that never came
     if (int rc = enqueue_frames(h, h->pipe_head, 1)) return rc;
-  PM_HIP(h, hipEventSynchronize(sl.out_done));
+  // a LATER frame that is being held starts as soon as the device has nothing else to do: before the wait if the
+  // device went idle since it was submitted, after it if the frame collected here was what kept the device busy (the
+  // loop submit(k + 1); collect(k) would otherwise leave the device idle until the next call)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int held = held_slot(h);
+    if (held >= 0 && !device_busy(h))
+      if (int rc = enqueue_frames(h, held, 1)) return rc;
+    if (pass == 0) PM_HIP(h, hipEventSynchronize(sl.out_done));
+  }
   if (!sl.device_io) {
     const PinnedSlot ps = pinned_slot(h, h->pipe_head, (size_t)rows * cols);
     if (!sl.direct_l) h->copy_pool->Copy2D(out_l, out_step, ps.dl, frow, frow, rows);

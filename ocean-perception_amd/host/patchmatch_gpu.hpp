@@ -126,6 +126,11 @@ class PatchmatchGpu final {
     int device = 0;
     int max_rows = 0, max_cols = 0;  // 0: plan on the first Match()
     int max_batch = 1;
+    // the priority class of the object's GPU streams (pm_stream_priority): HIGH keeps its two view streams off the
+    // hardware queues of the host application's default-class streams; an application that must keep its own kernels
+    // in front of the matcher's sets PM_STREAM_PRIO_DEFAULT or PM_STREAM_PRIO_LOW
+    int stream_priority = PM_STREAM_PRIO_HIGH;
+    bool small_image_graph = true;  // Match() on small host images replays a recorded HIP graph (pm_params)
 
     // Fills a pm_params from these fields.
     pm_params ToC() const;
@@ -157,9 +162,9 @@ class PatchmatchGpu final {
              GpuImage1f& disp, void* stream = nullptr);
 
   // Several pairs of one size in ONE call (BASELINE configs[2]'s per-GPU share; at most Params::max_batch): the engine
-  // runs them as pipelines side by side.  From host images the copies stand in front of and behind the whole batch:
-  // 315-320 pairs/s at 720p, what pair-by-pair Match() calls reach; a caller whose pairs are already on the device
-  // gets 390-418 through pm_match_device(handle(), n, ...).  Every pair seeds itself like Match() does (seed maps set
+  // runs them as pipelines side by side.  From host images the copies overlap the matching of neighbouring chunks:
+  // 461-475 pairs/s at 720p (pair-by-pair Match() calls: 363-381); a caller whose pairs are already on the device
+  // gets 480-484 through pm_match_device(handle(), n, ...) (round 4).  Every pair seeds itself like Match() does (seed maps set
   // through SetSeeds() are for single pairs: not allowed here).  Results equal Match()'s, pair by pair.
   void MatchBatch(const std::vector<Image1b>& imls, const std::vector<Image1b>& imrs, std::vector<Image1f>& disps,
                   std::vector<Image1f>& disprs);

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-PM_ABI_VERSION = 5
+PM_ABI_VERSION = 6
 PM_MAX_ITERS = 16
 PM_MAX_PATCH = 15
 PM_SEM_CPU, PM_SEM_GPU = 0, 1
@@ -97,6 +97,8 @@ class PmParams(C.Structure):
         ("plane_lr_tol", C.c_float),
         ("plane_window", C.c_int),
         ("plane_neighbours", C.c_int),
+        ("stream_priority", C.c_int),
+        ("small_image_graph", C.c_int),
     ]
 
 
@@ -340,8 +342,9 @@ class Engine:
 
     def close(self):
         if self.h:
-            self.lib.pm_destroy(self.h)
+            self.lib.pm_destroy(self.h)  # (also gives back / un-registers every pm_host_alloc / pm_host_register range)
             self.h = C.c_void_p()
+        self._registered = {}
 
     def __enter__(self):
         return self
@@ -492,10 +495,16 @@ class Engine:
             self.host_unregister(a)
 
     def host_register(self, a):
+        """Page-locks the array's memory in place.  The engine keeps a reference to the array until host_unregister /
+        close(): memory the library treats as page-locked (DMA in place, k_download's direct stores) must not go back to
+        the allocator while the range is registered."""
         self._check(self.lib.pm_host_register(self.h, a.ctypes.data, a.nbytes), "pm_host_register")
+        self._registered = getattr(self, "_registered", {})
+        self._registered[a.ctypes.data] = a
 
     def host_unregister(self, a):
         self._check(self.lib.pm_host_unregister(self.h, a.ctypes.data), "pm_host_unregister")
+        getattr(self, "_registered", {}).pop(a.ctypes.data, None)
 
     def debug_capture_fork(self):
         self._check(self.lib.pm_debug_capture_fork(self.h), "pm_debug_capture_fork")

@@ -413,6 +413,67 @@ def test_device_resident_sequence_and_self_seeded_frames(pm, oracle, synth):
         assert_same(DR[i].cpu().numpy(), want[i][1], f"frame {i} right")
 
 
+@pytest.mark.parametrize("self_seed", [0, 1])
+def test_device_sequence_is_ordered_behind_the_producer_on_the_handles_stream(pm, synth, self_seed):
+    """pm_submit_device is stream-ordered like pm_match_device: inputs written by work enqueued on pm_stream(h) -- here
+    torch copies on an ExternalStream wrapper, behind a long chain of filler kernels, with NO host synchronisation -- are
+    complete before either view (the second runs on an internal stream) or the self-seeding head reads them."""
+    torch = pytest.importorskip("torch")
+    rows, cols = 96, 160
+    dev = torch.device("cuda:0")
+    n = 4
+    pairs = [small_pair(synth, 170 + i, rows, cols, n_points=25, dilate_factor=2) for i in range(n)]
+    params = pm.default_params(0, patch=5, patchmatch_iters=2, sparse_init=self_seed)
+    with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
+        want = [e.match(p[0], p[1], None if self_seed else p[2], None if self_seed else p[3]) for p in pairs]
+    src = {k: torch.from_numpy(np.stack([p[j] for p in pairs])).to(dev) for j, k in enumerate(("l", "r", "sl", "sr"))}
+    L, R = torch.zeros_like(src["l"]), torch.zeros_like(src["r"])          # garbage until the producer has run
+    SL, SR = torch.zeros_like(src["sl"]), torch.zeros_like(src["sr"])
+    DL = torch.full((n, rows, cols), -1.0, dtype=torch.float32, device=dev)
+    DR = torch.full_like(DL, -1.0)
+    filler = torch.zeros((4096, 4096), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=4) as e:
+        es = torch.cuda.ExternalStream(e.stream())
+        for i in range(n):
+            with torch.cuda.stream(es):
+                for _ in range(20):          # ~ a millisecond of work in front of the inputs
+                    filler.add_(1.0)
+                L[i].copy_(src["l"][i]); R[i].copy_(src["r"][i])
+                SL[i].copy_(src["sl"][i]); SR[i].copy_(src["sr"][i])
+            e.submit_device(L[i].data_ptr(), R[i].data_ptr(), rows, cols, None if self_seed else SL[i].data_ptr(),
+                            None if self_seed else SR[i].data_ptr(), DL[i].data_ptr(), DR[i].data_ptr(), tag=i)
+        while e.in_flight():
+            e.collect_device()
+    for i in range(n):
+        assert_same(DL[i].cpu().numpy(), want[i][0], f"frame {i} left")
+        assert_same(DR[i].cpu().numpy(), want[i][1], f"frame {i} right")
+
+
+def test_collect_starts_a_held_frame(pm, synth):
+    """The loop submit(k + 1); collect(k) at depth 2: frame k + 1 is held while the device is busy with frame k, and
+    pm_collect(k) enqueues it once k is through -- in_flight frames never sit idle until the next call."""
+    import time
+    rows, cols = 720, 1280
+    p = synth.make_pair(3, rows, cols)
+    params = pm.default_params(0, patch=11, patchmatch_iters=8)
+    with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=3) as e:
+        a = e.match(p["left"], p["right"], p["seed_l"], p["seed_r"])
+        # maps bound in page-locked memory: pm_collect is the event wait and nothing else
+        outs = [(e.host_alloc((rows, cols), np.float32), e.host_alloc((rows, cols), np.float32)) for _ in range(2)]
+        e.submit(p["left"], p["right"], p["seed_l"], p["seed_r"], tag=0, out=outs[0])
+        e.submit(p["left"], p["right"], p["seed_l"], p["seed_r"], tag=1, out=outs[1])  # held: the device is busy with frame 0
+        e.collect()                         # ... and started by this call, once frame 0 is through
+        time.sleep(0.05)                    # frame 1 (~2.5 ms of device work) finishes without any further call
+        t0 = time.perf_counter()
+        e.collect()
+        waited = time.perf_counter() - t0
+        for o in outs:
+            assert_same(o[0], a[0], "left")
+            assert_same(o[1], a[1], "right")
+    assert waited < 0.001, f"the held frame was only started by the second collect ({1e3 * waited:.2f} ms wait)"
+
+
 def test_edges_no_seeds_one_view_strides_and_errors(pm, oracle, synth):
     rows, cols = 33, 47
     l, r, sl, sr, _ = small_pair(synth, 50, rows, cols, n_points=12, dilate_factor=2)
