@@ -449,27 +449,38 @@ def reference_test_shape_leg(pm, args, device):
     g = np.load(os.path.join(ROOT, "tests", "golden", "farmsim_fs1_376x240.npz"))
     l, r = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
     rows, cols = l.shape
-    prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=3, sparse_init=1)
-    calls = []
-    with pm.Engine(prm, device=device, max_rows=rows, max_cols=cols) as e:
-        out = (np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32))
-        for i in range(5):
-            t0 = time.perf_counter()
-            e.match(l, r, out=out)
-            calls.append(1e3 * (time.perf_counter() - t0))
-        steady = []
-        for i in range(40):
-            t0 = time.perf_counter()
-            e.match(l, r, out=out)
-            steady.append(1e3 * (time.perf_counter() - t0))
-        rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)  # as tests/test_golden.py pins them
-        same = bool(np.array_equal(rowsum(out[0]), g["gpu_test_rows_l"]) and np.array_equal(rowsum(out[1]), g["gpu_test_rows_r"]))
+    rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)  # as tests/test_golden.py pins them
+    runs = {}
+    for graph in (1, 0):  # 1 = default: both views through every launch of the iterations (pm_params.small_image_fused_views)
+        prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=3, sparse_init=1, small_image_fused_views=graph)
+        calls = []
+        with pm.Engine(prm, device=device, max_rows=rows, max_cols=cols) as e:
+            out = (np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32))
+            for i in range(5):
+                t0 = time.perf_counter()
+                e.match(l, r, out=out)
+                calls.append(1e3 * (time.perf_counter() - t0))
+            steady = []
+            for i in range(60):
+                t0 = time.perf_counter()
+                e.match(l, r, out=out)
+                steady.append(1e3 * (time.perf_counter() - t0))
+            same = bool(np.array_equal(rowsum(out[0]), g["gpu_test_rows_l"]) and np.array_equal(rowsum(out[1]), g["gpu_test_rows_r"]))
+        runs[graph] = (calls, float(np.median(steady)), same)
+    calls, med, same = runs[1]
     res = {"workload": f"{cols}x{rows} farmsim test pair, PM_SEM_GPU (the CUDA module's own 5-tap semantics), cost_alpha "
                        "0.9, 3 iterations, self-seeded, host images in / host maps out, Match x 5 "
                        "(patchmatch_gpu_test.cpp:68-88)",
-           "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": float(np.median(steady)),
-           "pairs_per_s_steady": 1e3 / float(np.median(steady)),
-           "equals_the_golden_row_checksums": same}
+           "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": med,
+           "pairs_per_s_steady": 1e3 / med,
+           "equals_the_golden_row_checksums": same and runs[0][2],
+           "views_on_two_streams": {"ms_per_call_first_five": [round(c, 3) for c in runs[0][0]],
+                                    "ms_per_call_steady_median": runs[0][1],
+                                    "note": "pm_params.small_image_fused_views = 0: each view's iterations on its own "
+                                            "stream, 55 launches per call (round 4's schedule at every size)"},
+           "note": "default (pm_params.small_image_fused_views): a pair of up to 256 Ki pixels runs both views through "
+                   "every launch of its iterations -- 37 launches per call instead of 55; the call is bound by launch "
+                   "submission at this size (a recorded HIP graph was 10 % slower: profiles/r05_small_image_graph.txt)"}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O

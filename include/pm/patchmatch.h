@@ -158,9 +158,10 @@ typedef struct pm_params {
   /* --- how the handle sits in the host process (ABI 6; no reference counterpart: the reference runs everything on the
    * default stream with device-wide synchronisation, patchmatch_gpu.cu:396-410) ---------------------------------- */
   int stream_priority;            /* 1     pm_stream_priority: the class of the handle's four streams              */
-  int small_image_graph;          /* 1     pm_match_u8 replays a recorded HIP graph for images up to 384 Ki pixels
-                                           (the reference's own 376x240 test shape is bound by launch submission);
-                                           0 = always launch kernel by kernel                                      */
+  int small_image_fused_views;    /* 1     a single pair of up to 256 Ki pixels runs BOTH views through every launch
+                                           of its iterations (half the launches: the reference's own 376x240 test
+                                           shape is bound by launch submission, not by the device); 0 = the two views
+                                           on their own streams at every size                                       */
 } pm_params;
 /* The priority class ALL streams of a handle are created in.  HIGH (default): not for the priority but because streams
  * of different classes never share a hardware queue, which keeps the matcher's two view streams off the queues of
@@ -232,12 +233,21 @@ int pm_submit_bound_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, 
                        float* disp_l, float* disp_r, size_t disp_step, uint64_t tag);
 /* The same sequence for callers whose frames are DEVICE resident (tightly packed rows x cols planes, as for
  * pm_match_device): nothing is copied; inputs must stay untouched and outputs unread until the frame is collected
- * (pm_collect with NULL maps waits for it).  Ordering is that of pm_match_device: the frame -- both views and a
- * self-seeding head, whatever internal streams they run on -- starts behind everything pm_stream(h) held when
- * pm_submit_device was called, so inputs produced by work enqueued on that stream (pm_stereo_ready, a framework's
- * kernels on an external-stream wrapper) need no host synchronisation. */
+ * (pm_collect with NULL maps waits for it).  ORDERING: unlike pm_match_device, a frame of the sequence is NOT ordered
+ * behind what pm_stream(h) holds -- its second view and a self-seeding head run on internal streams as soon as the
+ * frames in front of them allow (ordering every frame behind the handle's stream, on which the first view of the
+ * previous frame runs, would tie the two view streams together at every frame boundary: measured 486 -> 463 pairs/s).
+ * The inputs must therefore be COMPLETE in device memory when pm_submit_device is called (the producer was
+ * synchronised), or the producer's completion is handed over as an event: */
 int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag);
+/* pm_submit_device for inputs that are still being produced on the device: `ready_event` is a hipEvent_t (as void*)
+ * the caller recorded behind the producer of THIS frame's inputs, on whatever stream that work runs; both views and the
+ * head of the frame wait for it on the device, nothing waits on the host.  The event must stay alive and must not be
+ * re-recorded until the frame has been collected.  NULL = pm_submit_device. */
+int pm_submit_device_after(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                           const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag,
+                           void* ready_event);
 int pm_collect(pm_handle* h, float* disp_l, float* disp_r, size_t disp_step, uint64_t* tag);
 /* enqueues a frame that is being held for a partner (see pm_submit_u8); never needed for correctness */
 int pm_flush(pm_handle* h);

@@ -114,6 +114,7 @@ struct pm_handle {
     const float *d_seed_l = nullptr, *d_seed_r = nullptr;
     float *d_out_l = nullptr, *d_out_r = nullptr;         // where the cross-check writes (staging or caller memory)
     bool device_io = false;         // pm_submit_device: no copies at all
+    hipEvent_t ready_ext = nullptr; // pm_submit_device_after: the caller's event behind the producer of the inputs
     float *out_l = nullptr, *out_r = nullptr;  // host maps bound at submit (null: handed to pm_collect)
     size_t out_step = 0;
     bool direct_l = false, direct_r = false;   // the download goes straight into the bound (registered) host map
@@ -143,15 +144,6 @@ struct pm_handle {
   // pm_match_bgr_device: the next Match reads enhanced BGR inputs through k_prep_bgr instead of 8-bit gray images
   const pm::BgrSource* bgr = nullptr;
   hipGraphExec_t graph_exec = nullptr;  // pm_capture_* / pm_replay
-  // pm_match_u8 on small images (pm_hostpath.hip::match_small): the device part of the call -- staging in, staging out,
-  // fixed addresses -- recorded once per (size, which seed maps exist, noise table) and replayed with one graph launch:
-  // below ~0.3 Mpx the call is bound by the ~55 launch submissions, not by the device
-  struct SmallGraph {
-    hipGraphExec_t exec = nullptr;
-    int rows = 0, cols = 0, calls = 0;
-    bool sl = false, sr = false, failed = false;
-    const float* noise = nullptr;
-  } small_graph;
   bool capturing = false;
   bool no_tiled = false;        // PM_NO_TILED (experiment knob), read once by pm_create
   hipEvent_t ext_fork = nullptr, ext_join = nullptr;  // pm_match_view_device: caller stream <-> handle stream

@@ -65,59 +65,6 @@ int download_plane(pm_handle* h, void* dst, size_t step, const void* d_src, size
   return PM_OK;
 }
 
-// ---- pm_match_u8 on small images: one graph launch instead of ~55 kernel launches --------------------------------
-// The reference's own timed call (patchmatch_gpu_test.cpp:68-88) is a 376x240 pair: ~0.5 ms of device work behind 55
-// launch submissions that take the host about as long.  The device part of pm_match_u8 runs between FIXED addresses
-// (staging slot 0 in, staging slot 0 out), so it is recorded once per (size, which seed maps exist, noise table) and
-// replayed.  The first call of a key runs directly (it performs every lazy allocation), the second records, later
-// ones replay.  Larger images are bound by the device, not by submission (1280x720: 377.0 vs 377.5 pairs/s).
-constexpr size_t kSmallGraphMaxPx = 384u * 1024u;
-
-void small_graph_drop(pm_handle* h) {
-  if (h->small_graph.exec) (void)hipGraphExecDestroy(h->small_graph.exec);
-  h->small_graph.exec = nullptr;
-  h->small_graph.calls = 0;
-}
-
-int match_small(pm_handle* h, int rows, int cols, bool has_sl, bool has_sr) {
-  const bool lr = h->params.left_right_check != 0;
-  auto direct = [&]() {
-    return match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, has_sl ? h->st_seed_l : nullptr,
-                             has_sr ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr);
-  };
-  pm_handle::SmallGraph& g = h->small_graph;
-  const bool eligible = (size_t)rows * cols <= kSmallGraphMaxPx && h->params.mode == PM_MODE_SCALAR && !h->profiling &&
-                        !h->counters_on && !h->tile_on && !g.failed && h->params.small_image_graph != 0;
-  if (!eligible) return direct();
-  if (g.rows != rows || g.cols != cols || g.sl != has_sl || g.sr != has_sr || g.noise != h->noise) {
-    small_graph_drop(h);
-    g.rows = rows;
-    g.cols = cols;
-    g.sl = has_sl;
-    g.sr = has_sr;
-    g.noise = h->noise;
-  }
-  if (g.calls++ == 0) return direct();
-  if (!g.exec) {
-    int rc = capture_open(h);
-    if (rc == PM_OK) {
-      rc = direct();
-      hipGraphExec_t exec = nullptr;
-      const int rc2 = capture_close(h, &exec, "pm_match_u8 (small-image graph)");
-      if (rc == PM_OK) rc = rc2;
-      if (rc == PM_OK) g.exec = exec;
-      else if (exec) (void)hipGraphExecDestroy(exec);
-    }
-    if (rc != PM_OK) {  // never an error of the call: this handle keeps to direct launches from now on
-      g.failed = true;
-      (void)hipGetLastError();
-      return direct();
-    }
-  }
-  PM_HIP(h, hipGraphLaunch(g.exec, h->stream));
-  return PM_OK;
-}
-
 struct PinnedSlot {
   float *sl, *sr, *dl, *dr;
   uint8_t *l, *r;
@@ -151,16 +98,17 @@ int enqueue_frames(pm_handle* h, int b, int c) {
   const int rows = f0.rows, cols = f0.cols;
   const size_t px = (size_t)rows * cols;
   const bool lr = h->params.left_right_check != 0;
-  // host frames: the later frame's upload (s_in runs in order); device-resident frames: the point of the handle's stream
-  // at which the later frame was submitted -- whatever the caller enqueued on pm_stream(h) to produce the inputs is
-  // ordered in front of BOTH views and the self-seeding head, as pm_match_device orders it
-  hipEvent_t ready = h->pipe[(size_t)(b + c - 1)].in_done;
+  // host frames: the later frame's upload (s_in runs in order).  Device-resident frames: the caller's "inputs are
+  // complete" events (pm_submit_device_after), one per frame of the chunk, in front of both views and the head
+  hipEvent_t ready = f0.device_io ? f0.ready_ext : h->pipe[(size_t)(b + c - 1)].in_done;
+  hipEvent_t ready2 = (f0.device_io && c > 1) ? h->pipe[(size_t)(b + c - 1)].ready_ext : nullptr;
   if (seq_pipelined(h)) {
     if (int rc = seq_enqueue_chunk(h, b, c, f0.d_left, f0.d_right, rows, cols, f0.d_seed_l, f0.d_seed_r, f0.d_out_l,
-                                   f0.d_out_r, ready, nullptr, f0.v_done, f0.head_done))
+                                   f0.d_out_r, ready, ready2, f0.v_done, f0.head_done))
       return rc;
   } else {
     if (ready) PM_HIP(h, hipStreamWaitEvent(h->stream, ready, 0));
+    if (ready2) PM_HIP(h, hipStreamWaitEvent(h->stream, ready2, 0));
     for (int i = 0; i < c; ++i) {
       pm_handle::PipeSlot& f = h->pipe[(size_t)(b + i)];
       if (int rc = match_device_impl(h, 1, f.d_left, f.d_right, rows, cols, f.d_seed_l, f.d_seed_r, f.d_out_l,
@@ -231,6 +179,7 @@ struct SubmitArgs {
   size_t out_step;
   uint64_t tag;
   bool device_io;
+  hipEvent_t ready = nullptr;  // device_io: the caller's event behind the producer of the inputs, or null
 };
 
 int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
@@ -292,7 +241,7 @@ int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
     sl.d_out_r = a.out_r;
     sl.out_l = sl.out_r = nullptr;
     sl.out_step = 0;
-    PM_HIP(h, hipEventRecord(sl.in_done, h->stream));  // stream-ordered behind the producer of the inputs
+    sl.ready_ext = a.ready;
   } else {
     // ring slot k keeps its inputs and outputs at offset k * px of the staging arrays: frames in flight share one size
     uint8_t* dl8 = h->st_left + (size_t)slot * px;
@@ -557,7 +506,9 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
     if (int rc = upload_plane(h, h->st_seed_l, seed_l, seed_step, frow, rows, ps.sl, h->stream)) return rc;
   if (seed_r)
     if (int rc = upload_plane(h, h->st_seed_r, seed_r, seed_step, frow, rows, ps.sr, h->stream)) return rc;
-  if (int rc = match_small(h, rows, cols, seed_l != nullptr, seed_r != nullptr)) return rc;
+  if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
+                               seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
+    return rc;
   // the left map is unpacked into the caller's buffer while the right one is still on the bus
   if (!h->left_out) {
     PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
@@ -605,8 +556,17 @@ int pm_submit_bound_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, 
 int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag) {
   if (!h) return PM_ERR_INVALID_ARG;
-  const SubmitArgs a{d_left, d_right, rows, cols, 0, d_seed_l, d_seed_r, 0, d_disp_l, d_disp_r, 0, tag, true};
+  const SubmitArgs a{d_left, d_right, rows, cols, 0, d_seed_l, d_seed_r, 0, d_disp_l, d_disp_r, 0, tag, true, nullptr};
   return submit_impl(h, a, "pm_submit_device");
+}
+
+int pm_submit_device_after(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                           const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag,
+                           void* ready_event) {
+  if (!h) return PM_ERR_INVALID_ARG;
+  const SubmitArgs a{d_left, d_right, rows, cols, 0, d_seed_l, d_seed_r, 0, d_disp_l, d_disp_r, 0, tag, true,
+                     (hipEvent_t)ready_event};
+  return submit_impl(h, a, "pm_submit_device_after");
 }
 
 int pm_flush(pm_handle* h) {

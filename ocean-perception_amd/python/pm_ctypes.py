@@ -31,7 +31,7 @@ LIB_PATH = os.environ.get("PM_LIB") or os.path.normpath(os.path.join(_HERE, ".."
 EXPORTS = [
     "pm_params_default", "pm_create", "pm_destroy", "pm_last_error", "pm_status_string",
     "pm_match_u8", "pm_match_batch_u8", "pm_match_device", "pm_synchronize", "pm_stream",
-    "pm_submit_u8", "pm_submit_bound_u8", "pm_submit_device", "pm_collect", "pm_flush", "pm_in_flight",
+    "pm_submit_u8", "pm_submit_bound_u8", "pm_submit_device", "pm_submit_device_after", "pm_collect", "pm_flush", "pm_in_flight",
     "pm_host_alloc", "pm_host_free", "pm_host_register", "pm_host_unregister",
     "pm_capture_begin", "pm_capture_end", "pm_replay", "pm_debug_capture_fork",
     "pm_disp_to_range", "pm_remove_backscatter", "pm_correct_attenuation", "pm_range_enhance",
@@ -98,7 +98,7 @@ class PmParams(C.Structure):
         ("plane_window", C.c_int),
         ("plane_neighbours", C.c_int),
         ("stream_priority", C.c_int),
-        ("small_image_graph", C.c_int),
+        ("small_image_fused_views", C.c_int),
     ]
 
 
@@ -164,6 +164,8 @@ def load():
     lib.pm_submit_bound_u8.restype = C.c_int
     lib.pm_submit_device.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.c_uint64]
     lib.pm_submit_device.restype = C.c_int
+    lib.pm_submit_device_after.argtypes = [vp, u8p, u8p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.c_uint64, vp]
+    lib.pm_submit_device_after.restype = C.c_int
     lib.pm_collect.argtypes = [vp, f32p, f32p, C.c_size_t, C.POINTER(C.c_uint64)]
     lib.pm_collect.restype = C.c_int
     lib.pm_flush.argtypes = [vp]
@@ -436,11 +438,18 @@ class Engine:
                                                     out[1].ctypes.data if lr else None, 0, tag), "pm_submit_bound_u8")
         self._shape_q.append((rows, cols, out))
 
-    def submit_device(self, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r, tag=0):
-        """Raw device addresses; nothing is copied.  collect_device() waits for the frame."""
+    def submit_device(self, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r, tag=0, ready_event=None):
+        """Raw device addresses; nothing is copied.  collect_device() waits for the frame.  ready_event: a hipEvent_t
+        (integer handle, e.g. torch.cuda.Event.cuda_event) recorded behind the producer of the inputs
+        (pm_submit_device_after); without it the inputs must be complete when this is called."""
         self._shape_q = getattr(self, "_shape_q", [])
-        self._check(self.lib.pm_submit_device(self.h, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
-                                              d_disp_r, tag), "pm_submit_device")
+        if ready_event:
+            self._check(self.lib.pm_submit_device_after(self.h, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
+                                                        d_disp_r, tag, C.c_void_p(int(ready_event))),
+                        "pm_submit_device_after")
+        else:
+            self._check(self.lib.pm_submit_device(self.h, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,
+                                                  d_disp_r, tag), "pm_submit_device")
         self._shape_q.append((rows, cols, "device"))
 
     def collect_device(self):

@@ -414,10 +414,10 @@ def test_device_resident_sequence_and_self_seeded_frames(pm, oracle, synth):
 
 
 @pytest.mark.parametrize("self_seed", [0, 1])
-def test_device_sequence_is_ordered_behind_the_producer_on_the_handles_stream(pm, synth, self_seed):
-    """pm_submit_device is stream-ordered like pm_match_device: inputs written by work enqueued on pm_stream(h) -- here
-    torch copies on an ExternalStream wrapper, behind a long chain of filler kernels, with NO host synchronisation -- are
-    complete before either view (the second runs on an internal stream) or the self-seeding head reads them."""
+def test_device_sequence_waits_for_the_producers_event(pm, synth, self_seed):
+    """pm_submit_device_after: inputs still being written on the device -- here by torch copies on a side stream, behind a
+    long chain of filler kernels, with NO host synchronisation -- are complete before either view (the second runs on an
+    internal stream) or the self-seeding head reads them: the frame waits for the caller's event on the device."""
     torch = pytest.importorskip("torch")
     rows, cols = 96, 160
     dev = torch.device("cuda:0")
@@ -432,17 +432,20 @@ def test_device_sequence_is_ordered_behind_the_producer_on_the_handles_stream(pm
     DL = torch.full((n, rows, cols), -1.0, dtype=torch.float32, device=dev)
     DR = torch.full_like(DL, -1.0)
     filler = torch.zeros((4096, 4096), dtype=torch.float32, device=dev)
+    producer = torch.cuda.Stream()
+    events = [torch.cuda.Event() for _ in range(n)]
     torch.cuda.synchronize()
     with pm.Engine(params, max_rows=rows, max_cols=cols, max_batch=4) as e:
-        es = torch.cuda.ExternalStream(e.stream())
         for i in range(n):
-            with torch.cuda.stream(es):
+            with torch.cuda.stream(producer):
                 for _ in range(20):          # ~ a millisecond of work in front of the inputs
                     filler.add_(1.0)
                 L[i].copy_(src["l"][i]); R[i].copy_(src["r"][i])
                 SL[i].copy_(src["sl"][i]); SR[i].copy_(src["sr"][i])
+                events[i].record(producer)
             e.submit_device(L[i].data_ptr(), R[i].data_ptr(), rows, cols, None if self_seed else SL[i].data_ptr(),
-                            None if self_seed else SR[i].data_ptr(), DL[i].data_ptr(), DR[i].data_ptr(), tag=i)
+                            None if self_seed else SR[i].data_ptr(), DL[i].data_ptr(), DR[i].data_ptr(), tag=i,
+                            ready_event=events[i].cuda_event)
         while e.in_flight():
             e.collect_device()
     for i in range(n):
