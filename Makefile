@@ -38,12 +38,14 @@ oracle:
 
 # The tuning build: the same sources with -DPM_TUNING, in which the A/B knobs of pm_tune.hpp are read from the
 # environment.  Not part of `all`; tools/ load it through PM_LIB.  The shipped library reads no environment variable.
+# TUNE_DEFS: extra -D switches of an experiment (e.g. -DPL_EARLY_EXIT=1); `rm -rf $(PKG)/build/tuning` between experiments
+TUNE_DEFS ?=
 TOBJDIR := $(PKG)/build/tuning
 TLIB    := $(PKG)/lib/libvehicle_pm_gpu_tuning.so
 TOBJS   := $(HIP_UNITS:%=$(TOBJDIR)/%.o) $(HOST_UNITS:%=$(OBJDIR)/host_%.o)
 $(TOBJDIR)/%.o: $(PKG)/csrc/%.hip $(HDRS)
 	@mkdir -p $(TOBJDIR)
-	$(HIPCC) $(HIPFLAGS) -DPM_TUNING -Iinclude -I$(PKG)/csrc -c -o $@ $<
+	$(HIPCC) $(HIPFLAGS) -DPM_TUNING $(TUNE_DEFS) -Iinclude -I$(PKG)/csrc -c -o $@ $<
 $(TLIB): $(TOBJS)
 	@mkdir -p $(PKG)/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(TOBJS) -lz

@@ -372,6 +372,52 @@ def host_buffer_leg(pm, args, pairs, device):
     return out
 
 
+def host_sequence_all_ranks(pm, args, pairs, d):
+    """BASELINE configs[2] INCLUDING the PCIe transfers ("aggregate pairs/s incl. H2D/D2H (pinned,
+    overlapped)"), on EVERY rank of the run: host images in, host maps out through the frame sequence pm_submit_bound_u8 /
+    pm_collect, all caller buffers page-locked (pm_host_alloc: DMA in place, nothing staged), `depth` frames in flight.
+    Bracketed like the headline -- barrier on both sides, max elapsed over ranks -- and reduced like `value`: frames of
+    all ranks / that time.  Collective: every rank must call it.  What it mirrors: upload ... download inside the
+    reference's host Match() (patchmatch_gpu.cu:343-375); eight ranks with their own pinned buffers and DMA queues are
+    where a host path could stop scaling, which a device-resident headline cannot see.  Never `value`."""
+    import numpy as np
+    n, depth = args.host_pairs, 4
+    rows, cols = args.rows, args.cols
+    if args.dry_run:  # plumbing only (tests/test_dist.py): same barriers and reduction, no engine
+        d.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.001 * n * (1 + d.rank))
+        local = time.perf_counter() - t0
+    else:
+        params = pm.default_params(args.semantics, patch=args.patch, patchmatch_iters=args.iters, engine=args.engine,
+                                   sparse_init=1 if args.self_seed else 0)
+        seeds = (lambda p: (None, None)) if args.self_seed else (lambda p: (p["seed_l"], p["seed_r"]))
+        with pm.Engine(params, device=d.local_rank, max_rows=rows, max_cols=cols, max_batch=depth) as e:
+            pin = lambda a_: (lambda b_: (np.copyto(b_, a_), b_)[1])(e.host_alloc(a_.shape, a_.dtype))
+            src = [{k: pin(p[k]) for k in ("left", "right", "seed_l", "seed_r")} for p in pairs]
+            dst = [(e.host_alloc((rows, cols), np.float32), e.host_alloc((rows, cols), np.float32)) for _ in range(depth)]
+
+            def run(k):
+                for i in range(k):
+                    if e.in_flight() == depth:
+                        e.collect()
+                    p = src[i % len(src)]
+                    e.submit(p["left"], p["right"], *seeds(p), tag=i, out=dst[i % depth])
+                while e.in_flight():
+                    e.collect()
+            run(2 * depth)
+            d.barrier()
+            t0 = time.perf_counter()
+            run(n)
+            local = time.perf_counter() - t0
+    d.barrier()
+    elapsed = d.max_over_ranks(local)
+    return {"value": d.world * n / elapsed, "unit": "pairs/s", "frames_per_rank": n, "depth": depth, "ranks": d.world,
+            "ms_per_frame_per_rank": 1e3 * elapsed / n,
+            "note": "PCIe-inclusive: every rank's frame sequence on page-locked caller buffers (2 x 0.92 MB in + 2 x 3.69 MB "
+                    "seeds in + 2 x 3.69 MB maps out per pair), frames of all ranks / max elapsed over ranks"}
+
+
 def sequence_device_leg(pm, torch, w, args, device, depth=4, frames=96):
     """pm_submit_device / pm_collect on the headline's resident pairs: one pair per call as in the headline, but the engine
     may overlap consecutive frames (two frames advanced through every launch together while the device is busy)."""
@@ -450,37 +496,29 @@ def reference_test_shape_leg(pm, args, device):
     l, r = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
     rows, cols = l.shape
     rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)  # as tests/test_golden.py pins them
-    runs = {}
-    for graph in (1, 0):  # 1 = default: both views through every launch of the iterations (pm_params.small_image_fused_views)
-        prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=3, sparse_init=1, small_image_fused_views=graph)
-        calls = []
-        with pm.Engine(prm, device=device, max_rows=rows, max_cols=cols) as e:
-            out = (np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32))
-            for i in range(5):
-                t0 = time.perf_counter()
-                e.match(l, r, out=out)
-                calls.append(1e3 * (time.perf_counter() - t0))
-            steady = []
-            for i in range(60):
-                t0 = time.perf_counter()
-                e.match(l, r, out=out)
-                steady.append(1e3 * (time.perf_counter() - t0))
-            same = bool(np.array_equal(rowsum(out[0]), g["gpu_test_rows_l"]) and np.array_equal(rowsum(out[1]), g["gpu_test_rows_r"]))
-        runs[graph] = (calls, float(np.median(steady)), same)
-    calls, med, same = runs[1]
+    prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=3, sparse_init=1)
+    calls = []
+    with pm.Engine(prm, device=device, max_rows=rows, max_cols=cols) as e:
+        out = (np.zeros((rows, cols), np.float32), np.zeros((rows, cols), np.float32))
+        for i in range(5):
+            t0 = time.perf_counter()
+            e.match(l, r, out=out)
+            calls.append(1e3 * (time.perf_counter() - t0))
+        steady = []
+        for i in range(60):
+            t0 = time.perf_counter()
+            e.match(l, r, out=out)
+            steady.append(1e3 * (time.perf_counter() - t0))
+        same = bool(np.array_equal(rowsum(out[0]), g["gpu_test_rows_l"]) and np.array_equal(rowsum(out[1]), g["gpu_test_rows_r"]))
+    med = float(np.median(steady))
     res = {"workload": f"{cols}x{rows} farmsim test pair, PM_SEM_GPU (the CUDA module's own 5-tap semantics), cost_alpha "
                        "0.9, 3 iterations, self-seeded, host images in / host maps out, Match x 5 "
                        "(patchmatch_gpu_test.cpp:68-88)",
            "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": med,
-           "pairs_per_s_steady": 1e3 / med,
-           "equals_the_golden_row_checksums": same and runs[0][2],
-           "views_on_two_streams": {"ms_per_call_first_five": [round(c, 3) for c in runs[0][0]],
-                                    "ms_per_call_steady_median": runs[0][1],
-                                    "note": "pm_params.small_image_fused_views = 0: each view's iterations on its own "
-                                            "stream, 55 launches per call (round 4's schedule at every size)"},
-           "note": "default (pm_params.small_image_fused_views): a pair of up to 256 Ki pixels runs both views through "
-                   "every launch of its iterations -- 37 launches per call instead of 55; the call is bound by launch "
-                   "submission at this size (a recorded HIP graph was 10 % slower: profiles/r05_small_image_graph.txt)"}
+           "pairs_per_s_steady": 1e3 / med, "equals_the_golden_row_checksums": same,
+           "note": "bound by the chain of ~24 dependent launches of one view on the device (the views already overlap on "
+                   "two streams); a recorded HIP graph (0.71 ms) and both views per launch (0.69 ms) were built in round "
+                   "5, measured slower than this and removed: profiles/r05_reference_call_pattern.txt"}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -850,8 +888,11 @@ def main():
             time.sleep(0.001 * (1 + d.rank))
         elapsed = d.max_over_ranks(time.perf_counter() - t0)
         d.barrier()
+        host_seq = host_sequence_all_ranks(None, args, None, d) if (not planes and args.host_pairs > 0) else None
         if d.rank == 0:
             result.update(value=d.world * steps / elapsed, ms_per_step=1e3 * elapsed / steps, dry_run=True)
+            if host_seq is not None:
+                result["host_sequence_all_ranks"] = host_seq
             if tiled_result is not None:
                 result["tiled_4096x2160"] = tiled_result
             print(json.dumps(result), flush=True)
@@ -895,6 +936,10 @@ def main():
     # pair 0's maps (rank 0: synth pair 0, the pair the CPU baselines run) for the whole-frame comparison below
     maps0 = w.maps0() if (d.rank == 0 and not args.enhance and not args.self_seed) else None
 
+    # the PCIe-inclusive frame sequence on every rank (collective: barriers + max over ranks inside)
+    host_seq = None
+    if not planes and args.host_pairs > 0 and nb == 1:
+        host_seq = host_sequence_all_ranks(pm, args, w.pairs[:N_ROTATE], d)
     if d.rank == 0:
         gpu_ms = sum(v[1] for v in prof.values())
         result.update(
@@ -909,6 +954,8 @@ def main():
         )
         if counters is not None:
             result["run_engine_counters_per_step"] = counters
+        if host_seq is not None:
+            result["host_sequence_all_ranks"] = host_seq
         side = d.world == 1 and not planes and nb == 1 and not args.no_side_legs
         if d.world == 1 and not planes and args.host_pairs > 0:
             # every leg below runs in THIS process, beside the headline's handle (one stream policy: DESIGN.md 6)

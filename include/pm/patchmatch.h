@@ -158,10 +158,6 @@ typedef struct pm_params {
   /* --- how the handle sits in the host process (ABI 6; no reference counterpart: the reference runs everything on the
    * default stream with device-wide synchronisation, patchmatch_gpu.cu:396-410) ---------------------------------- */
   int stream_priority;            /* 1     pm_stream_priority: the class of the handle's four streams              */
-  int small_image_fused_views;    /* 1     a single pair of up to 256 Ki pixels runs BOTH views through every launch
-                                           of its iterations (half the launches: the reference's own 376x240 test
-                                           shape is bound by launch submission, not by the device); 0 = the two views
-                                           on their own streams at every size                                       */
 } pm_params;
 /* The priority class ALL streams of a handle are created in.  HIGH (default): not for the priority but because streams
  * of different classes never share a hardware queue, which keeps the matcher's two view streams off the queues of

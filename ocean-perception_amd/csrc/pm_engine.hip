@@ -431,13 +431,6 @@ bool view_streams_enabled() {
   return v;
 }
 
-// pm_params.small_image_fused_views: a single pair of at most this many pixels runs its iterations with both views in
-// every launch (run_views_on)
-constexpr size_t kFusedViewsMaxPx = 256u * 1024u;
-bool fused_small_views(const pm_handle* h, const PlaneSet& ps, int slots) {
-  return h->params.small_image_fused_views != 0 && slots == 2 && (size_t)ps.rows * (size_t)ps.cols <= kFusedViewsMaxPx;
-}
-
 int seed_views(pm_handle* h, const PlaneSet& ps, int n_pairs, int view, int scratch) {
   if (!h->need_seed[view]) return PM_OK;
   Launch l(h, PM_K_SEED);
@@ -557,15 +550,7 @@ int run_views_on(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* s
     if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, scratch + v);
     h->stream = main_stream;
   }
-  if (rc == PM_OK && fused_small_views(h, ps, slots) && vstream[0] == main_stream) {
-    // a small pair: the heads of the two views (planes, seeder) ran side by side on the two streams; the iterations run
-    // BOTH views through every launch on the handle's stream -- half the launches (the reference's 376x240 test shape is
-    // bound by their submission: 55 launches for ~0.5 ms of device work), and a launch of 240 chains fills no chip anyway
-    rc = join_stream(h, vstream[1], h->view1_join, main_stream);
-    if (rc == PM_OK) rc = run_view_sets(h, &ps, &main_stream, 1, slots);
-  } else if (rc == PM_OK) {
-    rc = run_view_sets(h, pv, vstream, 2, slots / 2);
-  }
+  if (rc == PM_OK) rc = run_view_sets(h, pv, vstream, 2, slots / 2);
   if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
   return rc;
 }
@@ -804,9 +789,8 @@ int validate_params(pm_handle* h, const pm_params& p) {
       return PM_ERR_INVALID_ARG;
     }
   }
-  if (p.stream_priority < PM_STREAM_PRIO_LOW || p.stream_priority > PM_STREAM_PRIO_HIGH ||
-      (p.small_image_fused_views != 0 && p.small_image_fused_views != 1)) {
-    set_err(h, "stream_priority must be one of pm_stream_priority (-1, 0, 1) and small_image_fused_views 0 or 1");
+  if (p.stream_priority < PM_STREAM_PRIO_LOW || p.stream_priority > PM_STREAM_PRIO_HIGH) {
+    set_err(h, "stream_priority must be one of pm_stream_priority (-1, 0, 1)");
     return PM_ERR_INVALID_ARG;
   }
   return PM_OK;
@@ -1002,7 +986,6 @@ void pm_params_default(pm_params* p, int semantics) {
   p->plane_window = PM_PL_WINDOW_CHECKER;
   p->plane_neighbours = PM_PL_NEIGH_FOUR;
   p->stream_priority = PM_STREAM_PRIO_HIGH;
-  p->small_image_fused_views = 1;
 }
 
 const char* pm_status_string(int status) {

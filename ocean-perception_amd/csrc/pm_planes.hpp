@@ -254,7 +254,7 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
 }
 template <int P>
 __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
-                                                 const PlanesParams& pp) {
+                                                 const PlanesParams& pp, float bound = __builtin_inff()) {
   constexpr int h = P / 2;
   constexpr int TR = kPlTileH + P - 1;
   constexpr int NE = (P + 1) / 2, NO = P / 2;  // taps of an even / an odd window row
@@ -293,6 +293,12 @@ __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty
       plo += lww2;
       pgo += lww2;
     }
+    // early termination (exact, see pl_cost; -DPL_EARLY_EXIT=1 builds only): after window rows 0..3, 0..5, 0..7
+    if (PL_EARLY_EXIT && i >= 2 && i + 4 < P) {
+      const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
+      const float part = pp.alpha * fminf(mc, pp.tau_color) + pp.one_minus_alpha * fminf(mg, pp.tau_grad);
+      if (!__any(part < bound)) return part;
+    }
   }
   const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
   const float t0 = pp.alpha * fminf(mc, pp.tau_color);
@@ -302,7 +308,7 @@ __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty
 template <int P, int WIN>
 __device__ __forceinline__ float pl_cost_w(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                            const PlanesParams& pp, float bound = __builtin_inff()) {
-  if constexpr (WIN == 1) return pl_cost_checker<P>(t, lx, ty, xrel, a, b, z, pp);
+  if constexpr (WIN == 1) return pl_cost_checker<P>(t, lx, ty, xrel, a, b, z, pp, bound);
   else return pl_cost<P>(t, lx, ty, xrel, a, b, z, pp, bound);
 }
 

@@ -45,7 +45,6 @@ pm_params PatchmatchGpu::Params::ToC() const {
   p.max_disp = matcher_params.max_disp;
   p.max_matching_cost = matcher_params.max_matching_cost;
   p.stream_priority = stream_priority;
-  p.small_image_fused_views = small_image_fused_views ? 1 : 0;
   return p;
 }
 

@@ -130,7 +130,6 @@ class PatchmatchGpu final {
     // hardware queues of the host application's default-class streams; an application that must keep its own kernels
     // in front of the matcher's sets PM_STREAM_PRIO_DEFAULT or PM_STREAM_PRIO_LOW
     int stream_priority = PM_STREAM_PRIO_HIGH;
-    bool small_image_fused_views = true;  // small pairs run both views through every launch (pm_params)
 
     // Fills a pm_params from these fields.
     pm_params ToC() const;

@@ -98,7 +98,6 @@ class PmParams(C.Structure):
         ("plane_window", C.c_int),
         ("plane_neighbours", C.c_int),
         ("stream_priority", C.c_int),
-        ("small_image_fused_views", C.c_int),
     ]
 
 

@@ -34,6 +34,11 @@ def test_bench_two_ranks_gloo_dry_run():
     # rank 1 sleeps 2 ms per step: the max over ranks (>= 10 ms for 5 steps) must be what is reported
     assert out["ms_per_step"] >= 2.0
     assert abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5 / 1e3)) < 1e-6 * out["value"]
+    # the PCIe-inclusive frame-sequence leg runs on EVERY rank and is reduced like `value`: frames of all ranks over the
+    # max elapsed (rank 1 "takes" 2 ms per frame in the dry run)
+    hs = out["host_sequence_all_ranks"]
+    assert hs["ranks"] == 2 and hs["frames_per_rank"] == 64 and hs["ms_per_frame_per_rank"] >= 2.0
+    assert abs(hs["value"] - 2 * 64 / (hs["ms_per_frame_per_rank"] * 64 / 1e3)) < 1e-6 * hs["value"]
 
 
 def test_failing_tiled_leg_does_not_cost_the_line():
@@ -107,7 +112,7 @@ def test_bench_with_a_one_rank_rccl_group_on_the_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-           "--host-pairs", "0", "--no-side-legs"]
+           "--host-pairs", "16", "--no-side-legs"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -116,3 +121,6 @@ def test_bench_with_a_one_rank_rccl_group_on_the_gpu():
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["unit"] == "pairs/s"
     assert out["check"]["deterministic_across_steps"] is True
     assert out["value"] > 150.0, out["value"]  # (one queue for both views reads ~275 on an MI355X; far lower = broken)
+    # the PCIe-inclusive frame sequence of configs[2] ran on the rank, between RCCL barriers, reduced over the group
+    hs = out["host_sequence_all_ranks"]
+    assert hs["ranks"] == 1 and hs["frames_per_rank"] == 16 and hs["value"] > 150.0, hs

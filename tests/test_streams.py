@@ -127,32 +127,7 @@ def test_stream_priority_classes_give_the_same_maps(pm, synth, prio):
 
 
 def test_stream_priority_out_of_range_is_refused(pm):
-    for field, bad in (("stream_priority", 2), ("stream_priority", -2), ("small_image_fused_views", 3)):
+    for field, bad in (("stream_priority", 2), ("stream_priority", -2)):
         with pytest.raises(pm.PmError) as ex:
             pm.Engine(pm.default_params(0, **{field: bad}), max_rows=64, max_cols=64)
         assert ex.value.status == pm.PM_ERR_INVALID_ARG
-
-
-def test_small_pairs_with_fused_views_give_the_two_stream_maps(pm, synth):
-    """pm_params.small_image_fused_views: a single pair of up to 256 Ki pixels runs both views through every launch of
-    its iterations (the heads stay on the two view streams); a schedule, never a result -- host calls, seeded and
-    self-seeded, both semantics, and frames of a sequence equal the two-stream schedule bit for bit."""
-    cases = [(96, 160, True), (96, 160, False), (64, 120, True), (240, 376, True), (240, 376, False)]
-    for sem, patch, self_seed in ((0, 5, 0), (1, 3, 1), (0, 7, 1)):
-        prm_f = pm.default_params(sem, patch=patch, patchmatch_iters=2, sparse_init=self_seed)
-        prm_t = pm.default_params(sem, patch=patch, patchmatch_iters=2, sparse_init=self_seed, small_image_fused_views=0)
-        assert prm_f.small_image_fused_views == 1
-        with pm.Engine(prm_f, max_rows=240, max_cols=376, max_batch=3) as ef, \
-                pm.Engine(prm_t, max_rows=240, max_cols=376, max_batch=3) as et:
-            for i, (rows, cols, seeded) in enumerate(cases):
-                p = synth.make_pair(40 + i, rows=rows, cols=cols, n_points=30, dilate_factor=2)
-                sl, sr = (p["seed_l"], p["seed_r"]) if seeded else (None, None)
-                got, want = ef.match(p["left"], p["right"], sl, sr), et.match(p["left"], p["right"], sl, sr)
-                assert_same(got[0], want[0], f"case {i} left (semantics {sem})")
-                assert_same(got[1], want[1], f"case {i} right (semantics {sem})")
-                for k in range(3):
-                    ef.submit(p["left"], p["right"], sl, sr, tag=k)
-                for k in range(3):
-                    seq = ef.collect()
-                    assert_same(seq[0], want[0], f"case {i} frame {k} left")
-                    assert_same(seq[1], want[1], f"case {i} frame {k} right")
