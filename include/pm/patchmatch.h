@@ -366,6 +366,18 @@ int pm_tile_sweep_masked(pm_handle* h, int iteration, int k, const int* d_mask);
 /* one image row of the disparity planes: [n_views][cols] floats */
 int pm_tile_get_row(pm_handle* h, int image_row, float* d_dst);
 int pm_tile_set_row(pm_handle* h, int image_row, const float* d_src);
+/* One exchange round of vertical sweep k (1 or 3) in two launches instead of five: d_incoming is the neighbour's
+ * boundary row as it stands now ([n_views][cols] floats; any device-readable address: the place the neighbour published
+ * it, also in a peer device's memory when peer access is enabled, or a local copy), d_used the row the last sweep
+ * used.  The columns where they differ are written to d_mask ([n_views][cols] ints), put back to the snapshot and
+ * re-swept with the incoming value stored at image row pred_image_row (a row of the neighbour, not one of the band's
+ * own); d_used_next (another buffer than d_used; may be d_incoming itself) receives the incoming row for the next
+ * round's comparison.  = compare + pm_tile_restore_cols + pm_tile_set_row + pm_tile_sweep_masked. */
+int pm_tile_exchange_round(pm_handle* h, int iteration, int k, int pred_image_row, const float* d_incoming,
+                           const float* d_used, float* d_used_next, int* d_mask);
+/* *d_flag |= 1 (device int) if image row `image_row` of the disparity planes differs from d_ref_row ([n_views][cols]):
+ * "did my boundary row move after the last row I sent?" in one launch. */
+int pm_tile_row_moved(pm_handle* h, int image_row, const float* d_ref_row, int* d_flag);
 int pm_tile_background(pm_handle* h);
 /* cross-check + un-mirror; writes the owned rows only: [own_rows][cols] each */
 int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own);

@@ -888,6 +888,62 @@ __global__ void __launch_bounds__(256) k_restore_cols(PlaneSet ps, const float* 
   ps.cost[o] = snap_cost[o];
 }
 
+// Row-tiled mode, one exchange round of a vertical sweep in ONE launch (round 4: a row copy, a row compare, a column
+// restore over the whole band and a row store were four launches and a copy).  `incoming` is the neighbour band's
+// boundary row as it stands NOW -- read where the neighbour published it, also across devices when peer access is
+// enabled -- `used` the one the last sweep saw.  A column whose value changed is flagged in `mask`, its rows
+// y_lo .. y_hi (the rows the sweeps of this band write) go back to the snapshot, and row `pred_r` of the band (the
+// neighbour's row, outside those) takes the incoming value; `used_next` (if not the incoming row itself) receives a copy
+// for the next round's comparison.  grid = (cols / 256, chunks of kTileRoundRows rows, views): a thread restores one
+// chunk of one column, all loads before the stores; blocks without a changed column end after two loads.
+constexpr int kTileRoundRows = 16;
+__global__ void __launch_bounds__(256) k_tile_round(PlaneSet ps, const float* __restrict__ snap_disp,
+                                                    const float* __restrict__ snap_cost, const float* __restrict__ incoming,
+                                                    const float* __restrict__ used, float* __restrict__ used_next,
+                                                    int* __restrict__ mask, int pred_r, int y_lo, int y_hi) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.z;
+  if (x >= ps.cols) return;
+  const size_t e = (size_t)v * ps.cols + x;
+  const float in = incoming[e];
+  const bool changed = in != used[e];
+  const size_t base = (size_t)v * ps.splane;
+  if (blockIdx.y == 0) {
+    mask[e] = changed ? 1 : 0;
+    if (used_next != incoming) used_next[e] = in;
+    if (changed) ps.disp[base + state_at(x, pred_r, ps.pitch)] = in;
+  }
+  if (!changed) return;
+  const int y0 = y_lo + (int)blockIdx.y * kTileRoundRows;
+  float d[kTileRoundRows], c[kTileRoundRows];
+#pragma unroll
+  for (int i = 0; i < kTileRoundRows; ++i) {
+    const int y = y0 + i;
+    const size_t o = base + state_at(x, y <= y_hi ? y : y_hi, ps.pitch);
+    d[i] = snap_disp[o];
+    c[i] = snap_cost[o];
+  }
+#pragma unroll
+  for (int i = 0; i < kTileRoundRows; ++i) {
+    const int y = y0 + i;
+    if (y <= y_hi) {
+      const size_t o = base + state_at(x, y, ps.pitch);
+      ps.disp[o] = d[i];
+      ps.cost[o] = c[i];
+    }
+  }
+}
+// ... and the question at the end of a vertical sweep in one launch (round 4: row copy + compare): does image row r of
+// the planes differ from `ref` ([n_views][cols], the row last sent to the successor)?  Then *flag becomes 1.
+__global__ void __launch_bounds__(256) k_state_row_moved(PlaneSet ps, int r, const float* __restrict__ ref,
+                                                         int* __restrict__ flag) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (x >= ps.cols) return;
+  const bool moved = ps.disp[(size_t)v * ps.splane + state_at(x, r, ps.pitch)] != ref[(size_t)v * ps.cols + x];
+  if (__builtin_amdgcn_ballot_w64(moved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // Row-tiled mode: image row r of every view between the disparity planes and a tight [n_views][cols] buffer.
 __global__ void __launch_bounds__(256) k_state_row(PlaneSet ps, int r, float* __restrict__ buf, int to_buf) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;

@@ -157,6 +157,19 @@ void launch_state_row(pm_handle* h, const PlaneSet& ps, int r, float* d_buf, int
                      d_buf, to_buf);
 }
 
+void launch_tile_round(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
+                       const float* d_incoming, const float* d_used, float* d_used_next, int* d_mask, int pred_r, int y_lo,
+                       int y_hi) {
+  const int chunks = (y_hi - y_lo + kTileRoundRows) / kTileRoundRows;
+  hipLaunchKernelGGL(k_tile_round, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)chunks, (unsigned)ps.n_views), dim3(256),
+                     0, h->stream, ps, snap_disp, snap_cost, d_incoming, d_used, d_used_next, d_mask, pred_r, y_lo, y_hi);
+}
+
+void launch_state_row_moved(pm_handle* h, const PlaneSet& ps, int r, const float* d_ref, int* d_flag) {
+  hipLaunchKernelGGL(k_state_row_moved, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.n_views), dim3(256), 0,
+                     h->stream, ps, r, d_ref, d_flag);
+}
+
 void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_disp, const float* snap_cost,
                          const int* d_mask) {
   hipLaunchKernelGGL(k_restore_cols, pixel_grid(ps.cols, ps.rows, ps.n_views), dim3(256), 0, h->stream, ps, snap_disp,

@@ -16,8 +16,14 @@ namespace pm {
 namespace {
 
 // Wavefronts per chain in PM_ENGINE_RUNBLK2: 4 up to ~1600 positions per chain, 8 beyond (measured:
-// 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4).  PM_RUNBLK_WAVES overrides.
-int runblk_waves(int chain_len, int axis, int group = 32) {
+// 720p best at 4, tools/sweep_group.sh; 4096x2160 38.7 ms per frame at 8 vs 42.6 at 4), 2 for chains shorter than 400
+// positions -- the column chains of a 270-row band of a row-tiled 4096x2160 image: 8 / 16 segments of 17-35 positions are
+// mostly speculation boundaries (round 5: eight bands on one device 51.0 -> 48.4 ms in the tuning build) -- but only
+// where the launch has chains enough to fill the chip without them: the 376 x 240 pair of the reference's own test is
+// short chains on an EMPTY chip, and two wavefronts per chain took its call from 0.65 to 0.79 ms.
+// PM_RUNBLK_WAVES overrides.
+constexpr int kShortChain = 400, kManyChains = 2048;
+int runblk_waves(int chain_len, int n_chains, int axis, int group = 32) {
   struct Knobs {
     int v[2][2];  // [axis][group == 16]
     Knobs() {
@@ -37,7 +43,7 @@ int runblk_waves(int chain_len, int axis, int group = 32) {
   static const Knobs k;  // initialised once, thread-safe
   const int g16 = group <= 16 ? 1 : 0;
   if (k.v[axis][g16]) return k.v[axis][g16];
-  return chain_len > 1600 ? 8 : 4;
+  return chain_len > 1600 ? 8 : ((chain_len < kShortChain && n_chains >= kManyChains) ? 2 : 4);
 }
 
 // One directional sweep, in place.
@@ -99,9 +105,9 @@ void launch_sweep(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, 
   } else {
     const int group = runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir);
     if (cp.semantics == PM_SEM_CPU)
-      launch_sweep_run3(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, stream);
+      launch_sweep_run3(ps, cp, g, slots, runblk_waves(chain_len, chains * slots, g.axis, group), group, stream);
     else
-      launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, g.axis, group), group, stream);
+      launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, chains * slots, g.axis, group), group, stream);
   }
 }
 

@@ -181,6 +181,47 @@ int pm_tile_restore_cols(pm_handle* h, const int* d_mask) {
   return launch_check(h, "restore_cols");
 }
 
+// One exchange round of vertical sweep k in two launches: k_tile_round (compare the incoming boundary row with the one
+// the last sweep used -> mask; flagged columns back to the snapshot; the incoming values into the planes and -- a copy
+// for the next round's comparison -- into d_used_next), then the masked sweep.  Equal to
+// pm_tile_restore_cols(mask of incoming != used) + pm_tile_set_row + pm_tile_sweep_masked.
+int pm_tile_exchange_round(pm_handle* h, int it, int k, int pred_image_row, const float* d_incoming, const float* d_used,
+                           float* d_used_next, int* d_mask) {
+  if (int rc = tile_check(h, "pm_tile_exchange_round")) return rc;
+  const int r = pred_image_row - h->tile.band_row0;
+  if (!h->snap_disp || !d_incoming || !d_used || !d_used_next || d_used_next == d_used || !d_mask || r < 0 ||
+      r >= h->tile_band_rows) {
+    set_err(h, "pm_tile_exchange_round: no snapshot, a null pointer, or row %d outside the band", pred_image_row);
+    return PM_ERR_INVALID_ARG;
+  }
+  if ((k & 1) == 0) {
+    set_err(h, "pm_tile_exchange_round: boundary rows belong to the vertical sweeps (k = 1, 3)");
+    return PM_ERR_INVALID_ARG;
+  }
+  const PlaneSet ps = tile_plane_set(h);
+  // the rows a sweep of this band can have written: the owned ones
+  const int y_lo = h->tile.own_row0 - h->tile.band_row0, y_hi = y_lo + h->tile.own_rows - 1;
+  if (r >= y_lo && r <= y_hi) {
+    set_err(h, "pm_tile_exchange_round: row %d is one of the band's own rows, not a neighbour's", pred_image_row);
+    return PM_ERR_INVALID_ARG;
+  }
+  launch_tile_round(h, ps, h->snap_disp, h->snap_cost, d_incoming, d_used, d_used_next, d_mask, r, y_lo, y_hi);
+  if (int rc = launch_check(h, "tile_round")) return rc;
+  return tile_sweep(h, it, k, d_mask);
+}
+
+int pm_tile_row_moved(pm_handle* h, int image_row, const float* d_ref_row, int* d_flag) {
+  if (int rc = tile_check(h, "pm_tile_row_moved")) return rc;
+  const int r = image_row - h->tile.band_row0;
+  if (r < 0 || r >= h->tile_band_rows || !d_ref_row || !d_flag) {
+    set_err(h, "pm_tile_row_moved: row %d outside the band or null pointer", image_row);
+    return PM_ERR_INVALID_ARG;
+  }
+  const PlaneSet ps = tile_plane_set(h);
+  launch_state_row_moved(h, ps, r, d_ref_row, d_flag);
+  return launch_check(h, "state_row_moved");
+}
+
 static int tile_row_copy(pm_handle* h, int image_row, float* d_dst, const float* d_src, const char* what) {
   if (int rc = tile_check(h, what)) return rc;
   const int r = image_row - h->tile.band_row0;

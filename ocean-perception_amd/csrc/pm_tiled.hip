@@ -15,17 +15,6 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_row_changed(int* __restrict__ mask, const float* __restrict__ a,
-                                                     const float* __restrict__ b, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) mask[i] = a[i] != b[i] ? 1 : 0;
-}
-__global__ void __launch_bounds__(256) k_row_moved(int* __restrict__ flag, const float* __restrict__ a,
-                                                   const float* __restrict__ b, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && a[i] != b[i]) atomicOr(flag, 1);
-}
-
 struct Band {
   pm_handle* h = nullptr;
   int dev = 0;
@@ -41,6 +30,9 @@ struct Band {
   hipEvent_t ev_read[2] = {nullptr, nullptr};  // the successor has copied sent[i] (recorded on ITS stream)
   bool read_pending[2] = {false, false};
   int last = 0;  // the buffer of `sent` that holds the row this band published last
+  // kernels of this band may read the `sent` buffers of band k - 1 / k + 1 where they lie: same device, or peer access
+  // enabled in both directions (pm_tiled_create); otherwise the row is copied over first (hipMemcpyPeerAsync)
+  bool direct_prev = false, direct_next = false;
 };
 
 }  // namespace
@@ -140,7 +132,6 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
   const pm_params& prm = pm_internal::params(p->bands[0].h);
   const int row_n = nv * cols;
   const size_t row_bytes = sizeof(float) * (size_t)row_n;
-  const dim3 rgrid((unsigned)((row_n + 255) / 256)), rblock(256);
   for (Band& b : p->bands) {
     TL_HIP(p, hipSetDevice(b.dev));
     TL_HIP(p, hipMemsetAsync(b.flag, 0, sizeof(int), b.stream));
@@ -214,11 +205,20 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
           Band& b = p->bands[(size_t)j];
           const int pr = pred_of(j);
           if (pr < 0 || pr >= n || pos_of(j) <= r) continue;  // no predecessor, or final since round pos - 1
-          if (int rc = fetch(j, pr, b.incoming)) return rc;
-          hipLaunchKernelGGL(k_row_changed, rgrid, rblock, 0, b.stream, b.mask, b.incoming, b.used, row_n);
-          TL_PM(p, b, pm_tile_restore_cols(b.h, b.mask));
-          TL_PM(p, b, pm_tile_set_row(b.h, pred_row(b), b.incoming));
-          TL_PM(p, b, pm_tile_sweep_masked(b.h, it, k, b.mask));
+          // compare + restore + row store in one launch, then the masked sweep (round 4: a copy and four launches);
+          // the incoming row is read where the predecessor published it when this band's kernels can reach it
+          Band& s = p->bands[(size_t)pr];
+          if (pr < j ? b.direct_prev : b.direct_next) {
+            TL_HIP(p, hipSetDevice(b.dev));
+            TL_HIP(p, hipStreamWaitEvent(b.stream, s.ev_sent[cur], 0));
+            TL_PM(p, b, pm_tile_exchange_round(b.h, it, k, pred_row(b), s.sent[cur], b.used, b.incoming, b.mask));
+            TL_HIP(p, hipEventRecord(s.ev_read[cur], b.stream));
+            s.read_pending[cur] = true;
+            ++*exchanges;
+          } else {
+            if (int rc = fetch(j, pr, b.incoming)) return rc;
+            TL_PM(p, b, pm_tile_exchange_round(b.h, it, k, pred_row(b), b.incoming, b.used, b.incoming, b.mask));
+          }
           float* t = b.used;
           b.used = b.incoming;
           b.incoming = t;
@@ -230,8 +230,7 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
         const int succ = down ? j + 1 : j - 1;
         if (succ < 0 || succ >= n) continue;
         TL_HIP(p, hipSetDevice(b.dev));
-        TL_PM(p, b, pm_tile_get_row(b.h, out_row(b), b.probe));
-        hipLaunchKernelGGL(k_row_moved, rgrid, rblock, 0, b.stream, b.flag, b.probe, b.sent[b.last], row_n);
+        TL_PM(p, b, pm_tile_row_moved(b.h, out_row(b), b.sent[b.last], b.flag));
       }
     }
   }
@@ -346,7 +345,10 @@ int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm
   // neighbouring bands on different devices: direct peer copies over xGMI where the platform allows them
   for (int k = 0; k + 1 < n_bands; ++k) {
     const int a = p->bands[(size_t)k].dev, c = p->bands[(size_t)k + 1].dev;
-    if (a == c) continue;  // bands sharing a device: hipMemcpyPeerAsync is then a plain device copy, nothing to enable
+    if (a == c) {  // bands sharing a device: hipMemcpyPeerAsync is then a plain device copy, nothing to enable
+      p->bands[(size_t)k].direct_next = p->bands[(size_t)k + 1].direct_prev = true;
+      continue;
+    }
     ++p->device_boundaries;
     int ok = 0;
     if (hipDeviceCanAccessPeer(&ok, a, c) == hipSuccess && ok) {
@@ -355,7 +357,10 @@ int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm
       (void)hipSetDevice(c);
       const hipError_t e2 = hipDeviceEnablePeerAccess(a, 0);
       const auto fine = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
-      if (fine(e1) && fine(e2)) ++p->peer_links;
+      if (fine(e1) && fine(e2)) {
+        ++p->peer_links;
+        p->bands[(size_t)k].direct_next = p->bands[(size_t)k + 1].direct_prev = true;
+      }
     }
     (void)hipGetLastError();
   }

@@ -178,6 +178,7 @@ def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_
         engine.tile_begin(tile, ptr(left_band), ptr(right_band), band_rows, cols, ptr(seed_l_band), ptr(seed_r_band))
         own_end = own_row0 + own_rows
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        mask = torch.zeros((n_views, cols), dtype=torch.int32, device=dev)
 
         def get_row(r):
             t = torch.empty((n_views, cols), dtype=torch.float32, device=dev)
@@ -210,17 +211,16 @@ def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_
                         sent = get_row(out_row)
                     new_in = comm.shift(sent, down, send=send, recv=recv)
                     if new_in is not None:
-                        mask = (new_in != used).to(torch.int32).contiguous()  # columns whose incoming value changed
-                        engine.tile_restore_cols(mask.data_ptr())
-                        engine.tile_set_row(pred_row, new_in.data_ptr())
-                        engine.tile_sweep_masked(it, k, mask.data_ptr())
+                        # columns whose incoming value changed: flagged, put back to the snapshot, the incoming row
+                        # stored -- one launch -- then the masked sweep (pm_tile_exchange_round)
+                        engine.tile_exchange_round(it, k, pred_row, new_in.data_ptr(), used.data_ptr(), new_in.data_ptr(), mask.data_ptr())
                         used = new_in
                 # did my boundary row move after the last row I sent?  then my successor is stale.  Only a rank
                 # that HAS a successor in this sweep's direction asks: the last band's row is an image border
                 # nobody consumes, and a change there must not make every rank repeat the Match.
                 succ = comm.rank + 1 if down else comm.rank - 1
                 if 0 <= succ < comm.world:
-                    flag = torch.maximum(flag, (get_row(out_row) != sent).any().to(torch.int32).reshape(1))
+                    engine.tile_row_moved(out_row, sent.data_ptr(), flag.data_ptr())
         engine.tile_background()
         out_l = torch.empty((own_rows, cols), dtype=torch.float32, device=dev)
         out_r = torch.empty_like(out_l) if n_views > 1 else None
