@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/valu.json: the issue-side roofs of the window kernels from rocprofv3 --pmc passes of the bench command.
 
-usage: tools/make_valu.py <insts.csv> <active.csv> <ta.csv> <out.json> [<merge-into.json>]
+usage: tools/make_valu.py <insts.csv> <active.csv> <ta.csv> <out.json> [<merge-into.json>] [--suffix @variant] [--head SHA]
   insts.csv   pass with SQ_INSTS_VALU (per dispatch, summed over the chip)
   active.csv  pass with SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE
   ta.csv      pass with TA_TA_BUSY_sum, TD_TD_BUSY_sum and GRBM_GUI_ACTIVE
@@ -31,6 +31,18 @@ def per_launch(path):
 
 
 def main():
+    argv = list(sys.argv)
+    suffix = head = ""
+    for flag in ("--suffix", "--head"):
+        if flag in argv:
+            i = argv.index(flag)
+            val = argv[i + 1]
+            del argv[i:i + 2]
+            if flag == "--suffix":
+                suffix = val
+            else:
+                head = val
+    sys.argv = argv
     insts, n_i = per_launch(sys.argv[1])
     act, _ = per_launch(sys.argv[2])
     ta, _ = per_launch(sys.argv[3])
@@ -40,9 +52,14 @@ def main():
            "kernels": {}}
     if len(sys.argv) > 5:
         try:
-            out["kernels"] = json.load(open(sys.argv[5]))["kernels"]
+            old = json.load(open(sys.argv[5]))
+            out["kernels"] = old["kernels"]
+            if "head" in old and not head:
+                head = old["head"]
         except Exception:
             pass
+    if head:
+        out["head"] = head
     for cls, _ in CLASSES:
         if cls not in act:
             continue
@@ -54,7 +71,7 @@ def main():
             c2 = ta[cls]["GRBM_GUI_ACTIVE"] / 8.0
             e["ta_busy_frac"] = ta[cls]["TA_TA_BUSY_sum"] / (256.0 * c2)
             e["td_busy_frac"] = ta[cls]["TD_TD_BUSY_sum"] / (256.0 * c2)
-        out["kernels"][cls] = e
+        out["kernels"][cls + suffix] = e
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
 
