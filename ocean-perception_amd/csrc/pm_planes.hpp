@@ -98,8 +98,8 @@ __device__ __forceinline__ float pl_clamp_slope(float v, float smax) { return fm
 typedef unsigned pl_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) pl_u2 pl_lds_u2;
 struct PlTile {
-  int tgt_entry0;       // ABSOLUTE LDS address / 8 of the target tile: [TR][rw] 8-byte entries
-                        // {P(c), P(c + 1)}, P = colour | gradient << 16, c = xs_lo + index
+  int tgt_entry0;       // ABSOLUTE LDS address / 8 of the target tile: [TR][rw] 8-byte entries pl_entry(P(c), P(c + 1)),
+                        // P = colour | gradient << 16, c = xs_lo + index
   // Reference window bytes: FOUR copies of the tile per channel, copy s shifted left by s bytes
   // (copy_s[k] = tile[k + s]), rows padded to whole dwords: a lane whose window starts at byte offset f of a row reads
   // ALIGNED dwords (f >> 2) of copy (f & 3) and gets its window bytes in place -- no v_alignbyte per dword.
@@ -109,6 +109,26 @@ struct PlTile {
   const unsigned* rg;   // gradient
   int rw, lww, copy_w;  // target row entries; reference row dwords; dwords per copy
 };
+
+// A target entry and the lerp of a tap (round 5).  The sample of a tap is (p0 (256 - w) + p1 w + 128) >> 8 per channel
+// (oracle: pmo_planes_cost); with the channels 16 bits apart that is ONE packed 16-bit multiply-add if the entry holds
+// {A, D}:  A = (P(c) << 8) + 0x00800080 (both channels times 256, plus the rounding term),  D = P(c + 1) - P(c) per
+// 16-bit channel (two's complement), and  sample = byte 1 / byte 3 of  A + D * w  in arithmetic modulo 2^16 per channel
+// -- the true value p0 * 256 + (p1 - p0) * w + 128 lies in [128, 65408], so the wrap-around of a negative D * w is
+// exact.  v_pk_mad_u16 with the weight's low half feeding both channels (op_sel_hi) replaces a subtract, two 24-bit
+// multiplies and a three-way add: 6 -> 4 vector instructions per tap besides the byte gathers.
+typedef short pl_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pl_u2 pl_entry(unsigned p0, unsigned p1) {  // p = colour | gradient << 16
+  pl_u2 v;
+  v.x = (p0 << 8) + 0x00800080u;
+  v.y = __builtin_bit_cast(unsigned, (pl_s16x2)(__builtin_bit_cast(pl_s16x2, p1) - __builtin_bit_cast(pl_s16x2, p0)));
+  return v;
+}
+__device__ __forceinline__ unsigned pl_lerp(pl_u2 e, unsigned w) {  // w = 8-bit weight of the right neighbour, bits 8..31 zero
+  unsigned r;
+  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e.y), "v"(w), "v"(e.x));
+  return r;
+}
 
 // Window cost of plane (a, b, z) for the pixel at tile position (lx, ty); xrel = its column - h - xs_lo.
 // oracle: pmo_planes_cost.
@@ -171,10 +191,7 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int j = 4 * q + k;
-        if (j < P) {
-          const unsigned w1 = wq[j], w0 = 256u - w1;
-          s[k] = __umul24(tp[j].x, w0) + (__umul24(tp[j].y, w1) + 0x00800080u);
-        }
+        if (j < P) s[k] = pl_lerp(tp[j], wq[j]);
       }
       // bytes 1 / 3 of every s[k] are the colour / gradient samples: gather four of each (a tap the window
       // does not have contributes s = 0, i.e. sample bytes 0: only the reference side needs the mask)
@@ -237,10 +254,7 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int j = 4 * q + k;
-      if (j < NT) {
-        const unsigned w1 = wq[j], w0 = 256u - w1;
-        s[k] = __umul24(tp[j].x, w0) + (__umul24(tp[j].y, w1) + 0x00800080u);
-      }
+      if (j < NT) s[k] = pl_lerp(tp[j], wq[j]);
     }
     const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
     const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
@@ -491,18 +505,8 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
 #endif
             if (rr < TR) {
               pl_u2* trow = s_tgt + rr * rw;
-              if (ia >= 0 && ia < rw) {
-                pl_u2 v;
-                v.x = ea;
-                v.y = eb;
-                trow[ia] = v;
-              }
-              if (ia + 1 < rw) {
-                pl_u2 v;
-                v.x = eb;
-                v.y = en;
-                trow[ia + 1] = v;
-              }
+              if (ia >= 0 && ia < rw) trow[ia] = pl_entry(ea, eb);
+              if (ia + 1 < rw) trow[ia + 1] = pl_entry(eb, en);
             }
           }
         }
@@ -519,12 +523,8 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
 #pragma unroll
           for (int k = 0; k < NRR; ++k) {
             const int rr = ty + NW * k;
-            if (rr < TR && cc < rw) {
-              pl_u2 v;
-              v.x = (p0[k] & 0xffu) | ((p0[k] & 0xff00u) << 8);
-              v.y = (p1[k] & 0xffu) | ((p1[k] & 0xff00u) << 8);
-              s_tgt[rr * rw + cc] = v;
-            }
+            if (rr < TR && cc < rw)
+              s_tgt[rr * rw + cc] = pl_entry((p0[k] & 0xffu) | ((p0[k] & 0xff00u) << 8), (p1[k] & 0xffu) | ((p1[k] & 0xff00u) << 8));
           }
         }
       }

@@ -40,8 +40,8 @@ python3 $root/tools/make_valu.py $(csvof insts_scalar) $(csvof active_scalar) $(
 python3 $root/tools/make_valu.py $(csvof insts_planes) $(csvof active_planes) $(csvof ta_planes) $out/valu.json $out/valu.json > /dev/null
 python3 $root/tools/make_valu.py $(csvof insts_planes2) $(csvof active_planes2) $(csvof ta_planes2) $out/valu.json $out/valu.json --suffix @two_neighbours > /dev/null
 bash $root/tools/r05_fetch_calib.sh > /dev/null 2>&1
-cp $root/gpurun_out/r05/fetch_calib.txt $out/fetch_calib.txt
-stamp $out/kernel_stats_*.csv $out/pmc_*.txt $out/fetch_calib.txt
+cp $root/gpurun_out/r05/fetch_calib.txt $out/calib_fetch_write.txt
+stamp $out/kernel_stats_*.csv $out/pmc_*.txt $out/calib_fetch_write.txt
 # the raw counter dumps are large: keep the summaries only
 rm -rf $out/fetch_* $out/write_* $out/insts_* $out/active_* $out/ta_* $out/tcp_* $out/tcc_* $out/stats_scalar $out/stats_planes $out/stats_planes2
 ls $out
