@@ -116,7 +116,8 @@ struct PlTile {
 // 16-bit channel (two's complement), and  sample = byte 1 / byte 3 of  A + D * w  in arithmetic modulo 2^16 per channel
 // -- the true value p0 * 256 + (p1 - p0) * w + 128 lies in [128, 65408], so the wrap-around of a negative D * w is
 // exact.  v_pk_mad_u16 with the weight's low half feeding both channels (op_sel_hi) replaces a subtract, two 24-bit
-// multiplies and a three-way add: 6 -> 4 vector instructions per tap besides the byte gathers.
+// multiplies and a three-way add: 6 -> 3.5 vector instructions per tap besides the byte gathers (column add, address
+// shift, half a weight gather, the multiply-add).
 typedef short pl_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pl_u2 pl_entry(unsigned p0, unsigned p1) {  // p = colour | gradient << 16
   pl_u2 v;
@@ -124,9 +125,17 @@ __device__ __forceinline__ pl_u2 pl_entry(unsigned p0, unsigned p1) {  // p = co
   v.y = __builtin_bit_cast(unsigned, (pl_s16x2)(__builtin_bit_cast(pl_s16x2, p1) - __builtin_bit_cast(pl_s16x2, p0)));
   return v;
 }
-__device__ __forceinline__ unsigned pl_lerp(pl_u2 e, unsigned w) {  // w = 8-bit weight of the right neighbour, bits 8..31 zero
+// The weights of two taps in one register (one v_perm_b32 per PAIR of taps instead of one bit-field extract per tap):
+// byte 1 of the first tap's 16.16 column in the low half, of the second tap's in the high half.
+__device__ __forceinline__ unsigned pl_weights2(int x_first, int x_second) {
+  return __builtin_amdgcn_perm((unsigned)x_second, (unsigned)x_first, 0x0c050c01u);
+}
+// HALF = 0 / 1: the low / high half of `w2` is the tap's weight, fed to BOTH channels (op_sel / op_sel_hi of source 1)
+template <int HALF>
+__device__ __forceinline__ unsigned pl_lerp(pl_u2 e, unsigned w2) {
   unsigned r;
-  asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e.y), "v"(w), "v"(e.x));
+  if constexpr (HALF == 0) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(e.y), "v"(w2), "v"(e.x));
+  else asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(e.y), "v"(w2), "v"(e.x));
   return r;
 }
 
@@ -172,13 +181,16 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
     // all LDS reads of the window row first (target pairs, then reference bytes), arithmetic afterwards: the
     // reads of a row are in flight together instead of one wait per tap
     pl_u2 tp[P];
-    unsigned wq[P];
+    unsigned wq[(P + 1) / 2];  // the weights of taps 2 m and 2 m + 1
+    int xs[P + 1];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const int X = xrow + xoff[j];
-      tp[j] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)X >> 16) << 3);  // absolute LDS byte address
-      wq[j] = ((unsigned)X >> 8) & 255u;
+      xs[j] = xrow + xoff[j];
+      tp[j] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)xs[j] >> 16) << 3);  // absolute LDS byte address
     }
+    xs[P] = 0;
+#pragma unroll
+    for (int m = 0; m < (P + 1) / 2; ++m) wq[m] = pl_weights2(xs[2 * m], xs[2 * m + 1]);
     unsigned lw[NG], lgw[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -191,7 +203,7 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int j = 4 * q + k;
-        if (j < P) s[k] = pl_lerp(tp[j], wq[j]);
+        if (j < P) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
       }
       // bytes 1 / 3 of every s[k] are the colour / gradient samples: gather four of each (a tap the window
       // does not have contributes s = 0, i.e. sample bytes 0: only the reference side needs the mask)
@@ -235,13 +247,16 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
                                             unsigned& sc, unsigned& sg) {
   constexpr int NG = (NT + 3) / 4;
   pl_u2 tp[NT];
-  unsigned wq[NT];
+  unsigned wq[(NT + 1) / 2];  // the weights of taps 2 m and 2 m + 1 of this row
+  int xs[NT + 1];
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int X = xrow + xoff[J0 + 2 * k];
-    tp[k] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)X >> 16) << 3);  // absolute LDS byte address
-    wq[k] = ((unsigned)X >> 8) & 255u;
+    xs[k] = xrow + xoff[J0 + 2 * k];
+    tp[k] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)xs[k] >> 16) << 3);  // absolute LDS byte address
   }
+  xs[NT] = 0;
+#pragma unroll
+  for (int m = 0; m < (NT + 1) / 2; ++m) wq[m] = pl_weights2(xs[2 * m], xs[2 * m + 1]);
   unsigned lw[NG], lgw[NG];
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
@@ -254,7 +269,7 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int j = 4 * q + k;
-      if (j < NT) s[k] = pl_lerp(tp[j], wq[j]);
+      if (j < NT) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
     }
     const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
     const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
