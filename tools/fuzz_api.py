@@ -107,18 +107,33 @@ for case in range(a.cases):
                     for i in range(n)]
             dl = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
             dr = torch.empty_like(dl)
+            # half of the cases: the inputs are still being produced on a side stream when the frame is submitted
+            # (pm_submit_device_after: the frame waits for the caller's event on the device)
+            late = bool(rng.random() < 0.5)
+            if late:
+                src = (tl, tr, tsl, tsr)
+                tl, tr, tsl, tsr = (torch.zeros_like(t) for t in src)
+                producer = torch.cuda.Stream()
+                evs = [torch.cuda.Event() for _ in range(n)]
             torch.cuda.synchronize()
             tags = []
             for i in range(n):
                 if e.in_flight() >= depth:
                     tags.append(e.collect_device())
+                ev = None
+                if late:
+                    with torch.cuda.stream(producer):
+                        for dst, s_ in zip((tl, tr, tsl, tsr), src):
+                            dst[i].copy_(s_[i])
+                        evs[i].record(producer)
+                    ev = evs[i].cuda_event
                 e.submit_device(tl[i].data_ptr(), tr[i].data_ptr(), rows, cols, tsl[i].data_ptr(), tsr[i].data_ptr(),
-                                dl[i].data_ptr(), dr[i].data_ptr(), tag=i)
+                                dl[i].data_ptr(), dr[i].data_ptr(), tag=i, ready_event=ev)
             while e.in_flight():
                 tags.append(e.collect_device())
             assert tags == list(range(n)), tags
             got = [(dl[i].cpu().numpy(), dr[i].cpu().numpy()) for i in range(n)]
-            name = f"submit_device depth {depth}"
+            name = f"submit_device{'_after' if late else ''} depth {depth}"
         elif what == 2:  # device-resident batch
             tl = torch.from_numpy(np.stack(L)).to(dev)
             tr = torch.from_numpy(np.stack(R)).to(dev)

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-5 final measurements on the GPU box (one call): tools/r05_final.sh <head-sha> [steps...]
+#   tests    the whole -m gpu suite
+#   fuzz     the six differential fuzzers, new seeds            -> gpurun_out/r05/fuzz.txt
+#   bench    the driver's command                                -> gpurun_out/r05/bench_default.json
+#   prof     tools/profile_r05.sh                                -> gpurun_out/prof_r05/
+head=${1:-unknown}; shift
+steps=${@:-tests fuzz bench prof}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/r05
+mkdir -p $out
+cd $root
+for s in $steps; do
+case $s in
+tests)
+  python -m pytest tests -m gpu -x -q > $out/final_tests.log 2>&1; rc=$?; tail -3 $out/final_tests.log; [ $rc -eq 0 ] || exit 1;;
+fuzz)
+  f=$out/fuzz.txt
+  echo "Differential fuzzers on the tree of commit $head (tools/r05_final.sh fuzz, one MI355X; every case bit-identical or the run stops)" > $f
+  run() { name=$1; shift; echo "## $name $*" >> $f; timeout -k 10 900 python tools/$name "$@" > $out/fuzz_$name.log 2>&1; rc=$?; tail -1 $out/fuzz_$name.log >> $f; echo "exit $rc" >> $f; echo "$name done ($rc)"; [ $rc -eq 0 ]; }
+  run fuzz_api.py --cases 500 --seed 561 || { cat $f; exit 1; }
+  run fuzz_engines.py --cases 400 --seed 562 || { cat $f; exit 1; }
+  run fuzz_engines.py --cases 16 --seed 567 --big || { cat $f; exit 1; }
+  run fuzz_planes.py --cases 500 --seed 563 || { cat $f; exit 1; }
+  run fuzz_seed.py --cases 300 --seed 564 || { cat $f; exit 1; }
+  run fuzz_selfseed.py --cases 200 --seed 565 || { cat $f; exit 1; }
+  run fuzz_tiled.py --cases 250 --seed 566 || { cat $f; exit 1; }
+  cat $f;;
+bench)
+  python bench.py > $out/bench_default.json 2> $out/bench_default.err
+  python -c "
+import json
+j=json.load(open('$out/bench_default.json'))
+print('headline', round(j['value'],1), j['check'].get('equals_oracle_full_frame'))
+print('roofline frac', j['roofline']['frac'], 'traffic', j['roofline']['traffic'], 'alg', j['roofline']['algorithmic_bytes_per_launch'])
+print('batch', {k:(round(v['value'],1), v['check']['passes']) for k,v in j['batch'].items()})
+print('seqdev', round(j['sequence_device']['value'],1), 'hostseq', round(j['host_sequence_all_ranks']['value'],1))
+print('planes', {k:(round(v['value'],1), v['check'].get('equals_oracle_full_frame',{}).get('differing_pixels')) for k,v in j['planes'].items() if 'value' in v and 'check' in v})
+print('ref', j['reference_test_shape']['ms_per_call_steady_median'], 'tiled', j['tiled_4096x2160']['ms_per_frame'], j['tiled_4096x2160']['eight_bands_on_this_device']['ms_per_frame'])
+";;
+prof)
+  bash tools/profile_r05.sh $head > $out/profile_r05.log 2>&1; tail -20 $out/profile_r05.log;;
+esac
+done
