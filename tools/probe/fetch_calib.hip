@@ -61,8 +61,8 @@ int main() {
   (void)hipMemset(d, 1, bytes);
   (void)hipDeviceSynchronize();
   const dim3 grid(256 * 16), block(256);
-  rd<4><<<grid, block>>>(d, bytes / 4, out);  // (the first dispatch of a process is not always captured by the profiler:
-  (void)hipDeviceSynchronize();               //  this one is not evaluated -- it appears twice, the first occurrence is dropped)
+  rd<4><<<grid, block>>>(d, bytes / 4, out);  // (a warm-up dispatch; rd<4> appears twice and is averaged per dispatch)
+  (void)hipDeviceSynchronize();
   rd<2><<<grid, block>>>(d, bytes / 2, out);
   rd<4><<<grid, block>>>(d, bytes / 4, out);
   rd<8><<<grid, block>>>(d, bytes / 8, out);

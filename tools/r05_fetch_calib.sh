@@ -22,11 +22,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         per[(k, int(r["Dispatch_Id"]))] = per.get((k, int(r["Dispatch_Id"])), 0.0) + float(r["Counter_Value"])
-    first = min(d for _, d in per)
-    tot = collections.OrderedDict()
-    for (k, d), v in per.items():
-        if d != first:  # the process's first dispatch (a second rd<4>) is not evaluated
-            tot[k] = tot.get(k, 0.0) + v
+    tot, cnt = collections.OrderedDict(), collections.Counter()
+    for (k, d), v in per.items():  # per-dispatch average (rd<4> runs twice: the process's first dispatch is a warm-up)
+        tot[k] = tot.get(k, 0.0) + v
+        cnt[k] += 1
+    for k in tot:
+        tot[k] /= cnt[k]
     for k, v in tot.items():
         kb = known.get(k)
         if kb is None:
