@@ -356,6 +356,9 @@ int pm_tile_noise(pm_handle* h, int iteration);         /* noise + clamp + cost 
 int pm_tile_sweep(pm_handle* h, int iteration, int k);  /* k: 0 row+, 1 col+, 2 row-, 3 col- (owned rows) */
 int pm_tile_snapshot(pm_handle* h);                     /* save disparity + cost planes                  */
 int pm_tile_restore(pm_handle* h);
+/* pm_tile_set_row(pred_image_row, d_row) -- if d_row is not NULL -- followed by pm_tile_snapshot, in ONE launch: what
+ * stands in front of every vertical sweep of a band (the neighbour's boundary row as the guess, then the snapshot). */
+int pm_tile_presweep(pm_handle* h, int pred_image_row, const float* d_row);
 /* Re-sweep after a boundary exchange without leaving the device timeline: d_mask is a DEVICE array of
  * [n_views][cols] ints (plane columns: view 1 in mirrored coordinates, as pm_tile_get_row delivers its rows);
  * pm_tile_restore_cols puts the flagged columns back to the snapshot, pm_tile_sweep_masked runs a vertical sweep

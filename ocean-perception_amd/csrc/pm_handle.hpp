@@ -323,6 +323,7 @@ void launch_tile_round(pm_handle* h, const PlaneSet& ps, const float* snap_disp,
                        const float* d_incoming, const float* d_used, float* d_used_next, int* d_mask, int pred_r,
                        int y_lo, int y_hi);
 void launch_state_row_moved(pm_handle* h, const PlaneSet& ps, int r, const float* d_ref, int* d_flag);
+void launch_tile_presweep(pm_handle* h, const PlaneSet& ps, float* snap_disp, float* snap_cost, const float* d_row, int pred_r);
 // rows x cols floats from tight device memory into page-locked host memory (its DEVICE address), row stride in floats
 void launch_download(pm_handle* h, float* dst_dev, size_t dst_step_floats, const float* d_src, int rows, int cols,
                      hipStream_t stream);

@@ -933,6 +933,28 @@ __global__ void __launch_bounds__(256) k_tile_round(PlaneSet ps, const float* __
     }
   }
 }
+// Row-tiled mode, in front of a vertical sweep, ONE launch (round 4: a row store and two runtime copies): the snapshot of
+// both state planes of every view (whole 16-byte pieces: four interleaved rows of a column), and -- if `row` is given --
+// the neighbour band's boundary row into row `pred_r` of the disparity plane (in the snapshot as well: a restore never
+// touches that row, but the snapshot is "the planes as the sweep found them").  grid = (ceil(pitch / 256), rows4 / 4... see launch).
+__global__ void __launch_bounds__(256) k_tile_presweep(PlaneSet ps, float* __restrict__ snap_disp, float* __restrict__ snap_cost,
+                                                       const float* __restrict__ row, int pred_r) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;  // column (one 16-byte piece = rows 4 q .. 4 q + 3 of column x)
+  const int q = blockIdx.y, v = blockIdx.z;
+  if (x >= ps.pitch) return;
+  const size_t o = (size_t)v * ps.splane + (((size_t)q * (size_t)ps.pitch + (size_t)x) << 2);
+  f32x4 d = *reinterpret_cast<const f32x4*>(ps.disp + o);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(ps.cost + o);
+  if (row && (pred_r >> 2) == q && x < ps.cols) {
+    const float in = row[(size_t)v * ps.cols + x];
+    d[pred_r & 3] = in;
+    ps.disp[o + (pred_r & 3)] = in;
+  }
+  *reinterpret_cast<f32x4*>(snap_disp + o) = d;
+  *reinterpret_cast<f32x4*>(snap_cost + o) = c;
+}
+
 // ... and the question at the end of a vertical sweep in one launch (round 4: row copy + compare): does image row r of
 // the planes differ from `ref` ([n_views][cols], the row last sent to the successor)?  Then *flag becomes 1.
 __global__ void __launch_bounds__(256) k_state_row_moved(PlaneSet ps, int r, const float* __restrict__ ref,

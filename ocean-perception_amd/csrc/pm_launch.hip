@@ -165,6 +165,12 @@ void launch_tile_round(pm_handle* h, const PlaneSet& ps, const float* snap_disp,
                      0, h->stream, ps, snap_disp, snap_cost, d_incoming, d_used, d_used_next, d_mask, pred_r, y_lo, y_hi);
 }
 
+void launch_tile_presweep(pm_handle* h, const PlaneSet& ps, float* snap_disp, float* snap_cost, const float* d_row, int pred_r) {
+  const int rows4 = (ps.rows + 3) / 4;  // 16-byte pieces per column (pm_device.hpp::state_at)
+  hipLaunchKernelGGL(k_tile_presweep, dim3((unsigned)((ps.pitch + 255) / 256), (unsigned)rows4, (unsigned)ps.n_views), dim3(256),
+                     0, h->stream, ps, snap_disp, snap_cost, d_row, pred_r);
+}
+
 void launch_state_row_moved(pm_handle* h, const PlaneSet& ps, int r, const float* d_ref, int* d_flag) {
   hipLaunchKernelGGL(k_state_row_moved, dim3((unsigned)((ps.cols + 255) / 256), (unsigned)ps.n_views), dim3(256), 0,
                      h->stream, ps, r, d_ref, d_flag);

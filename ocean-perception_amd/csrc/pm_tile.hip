@@ -157,6 +157,24 @@ int pm_tile_snapshot(pm_handle* h) {
   return PM_OK;
 }
 
+// pm_tile_set_row (optional) + pm_tile_snapshot in ONE launch: what stands in front of every vertical sweep of a band.
+int pm_tile_presweep(pm_handle* h, int pred_image_row, const float* d_row) {
+  if (int rc = tile_check(h, "pm_tile_presweep")) return rc;
+  const int r = pred_image_row - h->tile.band_row0;
+  if (d_row && (r < 0 || r >= h->tile_band_rows)) {
+    set_err(h, "pm_tile_presweep: row %d outside the band", pred_image_row);
+    return PM_ERR_INVALID_ARG;
+  }
+  const size_t plane = (size_t)align_up(h->max_rows, 4) * h->max_pitch;  // state planes (pm_device.hpp::state_at)
+  if (!h->snap_disp) {
+    PM_HIP(h, hipMalloc((void**)&h->snap_disp, sizeof(float) * 2 * plane));
+    PM_HIP(h, hipMalloc((void**)&h->snap_cost, sizeof(float) * 2 * plane));
+  }
+  const PlaneSet ps = tile_plane_set(h);
+  launch_tile_presweep(h, ps, h->snap_disp, h->snap_cost, d_row, d_row ? r : -4);
+  return launch_check(h, "tile_presweep");
+}
+
 int pm_tile_restore(pm_handle* h) {
   if (int rc = tile_check(h, "pm_tile_restore")) return rc;
   if (!h->snap_disp) {

@@ -181,11 +181,11 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
       for (int j = 0; j < n; ++j) {
         Band& b = p->bands[(size_t)j];
         const int pr = pred_of(j);
-        if (pr >= 0 && pr < n) {
+        const bool has_pred = pr >= 0 && pr < n;
+        if (has_pred)
           if (int rc = fetch(j, pr, b.used)) return rc;
-          TL_PM(p, b, pm_tile_set_row(b.h, pred_row(b), b.used));
-        }
-        TL_PM(p, b, pm_tile_snapshot(b.h));
+        // the guess into the planes and the snapshot in one launch (round 4: a row store and two runtime copies)
+        TL_PM(p, b, pm_tile_presweep(b.h, pred_row(b), has_pred ? b.used : nullptr));
         TL_PM(p, b, pm_tile_sweep(b.h, it, k));
       }
       // Round r hands band j the row its predecessor held after round r - 1.  The first band of the sweep direction has

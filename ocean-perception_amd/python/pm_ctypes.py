@@ -42,7 +42,7 @@ EXPORTS = [
     "pm_kernel_name", "pm_debug_counters", "pm_debug_counters_enable",
     "pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore", "pm_tile_get_row",
     "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols", "pm_tile_sweep_masked",
-    "pm_tile_exchange_round", "pm_tile_row_moved",
+    "pm_tile_exchange_round", "pm_tile_row_moved", "pm_tile_presweep",
     "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
@@ -267,6 +267,8 @@ def load():
     lib.pm_tile_exchange_round.restype = C.c_int
     lib.pm_tile_row_moved.argtypes = [vp, C.c_int, f32p, vp]
     lib.pm_tile_row_moved.restype = C.c_int
+    lib.pm_tile_presweep.argtypes = [vp, C.c_int, f32p]
+    lib.pm_tile_presweep.restype = C.c_int
     for name in ("pm_tile_begin", "pm_tile_noise", "pm_tile_sweep", "pm_tile_snapshot", "pm_tile_restore",
                  "pm_tile_get_row", "pm_tile_set_row", "pm_tile_background", "pm_tile_finish", "pm_tile_restore_cols",
                  "pm_tile_sweep_masked"):
@@ -701,6 +703,9 @@ class Engine:
     def tile_exchange_round(self, it, k, pred_image_row, d_incoming, d_used, d_used_next, d_mask):
         self._check(self.lib.pm_tile_exchange_round(self.h, it, k, pred_image_row, d_incoming, d_used, d_used_next, d_mask),
                     "pm_tile_exchange_round")
+
+    def tile_presweep(self, pred_image_row, d_row):
+        self._check(self.lib.pm_tile_presweep(self.h, pred_image_row, d_row), "pm_tile_presweep")
 
     def tile_row_moved(self, image_row, d_ref_row, d_flag):
         self._check(self.lib.pm_tile_row_moved(self.h, image_row, d_ref_row, d_flag), "pm_tile_row_moved")

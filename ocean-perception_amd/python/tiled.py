@@ -196,9 +196,8 @@ def match_band(engine, comm, params, left_band, right_band, seed_l_band, seed_r_
                 pred_row = own_row0 - 1 if down else own_end
                 sent = get_row(out_row)
                 used = comm.shift(sent, down)  # the neighbour's value before the sweep: the guess
-                if used is not None:
-                    engine.tile_set_row(pred_row, used.data_ptr())
-                engine.tile_snapshot()
+                # the guess into the planes and the snapshot in one launch
+                engine.tile_presweep(pred_row, used.data_ptr() if used is not None else None)
                 engine.tile_sweep(it, k)
                 # The band at position pos of the sweep direction (0 = the band without a predecessor) is final after
                 # round pos - 1: from round pos on it would receive the row it already has.  It skips those rounds and
