@@ -72,7 +72,7 @@ LEGS = {"single": (1, _run_single, 30), "batch": (NB, _run_batch, 6), "sequence"
 
 def _measure(run, e, t, k):
     run(e, t, max(2, k // 6))  # warm
-    return max(run(e, t, k) for _ in range(2))
+    return max(run(e, t, k) for _ in range(3))  # best of three: a rate, not a latency -- robust against a noisy moment
 
 
 def test_legs_keep_their_rate_beside_other_handles(pm, synth):
