@@ -898,9 +898,10 @@ __global__ void __launch_bounds__(256) k_restore_cols(PlaneSet ps, const float* 
 // chunk of one column, all loads before the stores; blocks without a changed column end after two loads.
 constexpr int kTileRoundRows = 16;
 __global__ void __launch_bounds__(256) k_tile_round(PlaneSet ps, const float* __restrict__ snap_disp,
-                                                    const float* __restrict__ snap_cost, const float* __restrict__ incoming,
-                                                    const float* __restrict__ used, float* __restrict__ used_next,
+                                                    const float* __restrict__ snap_cost, const float* incoming,
+                                                    const float* __restrict__ used, float* used_next,
                                                     int* __restrict__ mask, int pred_r, int y_lo, int y_hi) {
+  // (incoming and used_next may be the same buffer: no __restrict__ on them)
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.z;
   if (x >= ps.cols) return;
