@@ -22,6 +22,8 @@ Side legs in the same line (rank 0, N=1, never `value`; all measured in THIS pro
     host_buffers      PCIe-inclusive rates of the host-buffer entry points (pageable and page-locked caller memory,
                       seeded and self-seeded): synchronous, the frame sequence, batches of 32
     sequence_device   the frame sequence on device-resident pairs (pm_submit_device)
+    host_sequence_all_ranks  the PCIe-inclusive frame sequence on page-locked buffers on EVERY rank of the run, reduced like
+                      `value` (configs[2] incl. H2D / D2H; also in multi-rank runs)
     batch             4 and 32 pairs per pm_match_device call (configs[2]'s per-GPU share)
     reference_test_shape  the reference's own timed call pattern (patchmatch_gpu_test.cpp:68-88) with its CPU side
     tiled_4096x2160   configs[3]: untiled, and through the C-ABI driver in 8 bands on this device
