@@ -24,7 +24,7 @@ struct Band {
   uint8_t *d_left = nullptr, *d_right = nullptr;
   float *d_seed_l = nullptr, *d_seed_r = nullptr, *d_out_l = nullptr, *d_out_r = nullptr;
   float* sent[2] = {nullptr, nullptr};  // the boundary row this band hands to its successor (double-buffered)
-  float *used = nullptr, *incoming = nullptr, *probe = nullptr;
+  float *used = nullptr, *incoming = nullptr;
   int *mask = nullptr, *flag = nullptr;
   hipEvent_t ev_sent[2] = {nullptr, nullptr};  // sent[i] is written (this band's stream)
   hipEvent_t ev_read[2] = {nullptr, nullptr};  // the successor has copied sent[i] (recorded on ITS stream)
@@ -282,7 +282,7 @@ void pm_tiled_destroy(pm_tiled_plan* plan) {
     (void)hipSetDevice(b.dev);
     if (b.stream) (void)hipStreamSynchronize(b.stream);
     void* bufs[] = {b.d_left, b.d_right, b.d_seed_l, b.d_seed_r, b.d_out_l, b.d_out_r, b.sent[0], b.sent[1],
-                    b.used,   b.incoming, b.probe,   b.mask,     b.flag};
+                    b.used,   b.incoming, b.mask,    b.flag};
     for (void* q : bufs)
       if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {
@@ -338,7 +338,6 @@ int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm
     }
     TL_HIP(p, hipMalloc((void**)&b.used, row_bytes));
     TL_HIP(p, hipMalloc((void**)&b.incoming, row_bytes));
-    TL_HIP(p, hipMalloc((void**)&b.probe, row_bytes));
     TL_HIP(p, hipMalloc((void**)&b.mask, sizeof(int) * (size_t)p->n_views * cols));
     TL_HIP(p, hipMalloc((void**)&b.flag, sizeof(int)));
   }
