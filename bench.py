@@ -754,32 +754,43 @@ def tiled_children(args):
         for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
             env.pop(k, None)  # the child rendezvous is a plain env:// TCP store of its own
         cmd = base + ["--backend", args.backend]
+        single = False
     else:
+        single = True
         if rank != 0:
             return None
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
                   "TORCHELASTIC_USE_AGENT_STORE"):
             env.pop(k, None)
         cmd = base + ["--single-process", str(world)]
-    try:
-        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    except OSError as e:
-        return {"error": "could not start the tiled leg: %r" % (e,)}
-    try:
-        out, err = p.communicate(timeout=args.tiled_timeout)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        p.communicate()
-        return {"error": "tiled leg did not finish within %d s (killed)" % args.tiled_timeout}
-    if rank != 0:
-        return None
-    for line in reversed(out.strip().splitlines()):
-        if line.startswith("{"):
-            try:
-                return json.loads(line)
-            except ValueError:
-                break
-    return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": err[-400:]}
+    def run_child(cmd, deadline):
+        try:
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        except OSError as e:
+            return {"error": "could not start the tiled leg: %r" % (e,)}
+        try:
+            out, err = p.communicate(timeout=deadline)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            return {"error": "tiled leg did not finish within %d s (killed)" % deadline}
+        if rank != 0:
+            return None
+        for line in reversed(out.strip().splitlines()):
+            if line.startswith("{"):
+                try:
+                    return json.loads(line)
+                except ValueError:
+                    break
+        return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": err[-400:]}
+
+    res = run_child(cmd, args.tiled_timeout)
+    if (single and rank == 0 and res is not None and "error" not in res
+            and res.get("peer_links", 0) == res.get("device_boundaries", -1) > 0):
+        # peer access is enabled on every boundary and the default leg ran: the same frame with the receiving band's KERNEL reading the boundary row across the link (one copy less per
+        # round; PM_TILED_EXCHANGE_DIRECT) -- in a child of its own: whatever it does stays beside the default leg's number
+        res["direct_exchange"] = run_child(cmd + ["--exchange", "2"], args.tiled_timeout)
+    return res
 
 
 def device_count():

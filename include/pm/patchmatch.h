@@ -431,6 +431,16 @@ const char* pm_tiled_last_error(const pm_tiled_plan* plan);
  * many of those boundaries got direct peer access (hipDeviceEnablePeerAccess both ways; the rest is staged by the
  * runtime).  All bands on one device: 0 and 0 -- no peer access is requested at all. */
 int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* peer_links);
+/* How a band gets at its neighbour's boundary row in an exchange round.
+ *   AUTO (default)  neighbours on ONE device: the band's kernel reads the row where the neighbour published it;
+ *                   neighbours on different devices: hipMemcpyPeerAsync on the receiving band's stream first
+ *   COPY            always the copy
+ *   DIRECT          as AUTO, and across devices too wherever peer access could be enabled (pm_tiled_topology): the
+ *                   receiving band's kernel reads 32 KB across the link -- one copy less per round.  Kernel reads of peer
+ *                   memory have not been timed on a multi-GPU node yet, which is why this is not what AUTO does.
+ * Results are identical in every mode. */
+typedef enum pm_tiled_exchange { PM_TILED_EXCHANGE_AUTO = 0, PM_TILED_EXCHANGE_COPY = 1, PM_TILED_EXCHANGE_DIRECT = 2 } pm_tiled_exchange;
+int pm_tiled_set_exchange(pm_tiled_plan* plan, int mode);
 
 /* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------
  * pm_match_u8 / pm_match_batch_u8 / pm_submit_u8 / pm_match_device run the whole schedule

@@ -2,22 +2,42 @@
 // handles on up to n devices, through the public pm_tile_* stages.  Protocol and exactness argument: include/pm/patchmatch.h
 // (pm_tiled_match_u8) and ocean-perception_amd/python/tiled.py, which runs the same steps over torch.distributed.
 // Everything a band does is ordered on its handle's stream; what crosses bands is one row of disparities per vertical
-// sweep and round, copied by hipMemcpyPeerAsync on the RECEIVER's stream behind an event of the sender's stream.
+// sweep and round, read by the RECEIVER (a peer copy on its stream, or its kernel reading the row in place) behind an
+// event of the sender's stream.
+//
+// Device discipline (round 6).  With one band per GPU every runtime object belongs to ONE device, and the rules are:
+//   * an event is created on its owner's device and recorded ONLY on a stream of that device (hipEventRecord with an
+//     event and a stream of different devices is an error); waiting for an event of another device is legal;
+//   * a stream is used -- copies, memsets, launches, synchronisation -- with its device current;
+//   * an allocation is made with its band's device current;
+//   * a kernel of a band reads memory of another device only where that is the declared intent (`direct` exchange).
+// So the SENDER of a row owns "the row is written" (ev_sent, recorded on its stream) and the READER owns "the row is
+// consumed" (ev_done, recorded on the reader's stream; the sender waits for it before it overwrites the buffer).  A band
+// has a different reader per sweep direction, hence two pairs of ev_done.  Every HIP call of this file goes through the
+// rt_* functions below, which -- when the plan was made by pm_tiled_create_logical (include/pm/testing.h) -- keep a log
+// of (call, current device, device of the stream / event / pointers) in LOGICAL device ids, so that the discipline can
+// be proven on a box with ONE GPU: bands get distinct logical devices, all mapped onto the physical device of their
+// handle.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
+#include <unordered_map>
 #include <vector>
 
 #include "pm/patchmatch.h"
+#include "pm/testing.h"
 #include "pm_internal.hpp"
 
 namespace {
 
 struct Band {
   pm_handle* h = nullptr;
-  int dev = 0;
+  int index = 0;
+  int dev = 0;   // the physical device of the handle
+  int ldev = 0;  // the device the band is accounted to: = dev, or a logical id given to pm_tiled_create_logical
   hipStream_t stream = nullptr;
   pm_tile tile{};
   int band_rows = 0;
@@ -26,13 +46,28 @@ struct Band {
   float* sent[2] = {nullptr, nullptr};  // the boundary row this band hands to its successor (double-buffered)
   float *used = nullptr, *incoming = nullptr;
   int *mask = nullptr, *flag = nullptr;
-  hipEvent_t ev_sent[2] = {nullptr, nullptr};  // sent[i] is written (this band's stream)
-  hipEvent_t ev_read[2] = {nullptr, nullptr};  // the successor has copied sent[i] (recorded on ITS stream)
-  bool read_pending[2] = {false, false};
+  hipEvent_t ev_sent[2] = {nullptr, nullptr};  // sent[i] is written (this band's event, this band's stream)
+  // this band, as the READER of its predecessor's sent[i], has consumed it: [sweep direction: 0 down, 1 up][i].
+  // Created on THIS band's device and recorded on THIS band's stream; the predecessor waits for it.
+  hipEvent_t ev_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t unread[2] = {nullptr, nullptr};  // the reader's ev_done that guards sent[i], or null: nobody is reading it
   int last = 0;  // the buffer of `sent` that holds the row this band published last
-  // kernels of this band may read the `sent` buffers of band k - 1 / k + 1 where they lie: same device, or peer access
-  // enabled in both directions (pm_tiled_create); otherwise the row is copied over first (hipMemcpyPeerAsync)
-  bool direct_prev = false, direct_next = false;
+  // peer access is enabled in both directions between this band's device and its neighbour's (pm_tiled_create)
+  bool peer_prev = false, peer_next = false;
+};
+
+struct AuditRange {
+  const char* base;
+  size_t bytes;
+  int ldev;
+};
+struct Audit {
+  int cur = -1;  // the logical device that is current
+  std::vector<pm_tiled_audit_record> log;
+  std::vector<AuditRange> mem;
+  std::unordered_map<const void*, int> obj;  // events and streams -> logical device
+  int violations = 0;
+  int simulate_peer = 0;
 };
 
 }  // namespace
@@ -43,6 +78,8 @@ struct pm_tiled_plan {
   bool resident = false, have_seed_l = false, have_seed_r = false;  // a pair has been uploaded (pm_tiled_upload_u8)
   int device_boundaries = 0;  // neighbouring bands that live on DIFFERENT devices (their rows cross by peer copy)
   int peer_links = 0;         // ... of which direct peer access could be enabled (the others are staged by the runtime)
+  int exchange = PM_TILED_EXCHANGE_AUTO;
+  Audit* audit = nullptr;  // only plans of pm_tiled_create_logical keep a log
   char err[512] = {0};
 };
 
@@ -60,11 +97,158 @@ int fail(pm_tiled_plan* p, int code, const char* fmt, ...) {
     hipError_t e_ = (call);                                                                          \
     if (e_ != hipSuccess) return fail((p), PM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
-#define TL_PM(p, b, call)                                                                            \
+
+// ---- the runtime layer: the ONLY place of this file that calls HIP; logs in logical device ids when asked to ---------
+
+int au_mem(const Audit& a, const void* q) {  // the logical device an address belongs to; -1 = not one of the plan's
+  for (const AuditRange& r : a.mem)
+    if ((const char*)q >= r.base && (const char*)q < r.base + r.bytes) return r.ldev;
+  return -1;
+}
+int au_obj(const Audit& a, const void* o) {
+  auto it = a.obj.find(o);
+  return it == a.obj.end() ? -1 : it->second;
+}
+// one record; `stream`, `object`, `source`: logical devices or -1 (the call has no such argument).  Violations:
+//   1 the stream argument is not a stream of the current device      2 an event is recorded on a stream of another device
+//   4 the object (allocation, event being created, destination) does not belong to the current device
+//   8 the source lies on another device and the call is not one that may read there
+//   16 an argument is not known to the plan at all
+void au_log(pm_tiled_plan* p, int call, int band, int detail, bool has_stream, int stream, bool has_object, int object,
+            bool has_source, int source, bool foreign_ok) {
+  Audit& a = *p->audit;
+  pm_tiled_audit_record r{};
+  r.call = call;
+  r.band = band;
+  r.detail = detail;
+  r.current_device = a.cur;
+  r.stream_device = has_stream ? stream : -1;
+  r.object_device = has_object ? object : -1;
+  r.source_device = has_source ? source : -1;
+  r.foreign_allowed = foreign_ok ? 1 : 0;
+  int v = 0;
+  if (has_stream && stream < 0) v |= 16;
+  if (has_object && object < 0) v |= 16;
+  if (has_source && source < 0) v |= 16;
+  if (has_stream && stream >= 0 && stream != a.cur) v |= 1;
+  if (call == PM_TILED_CALL_EVENT_RECORD && has_stream && has_object && stream != object) v |= 2;
+  if (call != PM_TILED_CALL_STREAM_WAIT_EVENT && has_object && object >= 0 && object != a.cur) v |= 4;
+  if (has_source && source >= 0 && source != a.cur && !foreign_ok) v |= 8;
+  r.violation = v;
+  if (v) ++a.violations;
+  a.log.push_back(r);
+}
+
+// binds band b's device (physical) and accounts for it (logical)
+hipError_t rt_use(pm_tiled_plan* p, const Band& b) {
+  const hipError_t e = hipSetDevice(b.dev);
+  if (p->audit) {
+    p->audit->cur = b.ldev;
+    au_log(p, PM_TILED_CALL_SET_DEVICE, b.index, 0, false, -1, true, b.ldev, false, -1, false);
+  }
+  return e;
+}
+hipError_t rt_malloc(pm_tiled_plan* p, const Band& b, void** out, size_t bytes) {
+  const hipError_t e = hipMalloc(out, bytes);
+  if (p->audit) {
+    if (e == hipSuccess) p->audit->mem.push_back({(const char*)*out, bytes, p->audit->cur});
+    au_log(p, PM_TILED_CALL_MALLOC, b.index, 0, false, -1, true, b.ldev, false, -1, false);
+  }
+  return e;
+}
+hipError_t rt_event_create(pm_tiled_plan* p, const Band& b, hipEvent_t* ev) {
+  const hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (p->audit) {
+    if (e == hipSuccess) p->audit->obj[(const void*)*ev] = p->audit->cur;  // an event belongs to the device current at its creation
+    au_log(p, PM_TILED_CALL_EVENT_CREATE, b.index, 0, false, -1, true, b.ldev, false, -1, false);
+  }
+  return e;
+}
+hipError_t rt_event_record(pm_tiled_plan* p, const Band& b, hipEvent_t ev) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_EVENT_RECORD, b.index, 0, true, au_obj(*p->audit, b.stream), true, au_obj(*p->audit, ev), false,
+           -1, false);
+  return hipEventRecord(ev, b.stream);
+}
+hipError_t rt_wait_event(pm_tiled_plan* p, const Band& b, hipEvent_t ev) {  // the event may belong to any device
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_STREAM_WAIT_EVENT, b.index, 0, true, au_obj(*p->audit, b.stream), true, au_obj(*p->audit, ev),
+           false, -1, false);
+  return hipStreamWaitEvent(b.stream, ev, 0);
+}
+hipError_t rt_sync(pm_tiled_plan* p, const Band& b) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_STREAM_SYNC, b.index, 0, true, au_obj(*p->audit, b.stream), false, -1, false, -1, false);
+  return hipStreamSynchronize(b.stream);
+}
+hipError_t rt_memset(pm_tiled_plan* p, const Band& b, void* dst, int value, size_t bytes) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_MEMSET, b.index, 0, true, au_obj(*p->audit, b.stream), true, au_mem(*p->audit, dst), false, -1,
+           false);
+  return hipMemsetAsync(dst, value, bytes, b.stream);
+}
+hipError_t rt_h2d_2d(pm_tiled_plan* p, const Band& b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t w,
+                     size_t h) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_COPY_H2D, b.index, 0, true, au_obj(*p->audit, b.stream), true, au_mem(*p->audit, dst), false, -1,
+           false);
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, w, h, hipMemcpyHostToDevice, b.stream);
+}
+hipError_t rt_d2h_2d(pm_tiled_plan* p, const Band& b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t w,
+                     size_t h) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_COPY_D2H, b.index, 0, true, au_obj(*p->audit, b.stream), false, -1, true,
+           au_mem(*p->audit, src), false);
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, w, h, hipMemcpyDeviceToHost, b.stream);
+}
+hipError_t rt_d2h(pm_tiled_plan* p, const Band& b, void* dst, const void* src, size_t bytes) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_COPY_D2H, b.index, 0, true, au_obj(*p->audit, b.stream), false, -1, true,
+           au_mem(*p->audit, src), false);
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b.stream);
+}
+// a row of band s -> memory of band b, on b's stream: the one call that names both devices
+hipError_t rt_copy_peer(pm_tiled_plan* p, const Band& b, void* dst, const Band& s, const void* src, size_t bytes) {
+  if (p->audit)
+    au_log(p, PM_TILED_CALL_COPY_PEER, b.index, s.index, true, au_obj(*p->audit, b.stream), true, au_mem(*p->audit, dst),
+           true, au_mem(*p->audit, src), true);
+  return hipMemcpyPeerAsync(dst, b.dev, src, s.dev, bytes, b.stream);
+}
+// A pm_tile_* stage of band b: the entry point binds b's device itself (pm_tile.hip::tile_check) and launches on b's
+// stream; what is checked here is where its pointer arguments live.
+struct StageArg {
+  const void* ptr;
+  bool foreign_ok;  // the kernel may read this address in another device's memory (direct exchange)
+};
+void rt_stage(pm_tiled_plan* p, const Band& b, int stage, std::initializer_list<StageArg> args) {
+  if (!p->audit) return;
+  Audit& a = *p->audit;
+  a.cur = b.ldev;
+  int i = 0;
+  au_log(p, PM_TILED_CALL_STAGE, b.index, stage * 16, true, au_obj(a, b.stream), false, -1, false, -1, false);
+  for (const StageArg& g : args) {
+    ++i;
+    if (!g.ptr) continue;
+    au_log(p, PM_TILED_CALL_STAGE_ARG, b.index, stage * 16 + i, false, -1, false, -1, true, au_mem(a, g.ptr), g.foreign_ok);
+  }
+}
+#define TL_STAGE(p, b, stage, call, ...)                                                             \
   do {                                                                                               \
+    rt_stage((p), (b), (stage), {__VA_ARGS__});                                                      \
     int rc_ = (call);                                                                                \
     if (rc_ != PM_OK) return fail((p), rc_, "%s: %s", #call, pm_last_error((b).h));                  \
   } while (0)
+enum {
+  ST_BEGIN = 1,
+  ST_NOISE,
+  ST_SWEEP,
+  ST_GET_ROW,
+  ST_PRESWEEP,
+  ST_EXCHANGE_ROUND,
+  ST_ROW_MOVED,
+  ST_BACKGROUND,
+  ST_FINISH
+};
 
 int halo_rows(const pm_params& p) {
   if (p.semantics != PM_SEM_CPU) return 2;
@@ -82,23 +266,29 @@ void band_of(int k, int n, int rows, int halo, pm_tile* t, int* band_rows) {
   *band_rows = end - t->band_row0;
 }
 
+// may band b's kernels read the published row of its neighbour s where it lies?
+bool direct(const pm_tiled_plan* p, const Band& b, const Band& s) {
+  if (p->exchange == PM_TILED_EXCHANGE_COPY) return false;
+  if (b.ldev == s.ldev) return true;  // one device: the neighbour's buffer is ordinary device memory
+  if (p->exchange != PM_TILED_EXCHANGE_DIRECT) return false;
+  return s.index < b.index ? b.peer_prev : b.peer_next;
+}
+
 // the band images and seed maps of a pair -> the bands' devices (stream-ordered, on every band's stream)
 int upload(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t image_step, const float* seed_l,
            const float* seed_r, size_t seed_step) {
   const int cols = p->cols;
   for (Band& b : p->bands) {
-    TL_HIP(p, hipSetDevice(b.dev));
+    TL_HIP(p, rt_use(p, b));
     const size_t w = (size_t)cols;
-    TL_HIP(p, hipMemcpy2DAsync(b.d_left, w, left + (size_t)b.tile.band_row0 * image_step, image_step, w, (size_t)b.band_rows,
-                               hipMemcpyHostToDevice, b.stream));
-    TL_HIP(p, hipMemcpy2DAsync(b.d_right, w, right + (size_t)b.tile.band_row0 * image_step, image_step, w,
-                               (size_t)b.band_rows, hipMemcpyHostToDevice, b.stream));
+    TL_HIP(p, rt_h2d_2d(p, b, b.d_left, w, left + (size_t)b.tile.band_row0 * image_step, image_step, w, (size_t)b.band_rows));
+    TL_HIP(p, rt_h2d_2d(p, b, b.d_right, w, right + (size_t)b.tile.band_row0 * image_step, image_step, w, (size_t)b.band_rows));
     if (seed_l)
-      TL_HIP(p, hipMemcpy2DAsync(b.d_seed_l, w * 4, (const char*)seed_l + (size_t)b.tile.band_row0 * seed_step, seed_step,
-                                 w * 4, (size_t)b.band_rows, hipMemcpyHostToDevice, b.stream));
+      TL_HIP(p, rt_h2d_2d(p, b, b.d_seed_l, w * 4, (const char*)seed_l + (size_t)b.tile.band_row0 * seed_step, seed_step,
+                          w * 4, (size_t)b.band_rows));
     if (seed_r)
-      TL_HIP(p, hipMemcpy2DAsync(b.d_seed_r, w * 4, (const char*)seed_r + (size_t)b.tile.band_row0 * seed_step, seed_step,
-                                 w * 4, (size_t)b.band_rows, hipMemcpyHostToDevice, b.stream));
+      TL_HIP(p, rt_h2d_2d(p, b, b.d_seed_r, w * 4, (const char*)seed_r + (size_t)b.tile.band_row0 * seed_step, seed_step,
+                          w * 4, (size_t)b.band_rows));
   }
   p->have_seed_l = seed_l != nullptr;
   p->have_seed_r = seed_r != nullptr;
@@ -110,17 +300,17 @@ int upload(pm_tiled_plan* p, const uint8_t* left, const uint8_t* right, size_t i
 int download(pm_tiled_plan* p, float* disp_l, float* disp_r, size_t disp_step) {
   const int cols = p->cols, nv = p->n_views;
   for (Band& b : p->bands) {
-    TL_HIP(p, hipSetDevice(b.dev));
+    TL_HIP(p, rt_use(p, b));
     const size_t w4 = (size_t)cols * 4;
-    TL_HIP(p, hipMemcpy2DAsync((char*)disp_l + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_l, w4, w4,
-                               (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
+    TL_HIP(p, rt_d2h_2d(p, b, (char*)disp_l + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_l, w4, w4,
+                        (size_t)b.tile.own_rows));
     if (nv > 1 && disp_r)
-      TL_HIP(p, hipMemcpy2DAsync((char*)disp_r + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_r, w4, w4,
-                                 (size_t)b.tile.own_rows, hipMemcpyDeviceToHost, b.stream));
+      TL_HIP(p, rt_d2h_2d(p, b, (char*)disp_r + (size_t)b.tile.own_row0 * disp_step, disp_step, b.d_out_r, w4, w4,
+                          (size_t)b.tile.own_rows));
   }
   for (Band& b : p->bands) {
-    TL_HIP(p, hipSetDevice(b.dev));
-    TL_HIP(p, hipStreamSynchronize(b.stream));
+    TL_HIP(p, rt_use(p, b));
+    TL_HIP(p, rt_sync(p, b));
   }
   return PM_OK;
 }
@@ -133,45 +323,54 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
   const int row_n = nv * cols;
   const size_t row_bytes = sizeof(float) * (size_t)row_n;
   for (Band& b : p->bands) {
-    TL_HIP(p, hipSetDevice(b.dev));
-    TL_HIP(p, hipMemsetAsync(b.flag, 0, sizeof(int), b.stream));
-    TL_PM(p, b, pm_tile_begin(b.h, &b.tile, b.d_left, b.d_right, b.band_rows, cols, p->have_seed_l ? b.d_seed_l : nullptr,
-                              p->have_seed_r ? b.d_seed_r : nullptr));
+    TL_HIP(p, rt_use(p, b));
+    TL_HIP(p, rt_memset(p, b, b.flag, 0, sizeof(int)));
+    TL_STAGE(p, b, ST_BEGIN,
+             pm_tile_begin(b.h, &b.tile, b.d_left, b.d_right, b.band_rows, cols, p->have_seed_l ? b.d_seed_l : nullptr,
+                           p->have_seed_r ? b.d_seed_r : nullptr),
+             {b.d_left, false}, {b.d_right, false}, {p->have_seed_l ? b.d_seed_l : nullptr, false},
+             {p->have_seed_r ? b.d_seed_r : nullptr, false});
   }
   int cur = 0;
-  // band k's boundary row -> sent[cur] (behind the successor's last read of that buffer)
+  int dir = 0;  // 0: the sweep runs down (a band reads from the band above it), 1: up
+  // band k's boundary row -> sent[cur] (behind its reader's last use of that buffer)
   auto publish = [&](int k, int out_row) -> int {
     Band& b = p->bands[(size_t)k];
-    TL_HIP(p, hipSetDevice(b.dev));
-    if (b.read_pending[cur]) {
-      TL_HIP(p, hipStreamWaitEvent(b.stream, b.ev_read[cur], 0));
-      b.read_pending[cur] = false;
+    TL_HIP(p, rt_use(p, b));
+    if (b.unread[cur]) {
+      TL_HIP(p, rt_wait_event(p, b, b.unread[cur]));  // the reader's event, possibly of another device: waiting is legal
+      b.unread[cur] = nullptr;
     }
-    TL_PM(p, b, pm_tile_get_row(b.h, out_row, b.sent[cur]));
-    TL_HIP(p, hipEventRecord(b.ev_sent[cur], b.stream));
+    TL_STAGE(p, b, ST_GET_ROW, pm_tile_get_row(b.h, out_row, b.sent[cur]), {b.sent[cur], false});
+    TL_HIP(p, rt_event_record(p, b, b.ev_sent[cur]));
     b.last = cur;
+    return PM_OK;
+  };
+  // band k, with its device current, marks its predecessor's sent[cur] as consumed: ITS event on ITS stream
+  auto consumed = [&](Band& b, Band& s) -> int {
+    TL_HIP(p, rt_event_record(p, b, b.ev_done[dir][cur]));
+    s.unread[cur] = b.ev_done[dir][cur];
+    ++*exchanges;
     return PM_OK;
   };
   // band k copies its predecessor's published row into dst (on k's stream, behind the predecessor's event)
   auto fetch = [&](int k, int pred, float* dst) -> int {
     Band& b = p->bands[(size_t)k];
     Band& s = p->bands[(size_t)pred];
-    TL_HIP(p, hipSetDevice(b.dev));
-    TL_HIP(p, hipStreamWaitEvent(b.stream, s.ev_sent[cur], 0));
-    TL_HIP(p, hipMemcpyPeerAsync(dst, b.dev, s.sent[cur], s.dev, row_bytes, b.stream));
-    TL_HIP(p, hipEventRecord(s.ev_read[cur], b.stream));
-    s.read_pending[cur] = true;
-    ++*exchanges;
-    return PM_OK;
+    TL_HIP(p, rt_use(p, b));
+    TL_HIP(p, rt_wait_event(p, b, s.ev_sent[cur]));
+    TL_HIP(p, rt_copy_peer(p, b, dst, s, s.sent[cur], row_bytes));
+    return consumed(b, s);
   };
   for (int it = 0; it < prm.patchmatch_iters; ++it) {
-    for (Band& b : p->bands) TL_PM(p, b, pm_tile_noise(b.h, it));
+    for (Band& b : p->bands) TL_STAGE(p, b, ST_NOISE, pm_tile_noise(b.h, it));
     for (int k = 0; k < 4; ++k) {
       if (k == 0 || k == 2) {  // horizontal sweeps never leave the band
-        for (Band& b : p->bands) TL_PM(p, b, pm_tile_sweep(b.h, it, k));
+        for (Band& b : p->bands) TL_STAGE(p, b, ST_SWEEP, pm_tile_sweep(b.h, it, k));
         continue;
       }
       const bool down = k == 1;
+      dir = down ? 0 : 1;
       auto out_row = [&](const Band& b) { return down ? b.tile.own_row0 + b.tile.own_rows - 1 : b.tile.own_row0; };
       auto pred_row = [&](const Band& b) { return down ? b.tile.own_row0 - 1 : b.tile.own_row0 + b.tile.own_rows; };
       auto pred_of = [&](int j) { return down ? j - 1 : j + 1; };
@@ -185,8 +384,9 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
         if (has_pred)
           if (int rc = fetch(j, pr, b.used)) return rc;
         // the guess into the planes and the snapshot in one launch (round 4: a row store and two runtime copies)
-        TL_PM(p, b, pm_tile_presweep(b.h, pred_row(b), has_pred ? b.used : nullptr));
-        TL_PM(p, b, pm_tile_sweep(b.h, it, k));
+        TL_STAGE(p, b, ST_PRESWEEP, pm_tile_presweep(b.h, pred_row(b), has_pred ? b.used : nullptr),
+                 {has_pred ? b.used : nullptr, false});
+        TL_STAGE(p, b, ST_SWEEP, pm_tile_sweep(b.h, it, k));
       }
       // Round r hands band j the row its predecessor held after round r - 1.  The first band of the sweep direction has
       // no predecessor: its row is final after the first sweep; its successor is final after round 0, and so on -- the
@@ -208,16 +408,18 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
           // compare + restore + row store in one launch, then the masked sweep (round 4: a copy and four launches);
           // the incoming row is read where the predecessor published it when this band's kernels can reach it
           Band& s = p->bands[(size_t)pr];
-          if (pr < j ? b.direct_prev : b.direct_next) {
-            TL_HIP(p, hipSetDevice(b.dev));
-            TL_HIP(p, hipStreamWaitEvent(b.stream, s.ev_sent[cur], 0));
-            TL_PM(p, b, pm_tile_exchange_round(b.h, it, k, pred_row(b), s.sent[cur], b.used, b.incoming, b.mask));
-            TL_HIP(p, hipEventRecord(s.ev_read[cur], b.stream));
-            s.read_pending[cur] = true;
-            ++*exchanges;
+          if (direct(p, b, s)) {
+            TL_HIP(p, rt_use(p, b));
+            TL_HIP(p, rt_wait_event(p, b, s.ev_sent[cur]));
+            TL_STAGE(p, b, ST_EXCHANGE_ROUND,
+                     pm_tile_exchange_round(b.h, it, k, pred_row(b), s.sent[cur], b.used, b.incoming, b.mask),
+                     {s.sent[cur], true}, {b.used, false}, {b.incoming, false}, {b.mask, false});
+            if (int rc = consumed(b, s)) return rc;
           } else {
             if (int rc = fetch(j, pr, b.incoming)) return rc;
-            TL_PM(p, b, pm_tile_exchange_round(b.h, it, k, pred_row(b), b.incoming, b.used, b.incoming, b.mask));
+            TL_STAGE(p, b, ST_EXCHANGE_ROUND,
+                     pm_tile_exchange_round(b.h, it, k, pred_row(b), b.incoming, b.used, b.incoming, b.mask),
+                     {b.incoming, false}, {b.used, false}, {b.incoming, false}, {b.mask, false});
           }
           float* t = b.used;
           b.used = b.incoming;
@@ -229,23 +431,112 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
         Band& b = p->bands[(size_t)j];
         const int succ = down ? j + 1 : j - 1;
         if (succ < 0 || succ >= n) continue;
-        TL_HIP(p, hipSetDevice(b.dev));
-        TL_PM(p, b, pm_tile_row_moved(b.h, out_row(b), b.sent[b.last], b.flag));
+        TL_STAGE(p, b, ST_ROW_MOVED, pm_tile_row_moved(b.h, out_row(b), b.sent[b.last], b.flag), {b.sent[b.last], false},
+                 {b.flag, false});
       }
     }
   }
   for (Band& b : p->bands) {
-    TL_PM(p, b, pm_tile_background(b.h));
-    TL_PM(p, b, pm_tile_finish(b.h, b.d_out_l, nv > 1 ? b.d_out_r : nullptr));
+    TL_STAGE(p, b, ST_BACKGROUND, pm_tile_background(b.h));
+    TL_STAGE(p, b, ST_FINISH, pm_tile_finish(b.h, b.d_out_l, nv > 1 ? b.d_out_r : nullptr), {b.d_out_l, false},
+             {nv > 1 ? b.d_out_r : nullptr, false});
   }
   *moved = false;
   for (Band& b : p->bands) {
-    TL_HIP(p, hipSetDevice(b.dev));
+    TL_HIP(p, rt_use(p, b));
     int f = 0;
-    TL_HIP(p, hipMemcpyAsync(&f, b.flag, sizeof(int), hipMemcpyDeviceToHost, b.stream));
-    TL_HIP(p, hipStreamSynchronize(b.stream));
+    TL_HIP(p, rt_d2h(p, b, &f, b.flag, sizeof(int)));
+    TL_HIP(p, rt_sync(p, b));
     *moved = *moved || f != 0;
-    b.read_pending[0] = b.read_pending[1] = false;  // every stream is idle: nothing is pending any more
+  }
+  for (Band& b : p->bands) b.unread[0] = b.unread[1] = nullptr;  // every stream is idle: nothing is being read any more
+  return PM_OK;
+}
+
+int create(pm_handle* const* bands, int n_bands, int rows, int cols, const int* logical, int simulate_peer,
+           pm_tiled_plan** out) {
+  if (!out) return PM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!bands || n_bands < 1 || rows < n_bands || cols < 8) return PM_ERR_INVALID_ARG;
+  pm_tiled_plan* p = new pm_tiled_plan;
+  *out = p;  // also on failure: the plan then carries the message and is good for pm_tiled_destroy only
+  if (logical) {
+    p->audit = new Audit;
+    p->audit->simulate_peer = simulate_peer;
+  }
+  for (int k = 0; k < n_bands; ++k)
+    if (!bands[k]) return fail(p, PM_ERR_INVALID_ARG, "band %d is a null handle", k);
+  const pm_params& prm = pm_internal::params(bands[0]);
+  if (prm.mode != PM_MODE_SCALAR) return fail(p, PM_ERR_INVALID_ARG, "the row-tiled driver runs the scalar mode only");
+  for (int k = 1; k < n_bands; ++k)
+    if (std::memcmp(&pm_internal::params(bands[k]), &prm, sizeof(pm_params)) != 0)
+      return fail(p, PM_ERR_INVALID_ARG, "band %d was created with other parameters than band 0", k);
+  p->rows = rows;
+  p->cols = cols;
+  p->n_views = prm.left_right_check ? 2 : 1;
+  p->halo = halo_rows(prm);
+  p->bands.resize((size_t)n_bands);
+  for (int k = 0; k < n_bands; ++k) {
+    Band& b = p->bands[(size_t)k];
+    b.h = bands[k];
+    b.index = k;
+    b.dev = pm_internal::device(b.h);
+    b.ldev = logical ? logical[k] : b.dev;
+    if (b.ldev < 0) return fail(p, PM_ERR_INVALID_ARG, "band %d: negative logical device", k);
+    b.stream = pm_internal::stream(b.h);
+    if (p->audit) p->audit->obj[(const void*)b.stream] = b.ldev;  // the handle's stream lives on the handle's device
+    band_of(k, n_bands, rows, p->halo, &b.tile, &b.band_rows);
+    int mr, mc;
+    pm_internal::plan_size(b.h, &mr, &mc);
+    if (b.band_rows > mr || cols > mc)
+      return fail(p, PM_ERR_SIZE, "band %d needs a plan of %d x %d, its handle has %d x %d (pm_tiled_band_rows)", k, cols,
+                  b.band_rows, mc, mr);
+    TL_HIP(p, rt_use(p, b));
+    const size_t px = (size_t)b.band_rows * cols, own = (size_t)b.tile.own_rows * cols;
+    const size_t row_bytes = sizeof(float) * (size_t)p->n_views * cols;
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_left, px));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_right, px));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_seed_l, px * 4));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_seed_r, px * 4));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_out_l, own * 4));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.d_out_r, own * 4));
+    for (int i = 0; i < 2; ++i) {
+      TL_HIP(p, rt_malloc(p, b, (void**)&b.sent[i], row_bytes));
+      TL_HIP(p, rt_event_create(p, b, &b.ev_sent[i]));
+      TL_HIP(p, rt_event_create(p, b, &b.ev_done[0][i]));
+      TL_HIP(p, rt_event_create(p, b, &b.ev_done[1][i]));
+    }
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.used, row_bytes));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.incoming, row_bytes));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.mask, sizeof(int) * (size_t)p->n_views * cols));
+    TL_HIP(p, rt_malloc(p, b, (void**)&b.flag, sizeof(int)));
+  }
+  // neighbouring bands on different devices: peer access over xGMI where the platform allows it (hipMemcpyPeerAsync is
+  // then a direct copy; with PM_TILED_EXCHANGE_DIRECT the receiving band's kernel reads the row across the link)
+  for (int k = 0; k + 1 < n_bands; ++k) {
+    Band& a = p->bands[(size_t)k];
+    Band& c = p->bands[(size_t)k + 1];
+    if (a.ldev == c.ldev) continue;  // bands sharing a device: nothing to enable
+    ++p->device_boundaries;
+    bool linked = false;
+    if (a.dev == c.dev) {
+      linked = p->audit && p->audit->simulate_peer;  // logical devices on one physical device: as the test asks
+    } else {
+      int ok = 0;
+      if (hipDeviceCanAccessPeer(&ok, a.dev, c.dev) == hipSuccess && ok) {
+        (void)rt_use(p, a);
+        const hipError_t e1 = hipDeviceEnablePeerAccess(c.dev, 0);
+        (void)rt_use(p, c);
+        const hipError_t e2 = hipDeviceEnablePeerAccess(a.dev, 0);
+        const auto fine = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+        linked = fine(e1) && fine(e2);
+      }
+      (void)hipGetLastError();
+    }
+    if (linked) {
+      ++p->peer_links;
+      a.peer_next = c.peer_prev = true;
+    }
   }
   return PM_OK;
 }
@@ -276,93 +567,58 @@ int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* pe
   return PM_OK;
 }
 
+int pm_tiled_set_exchange(pm_tiled_plan* plan, int mode) {
+  if (!plan) return PM_ERR_INVALID_ARG;
+  if (mode != PM_TILED_EXCHANGE_AUTO && mode != PM_TILED_EXCHANGE_COPY && mode != PM_TILED_EXCHANGE_DIRECT)
+    return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_set_exchange: unknown mode %d", mode);
+  plan->exchange = mode;
+  return PM_OK;
+}
+
 void pm_tiled_destroy(pm_tiled_plan* plan) {
   if (!plan) return;
   for (Band& b : plan->bands) {
-    (void)hipSetDevice(b.dev);
-    if (b.stream) (void)hipStreamSynchronize(b.stream);
+    (void)rt_use(plan, b);
+    if (b.stream) (void)rt_sync(plan, b);
     void* bufs[] = {b.d_left, b.d_right, b.d_seed_l, b.d_seed_r, b.d_out_l, b.d_out_r, b.sent[0], b.sent[1],
                     b.used,   b.incoming, b.mask,    b.flag};
     for (void* q : bufs)
       if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {
       if (b.ev_sent[i]) (void)hipEventDestroy(b.ev_sent[i]);
-      if (b.ev_read[i]) (void)hipEventDestroy(b.ev_read[i]);
+      for (int d = 0; d < 2; ++d)
+        if (b.ev_done[d][i]) (void)hipEventDestroy(b.ev_done[d][i]);
     }
   }
+  delete plan->audit;
   delete plan;
 }
 
 int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm_tiled_plan** out) {
-  if (!out) return PM_ERR_INVALID_ARG;
-  *out = nullptr;
-  if (!bands || n_bands < 1 || rows < n_bands || cols < 8) return PM_ERR_INVALID_ARG;
-  pm_tiled_plan* p = new pm_tiled_plan;
-  *out = p;  // also on failure: the plan then carries the message and is good for pm_tiled_destroy only
-  for (int k = 0; k < n_bands; ++k)
-    if (!bands[k]) return fail(p, PM_ERR_INVALID_ARG, "band %d is a null handle", k);
-  const pm_params& prm = pm_internal::params(bands[0]);
-  if (prm.mode != PM_MODE_SCALAR) return fail(p, PM_ERR_INVALID_ARG, "the row-tiled driver runs the scalar mode only");
-  for (int k = 1; k < n_bands; ++k)
-    if (std::memcmp(&pm_internal::params(bands[k]), &prm, sizeof(pm_params)) != 0)
-      return fail(p, PM_ERR_INVALID_ARG, "band %d was created with other parameters than band 0", k);
-  p->rows = rows;
-  p->cols = cols;
-  p->n_views = prm.left_right_check ? 2 : 1;
-  p->halo = halo_rows(prm);
-  p->bands.resize((size_t)n_bands);
-  for (int k = 0; k < n_bands; ++k) {
-    Band& b = p->bands[(size_t)k];
-    b.h = bands[k];
-    b.dev = pm_internal::device(b.h);
-    b.stream = pm_internal::stream(b.h);
-    band_of(k, n_bands, rows, p->halo, &b.tile, &b.band_rows);
-    int mr, mc;
-    pm_internal::plan_size(b.h, &mr, &mc);
-    if (b.band_rows > mr || cols > mc)
-      return fail(p, PM_ERR_SIZE, "band %d needs a plan of %d x %d, its handle has %d x %d (pm_tiled_band_rows)", k, cols,
-                  b.band_rows, mc, mr);
-    TL_HIP(p, hipSetDevice(b.dev));
-    const size_t px = (size_t)b.band_rows * cols, own = (size_t)b.tile.own_rows * cols;
-    const size_t row_bytes = sizeof(float) * (size_t)p->n_views * cols;
-    TL_HIP(p, hipMalloc((void**)&b.d_left, px));
-    TL_HIP(p, hipMalloc((void**)&b.d_right, px));
-    TL_HIP(p, hipMalloc((void**)&b.d_seed_l, px * 4));
-    TL_HIP(p, hipMalloc((void**)&b.d_seed_r, px * 4));
-    TL_HIP(p, hipMalloc((void**)&b.d_out_l, own * 4));
-    TL_HIP(p, hipMalloc((void**)&b.d_out_r, own * 4));
-    for (int i = 0; i < 2; ++i) {
-      TL_HIP(p, hipMalloc((void**)&b.sent[i], row_bytes));
-      TL_HIP(p, hipEventCreateWithFlags(&b.ev_sent[i], hipEventDisableTiming));
-      TL_HIP(p, hipEventCreateWithFlags(&b.ev_read[i], hipEventDisableTiming));
-    }
-    TL_HIP(p, hipMalloc((void**)&b.used, row_bytes));
-    TL_HIP(p, hipMalloc((void**)&b.incoming, row_bytes));
-    TL_HIP(p, hipMalloc((void**)&b.mask, sizeof(int) * (size_t)p->n_views * cols));
-    TL_HIP(p, hipMalloc((void**)&b.flag, sizeof(int)));
-  }
-  // neighbouring bands on different devices: direct peer copies over xGMI where the platform allows them
-  for (int k = 0; k + 1 < n_bands; ++k) {
-    const int a = p->bands[(size_t)k].dev, c = p->bands[(size_t)k + 1].dev;
-    if (a == c) {  // bands sharing a device: hipMemcpyPeerAsync is then a plain device copy, nothing to enable
-      p->bands[(size_t)k].direct_next = p->bands[(size_t)k + 1].direct_prev = true;
-      continue;
-    }
-    ++p->device_boundaries;
-    int ok = 0;
-    if (hipDeviceCanAccessPeer(&ok, a, c) == hipSuccess && ok) {
-      (void)hipSetDevice(a);
-      const hipError_t e1 = hipDeviceEnablePeerAccess(c, 0);
-      (void)hipSetDevice(c);
-      const hipError_t e2 = hipDeviceEnablePeerAccess(a, 0);
-      const auto fine = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
-      if (fine(e1) && fine(e2)) {
-        ++p->peer_links;
-        p->bands[(size_t)k].direct_next = p->bands[(size_t)k + 1].direct_prev = true;
-      }
-    }
-    (void)hipGetLastError();
-  }
+  return create(bands, n_bands, rows, cols, nullptr, 0, out);
+}
+
+// ---- include/pm/testing.h -----------------------------------------------------------------------------------------
+int pm_tiled_create_logical(pm_handle* const* bands, int n_bands, int rows, int cols, const int* logical_devices,
+                            int simulate_peer_access, pm_tiled_plan** out) {
+  if (!logical_devices) return PM_ERR_INVALID_ARG;
+  return create(bands, n_bands, rows, cols, logical_devices, simulate_peer_access, out);
+}
+
+int pm_tiled_audit(const pm_tiled_plan* plan, pm_tiled_audit_record* records, int capacity, int* total, int* violations) {
+  if (!plan || !plan->audit) return PM_ERR_INVALID_ARG;
+  const Audit& a = *plan->audit;
+  if (total) *total = (int)a.log.size();
+  if (violations) *violations = a.violations;
+  if (records)
+    for (int i = 0; i < capacity && i < (int)a.log.size(); ++i) records[i] = a.log[(size_t)i];
+  return PM_OK;
+}
+
+int pm_tiled_audit_reset(pm_tiled_plan* plan) {
+  if (!plan || !plan->audit) return PM_ERR_INVALID_ARG;
+  plan->audit->log.clear();
+  plan->audit->violations = 0;
   return PM_OK;
 }
 

@@ -105,12 +105,25 @@ void PatchmatchGpu::UnregisterRange(void* ptr) {
   throw std::invalid_argument("PatchmatchGpu::Unregister: this image was not registered");
 }
 
-void PatchmatchGpu::SetSeeds(const Image1f& seed_l, const Image1f& seed_r) {
-  seed_l_ = seed_l;
-  seed_r_ = seed_r;
+namespace {
+// a tightly packed copy of a float map (seed maps are kept until replaced)
+void keep(core::Image<float>& dst, ConstView1f src) {
+  if (src.empty()) {
+    dst = core::Image<float>();
+    return;
+  }
+  dst.create(src.rows, src.cols);
+  for (int r = 0; r < src.rows; ++r)
+    std::memcpy(dst.ptr(r), reinterpret_cast<const char*>(src.data) + (size_t)r * src.step, sizeof(float) * (size_t)src.cols);
+}
+}  // namespace
+
+void PatchmatchGpu::SetSeedViews(ConstView1f seed_l, ConstView1f seed_r) {
+  keep(seed_l_, seed_l);
+  keep(seed_r_, seed_r);
 }
 
-void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr) {
+void PatchmatchGpu::MatchViews(View1b iml, View1b imr, View1f disp, View1f dispr) {
   if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
     throw std::invalid_argument("PatchmatchGpu::Match: images empty or of different size");
   if (!seed_l_.empty() && (seed_l_.rows != iml.rows || seed_l_.cols != iml.cols))
@@ -118,55 +131,51 @@ void PatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp,
   if (!seed_r_.empty() && (seed_r_.rows != iml.rows || seed_r_.cols != iml.cols))
     throw std::invalid_argument("PatchmatchGpu::Match: right seed map does not match the image size");
   if (iml.step != imr.step) throw std::invalid_argument("PatchmatchGpu::Match: the two images have different row steps");
-  if (!seed_l_.empty() && !seed_r_.empty() && seed_l_.step != seed_r_.step)
-    throw std::invalid_argument("PatchmatchGpu::Match: the two seed maps have different row steps");
+  const bool lr = params_.left_right_check;
+  if (!disp.data || disp.rows != iml.rows || disp.cols != iml.cols || disp.step < sizeof(float) * (size_t)iml.cols)
+    throw std::invalid_argument("PatchmatchGpu::Match: the left output map does not have the image size");
+  if (lr && (!dispr.data || dispr.rows != iml.rows || dispr.cols != iml.cols || dispr.step != disp.step))
+    throw std::invalid_argument("PatchmatchGpu::Match: the right output map does not have the left one's size and step");
   EnsurePlan(iml.rows, iml.cols);
-  // like GpuMat::download (patchmatch_gpu.cu:374-375) the outputs are (re)allocated to the image size
-  if (disp.rows != iml.rows || disp.cols != iml.cols) disp.create(iml.rows, iml.cols);
-  if (dispr.rows != iml.rows || dispr.cols != iml.cols) dispr.create(iml.rows, iml.cols);
-  const size_t seed_step = !seed_l_.empty() ? seed_l_.step : (!seed_r_.empty() ? seed_r_.step : 0);
-  Check(pm_match_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
-                    seed_l_.empty() ? nullptr : seed_l_.data(), seed_r_.empty() ? nullptr : seed_r_.data(), seed_step,
-                    disp.data(), dispr.data(), disp.step),
+  Check(pm_match_u8(handle_, iml.data, imr.data, iml.rows, iml.cols, iml.step, seed_l_.empty() ? nullptr : seed_l_.data(),
+                    seed_r_.empty() ? nullptr : seed_r_.data(), 0, disp.data, dispr.data, disp.step),
         "pm_match_u8");
 }
 
-void PatchmatchGpu::MatchBatch(const std::vector<Image1b>& imls, const std::vector<Image1b>& imrs,
-                               std::vector<Image1f>& disps, std::vector<Image1f>& disprs) {
+void PatchmatchGpu::MatchBatchViews(const std::vector<View1b>& imls, const std::vector<View1b>& imrs,
+                                    const std::vector<View1f>& disps, const std::vector<View1f>& disprs) {
   const size_t n = imls.size();
-  if (n == 0 || imrs.size() != n) throw std::invalid_argument("PatchmatchGpu::MatchBatch: no pairs, or left / right counts differ");
+  if (n == 0 || imrs.size() != n || disps.size() != n || disprs.size() != n)
+    throw std::invalid_argument("PatchmatchGpu::MatchBatch: no pairs, or left / right / output counts differ");
   if ((int)n > params_.max_batch)
     throw std::invalid_argument("PatchmatchGpu::MatchBatch: more pairs than Params::max_batch");
   if (!seed_l_.empty() || !seed_r_.empty())
     throw std::invalid_argument("PatchmatchGpu::MatchBatch: seed maps set through SetSeeds() apply to single pairs only");
   const int rows = imls[0].rows, cols = imls[0].cols;
-  for (size_t i = 0; i < n; ++i)
-    if (imls[i].empty() || imls[i].rows != rows || imls[i].cols != cols || imrs[i].rows != rows || imrs[i].cols != cols)
-      throw std::invalid_argument("PatchmatchGpu::MatchBatch: all images of a batch must have one size");
-  EnsurePlan(rows, cols);
-  disps.resize(n);
-  disprs.resize(n);
   std::vector<const uint8_t*> pl(n), pr(n);
   std::vector<float*> dl(n), dr(n);
   for (size_t i = 0; i < n; ++i) {
-    if (disps[i].rows != rows || disps[i].cols != cols) disps[i].create(rows, cols);
-    if (disprs[i].rows != rows || disprs[i].cols != cols) disprs[i].create(rows, cols);
-    pl[i] = imls[i].data();
-    pr[i] = imrs[i].data();
-    dl[i] = disps[i].data();
-    dr[i] = disprs[i].data();
+    const auto ok8 = [&](const View1b& v) { return !v.empty() && v.rows == rows && v.cols == cols && v.step == (size_t)cols; };
+    const auto okf = [&](const View1f& v) { return !v.empty() && v.rows == rows && v.cols == cols && v.step == sizeof(float) * (size_t)cols; };
+    if (!ok8(imls[i]) || !ok8(imrs[i]) || !okf(disps[i]) || !okf(disprs[i]))
+      throw std::invalid_argument("PatchmatchGpu::MatchBatch: all images of a batch must be continuous and of one size");
+    pl[i] = imls[i].data;
+    pr[i] = imrs[i].data;
+    dl[i] = disps[i].data;
+    dr[i] = disprs[i].data;
   }
+  EnsurePlan(rows, cols);
   Check(pm_match_batch_u8(handle_, (int)n, pl.data(), pr.data(), rows, cols, nullptr, nullptr, dl.data(), dr.data()),
         "pm_match_batch_u8");
 }
 
-bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, uint64_t tag) {
-  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
-    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size");
+bool PatchmatchGpu::SubmitViews(View1b iml, View1b imr, uint64_t tag) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols || iml.step != imr.step)
+    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size / row step");
   if (InFlight() == 0) EnsurePlan(iml.rows, iml.cols);  // re-planning destroys the handle: only when idle
   const bool seeded_l = !seed_l_.empty() && seed_l_.rows == iml.rows && seed_l_.cols == iml.cols;
   const bool seeded_r = !seed_r_.empty() && seed_r_.rows == iml.rows && seed_r_.cols == iml.cols;
-  const int rc = pm_submit_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
+  const int rc = pm_submit_u8(handle_, iml.data, imr.data, iml.rows, iml.cols, iml.step,
                               seeded_l ? seed_l_.data() : nullptr, seeded_r ? seed_r_.data() : nullptr, 0, tag);
   if (rc == PM_ERR_BUSY) return false;
   Check(rc, "pm_submit_u8");
@@ -174,17 +183,18 @@ bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, uint64_t tag)
   return true;
 }
 
-bool PatchmatchGpu::Submit(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, uint64_t tag) {
-  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
-    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size");
-  if (disp.rows != iml.rows || disp.cols != iml.cols || dispr.rows != iml.rows || dispr.cols != iml.cols)
+bool PatchmatchGpu::SubmitBoundViews(View1b iml, View1b imr, View1f disp, View1f dispr, uint64_t tag) {
+  if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols || iml.step != imr.step)
+    throw std::invalid_argument("PatchmatchGpu::Submit: images empty or of different size / row step");
+  if (disp.empty() || dispr.empty() || disp.rows != iml.rows || disp.cols != iml.cols || dispr.rows != iml.rows ||
+      dispr.cols != iml.cols || disp.step != dispr.step)
     throw std::invalid_argument("PatchmatchGpu::Submit: bound maps must already have the image size");
   if (InFlight() == 0) EnsurePlan(iml.rows, iml.cols);
   const bool seeded_l = !seed_l_.empty() && seed_l_.rows == iml.rows && seed_l_.cols == iml.cols;
   const bool seeded_r = !seed_r_.empty() && seed_r_.rows == iml.rows && seed_r_.cols == iml.cols;
-  const int rc = pm_submit_bound_u8(handle_, iml.data(), imr.data(), iml.rows, iml.cols, iml.step,
-                                    seeded_l ? seed_l_.data() : nullptr, seeded_r ? seed_r_.data() : nullptr, 0,
-                                    disp.data(), dispr.data(), disp.step, tag);
+  const int rc = pm_submit_bound_u8(handle_, iml.data, imr.data, iml.rows, iml.cols, iml.step,
+                                    seeded_l ? seed_l_.data() : nullptr, seeded_r ? seed_r_.data() : nullptr, 0, disp.data,
+                                    dispr.data, disp.step, tag);
   if (rc == PM_ERR_BUSY) return false;
   Check(rc, "pm_submit_bound_u8");
   in_flight_sizes_.emplace_back(iml.rows, iml.cols);
@@ -198,12 +208,20 @@ bool PatchmatchGpu::Collect(uint64_t* tag) {
   return true;
 }
 
-bool PatchmatchGpu::Collect(Image1f& disp, Image1f& dispr, uint64_t* tag) {
+bool PatchmatchGpu::NextCollectSize(int* rows, int* cols) const {
+  if (in_flight_sizes_.empty()) return false;
+  *rows = in_flight_sizes_.front().first;
+  *cols = in_flight_sizes_.front().second;
+  return true;
+}
+
+bool PatchmatchGpu::CollectViews(View1f disp, View1f dispr, uint64_t* tag) {
   if (in_flight_sizes_.empty()) return false;
   const int rows = in_flight_sizes_.front().first, cols = in_flight_sizes_.front().second;
-  if (disp.rows != rows || disp.cols != cols) disp.create(rows, cols);
-  if (dispr.rows != rows || dispr.cols != cols) dispr.create(rows, cols);
-  Check(pm_collect(handle_, disp.data(), dispr.data(), disp.step, tag), "pm_collect");
+  if (disp.empty() || dispr.empty() || disp.rows != rows || disp.cols != cols || dispr.rows != rows || dispr.cols != cols ||
+      disp.step != dispr.step)
+    throw std::invalid_argument("PatchmatchGpu::Collect: the maps do not have the size of the pair being collected");
+  Check(pm_collect(handle_, disp.data, dispr.data, disp.step, tag), "pm_collect");
   in_flight_sizes_.erase(in_flight_sizes_.begin());
   return true;
 }
@@ -229,16 +247,15 @@ void PatchmatchGpu::Match(const GpuImage1f& iml, const GpuImage1f& imr, const Gp
         "pm_match_view_device");
 }
 
-Image1f PatchmatchGpu::SparseInit(const Image1b& iml, const Image1b& imr, int dilate_factor) {
+void PatchmatchGpu::SparseInitViews(View1b iml, View1b imr, int dilate_factor, View1f seed) {
   if (iml.empty() || imr.empty() || iml.rows != imr.rows || iml.cols != imr.cols)
     throw std::invalid_argument("PatchmatchGpu::SparseInit: images empty or of different size");
   if (iml.step != (size_t)iml.cols || imr.step != (size_t)imr.cols)
     throw std::invalid_argument("PatchmatchGpu::SparseInit: images must be continuous (step == cols)");
+  if (seed.empty() || seed.rows != iml.rows || seed.cols != iml.cols || seed.step != sizeof(float) * (size_t)iml.cols)
+    throw std::invalid_argument("PatchmatchGpu::SparseInit: the seed map must be continuous and of the image size");
   EnsurePlan(iml.rows, iml.cols);
-  Image1f seed(iml.rows, iml.cols);
-  Check(pm_sparse_init(handle_, iml.data(), imr.data(), iml.rows, iml.cols, dilate_factor, seed.data()),
-        "pm_sparse_init");
-  return seed;
+  Check(pm_sparse_init(handle_, iml.data, imr.data, iml.rows, iml.cols, dilate_factor, seed.data), "pm_sparse_init");
 }
 
 // ---- TiledPatchmatchGpu ----------------------------------------------------------------------------------------------
@@ -283,19 +300,26 @@ TiledPatchmatchGpu::~TiledPatchmatchGpu() {
   for (pm_handle* h : bands_) pm_destroy(h);
 }
 
-void TiledPatchmatchGpu::SetSeeds(const Image1f& seed_l, const Image1f& seed_r) {
-  seed_l_ = seed_l;
-  seed_r_ = seed_r;
+void TiledPatchmatchGpu::SetSeedViews(ConstView1f seed_l, ConstView1f seed_r) {
+  keep(seed_l_, seed_l);
+  keep(seed_r_, seed_r);
 }
 
-void TiledPatchmatchGpu::Match(const Image1b& iml, const Image1b& imr, Image1f& disp, Image1f& dispr, int rounds) {
-  if (iml.rows != rows_ || iml.cols != cols_ || imr.rows != rows_ || imr.cols != cols_)
+void TiledPatchmatchGpu::SetExchange(int mode) {
+  const int rc = pm_tiled_set_exchange(plan_, mode);
+  if (rc != PM_OK)
+    throw std::runtime_error(std::string("pm_tiled_set_exchange: ") + pm_status_string(rc) + " -- " + pm_tiled_last_error(plan_));
+}
+
+void TiledPatchmatchGpu::MatchViews(View1b iml, View1b imr, View1f disp, View1f dispr, int rounds) {
+  if (iml.rows != rows_ || iml.cols != cols_ || imr.rows != rows_ || imr.cols != cols_ || iml.step != imr.step)
     throw std::runtime_error("TiledPatchmatchGpu::Match: image size differs from the plan");
-  disp.create(rows_, cols_);
-  dispr.create(rows_, cols_);
-  const int rc = pm_tiled_match_u8(plan_, iml.data(), imr.data(), (size_t)iml.step, seed_l_.empty() ? nullptr : seed_l_.data(),
-                                   seed_r_.empty() ? nullptr : seed_r_.data(), 0, disp.data(), dispr.data(),
-                                   (size_t)disp.step, rounds, &info_);
+  if (disp.empty() || dispr.empty() || disp.rows != rows_ || disp.cols != cols_ || dispr.rows != rows_ ||
+      dispr.cols != cols_ || disp.step != dispr.step)
+    throw std::runtime_error("TiledPatchmatchGpu::Match: output maps differ from the plan's size");
+  const int rc = pm_tiled_match_u8(plan_, iml.data, imr.data, iml.step, seed_l_.empty() ? nullptr : seed_l_.data(),
+                                   seed_r_.empty() ? nullptr : seed_r_.data(), 0, disp.data, dispr.data, disp.step, rounds,
+                                   &info_);
   if (rc != PM_OK)
     throw std::runtime_error(std::string("pm_tiled_match_u8: ") + pm_status_string(rc) + " -- " + pm_tiled_last_error(plan_));
 }

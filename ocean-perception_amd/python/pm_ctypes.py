@@ -46,7 +46,8 @@ EXPORTS = [
     "pm_match_view_device", "pm_set_unit_noise", "pm_initialize",
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
-    "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download", "pm_tiled_topology",
+    "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download", "pm_tiled_topology", "pm_tiled_set_exchange",
+    "pm_tiled_create_logical", "pm_tiled_audit", "pm_tiled_audit_reset",
 ]
 
 
@@ -108,6 +109,12 @@ class PmTile(C.Structure):
 
 class PmTiledInfo(C.Structure):
     _fields_ = [("rounds_used", C.c_int), ("repeated", C.c_int), ("exchanges", C.c_int)]
+
+
+class PmTiledAuditRecord(C.Structure):  # include/pm/testing.h
+    _fields_ = [("call", C.c_int), ("band", C.c_int), ("detail", C.c_int), ("current_device", C.c_int),
+                ("stream_device", C.c_int), ("object_device", C.c_int), ("source_device", C.c_int),
+                ("foreign_allowed", C.c_int), ("violation", C.c_int)]
 
 
 class PmProfile(C.Structure):
@@ -261,6 +268,15 @@ def load():
     lib.pm_tiled_last_error.restype = C.c_char_p
     lib.pm_tiled_topology.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.pm_tiled_topology.restype = C.c_int
+    lib.pm_tiled_set_exchange.argtypes = [vp, C.c_int]
+    lib.pm_tiled_set_exchange.restype = C.c_int
+    lib.pm_tiled_create_logical.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                            C.POINTER(vp)]
+    lib.pm_tiled_create_logical.restype = C.c_int
+    lib.pm_tiled_audit.argtypes = [vp, C.POINTER(PmTiledAuditRecord), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pm_tiled_audit.restype = C.c_int
+    lib.pm_tiled_audit_reset.argtypes = [vp]
+    lib.pm_tiled_audit_reset.restype = C.c_int
     lib.pm_tile_restore_cols.argtypes = [vp, vp]
     lib.pm_tile_sweep_masked.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.pm_tile_exchange_round.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp]
@@ -765,10 +781,21 @@ class Engine:
                 for k in range(PM_K_COUNT)}
 
 
-class TiledEngine:
-    """pm_tiled_*: one large pair row-tiled over `n_bands` handles of this process (devices[k] = the device of band k)."""
+PM_TILED_EXCHANGE_AUTO, PM_TILED_EXCHANGE_COPY, PM_TILED_EXCHANGE_DIRECT = 0, 1, 2
+# include/pm/testing.h: pm_tiled_audit_call
+TILED_CALLS = {1: "set_device", 2: "malloc", 3: "event_create", 4: "event_record", 5: "stream_wait_event",
+               6: "stream_sync", 7: "memset", 8: "copy_h2d", 9: "copy_d2h", 10: "copy_peer", 11: "stage", 12: "stage_arg"}
+TILED_STAGES = {1: "begin", 2: "noise", 3: "sweep", 4: "get_row", 5: "presweep", 6: "exchange_round", 7: "row_moved",
+                8: "background", 9: "finish"}
 
-    def __init__(self, params, rows, cols, n_bands, devices=None):
+
+class TiledEngine:
+    """pm_tiled_*: one large pair row-tiled over `n_bands` handles of this process (devices[k] = the device of band k).
+    logical_devices (include/pm/testing.h): the bands are ACCOUNTED to these device ids while they run on devices[k], and
+    the plan logs every runtime call with the logical devices involved (audit())."""
+
+    def __init__(self, params, rows, cols, n_bands, devices=None, logical_devices=None, simulate_peer_access=0,
+                 exchange=None):
         self.lib = load()
         self.rows, self.cols, self.n = rows, cols, n_bands
         self.params = params
@@ -779,11 +806,40 @@ class TiledEngine:
         self.bands = [Engine(params, device=devices[k], max_rows=band_rows, max_cols=cols) for k in range(n_bands)]
         arr = (C.c_void_p * n_bands)(*[b.h for b in self.bands])
         self.plan = C.c_void_p()
-        rc = self.lib.pm_tiled_create(arr, n_bands, rows, cols, C.byref(self.plan))
+        if logical_devices is None:
+            rc = self.lib.pm_tiled_create(arr, n_bands, rows, cols, C.byref(self.plan))
+        else:
+            ld = (C.c_int * n_bands)(*logical_devices)
+            rc = self.lib.pm_tiled_create_logical(arr, n_bands, rows, cols, ld, int(simulate_peer_access),
+                                                  C.byref(self.plan))
         if rc != PM_OK:
             msg = self.lib.pm_tiled_last_error(self.plan).decode() if self.plan else ""
             self.close()
             raise PmError(rc, "pm_tiled_create", msg)
+        if exchange is not None:
+            self.set_exchange(exchange)
+
+    def set_exchange(self, mode):
+        self._tcheck(self.lib.pm_tiled_set_exchange(self.plan, int(mode)), "pm_tiled_set_exchange")
+
+    def audit(self):
+        """(records as dicts, number of violations) of a plan made with logical_devices"""
+        total, bad = C.c_int(0), C.c_int(0)
+        self._tcheck(self.lib.pm_tiled_audit(self.plan, None, 0, C.byref(total), C.byref(bad)), "pm_tiled_audit")
+        recs = (PmTiledAuditRecord * max(total.value, 1))()
+        self._tcheck(self.lib.pm_tiled_audit(self.plan, recs, total.value, C.byref(total), C.byref(bad)), "pm_tiled_audit")
+        out = []
+        for r in recs[:total.value]:
+            d = {f: getattr(r, f) for f, _ in PmTiledAuditRecord._fields_}
+            d["call_name"] = TILED_CALLS.get(r.call, str(r.call))
+            if r.call in (11, 12):
+                d["stage"] = TILED_STAGES.get(r.detail // 16, str(r.detail // 16))
+                d["arg"] = r.detail % 16
+            out.append(d)
+        return out, bad.value
+
+    def audit_reset(self):
+        self._tcheck(self.lib.pm_tiled_audit_reset(self.plan), "pm_tiled_audit_reset")
 
     def topology(self):
         """(neighbouring bands on different devices, of which with direct peer access)"""

@@ -80,3 +80,58 @@ def test_wrapper_match_matches_oracle(wrapper_exe, tmp_path, oracle, synth, sem,
     vl = np.fromfile(os.path.join(tmp_path, "view_l.f32"), np.float32).reshape(rows, cols)
     ev = oracle.match(oracle.default_params(sem, patch=patch, n_iters=3, nthreads=8, left_right_check=0), l, r, sl, None)
     assert_same(vl, ev[0], "Match(GpuImage1f...)")
+
+
+# ---- callers that hold cv::Mat (the reference's Image1b / Image1f, src/vehicle/vision_core/cv_types.hpp:8-12) ----------
+@pytest.fixture(scope="module")
+def opencv_caller_exe(tmp_path_factory):
+    """tests/cpp/opencv_caller_main.cpp: the reference's include line, using-directives, image types and the call
+    sequence of test/stereo_matching/patchmatch_gpu_test.cpp:68-88, compiled against this build's header with a stand-in
+    for <opencv2/core.hpp> on the include path (OpenCV itself is not in the image)."""
+    out = tmp_path_factory.mktemp("cpp") / "opencv_caller_main"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "cpp", "fake_opencv"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"),
+           os.path.join(ROOT, "tests", "cpp", "opencv_caller_main.cpp"), "-L" + LIBDIR, "-lvehicle_pm_gpu",
+           "-Wl,-rpath," + LIBDIR, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(out)
+
+
+def test_reference_caller_with_cv_mat_types_builds_unchanged(opencv_caller_exe):
+    """The header takes cv::Mat1b / cv::Mat1f in the reference's three signatures when OpenCV's header is includable, and
+    its Image1b / Image1f typedefs sit beside vision_core/cv_types.hpp's in one translation unit."""
+    assert os.path.exists(opencv_caller_exe)
+
+
+def test_own_image_class_still_builds_with_opencv_switched_off(tmp_path):
+    """PM_NO_OPENCV_TYPES keeps bm::core::Image<T> as Image1b / Image1f even with an opencv2/core.hpp in reach."""
+    out = tmp_path / "wrapper_no_cv"
+    cmd = ["g++", "-std=c++17", "-O1", "-DPM_NO_OPENCV_TYPES", "-I" + os.path.join(ROOT, "tests", "cpp", "fake_opencv"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "host"),
+           os.path.join(ROOT, "tests", "cpp", "wrapper_main.cpp"), "-L" + LIBDIR, "-lvehicle_pm_gpu", "-Wl,-rpath," + LIBDIR,
+           "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_call_sequence_on_cv_mat_hits_the_farmsim_fixture(opencv_caller_exe, tmp_path, oracle):
+    """patchmatch_gpu_test.cpp:68-88 on its own image pair (fsl1 / fsr1 halved, tests/golden): empty Image1f outputs are
+    allocated by Match() as GpuMat::download does (patchmatch_gpu.cu:374-375), five calls, and the maps equal the
+    fixture's row checksums; ROI inputs with step > cols and wrongly sized outputs give the same maps."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "farmsim_fs1_376x240.npz"))
+    l, r = z["left"], z["right"]
+    rows, cols = l.shape
+    l.tofile(os.path.join(tmp_path, "left.u8"))
+    r.tofile(os.path.join(tmp_path, "right.u8"))
+    res = subprocess.run([opencv_caller_exe, str(tmp_path), str(rows), str(cols)], capture_output=True, text=True)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+    rd = lambda n: np.fromfile(os.path.join(tmp_path, n), np.float32).reshape(rows, cols)
+    rowsum = lambda d: d.view(np.uint32).astype(np.uint64).sum(axis=1)
+    dl, dr = rd("disp_l.f32"), rd("disp_r.f32")
+    assert np.array_equal(rowsum(dl), z["gpu_test_rows_l"]) and np.array_equal(rowsum(dr), z["gpu_test_rows_r"])
+    assert_same(rd("strided_l.f32"), dl, "ROI input (step > cols), left")
+    assert_same(rd("strided_r.f32"), dr, "ROI input (step > cols), right")
+    sp = oracle.seed_params(templ_cols=31, templ_rows=11, max_disp=128, max_matching_cost=0.15)
+    assert_same(rd("sparse_init.f32"), oracle.sparse_init(l, r, 4, sp), "SparseInit into a cv::Mat1f")
