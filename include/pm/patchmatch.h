@@ -239,8 +239,9 @@ int pm_submit_device(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right
                      const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag);
 /* pm_submit_device for inputs that are still being produced on the device: `ready_event` is a hipEvent_t (as void*)
  * the caller recorded behind the producer of THIS frame's inputs, on whatever stream that work runs; both views and the
- * head of the frame wait for it on the device, nothing waits on the host.  The event must stay alive and must not be
- * re-recorded until the frame has been collected.  NULL = pm_submit_device. */
+ * head of the frame wait for it on the device, nothing waits on the host.  The event is consumed INSIDE the call (an
+ * internal stream is made to wait for it and the frame waits for that stream), also when the frame is held for a
+ * partner: the caller may re-record or destroy the event as soon as the call returns.  NULL = pm_submit_device. */
 int pm_submit_device_after(pm_handle* h, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
                            const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r, uint64_t tag,
                            void* ready_event);

@@ -241,7 +241,15 @@ int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
     sl.d_out_r = a.out_r;
     sl.out_l = sl.out_r = nullptr;
     sl.out_step = 0;
-    sl.ready_ext = a.ready;
+    // The caller's "inputs are complete" event is CONSUMED here: s_in waits for it and the slot's own event is recorded
+    // behind it.  A held frame is only enqueued by a later submit / collect / flush -- by then the caller may have
+    // re-recorded or destroyed its event (a torch.cuda.Event dropped after the call); the slot's event is ours.
+    sl.ready_ext = nullptr;
+    if (a.ready) {
+      PM_HIP(h, hipStreamWaitEvent(h->s_in, a.ready, 0));
+      PM_HIP(h, hipEventRecord(sl.in_done, h->s_in));
+      sl.ready_ext = sl.in_done;
+    }
   } else {
     // ring slot k keeps its inputs and outputs at offset k * px of the staging arrays: frames in flight share one size
     uint8_t* dl8 = h->st_left + (size_t)slot * px;
@@ -281,11 +289,20 @@ int submit_impl(pm_handle* h, const SubmitArgs& a, const char* what) {
   } else {
     rc = enqueue_or_hold(h, slot);
   }
-  if (rc != PM_OK && sl.state == 1) {
-    // the frame never reached the device: it leaves the ring again, so that the caller's count of frames in flight
-    // (an error return = nothing submitted) stays right
-    sl.state = 0;
-    --h->pipe_count;
+  if (rc != PM_OK) {
+    // An enqueue that failed midway may have left launches of this frame (or of the partner it was ganged with) on the
+    // streams.  Nothing of them may outlive this call: the caller is told "not submitted" and is free to reuse its
+    // buffers.  After the wait, a partner that is still marked as held is simply enqueued again by the next submit /
+    // collect -- a Match() is a pure function of its inputs, a second run rewrites the same maps.
+    for (hipStream_t q : {h->stream, h->view1_stream, h->s_in, h->s_out})
+      if (q) (void)hipStreamSynchronize(q);
+    (void)hipGetLastError();
+    if (sl.state == 1) {
+      // the frame leaves the ring again, so that the caller's count of frames in flight (an error return = nothing
+      // submitted) stays right
+      sl.state = 0;
+      --h->pipe_count;
+    }
   }
   return rc;
 }

@@ -134,13 +134,6 @@ struct Run3Lane {
   float dmposf;      // (float)(DIR * mpos)
   int rofs;          // row sweeps: target column of the lane's line minus the first target column of the step
   int lim;           // segment end for position lanes of an active segment, INT_MIN otherwise
-  // tiled row sweeps (k_runrow_tiled): the target records of the phase's column range staged in LDS
-  unsigned tile_lds;        // absolute LDS byte address of the tile: [line triple m][tile_w] 16-byte records
-  unsigned tile_line_bytes; // tile_w * 16
-  int tile_x0, tile_w;      // first image column of the tile, columns staged
-  unsigned qtile_lds;       // the reference quads of the phase's own columns: [quad q][qtile_w] 8-byte records
-  int qtile_x0, qtile_w;
-  unsigned long long fmask; // the 64-bit mask of the lane's group field
 };
 
 // Wave-uniform base pointers of the window's line pairs (and reference quads), fixed for the whole kernel: with them
@@ -165,17 +158,6 @@ __device__ __forceinline__ TripleRec ld_rec_g(GlobalPtr base, unsigned byte_off)
   // trips through the memory pipeline).  The elements go through scalar temporaries: hipcc 7.2 evaluates
   // __builtin_bit_cast(float, t.y) on a vector element as element 0.
   const u32x4 t = *(const __attribute__((address_space(1))) u32x4*)(base + (size_t)byte_off);
-  const unsigned t0 = t.x, t1 = t.y, t2 = t.z, t3 = t.w;
-  TripleRec r;
-  r.g0 = __builtin_bit_cast(float, t0);
-  r.g1 = __builtin_bit_cast(float, t1);
-  r.g2 = __builtin_bit_cast(float, t2);
-  r.c = t3;
-  return r;
-}
-// the same record out of the LDS tile of a tiled row sweep: one ds_read_b128 at an absolute LDS byte address
-__device__ __forceinline__ TripleRec ld_rec_l(unsigned lds_byte_addr) {
-  const u32x4 t = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_byte_addr;
   const unsigned t0 = t.x, t1 = t.y, t2 = t.z, t3 = t.w;
   TripleRec r;
   r.g0 = __builtin_bit_cast(float, t0);
@@ -218,7 +200,7 @@ __device__ __forceinline__ Run3Bases run3_bases(const View& v, const PlaneSet& p
 
 // TP = square window 3 .. 11, or 0: any window from cp (GS = 32).  One step of every group of the wavefront.
 // inr_m: lanes whose position exists (inside their segment, group still running).
-template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX, bool TILE = false>
+template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX>
 __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g,
                                           int chain, const Run3Lane& k, const Run3Bases& bases,
                                           unsigned long long inr_m, int& ipm, float4* st4, LdsSlot cand_slot,
@@ -284,25 +266,8 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
         unsigned tcol[4 * NQR + 4];  // colour lerp sums r0 * a11 + r1 * a12 + 2^15: the sample is byte 2
         float gv[3 * NT + 1];
         TripleRec recs[NT];
-        bool from_tile = false;
-        if constexpr (TILE) {
-          // the records of the phase's column range sit in LDS; a step whose columns leave the tile (a disparity beyond
-          // the staged reach) takes the global path for the whole wavefront.  Only lanes of groups that evaluate count;
-          // the others read some record of the tile (their result is never used).
-          const unsigned tc = (unsigned)(R0 - k.tile_x0);
-          const bool in_tile = tc < (unsigned)k.tile_w;
-          const bool care = ((need_m & valid_m) & k.fmask) != 0ull;
-          from_tile = mask_of(care && !in_tile) == 0ull;
-          if (from_tile) {
-            const unsigned ta = k.tile_lds + ((in_tile ? tc : 0u) << 4);
 #pragma unroll
-            for (int m = 0; m < NT; ++m) recs[m] = ld_rec_l(ta + (unsigned)m * k.tile_line_bytes);
-          }
-        }
-        if (!from_tile) {
-#pragma unroll
-          for (int m = 0; m < NT; ++m) recs[m] = ld_rec_g(bases.line[m], rv);
-        }
+        for (int m = 0; m < NT; ++m) recs[m] = ld_rec_g(bases.line[m], rv);
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           const TripleRec rec = recs[m];
@@ -341,23 +306,9 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
           }
         } else {
           const unsigned qv = (unsigned)X << 3;
-          unsigned qa = 0;
-          if constexpr (TILE) {
-            // (every lane of a group that evaluates reads inside the staged columns by construction: the clamp only
-            // moves lanes of finished segments, whose result is never used)
-            const int qc = min(max(X - k.qtile_x0, 0), k.qtile_w - 1);
-            qa = k.qtile_lds + ((unsigned)qc << 3);
-          }
 #pragma unroll
           for (int q = 0; q < NQR; ++q) {
-            QuadRec rr;
-            if constexpr (TILE) {
-              const pm_u32x2 t = *(const __attribute__((address_space(3))) pm_u32x2*)(uintptr_t)(qa + (unsigned)q * ((unsigned)k.qtile_w << 3));
-              rr.c = t.x;
-              rr.g = t.y;
-            } else {
-              rr = ld_quad_g(bases.quad[q], qv);
-            }
+            const QuadRec rr = ld_quad_g(bases.quad[q], qv);
             const int rem = TP - 4 * q;
             const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
             rq_c[q] = rr.c & mask;
@@ -787,266 +738,6 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   }
 }
 
-#ifdef PM_TUNING
-// ---- tiled row sweeps (round 5): MEASURED AND NOT SHIPPED -- tuning build only (PM_ROWTILE=1) -------------------------
-// Result (profiles/r05_row_tile.txt): bit-identical (118 parity tests and 240 fuzz cases with the kernel forced onto
-// every chain and a reach of 3-40 columns, i.e. constant fallbacks), and SLOWER: headline 438 -> 353 pairs/s with the
-// target records in LDS, 312 with the reference quads there as well.  A tile costs 40-50 KB per chain (the reach of 160
-// columns alone is 10 KB per line triple) against the plain kernel's 20 KB: two row sweeps of 720 chains each no longer
-// fit the chip's 40 MB of LDS beside each other, and the phases add barriers and four times the speculation
-// boundaries.  What the idea was:
-// Round-4 counters: a row launch sends 3.1-5.8 M L1 -> L2 read requests for 22 MB of algorithmic traffic -- every step
-// pulls four 16-byte target records per lane through the vector memory pipeline, and the next step of the group, a few
-// columns on, finds little of it in a 32 KB L1 that 11-20 wavefronts share.  Here a workgroup still owns ONE row chain,
-// but walks it in PHASES of `plen` positions in sweep direction and stages, per phase, the four line-triple records of
-// the columns the phase can reach ([first column - reach, last column + a group], clamped to the image) in LDS: a step's
-// target side is four ds_read_b128 instead of four global_load_dwordx4.  A step whose columns leave the tile (a
-// disparity beyond `reach`) takes the global path as before, so any disparity field is exact.  A phase is the old
-// kernel on a sub-chain: its segments run speculatively and are repaired by fix-up rounds; the phase's first segment
-// starts from the FINAL value of the phase before it (carried in a register), so phases add no speculation.  The chain
-// state of one phase only is held in LDS: ~5 KB + the tile (~32 KB at four phases of a 1280-wide row) instead of 20 KB.
-template <int GS, int TP, int DIR>
-__global__ void __launch_bounds__(64 * kMaxSegWaves) k_runrow_tiled(PlaneSet ps, CostParams cp, SweepGeom g, int plen,
-                                                                   int reach, int tile_cap, int qtile_cap) {
-  extern __shared__ float lds[];
-  constexpr int AXIS = 0;
-  const int n = (g.s_last - g.s_first) * DIR + 1;
-  constexpr int kPerWave = kWave / GS;
-  const int nw = blockDim.x >> 6;
-  const int nseg = kPerWave * nw;
-  const int pl1 = plen + 1;
-  float4* st4 = (float4*)lds;            // [plen + 1]
-  float* s_last = lds + 4 * pl1;         // [nseg + 1]
-  float* s_cand = s_last + nseg + 1;     // [nseg]
-  int* s_changed = (int*)(s_cand + nseg);  // [2]
-  // the tile behind them, 16-byte aligned
-  const unsigned head_words = (unsigned)(4 * pl1 + 2 * nseg + 3);
-  const unsigned tile_word0 = (head_words + 3u) & ~3u;
-  u32x4* tile = (u32x4*)(lds + tile_word0);
-  constexpr int NTL = (TP + 2) / 3, NQL = (TP + 3) / 4;
-  const unsigned qtile_word0 = tile_word0 + (unsigned)(NTL * tile_cap * 4);
-  pm_u32x2* qtile = (pm_u32x2*)(lds + qtile_word0);
-
-  const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
-  if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
-  const View v = make_view(ps, blockIdx.z);
-  const Run3Bases bases = run3_bases<AXIS, TP>(v, ps, chain);
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  constexpr int pw = TP;
-  constexpr int nd = GS - pw;
-  constexpr int POS0 = DIR < 0 ? 1 : 0;
-  Run3Lane k;
-  k.gl = lane & (GS - 1);
-  k.gbase = lane & ~(GS - 1);
-  k.mpos = k.gl - POS0;
-  k.dmposf = (float)(DIR * k.mpos);
-  k.rofs = DIR > 0 ? k.gl : pw - k.gl;
-  k.fmask = (GS == 32 ? 0xffffffffull : 0xffffull) << k.gbase;
-  k.tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + tile_word0 * 4u;
-  k.qtile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + qtile_word0 * 4u;
-  const int sidx = kPerWave * w + lane / GS;
-  LdsSlot cand_slot = (LdsSlot)(s_cand + sidx);
-  unsigned n_steps = 0, n_fix = 0, n_rounds = 0;
-  float carry = 0.f;  // final value of the position before the phase
-
-  for (int P0 = 0; P0 < n; P0 += plen) {
-    const int np = min(plen, n - P0);  // positions of this phase: chain indices P0 + 1 .. P0 + np
-    SweepGeom gp = g;
-    gp.s_first = g.s_first + DIR * P0;
-    // ---- the tile: columns [x_lo - reach - GS, x_hi + GS + 8] of the four line triples ------------------------------
-    const int xa = gp.s_first, xb = gp.s_first + DIR * (np - 1);
-    const int x_lo = DIR > 0 ? xa : xb, x_hi = DIR > 0 ? xb : xa;
-    const int tx0 = max(0, x_lo - reach - GS);
-    const int tw = min(min(ps.cols - 1, x_hi + GS + 8) - tx0 + 1, tile_cap);
-    k.tile_x0 = tx0;
-    k.tile_w = tw;
-    k.tile_line_bytes = (unsigned)tw << 4;
-    {
-      constexpr int NT = (TP + 2) / 3;
-      for (int c = threadIdx.x; c < tw; c += blockDim.x) {
-        u32x4 r[NT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)  // (static index: a runtime one would put the base pointers into scratch)
-          r[m] = *(const __attribute__((address_space(1))) u32x4*)(bases.line[m] + ((size_t)(tx0 + c) << 4));
-#pragma unroll
-        for (int m = 0; m < NT; ++m) tile[m * tw + c] = r[m];
-      }
-      // the reference quads of the columns the phase's lanes stand on: [x_lo - half - GS, x_hi + half + GS]
-      const int qx0 = max(0, x_lo - TP / 2 - GS);
-      const int qw = min(min(ps.cols - 1, x_hi + TP / 2 + GS) - qx0 + 1, qtile_cap);
-      k.qtile_x0 = qx0;
-      k.qtile_w = qw;
-      for (int c = threadIdx.x; c < qw; c += blockDim.x) {
-        pm_u32x2 r[NQL];
-#pragma unroll
-        for (int q = 0; q < NQL; ++q)
-          r[q] = *(const __attribute__((address_space(1))) pm_u32x2*)(bases.quad[q] + ((size_t)(qx0 + c) << 3));
-#pragma unroll
-        for (int q = 0; q < NQL; ++q) qtile[q * qw + c] = r[q];
-      }
-    }
-    // ---- the phase's chain state ------------------------------------------------------------------------------------
-    {
-      constexpr int U = 4;
-      const int bd = blockDim.x;
-      for (int j0 = threadIdx.x; j0 <= np; j0 += U * bd) {
-        float dd[U], cc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + u * bd;
-          dd[u] = cc[u] = 0.f;
-          if (j <= np) {
-            const size_t o = chain_at(AXIS, chain, gp.s_first + DIR * (j - 1), ps.pitch);
-            dd[u] = v.disp[o];
-            if (j > 0) cc[u] = v.cost[o];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + u * bd;
-          if (j <= np) {
-            // [0] of a later phase: the value the phase before it ended on (not yet visible in memory to every wavefront)
-            if (j == 0 && P0 > 0) dd[u] = carry;
-            st4[j] = make_float4(dd[u], cc[u], dd[u], cc[u]);
-          }
-        }
-      }
-    }
-    __syncthreads();
-
-    const int seg_len = max(8, (np + nseg - 1) / nseg);
-    const int i0 = sidx * seg_len;
-    const int i1 = min(np, i0 + seg_len);
-    const bool active = i0 < np;
-    k.lim = (active && k.mpos >= 0 && k.mpos < nd) ? i1 : (int)0x80000000;
-    unsigned long long no_merge = 0ull;
-
-    // ---- round 1: every segment speculatively from the OLD value of the pixel before it ---------------------------
-    float in_used = active ? st4[i0].x : 0.f;
-    if (k.gl == 0) *cand_slot = in_used;
-    int ipm = i0 + k.mpos;
-    for (;;) {
-      const unsigned long long inr_m = mask_of(ipm < k.lim);
-      if (inr_m == 0ull) break;
-      run3_step<GS, AXIS, TP, DIR, false, false, true>(v, ps, cp, gp, chain, k, bases, inr_m, ipm, st4, cand_slot, no_merge);
-      ++n_steps;
-    }
-    float lastv = *cand_slot;
-    if (active && k.gl == 0) s_last[sidx + 1] = lastv;
-    if (threadIdx.x == 0) s_last[0] = in_used;
-
-    // ---- fix-up rounds ---------------------------------------------------------------------------------------------
-    for (int round = 1; round < nseg; ++round) {
-      if (threadIdx.x == 0) s_changed[round & 1] = 0;
-      __syncthreads();
-      const float in = (active && sidx > 0) ? s_last[sidx] : in_used;
-      const bool redo = active && sidx > 0 && (in != in_used);
-      const unsigned long long redo_m = mask_of(redo);
-      bool new_last = false;
-      if (redo_m != 0ull) {
-        if (redo) {
-          in_used = in;
-          ipm = i0 + k.mpos;
-          if (k.gl == 0) *cand_slot = in;
-        }
-        unsigned long long merged_fill = 0ull;
-        for (;;) {
-          const unsigned long long inr_m = mask_of(ipm < k.lim) & redo_m & ~merged_fill;
-          if (inr_m == 0ull) break;
-          run3_step<GS, AXIS, TP, DIR, false, true, true>(v, ps, cp, gp, chain, k, bases, inr_m, ipm, st4, cand_slot,
-                                                          merged_fill);
-          ++n_fix;
-        }
-        const float c2 = *cand_slot;
-        if (redo && !in_mask(merged_fill) && c2 != lastv) {
-          lastv = c2;
-          new_last = true;
-        }
-      }
-      __syncthreads();
-      if (new_last && k.gl == 0) {
-        s_last[sidx + 1] = lastv;
-        s_changed[round & 1] = 1;
-      }
-      __syncthreads();
-      ++n_rounds;
-      if (!s_changed[round & 1]) break;
-    }
-    __syncthreads();
-
-    // ---- write-back of the phase; its last value goes on to the next one --------------------------------------------
-    carry = st4[np].z;
-    for (int j = threadIdx.x + 1; j <= np; j += blockDim.x) {
-      const float4 t = st4[j];
-      if (t.z != t.x) {
-        const size_t o = chain_at(AXIS, chain, gp.s_first + DIR * (j - 1), ps.pitch);
-        v.disp[o] = t.z;
-        v.cost[o] = t.w;
-      }
-    }
-    __syncthreads();  // the next phase overwrites the state and the tile
-  }
-  if (ps.counters && lane == 0) {
-    atomicAdd(&ps.counters[0], (unsigned long long)n_steps);
-    atomicAdd(&ps.counters[1], (unsigned long long)n_fix);
-    if (w == 0) atomicAdd(&ps.counters[2], (unsigned long long)n_rounds);
-    if (w == 0) atomicAdd(&ps.counters[3], (unsigned long long)n);
-  }
-}
-
-// Phases and reach of the tiled row sweeps (tuning build: PM_ROWTILE = 0 switches them off, PM_ROWTILE_PHASES,
-// PM_ROWTILE_REACH).  Reach 160 columns: the seeder's disparities end at max_disp - templ_cols + 1 = 98 and the first
-// iteration's noise adds up to 32; what lies beyond takes the global path, exactly.
-inline int run3_rowtile_phases() {
-  static const int v = [] {
-    const char* on = pm::tune_env("PM_ROWTILE");
-    if (!on || atoi(on) == 0) return 0;  // off unless asked for
-    const char* e = pm::tune_env("PM_ROWTILE_PHASES");
-    const int x = e ? atoi(e) : 4;
-    return x < 1 ? 1 : x;
-  }();
-  return v;
-}
-inline int run3_rowtile_reach() {
-  static const int v = [] {
-    const char* e = pm::tune_env("PM_ROWTILE_REACH");
-    return e ? atoi(e) : 160;
-  }();
-  return v;
-}
-// shorter row chains (small images) keep the plain kernel (tuning build: PM_ROWTILE_MIN, so that the small parity cases
-// reach the tiled kernel too)
-inline int run3_rowtile_min_chain() {
-  static const int v = [] {
-    const char* e = pm::tune_env("PM_ROWTILE_MIN");
-    return e ? atoi(e) : 512;
-  }();
-  return v;
-}
-
-template <int GS, int TP, int DIR>
-inline void launch_runrow_tiled(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,
-                                int phases, hipStream_t stream) {
-  const int chains = g.c_hi - g.c_lo + 1;
-  const int n = (g.s_last - g.s_first) * g.dir + 1;
-  const int nwv = waves < 1 ? 1 : (waves > kMaxSegWaves ? kMaxSegWaves : waves);
-  const int nseg = (kWave / GS) * nwv;
-  const int plen = (n + phases - 1) / phases;
-  const int reach = run3_rowtile_reach();
-  int tile_cap = plen + reach + 2 * GS + 9;
-  if (tile_cap > ps.cols) tile_cap = ps.cols;
-  int qtile_cap = plen + TP + 2 * GS;
-  if (qtile_cap > ps.cols) qtile_cap = ps.cols;
-  constexpr int NT = (TP + 2) / 3, NQ = (TP + 3) / 4;
-  const size_t head_words = ((size_t)(4 * (plen + 1) + 2 * nseg + 3) + 3) & ~(size_t)3;
-  const size_t lds_bytes = sizeof(float) * head_words + (size_t)NT * tile_cap * 16 + (size_t)NQ * qtile_cap * 8;
-  allow_big_lds(k_runrow_tiled<GS, TP, DIR>, lds_bytes);
-  hipLaunchKernelGGL((k_runrow_tiled<GS, TP, DIR>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv), lds_bytes,
-                     stream, ps, cp, g, plen, reach, tile_cap, qtile_cap);
-}
-
-#endif  // PM_TUNING
 
 inline int run3_dbg() {
   static const int v = [] {
@@ -1084,18 +775,6 @@ inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepG
                           hipStream_t stream) {
   // column sweeps of the benchmark window stage their reference lines in LDS while that leaves room for at least
   // four workgroups per CU (PM_RUN2_LREF / PM_RUN2_LREF_KB: A/B knobs)
-#ifdef PM_TUNING
-  if constexpr (TP == 11 && AXIS == 0) {
-    // long row chains of the benchmark window walk their chain in phases over an LDS tile of the target records
-    const int n = (g.s_last - g.s_first) * g.dir + 1;
-    const int phases = run3_rowtile_phases();
-    if (phases > 0 && n >= run3_rowtile_min_chain() && run3_dbg() == 0) {
-      if (g.dir > 0) launch_runrow_tiled<GS, TP, 1>(ps, cp, g, slots, waves, phases, stream);
-      else launch_runrow_tiled<GS, TP, -1>(ps, cp, g, slots, waves, phases, stream);
-      return;
-    }
-  }
-#endif
   if constexpr (TP == 11) {
     const int n = (g.s_last - g.s_first) * g.dir + 1;
     const size_t total = run3_lds_bytes(n, 64) + run3_lref_bytes<AXIS>(ps);

@@ -18,6 +18,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "rate: asserts on a measured rate (wall clock); collected LAST so that a noisy box "
+                                       "cannot cost a -x run the parity tests behind it")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: 1 if it.get_closest_marker("rate") else 0)  # stable: everything else keeps its order
 
 
 @pytest.fixture(scope="session")

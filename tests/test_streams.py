@@ -75,6 +75,7 @@ def _measure(run, e, t, k):
     return max(run(e, t, k) for _ in range(3))  # best of three: a rate, not a latency -- robust against a noisy moment
 
 
+@pytest.mark.rate
 def test_legs_keep_their_rate_beside_other_handles(pm, synth):
     import torch
     t = _resident(synth)
@@ -103,8 +104,12 @@ def test_legs_keep_their_rate_beside_other_handles(pm, synth):
         for e in list(engines.values()) + [host]:
             e.close()
     report = {n: (round(alone[n], 1), round(beside[n], 1)) for n in LEGS}
+    # What the guard is for: both views of a pair landing on ONE hardware queue costs 28 % (384 -> 275 pairs/s),
+    # mixed priority classes cost 30-50 %.  Measured with the policy in place: every leg within 3 % (0.97-1.02).  The floor
+    # sits between the two, far enough from the healthy value that a busy box does not trip it; this test is collected
+    # last (marker `rate`) and states a rate, never a result.
     for n in LEGS:
-        assert beside[n] >= 0.85 * alone[n], f"{n}: {report} (pairs/s alone, beside the other handles)"
+        assert beside[n] >= 0.80 * alone[n], f"{n}: {report} (pairs/s alone, beside the other handles)"
     # and the two views of a pair do run side by side: a single pair is no slower than 75 % of the batch rate
     assert alone["single"] >= 0.75 * alone["batch"], report
 

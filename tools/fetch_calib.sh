@@ -1,8 +1,8 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE calibration on this box: builds tools/probe/fetch_calib, two separate --pmc passes (no tracing
-# domains), prints counter KiB per kernel against the known byte count.  -> gpurun_out/r05/fetch_calib.txt
+# domains), prints counter KiB per kernel against the known byte count.  -> gpurun_out/$ROUND/fetch_calib.txt
 root=$GRAFT_REPO_ROOT
-out=$root/gpurun_out/r05
+out=$root/gpurun_out/${ROUND:-r06}
 mkdir -p $out
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/fetch_calib $root/tools/probe/fetch_calib.hip || exit 1
 cd /tmp && export TMPDIR=/tmp

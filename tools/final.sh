@@ -1,13 +1,14 @@
 #!/bin/bash
-# Round-5 final measurements on the GPU box (one call): tools/r05_final.sh <head-sha> [steps...]
+# Final measurements of a round on the GPU box (one call): ROUND=r06 tools/final.sh <head-sha> [steps...]
 #   tests    the whole -m gpu suite
-#   fuzz     the six differential fuzzers, new seeds            -> gpurun_out/r05/fuzz.txt
-#   bench    the driver's command                                -> gpurun_out/r05/bench_default.json
-#   prof     tools/profile_r05.sh                                -> gpurun_out/prof_r05/
+#   fuzz     the six differential fuzzers, new seeds            -> gpurun_out/$ROUND/fuzz.txt
+#   bench    the driver's command                                -> gpurun_out/$ROUND/bench_default.json
+#   prof     tools/profile.sh                                    -> gpurun_out/prof_$ROUND/
 head=${1:-unknown}; shift
 steps=${@:-tests fuzz bench prof}
 root=$GRAFT_REPO_ROOT
-out=$root/gpurun_out/r05
+export ROUND=${ROUND:-r06}
+out=$root/gpurun_out/$ROUND
 mkdir -p $out
 cd $root
 for s in $steps; do
@@ -16,7 +17,7 @@ tests)
   python -m pytest tests -m gpu -x -q > $out/final_tests.log 2>&1; rc=$?; tail -3 $out/final_tests.log; [ $rc -eq 0 ] || exit 1;;
 fuzz)
   f=$out/fuzz.txt
-  echo "Differential fuzzers on the tree of commit $head (tools/r05_final.sh fuzz, one MI355X; every case bit-identical or the run stops)" > $f
+  echo "Differential fuzzers on the tree of commit $head (tools/final.sh fuzz, one MI355X; every case bit-identical or the run stops)" > $f
   run() { name=$1; shift; echo "## $name $*" >> $f; timeout -k 10 900 python tools/$name "$@" > $out/fuzz_$name.log 2>&1; rc=$?; tail -1 $out/fuzz_$name.log >> $f; echo "exit $rc" >> $f; echo "$name done ($rc)"; [ $rc -eq 0 ]; }
   run fuzz_api.py --cases 500 --seed 561 || { cat $f; exit 1; }
   run fuzz_engines.py --cases 400 --seed 562 || { cat $f; exit 1; }
@@ -39,6 +40,6 @@ print('planes', {k:(round(v['value'],1), v['check'].get('equals_oracle_full_fram
 print('ref', j['reference_test_shape']['ms_per_call_steady_median'], 'tiled', j['tiled_4096x2160']['ms_per_frame'], j['tiled_4096x2160']['eight_bands_on_this_device']['ms_per_frame'])
 ";;
 prof)
-  bash tools/profile_r05.sh $head > $out/profile_r05.log 2>&1; tail -20 $out/profile_r05.log;;
+  bash tools/profile.sh $head > $out/profile.log 2>&1; tail -20 $out/profile.log;;
 esac
 done

@@ -2,7 +2,7 @@
 // (/opt/skills/guides/MI355X_MICROARCH.md, HBM section: "FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
 // streaming read (16 B/lane) ... other access widths are uncalibrated: calibrate on a known byte count in your own access
 // pattern").  Every kernel below moves a KNOWN number of bytes of a 512 MiB buffer (beyond L2 + Infinity Cache) exactly
-// once; tools/r05_fetch_calib.sh runs it under --pmc FETCH_SIZE and --pmc WRITE_SIZE and divides.
+// once; tools/fetch_calib.sh runs it under --pmc FETCH_SIZE and --pmc WRITE_SIZE and divides.
 //   rd<2> / rd<4> / rd<8> / rd<16>   coalesced streaming reads of 2 / 4 / 8 / 16 bytes per lane
 //   rd_rec16                         16-byte records in runs of 16 lanes at unrelated places (a sweep step's gather)
 //   wr<4> / wr<16>                   coalesced streaming writes

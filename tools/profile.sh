@@ -1,13 +1,14 @@
 #!/bin/bash
-# Round-5 profile artefacts on the GPU box: tools/profile_r05.sh <head-sha>   (results -> gpurun_out/prof_r05/)
+# Profile artefacts of a round on the GPU box: ROUND=r06 tools/profile.sh <head-sha>   (results -> gpurun_out/prof_$ROUND/)
 # ONE script for everything under profiles/ that describes the benchmarked tree: kernel-trace stats of the default bench
 # command (scalar headline, plane mode, plane mode with two neighbours), then separate --pmc passes (never combined with a
 # tracing domain): FETCH_SIZE, WRITE_SIZE (traffic.json), the issue side (valu.json, incl. the two-neighbour variant), TCP
 # and TCC requests, and the FETCH_SIZE / WRITE_SIZE calibration.  The sha of the tree is written into every file.
 head=${1:-unknown}
+round=${ROUND:-r06}
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-out=$root/gpurun_out/prof_r05
+out=$root/gpurun_out/prof_$round
 mkdir -p $out
 common="--warmup 1 --no-cpu-baseline --no-side-legs --host-pairs 0"
 pmc() {  # pmc <tag> "<mode args>" <name> <counters...>
@@ -16,7 +17,7 @@ pmc() {  # pmc <tag> "<mode args>" <name> <counters...>
   echo "$name $tag done"
 }
 csvof() { find $out/$1 -name "*counter_collection.csv" | head -1; }
-stamp() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # tree of commit $head (tools/profile_r05.sh)" "$f"; done; }
+stamp() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # tree of commit $head (tools/profile.sh)" "$f"; done; }
 for tag in scalar planes planes2; do
   case $tag in scalar) margs="--mode scalar";; planes) margs="--mode planes";; planes2) margs="--mode planes --plane-neighbours 1";; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats_$tag -o stats --output-format csv -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-side-legs --host-pairs 0 $margs > $out/bench_under_rocprof_$tag.json 2> $out/stats_$tag.err
@@ -39,8 +40,8 @@ python3 $root/tools/make_traffic.py $(csvof fetch_planes2) $(csvof write_planes2
 python3 $root/tools/make_valu.py $(csvof insts_scalar) $(csvof active_scalar) $(csvof ta_scalar) $out/valu.json --head $head > /dev/null
 python3 $root/tools/make_valu.py $(csvof insts_planes) $(csvof active_planes) $(csvof ta_planes) $out/valu.json $out/valu.json > /dev/null
 python3 $root/tools/make_valu.py $(csvof insts_planes2) $(csvof active_planes2) $(csvof ta_planes2) $out/valu.json $out/valu.json --suffix @two_neighbours > /dev/null
-bash $root/tools/r05_fetch_calib.sh > /dev/null 2>&1
-cp $root/gpurun_out/r05/fetch_calib.txt $out/calib_fetch_write.txt
+ROUND=$round bash $root/tools/fetch_calib.sh > /dev/null 2>&1
+cp $root/gpurun_out/$round/fetch_calib.txt $out/calib_fetch_write.txt
 stamp $out/kernel_stats_*.csv $out/pmc_*.txt $out/calib_fetch_write.txt
 # the raw counter dumps are large: keep the summaries only
 rm -rf $out/fetch_* $out/write_* $out/insts_* $out/active_* $out/ta_* $out/tcp_* $out/tcc_* $out/stats_scalar $out/stats_planes $out/stats_planes2
