@@ -28,6 +28,7 @@
 // Results are bit-identical to the serial engine, the wave engine and the oracle (tests/test_gpu_parity.py,
 // tools/fuzz_engines.py).
 #pragma once
+#include <vector>
 
 #include "pm_run2.hpp"
 #include "pm_tune.hpp"
@@ -496,8 +497,15 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
 // One workgroup per chain; a wavefront carries 64 / GS segments.  grid = (chains, 1, slots), block = 64 * nw,
 // dynamic LDS = run3_lds_bytes().
 template <int GS, int AXIS, int TP, int DIR, bool LREF>
-__global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
+__global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len
+#ifdef PM_RUN3_STATS
+                                                               , unsigned* chain_log  // [workgroup][8], this launch's
+#endif
+) {
   extern __shared__ float lds[];
+#ifdef PM_RUN3_STATS
+  const unsigned t_wall0 = (unsigned)wall_clock64();  // 100 MHz, shared by all CUs: launch time = max end - min start
+#endif
   const int n = (g.s_last - g.s_first) * DIR + 1;
   const int n1 = n + 1;
   constexpr int kPerWave = kWave / GS;
@@ -719,6 +727,27 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
       atomicAdd(&ps.counters[14], (unsigned long long)nseg);
     }
   }
+  if (chain_log && blockIdx.z == 0) {  // per chain: what its slowest wavefront did, and when (tools/chain_tail.py)
+    __shared__ unsigned s_ms, s_mf;
+    if (threadIdx.x == 0) s_ms = s_mf = 0;
+    __syncthreads();
+    if (lane == 0) {
+      atomicMax(&s_ms, n_steps);
+      atomicMax(&s_mf, n_fix);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned* r = chain_log + 8 * (size_t)blockIdx.x;
+      r[0] = (unsigned)chain;
+      r[1] = s_ms;
+      r[2] = s_mf;
+      r[3] = n_rounds;
+      r[4] = t_wall0;
+      r[5] = (unsigned)wall_clock64();
+      r[6] = (unsigned)(t_r1 - t_start);
+      r[7] = (unsigned)(clock64() - t_r1);
+    }
+  }
 #endif
   if (ps.counters && lane == 0) {
     const int base = AXIS * 4;
@@ -746,6 +775,35 @@ inline int run3_dbg() {
   }();
   return v;
 }
+#ifdef PM_RUN3_STATS
+// ---- per-chain log of the stats build (make tuning TUNE_DEFS=-DPM_RUN3_STATS; tools/chain_tail.py) -----------------------
+// Every k_runblk3 launch gets a slot of [workgroups][8] words in one device buffer and a host record of what it was;
+// pm_run3_stats_dump (pm_sweeps.hip, exported by this build only) writes both to a file.
+struct Run3StatsRec {
+  unsigned long long stream;
+  int axis, dir, gs, n, chains, waves;
+};
+struct Run3Stats {
+  static constexpr int kMaxLaunch = 4096, kMaxChains = 4096;
+  unsigned* d_log = nullptr;
+  std::vector<Run3StatsRec> recs;
+  bool on = false;
+};
+inline Run3Stats& run3_stats() {
+  static Run3Stats s;
+  return s;
+}
+inline unsigned* run3_stats_slot(hipStream_t stream, int axis, int dir, int gs, int n, int chains, int waves) {
+  Run3Stats& s = run3_stats();
+  if (!s.on || chains > Run3Stats::kMaxChains || (int)s.recs.size() >= Run3Stats::kMaxLaunch) return nullptr;
+  if (!s.d_log) {
+    if (hipMalloc((void**)&s.d_log, sizeof(unsigned) * 8 * (size_t)Run3Stats::kMaxChains * Run3Stats::kMaxLaunch) != hipSuccess)
+      return nullptr;
+  }
+  s.recs.push_back({(unsigned long long)(uintptr_t)stream, axis, dir, gs, n, chains, waves});
+  return s.d_log + 8 * (size_t)Run3Stats::kMaxChains * (s.recs.size() - 1);
+}
+#endif
 inline size_t run3_lds_bytes(int n, int nseg) { return sizeof(float) * (4 * (size_t)(n + 1) + 2 * (size_t)nseg + 3); }
 
 template <int GS, int AXIS, int TP, int DIR, bool LREF>
@@ -767,8 +825,14 @@ inline void launch_run3_l(const PlaneSet& ps, const CostParams& cp, const SweepG
     lds_bytes += (size_t)extra * 1024;
   }
   allow_big_lds(k_runblk3<GS, AXIS, TP, DIR, LREF>, lds_bytes);
+#ifdef PM_RUN3_STATS
+  hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
+                     dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len | (run3_dbg() << 24),
+                     run3_stats_slot(stream, AXIS, DIR, GS, n, chains, nwv));
+#else
   hipLaunchKernelGGL((k_runblk3<GS, AXIS, TP, DIR, LREF>), dim3((unsigned)chains, 1, (unsigned)slots),
                      dim3(kWave * nwv), lds_bytes, stream, ps, cp, g, len | (run3_dbg() << 24));
+#endif
 }
 template <int GS, int AXIS, int TP>
 inline void launch_run3_d(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, int slots, int waves,

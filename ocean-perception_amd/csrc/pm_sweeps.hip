@@ -3,7 +3,9 @@
 // four passes (patchmatch.cpp:248-311).
 #include "pm_sweeps.hpp"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "pm/patchmatch.h"
 #include "pm_serial.hpp"
@@ -112,3 +114,37 @@ void launch_sweep(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, 
 }
 
 }  // namespace pm
+
+#ifdef PM_RUN3_STATS
+// stats build only: start / stop the per-chain log, write it out.  File: "RUN3LOG1", launches, then per launch the host
+// record (8 x int64: stream, axis, dir, gs, n, chains, waves, 0) and chains x 8 uint32 device words.
+extern "C" __attribute__((visibility("default"))) int pm_run3_stats_enable(int on) {
+  pm::run3_stats().on = on != 0;
+  if (on) pm::run3_stats().recs.clear();
+  return 0;
+}
+extern "C" __attribute__((visibility("default"))) int pm_run3_stats_dump(const char* path) {
+  pm::Run3Stats& s = pm::run3_stats();
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  const long long nl = (long long)s.recs.size();
+  fwrite("RUN3LOG1", 1, 8, f);
+  fwrite(&nl, sizeof(nl), 1, f);
+  std::vector<unsigned> buf;
+  for (size_t i = 0; i < s.recs.size(); ++i) {
+    const pm::Run3StatsRec& r = s.recs[i];
+    const long long rec[8] = {(long long)r.stream, r.axis, r.dir, r.gs, r.n, r.chains, r.waves, 0};
+    fwrite(rec, sizeof(rec), 1, f);
+    buf.resize(8 * (size_t)r.chains);
+    if (hipMemcpy(buf.data(), s.d_log + 8 * (size_t)pm::Run3Stats::kMaxChains * i, sizeof(unsigned) * buf.size(),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+      fclose(f);
+      return -3;
+    }
+    fwrite(buf.data(), sizeof(unsigned), buf.size(), f);
+  }
+  fclose(f);
+  return (int)nl;
+}
+#endif
