@@ -39,6 +39,8 @@ def test_bench_two_ranks_gloo_dry_run():
     hs = out["host_sequence_all_ranks"]
     assert hs["ranks"] == 2 and hs["frames_per_rank"] == 64 and hs["ms_per_frame_per_rank"] >= 2.0
     assert abs(hs["value"] - 2 * 64 / (hs["ms_per_frame_per_rank"] * 64 / 1e3)) < 1e-6 * hs["value"]
+    # an N > 1 line says where the CPU leg is instead of leaving the key out
+    assert out["cpu_baseline"] is None and "N = 1" in out["cpu_baseline_reason"]
 
 
 def test_failing_tiled_leg_does_not_cost_the_line():
@@ -63,9 +65,11 @@ def test_shard_is_rank_local():
     import bench
     # rank 3 of 8, one pair per step: its four resident pairs 12..15 in rotation, nobody else's
     assert bench.shard(3, 8, 6, 1) == [[12], [13], [14], [15], [12], [13]]
+    # a batch repeats the rank's own four pairs (round 6: the batch legs match the headline's pairs, not 4 x nb others)
+    assert bench.shard(3, 8, 2, 6) == [[12, 13, 14, 15, 12, 13], [13, 14, 15, 12, 13, 14]]
     mine = {i for step in bench.shard(3, 8, 8, 2) for i in step}
     other = {i for r in (2, 4) for step in bench.shard(r, 8, 8, 2) for i in step}
-    assert mine == set(range(24, 32)) and not (mine & other)
+    assert mine == set(range(12, 16)) and not (mine & other)
 
 
 def test_bench_gpus_flag_launches_its_own_ranks():
