@@ -31,7 +31,17 @@ namespace pm {
 enum { PL_INIT = 0, PL_SPATIAL = 1, PL_VIEW = 2, PL_REFINE = 3, PL_VIEW_REFINE = 4 };  // 4 = 2 then 3, one tile fill
 enum { PL_RAND_INIT = 0, PL_RAND_REFINE = 1 };  // `stage` of the random key (oracle: ST_INIT / ST_REFINE)
 
-constexpr int kPlTileH = 8;
+// Tile height (rows = wavefronts of a block) per stage.  Results do not depend on it; what it trades is the halo (P - 1
+// extra rows of reference and target tile per block), the wavefronts a CU holds, and how evenly a launch's blocks fill
+// the chip's block slots (a 1280x720 view is 1800 blocks of 8 rows: 2.3 rounds on the 768 slots three blocks per CU give).
+// -DPL_TILE_H_SPATIAL / -DPL_TILE_H_OTHER: A/B builds (profiles/r06_planes_tile_height.txt).
+#ifndef PL_TILE_H_SPATIAL
+#define PL_TILE_H_SPATIAL 8
+#endif
+#ifndef PL_TILE_H_OTHER
+#define PL_TILE_H_OTHER 8
+#endif
+__host__ __device__ constexpr int pl_tile_h(int stage) { return stage == 1 /* PL_SPATIAL */ ? PL_TILE_H_SPATIAL : PL_TILE_H_OTHER; }
 
 struct PlanesParams {
   int patch, max_disp, refine_steps, margin;
@@ -104,10 +114,12 @@ struct PlTile {
   // (copy_s[k] = tile[k + s]), rows padded to whole dwords: a lane whose window starts at byte offset f of a row reads
   // ALIGNED dwords (f >> 2) of copy (f & 3) and gets its window bytes in place -- no v_alignbyte per dword.
   // Checkerboard window: the tile's columns are split by parity first (the taps of a window row are every other column),
-  // each half then kept as four shifted copies: [2 parities][4][TR][lww].
-  const unsigned* rc;   // [4][TR][lww] dwords, colour
-  const unsigned* rg;   // gradient
-  int rw, lww, copy_w;  // target row entries; reference row dwords; dwords per copy
+  // each half then kept as four shifted copies: [2 parities][4][TR][2 LWW].
+  // A row holds its LWW colour dwords and then its LWW gradient dwords (round 6; two planes before): the gradient sits
+  // at a compile-time offset from the colour, so one address register and the offset fields of ds_read2_b32 serve both.
+  const unsigned* rc;   // [4][TR][2 LWW] dwords: colour, gradient = + LWW
+  int rw, copy_w;       // target row entries; dwords per copy (TR * 2 LWW)
+  int tr;               // rows of the staged tiles: tile height + P - 1
 };
 
 // A target entry and the lerp of a tap (round 5).  The sample of a tap is (p0 (256 - w) + p1 w + 128) >> 8 per channel
@@ -150,7 +162,7 @@ __device__ __forceinline__ unsigned pl_lerp(pl_u2 e, unsigned w2) {
 #ifndef PL_EARLY_EXIT
 #define PL_EARLY_EXIT 0
 #endif
-template <int P>
+template <int P, int LWW>
 __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                          const PlanesParams& pp, float bound = __builtin_inff()) {
   constexpr int h = P / 2;
@@ -173,9 +185,8 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
   const int rowstep = (t.rw << 16) - B;
   unsigned sc = 0, sg = 0;
   // reference side: the lane's copy and dword column are fixed for the whole window (rows are whole dwords)
-  const int ref0 = (lx & 3) * t.copy_w + ty * t.lww + (lx >> 2);
+  const int ref0 = (lx & 3) * t.copy_w + ty * (2 * LWW) + (lx >> 2);
   const unsigned* pl = t.rc + ref0;
-  const unsigned* pg = t.rg + ref0;
 #pragma unroll 1
   for (int i = 0; i < P; ++i) {
     // all LDS reads of the window row first (target pairs, then reference bytes), arithmetic afterwards: the
@@ -195,7 +206,7 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       lw[q] = pl[q];
-      lgw[q] = pg[q];
+      lgw[q] = pl[LWW + q];
     }
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -217,8 +228,7 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
       sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pg, sg);
     }
     xrow += rowstep;
-    pl += t.lww;
-    pg += t.lww;
+    pl += 2 * LWW;
     // Early termination (exact): the sums only grow and the cost is monotone in them (one rounding per monotone
     // operation), so a partial cost that has reached `bound` -- the cost the candidate has to beat -- can only end
     // in a reject.  When that holds for every lane of the wavefront the remaining rows are skipped and the partial
@@ -242,9 +252,29 @@ __device__ __forceinline__ float pl_cost(const PlTile& t, int lx, int ty, int xr
 // 1 px of the truth stay at 99.86 % (DESIGN.md 5b has the table).  The reference bytes of a row's taps are every other
 // column of the tile: the tile is kept split by column parity, so that they are consecutive bytes again and the aligned
 // dword reads of the shifted copies work as for the full window.
-template <int P, int NT, int J0>
-__device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], const unsigned* pl, const unsigned* pg,
-                                            unsigned& sc, unsigned& sg) {
+// The colour bytes (byte 1) and the gradient bytes (byte 3) of up to four lerp results, four of each per dword, zeros where
+// the group is short.  n = 4: four v_perm_b32; 3 and 2: three; 1: two.
+__device__ __forceinline__ void pl_gather(const unsigned (&s)[4], int n, unsigned& pc, unsigned& pg) {
+  if (n >= 4) {
+    const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
+    const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
+    pc = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+    pg = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+  } else if (n == 3) {
+    const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);  // c0 c1 g0 g1
+    pc = __builtin_amdgcn_perm(s[2], u01, 0x0c050100u);
+    pg = __builtin_amdgcn_perm(s[2], u01, 0x0c070302u);
+  } else if (n == 2) {
+    const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
+    pc = __builtin_amdgcn_perm(0u, u01, 0x0c0c0100u);
+    pg = __builtin_amdgcn_perm(0u, u01, 0x0c0c0302u);
+  } else {
+    pc = __builtin_amdgcn_perm(0u, s[0], 0x0c0c0c01u);
+    pg = __builtin_amdgcn_perm(0u, s[0], 0x0c0c0c03u);
+  }
+}
+template <int P, int NT, int J0, int LWW>
+__device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], const unsigned* pl, unsigned& sc, unsigned& sg) {
   constexpr int NG = (NT + 3) / 4;
   pl_u2 tp[NT];
   unsigned wq[(NT + 1) / 2];  // the weights of taps 2 m and 2 m + 1 of this row
@@ -261,7 +291,7 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
     lw[q] = pl[q];
-    lgw[q] = pg[q];
+    lgw[q] = pl[LWW + q];
   }
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
@@ -271,21 +301,101 @@ __device__ __forceinline__ void pl_row_taps(int xrow, const int (&xoff)[P], cons
       const int j = 4 * q + k;
       if (j < NT) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
     }
-    const unsigned u01 = __builtin_amdgcn_perm(s[1], s[0], 0x07030501u);
-    const unsigned u23 = __builtin_amdgcn_perm(s[3], s[2], 0x07030501u);
-    const unsigned pc = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
-    const unsigned pgs = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+    unsigned pc, pgs;
+    pl_gather(s, NT - 4 * q, pc, pgs);
     const int rem = NT - 4 * q;
     const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
     sc = __builtin_amdgcn_sad_u8(lw[q] & mask, pc, sc);
     sg = __builtin_amdgcn_sad_u8(lgw[q] & mask, pgs, sg);
   }
 }
+// Two window rows of the checkerboard at once (round 6): an even row has NE = (P + 1) / 2 taps, the odd row behind it
+// NO = P / 2 -- 6 and 5 for P = 11 -- so both end in a partial group of four (2 taps and 1 tap), and a partial group costs
+// what a full one does (byte gathers, two v_sad_u8, masks).  Where the two leftovers fit ONE group they share it: the
+// samples are taken in the order [even full groups | odd full groups | even leftover, odd leftover], the reference bytes of
+// the shared group come from one v_perm_b32 of the two rows' last dwords (zero where the group is short: no masks).
+// P = 11: 3 groups per row pair instead of 4, 20 vector instructions for gathers and SADs instead of 26.
 template <int P>
+struct PlPairOrder {
+  static constexpr int NE = (P + 1) / 2, NO = P / 2, QE = NE / 4, QO = NO / 4, RE = NE % 4, RO = NO % 4, NT = NE + NO;
+  static constexpr bool shared = RE > 0 && RO > 0 && RE + RO <= 4;
+  int odd[NT], idx[NT];
+  constexpr PlPairOrder() : odd{}, idx{} {
+    int k = 0;
+    for (int j = 0; j < 4 * QE; ++j, ++k) { odd[k] = 0; idx[k] = j; }
+    for (int j = 0; j < 4 * QO; ++j, ++k) { odd[k] = 1; idx[k] = j; }
+    for (int j = 4 * QE; j < NE; ++j, ++k) { odd[k] = 0; idx[k] = j; }
+    for (int j = 4 * QO; j < NO; ++j, ++k) { odd[k] = 1; idx[k] = j; }
+  }
+  // v_perm_b32 selector of the shared group's reference bytes: RE bytes of the even row's last dword (source 1: bytes
+  // 0..3), then RO bytes of the odd row's (source 0: bytes 4..7), then zeros (0x0c)
+  static constexpr unsigned sel() {
+    unsigned v = 0;
+    for (int b = 0; b < 4; ++b) {
+      const unsigned s = b < RE ? (unsigned)b : (b < RE + RO ? (unsigned)(4 + b - RE) : 0x0cu);
+      v |= s << (8 * b);
+    }
+    return v;
+  }
+};
+template <int P, int LWW>
+__device__ __forceinline__ void pl_rowpair_taps(int xrow_e, int xrow_o, const int (&xoff)[P], const unsigned* ple,
+                                                const unsigned* plo, unsigned& sc, unsigned& sg) {
+  using O = PlPairOrder<P>;
+  constexpr O ord{};
+  constexpr int NT = O::NT, NQ = O::QE + O::QO + 1;
+  pl_u2 tp[NT];
+  unsigned wq[(NT + 1) / 2];
+  int xs[NT + 1];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    xs[k] = (ord.odd[k] ? xrow_o : xrow_e) + xoff[2 * ord.idx[k] + ord.odd[k]];
+    tp[k] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)xs[k] >> 16) << 3);  // absolute LDS byte address
+  }
+  xs[NT] = 0;
+#pragma unroll
+  for (int m = 0; m < (NT + 1) / 2; ++m) wq[m] = pl_weights2(xs[2 * m], xs[2 * m + 1]);
+  unsigned ec[O::QE + 1], eg[O::QE + 1], oc[O::QO + 1], og[O::QO + 1];
+#pragma unroll
+  for (int q = 0; q <= O::QE; ++q) {
+    ec[q] = ple[q];
+    eg[q] = ple[LWW + q];
+  }
+#pragma unroll
+  for (int q = 0; q <= O::QO; ++q) {
+    oc[q] = plo[q];
+    og[q] = plo[LWW + q];
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    unsigned s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = 4 * q + k;
+      if (j < NT) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
+    }
+    unsigned pc, pgs;
+    pl_gather(s, NT - 4 * q, pc, pgs);
+    unsigned rc, rg;
+    if (q < O::QE) {
+      rc = ec[q];
+      rg = eg[q];
+    } else if (q < O::QE + O::QO) {
+      rc = oc[q - O::QE];
+      rg = og[q - O::QE];
+    } else {
+      rc = __builtin_amdgcn_perm(oc[O::QO], ec[O::QE], O::sel());
+      rg = __builtin_amdgcn_perm(og[O::QO], eg[O::QE], O::sel());
+    }
+    sc = __builtin_amdgcn_sad_u8(rc, pc, sc);
+    sg = __builtin_amdgcn_sad_u8(rg, pgs, sg);
+  }
+}
+template <int P, int LWW>
 __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                                  const PlanesParams& pp, float bound = __builtin_inff()) {
   constexpr int h = P / 2;
-  constexpr int TR = kPlTileH + P - 1;
+  const int TR = t.tr;
   constexpr int NE = (P + 1) / 2, NO = P / 2;  // taps of an even / an odd window row
   const int Z = __float2int_rn(z * 65536.0f), A = __float2int_rn(a * 65536.0f), B = __float2int_rn(b * 65536.0f);
   int xrow = ((xrel + t.tgt_entry0 + ty * t.rw) << 16) - Z + A * h + B * h;  // tap (0, 0)
@@ -303,30 +413,42 @@ __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty
   unsigned sc = 0, sg = 0;
   // even window rows start at tile column lx, odd ones at lx + 1: parity plane, shifted copy and dword of both
   const int ie = lx >> 1, io = (lx + 1) >> 1;
-  const int refe = (((lx & 1) * 4 + (ie & 3)) * TR + ty) * t.lww + (ie >> 2);
-  const int refo = ((((lx + 1) & 1) * 4 + (io & 3)) * TR + ty) * t.lww + (io >> 2);
+  const int refe = (((lx & 1) * 4 + (ie & 3)) * TR + ty) * (2 * LWW) + (ie >> 2);
+  const int refo = ((((lx + 1) & 1) * 4 + (io & 3)) * TR + ty) * (2 * LWW) + (io >> 2);
   const unsigned* ple = t.rc + refe;
-  const unsigned* pge = t.rg + refe;
-  const unsigned* plo = t.rc + refo + t.lww;  // window row 1
-  const unsigned* pgo = t.rg + refo + t.lww;
-  const int lww2 = 2 * t.lww;
+  const unsigned* plo = t.rc + refo + 2 * LWW;  // window row 1
+  constexpr int lww2 = 4 * LWW;                 // two rows further
+  if constexpr (PlPairOrder<P>::shared) {
+    // row pairs (0, 1), (2, 3), ... share their leftover group; the last (even) row stands alone
 #pragma unroll 1
-  for (int i = 0; i < P; i += 2) {
-    pl_row_taps<P, NE, 0>(xrow, xoff, ple, pge, sc, sg);
-    xrow += rowstep;
-    ple += lww2;
-    pge += lww2;
-    if (i + 1 < P) {
-      pl_row_taps<P, NO, 1>(xrow, xoff, plo, pgo, sc, sg);
-      xrow += rowstep;
+    for (int i = 0; i < P / 2; ++i) {
+      // (opaque: otherwise the loop optimiser keeps one running column per tap and spends an add on each per iteration)
+      asm volatile("" : "+v"(xrow));
+      int xrow_o = xrow + rowstep;
+      asm volatile("" : "+v"(xrow_o));
+      pl_rowpair_taps<P, LWW>(xrow, xrow_o, xoff, ple, plo, sc, sg);
+      xrow = xrow_o + rowstep;
+      ple += lww2;
       plo += lww2;
-      pgo += lww2;
     }
-    // early termination (exact, see pl_cost; -DPL_EARLY_EXIT=1 builds only): after window rows 0..3, 0..5, 0..7
-    if (PL_EARLY_EXIT && i >= 2 && i + 4 < P) {
-      const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
-      const float part = pp.alpha * fminf(mc, pp.tau_color) + pp.one_minus_alpha * fminf(mg, pp.tau_grad);
-      if (!__any(part < bound)) return part;
+    pl_row_taps<P, NE, 0, LWW>(xrow, xoff, ple, sc, sg);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < P; i += 2) {
+      pl_row_taps<P, NE, 0, LWW>(xrow, xoff, ple, sc, sg);
+      xrow += rowstep;
+      ple += lww2;
+      if (i + 1 < P) {
+        pl_row_taps<P, NO, 1, LWW>(xrow, xoff, plo, sc, sg);
+        xrow += rowstep;
+        plo += lww2;
+      }
+      // early termination (exact, see pl_cost; -DPL_EARLY_EXIT=1 builds only): after window rows 0..3, 0..5, 0..7
+      if (PL_EARLY_EXIT && i >= 2 && i + 4 < P) {
+        const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
+        const float part = pp.alpha * fminf(mc, pp.tau_color) + pp.one_minus_alpha * fminf(mg, pp.tau_grad);
+        if (!__any(part < bound)) return part;
+      }
     }
   }
   const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
@@ -334,18 +456,18 @@ __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty
   const float t1 = pp.one_minus_alpha * fminf(mg, pp.tau_grad);
   return t0 + t1;
 }
-template <int P, int WIN>
+template <int P, int WIN, int LWW>
 __device__ __forceinline__ float pl_cost_w(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                            const PlanesParams& pp, float bound = __builtin_inff()) {
-  if constexpr (WIN == 1) return pl_cost_checker<P>(t, lx, ty, xrel, a, b, z, pp, bound);
-  else return pl_cost<P>(t, lx, ty, xrel, a, b, z, pp, bound);
+  if constexpr (WIN == 1) return pl_cost_checker<P, LWW>(t, lx, ty, xrel, a, b, z, pp, bound);
+  else return pl_cost<P, LWW>(t, lx, ty, xrel, a, b, z, pp, bound);
 }
 
 // Pixel state in registers + the candidate rule (oracle: offer()).
 struct PlPix {
   float a, b, z, c;
 };
-template <int P, typename ST, int WIN>
+template <int P, typename ST, int WIN, int LWW>
 __device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xrel, int x, bool on, float ca, float cb,
                                          float cz, PlPix& px, const PlanesParams& pp) {
   ca = pl_quant<ST>(ca);
@@ -355,7 +477,7 @@ __device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xr
   const bool need = on && cz >= 0.0f && cz <= zmax && !(ca == px.a && cb == px.b && cz == px.z);
   if (!__any(need)) return;  // wave-uniform skip
   // lanes without a candidate evaluate a harmless plane (their result is discarded)
-  const float c = pl_quant<ST>(pl_cost_w<P, WIN>(t, lx, ty, xrel, need ? ca : 0.f, need ? cb : 0.f, need ? cz : 0.f, pp,
+  const float c = pl_quant<ST>(pl_cost_w<P, WIN, LWW>(t, lx, ty, xrel, need ? ca : 0.f, need ? cb : 0.f, need ? cz : 0.f, pp,
                                                  need ? px.c : -1.0f));
   if (need && c < px.c) {
     px.a = ca;
@@ -378,8 +500,7 @@ struct PlArgs {
   int dbg;  // tuning build only (PM_PLANES_DBG): bit 0 no window evaluation, bit 1 no tile fill -- timing experiments
 };
 
-// grid = (ceil(cols / TW), ceil(rows / 8), slots), block = 512, dynamic LDS = pl_lds_bytes().
-constexpr int kPlThreads = 512;
+// grid = (ceil(cols / TW), ceil(rows / tile height), slots), block = 64 x tile height, dynamic LDS = pl_lds_bytes().
 // Tile width.  The spatial stage updates one colour: 64 active lanes per row of a 128-wide tile.  The other stages update
 // every pixel: 64-wide tiles, one pixel per lane.  -DPL_WIDE_TW=128 gives them 128-wide tiles whose lanes take two pixels
 // of a row one after the other (half as many blocks per launch, the 164 extra target columns of a tile row amortised
@@ -395,20 +516,20 @@ __host__ __device__ constexpr int pl_ref_row_dwords(int LW, int win) {
   return win == 1 ? ((LW + 1) / 2 + 3) / 4 + 1 : (LW + 3) / 4 + 1;
 }
 template <int P, int STAGE, typename ST, int WIN>
-__global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
+__global__ void __launch_bounds__(64 * pl_tile_h(STAGE)) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
   constexpr int h = P / 2;
+  constexpr int kPlTileH = pl_tile_h(STAGE), kPlThreads = 64 * kPlTileH;
   constexpr int TW = pl_tile_w(STAGE);  // 64 lanes per tile row either way
   constexpr int SUBS = STAGE == PL_SPATIAL ? 1 : TW / 64;  // pixels of a row per lane
   constexpr int TR = kPlTileH + P - 1;
   constexpr int LW = TW + P - 1;
   constexpr int LWW = pl_ref_row_dwords(LW, WIN);
-  constexpr int COPYW = TR * LWW;                // dwords per shifted copy
-  constexpr int NREF = ((WIN == 1 ? 8 : 4) * COPYW + 1) & ~1;  // per channel, even
+  constexpr int COPYW = TR * 2 * LWW;            // dwords per shifted copy: rows of LWW colour + LWW gradient dwords
+  constexpr int NREF = (WIN == 1 ? 8 : 4) * (COPYW / 2);  // per channel (COPYW / 2 = TR * LWW); 2 NREF is even
   extern __shared__ __attribute__((aligned(16))) unsigned pl_lds[];
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
   unsigned* s_rc = pl_lds;
-  unsigned* s_rg = pl_lds + NREF;
-  pl_u2* s_tgt = (pl_u2*)(pl_lds + 2 * NREF);  // NREF is even: 8-byte aligned
+  pl_u2* s_tgt = (pl_u2*)(pl_lds + 2 * NREF);  // 2 NREF is even: 8-byte aligned
   float* s_pl = (float*)(s_tgt + TR * rw);     // SPATIAL only: [3][kPlTileH + 2][TW + 2]
 
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -428,7 +549,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   // window evaluation switched off, it was 34 of a spatial launch's 96 us when each element waited for its own load) ---
   {
     uint8_t* rc8 = (uint8_t*)s_rc;
-    uint8_t* rg8 = (uint8_t*)s_rg;
+    uint8_t* rg8 = rc8 + 4 * LWW;  // the gradient half of every row
     const int ry0 = y0 - h, lx0 = x0 - h;
     const int xs_lo = x0 - h - pp.max_disp - pp.margin;
     constexpr int NW = kPlThreads / 64;          // wavefronts
@@ -469,7 +590,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
 #pragma unroll
               for (int sft = 0; sft < 4; ++sft)
                 if (ci >= sft) {
-                  const int o = 4 * ((par * 4 + sft) * COPYW + rr * LWW) + ci - sft;
+                  const int o = 4 * ((par * 4 + sft) * COPYW + rr * 2 * LWW) + ci - sft;
                   rc8[o] = (uint8_t)(pk & 0xffu);
                   rg8[o] = (uint8_t)(pk >> 8);
                 }
@@ -582,10 +703,9 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
   // absolute LDS address of the target tile in 8-byte units (the dynamic LDS block is 16-byte aligned)
   t.tgt_entry0 = (int)((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)pl_lds >> 3) + NREF;
   t.rc = s_rc;
-  t.rg = s_rg;
   t.rw = rw;
-  t.lww = LWW;
   t.copy_w = COPYW;
+  t.tr = TR;
   const float smax = pp.slope_max;
 #pragma unroll 1
   for (int sub = 0; sub < SUBS; ++sub) {
@@ -618,7 +738,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
     px.a = a;
     px.b = b;
     px.z = z;
-    px.c = pl_quant<ST>(pl_cost_w<P, WIN>(t, lx, ty, xrel, on ? a : 0.f, on ? b : 0.f, on ? z : 0.f, pp));
+    px.c = pl_quant<ST>(pl_cost_w<P, WIN, LWW>(t, lx, ty, xrel, on ? a : 0.f, on ? b : 0.f, on ? z : 0.f, pp));
   } else {
     if (on) {
       px.a = pl_load(pa, o);
@@ -638,19 +758,19 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
       const bool lu = !two || !odd_it, rd = !two || odd_it;
       if (lu) {
         const float na = sa[c - 1], nb = sb[c - 1], nz = sz[c - 1];
-        pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp);
+        pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp);
       }
       if (rd) {
         const float na = sa[c + 1], nb = sb[c + 1], nz = sz[c + 1];
-        pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && x < cols - 1, na, nb, nz - na, px, pp);
+        pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && x < cols - 1, na, nb, nz - na, px, pp);
       }
       if (lu) {
         const float na = sa[c - PW2], nb = sb[c - PW2], nz = sz[c - PW2];
-        pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && y > 0, na, nb, nz + nb, px, pp);
+        pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && y > 0, na, nb, nz + nb, px, pp);
       }
       if (rd) {
         const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
-        pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
+        pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
       }
     }
     if constexpr (STAGE == PL_VIEW || STAGE == PL_VIEW_REFINE) {
@@ -674,7 +794,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
       const float dx = (float)x - xc;
       const float tt = na * dx;
       const float nz = zo + tt;
-      pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, ok, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
+      pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, ok, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
     }
     if constexpr (STAGE == PL_REFINE || STAGE == PL_VIEW_REFINE) {
       float dz = ar.refine_amp;
@@ -685,7 +805,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
         const float u2 = pl_pm1(pl_rand(pp.seed, PL_RAND_REFINE, ar.arg, k, view, 2, x, y));
         const float t0 = dz * u0, t1 = ds * u1, t2 = ds * u2;
         const float nz = px.z + t0, na = px.a + t1, nb = px.b + t2;
-        pl_offer<P, ST, WIN>(t, lx, ty, xrel, x, on, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
+        pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on, pl_clamp_slope(na, smax), pl_clamp_slope(nb, smax), nz, px, pp);
         dz = dz * 0.5f;
       }
     }
@@ -702,7 +822,7 @@ __global__ void __launch_bounds__(kPlThreads) k_planes(PlaneSet ps, PlaneState<S
 template <int STAGE>
 inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
   const int h = P / 2;
-  const int TW = pl_tile_w(STAGE);
+  const int TW = pl_tile_w(STAGE), kPlTileH = pl_tile_h(STAGE);
   const int TR = kPlTileH + P - 1, LW = TW + P - 1;
   const int nref = ((pp.window == 1 ? 8 : 4) * TR * pl_ref_row_dwords(LW, pp.window) + 1) & ~1;
   const int rw = TW + 2 * h + pp.max_disp + 2 * pp.margin + 2;
@@ -714,7 +834,7 @@ inline size_t pl_lds_bytes(int P, const PlanesParams& pp) {
 template <int P, int STAGE, typename ST, int WIN>
 inline hipError_t pl_launch_w(const PlaneSet& ps, void* state, const PlanesParams& pp, const PlArgs& ar, int slots,
                               hipStream_t stream) {
-  const int TW = pl_tile_w(STAGE);
+  const int TW = pl_tile_w(STAGE), kPlTileH = pl_tile_h(STAGE);
   const size_t lds = pl_lds_bytes<STAGE>(P, pp);
   if (lds > kChainLdsMax) return hipErrorInvalidValue;
   allow_big_lds(k_planes<P, STAGE, ST, WIN>, lds);
@@ -723,7 +843,7 @@ inline hipError_t pl_launch_w(const PlaneSet& ps, void* state, const PlanesParam
   st.plane = ps.plane;
   st.half_pitch = ps.pitch / 2;
   const dim3 grid((unsigned)((ps.cols + TW - 1) / TW), (unsigned)((ps.rows + kPlTileH - 1) / kPlTileH), (unsigned)slots);
-  hipLaunchKernelGGL((k_planes<P, STAGE, ST, WIN>), grid, dim3(kPlThreads), lds, stream, ps, st, pp, ar);
+  hipLaunchKernelGGL((k_planes<P, STAGE, ST, WIN>), grid, dim3(64 * kPlTileH), lds, stream, ps, st, pp, ar);
   return hipGetLastError();
 }
 template <int P, int STAGE, typename ST>
