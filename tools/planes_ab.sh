@@ -13,7 +13,7 @@ for name in "$@"; do
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=j['roofline']
-print('$name', '$extra', 'pairs/s', round(j['value'],1), 'ms', round(j['ms_per_step'],3), r['kernel'], round(r['avg_launch_ms']*1e3,1), 'us', {k: round(v[1]/max(v[0],1)*1e3,1) for k,v in j.get('profile',{}).items() if v[0]} if 'profile' in j else '')" >> $f
+print('$name', '$extra', 'pairs/s', round(j['value'],1), 'ms', round(j['ms_per_step'],3), r['kernel'], round(r['avg_launch_ms']*1e3,1), 'us', {k: round(v*1e3/16.0,1) for k,v in j['kernels_ms_per_step'].items() if k.startswith('planes_s') or k.startswith('planes_v')})" >> $f
   done
 done
 cat $f
