@@ -99,7 +99,7 @@ def test_the_shipped_library_carries_no_tuning_knob():
     assert names == [], names
     src = os.path.join(ROOT, "ocean-perception_amd", "csrc")
     for f in sorted(os.listdir(src)):
-        if f != "pm_tune.hpp":
+        if f != "pm_tune.hpp" and os.path.isfile(os.path.join(src, f)):  # (csrc/experimental/ holds records, not sources)
             assert "getenv" not in open(os.path.join(src, f)).read().replace("tune_env", ""), f
 
 
