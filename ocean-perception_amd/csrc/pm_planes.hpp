@@ -41,6 +41,12 @@ enum { PL_RAND_INIT = 0, PL_RAND_REFINE = 1 };  // `stage` of the random key (or
 #ifndef PL_TILE_H_OTHER
 #define PL_TILE_H_OTHER 8
 #endif
+#ifndef PL_SPATIAL_REF_REGS
+#define PL_SPATIAL_REF_REGS 1
+#endif
+#ifndef PL_PAIR_BARRIER
+#define PL_PAIR_BARRIER  // (a scheduling barrier between the unrolled row pairs costs 12 spilled registers at the 128 allowed)
+#endif
 __host__ __device__ constexpr int pl_tile_h(int stage) { return stage == 1 /* PL_SPATIAL */ ? PL_TILE_H_SPATIAL : PL_TILE_H_OTHER; }
 
 struct PlanesParams {
@@ -456,6 +462,133 @@ __device__ __forceinline__ float pl_cost_checker(const PlTile& t, int lx, int ty
   const float t1 = pp.one_minus_alpha * fminf(mg, pp.tau_grad);
   return t0 + t1;
 }
+// The red-black stage keeps a pixel's reference window in REGISTERS (round 6): the window is the same for all four
+// neighbour candidates, the stage runs four wavefronts per SIMD (two 78 KB blocks per CU) and has the registers, and a
+// timing build said what the reads cost it (reference dwords out of a register: 74 -> 67 us per launch, while fewer
+// vector instructions and conflict-free target reads gave it nothing: profiles/r06_planes_experiments.txt).  Per row
+// pair the three group dwords of each channel in the order pl_rowpair_taps consumes them, then the last row's.
+template <int P>
+struct PlRefRegs {
+  using O = PlPairOrder<P>;
+  static constexpr int NP = P / 2, NQ = O::QE + O::QO + 1, NL = (O::NE + 3) / 4;
+  unsigned c[NP][NQ], g[NP][NQ], lc[NL], lg[NL];
+};
+template <int P, int LWW>
+__device__ __forceinline__ void pl_ref_load(const PlTile& t, int lx, int ty, PlRefRegs<P>& R) {
+  using O = PlPairOrder<P>;
+  const int TR = t.tr;
+  const int ie = lx >> 1, io = (lx + 1) >> 1;
+  const unsigned* ple = t.rc + (((lx & 1) * 4 + (ie & 3)) * TR + ty) * (2 * LWW) + (ie >> 2);
+  const unsigned* plo = t.rc + ((((lx + 1) & 1) * 4 + (io & 3)) * TR + ty) * (2 * LWW) + (io >> 2) + 2 * LWW;
+#pragma unroll
+  for (int i = 0; i < PlRefRegs<P>::NP; ++i) {
+    const unsigned* e = ple + 4 * LWW * i;
+    const unsigned* o = plo + 4 * LWW * i;
+#pragma unroll
+    for (int q = 0; q < O::QE; ++q) {
+      R.c[i][q] = e[q];
+      R.g[i][q] = e[LWW + q];
+    }
+#pragma unroll
+    for (int q = 0; q < O::QO; ++q) {
+      R.c[i][O::QE + q] = o[q];
+      R.g[i][O::QE + q] = o[LWW + q];
+    }
+    R.c[i][O::QE + O::QO] = __builtin_amdgcn_perm(o[O::QO], e[O::QE], O::sel());
+    R.g[i][O::QE + O::QO] = __builtin_amdgcn_perm(o[LWW + O::QO], e[LWW + O::QE], O::sel());
+  }
+  const unsigned* e = ple + 4 * LWW * PlRefRegs<P>::NP;
+#pragma unroll
+  for (int q = 0; q < PlRefRegs<P>::NL; ++q) {
+    const int rem = O::NE - 4 * q;
+    const unsigned mask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+    R.lc[q] = e[q] & mask;
+    R.lg[q] = e[LWW + q] & mask;
+  }
+}
+template <int P>
+__device__ __forceinline__ float pl_cost_checker_regs(const PlTile& t, int ty, int xrel, float a, float b, float z,
+                                                      const PlanesParams& pp, const PlRefRegs<P>& R) {
+  using O = PlPairOrder<P>;
+  constexpr O ord{};
+  constexpr int h = P / 2, NT = O::NT, NQ = PlRefRegs<P>::NQ, NP = PlRefRegs<P>::NP, NE = O::NE;
+  const int Z = __float2int_rn(z * 65536.0f), A = __float2int_rn(a * 65536.0f), B = __float2int_rn(b * 65536.0f);
+  int xrow = ((xrel + t.tgt_entry0 + ty * t.rw) << 16) - Z + A * h + B * h;  // tap (0, 0)
+  int stepj = 65536 - A;
+  asm volatile("" : "+v"(stepj));
+  int xoff[P];
+  xoff[0] = 0;
+#pragma unroll
+  for (int j = 1; j < P; ++j) {
+    int tt = xoff[j - 1] + stepj;
+    asm volatile("" : "+v"(tt));
+    xoff[j] = tt;
+  }
+  const int rowstep = (t.rw << 16) - B;
+  unsigned sc = 0, sg = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    asm volatile("" : "+v"(xrow));  // (one row base per pair: see pl_cost_checker)
+    int xrow_o = xrow + rowstep;
+    asm volatile("" : "+v"(xrow_o));
+    pl_u2 tp[NT];
+    unsigned wq[(NT + 1) / 2];
+    int xs[NT + 1];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      xs[k] = (ord.odd[k] ? xrow_o : xrow) + xoff[2 * ord.idx[k] + ord.odd[k]];
+      tp[k] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)xs[k] >> 16) << 3);
+    }
+    xs[NT] = 0;
+#pragma unroll
+    for (int m = 0; m < (NT + 1) / 2; ++m) wq[m] = pl_weights2(xs[2 * m], xs[2 * m + 1]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      unsigned s[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = 4 * q + k;
+        if (j < NT) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
+      }
+      unsigned pc, pgs;
+      pl_gather(s, NT - 4 * q, pc, pgs);
+      sc = __builtin_amdgcn_sad_u8(R.c[i][q], pc, sc);
+      sg = __builtin_amdgcn_sad_u8(R.g[i][q], pgs, sg);
+    }
+    xrow = xrow_o + rowstep;
+    PL_PAIR_BARRIER
+  }
+  {  // the last (even) row
+    pl_u2 tp[NE];
+    unsigned wq[(NE + 1) / 2];
+    int xs[NE + 1];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      xs[k] = xrow + xoff[2 * k];
+      tp[k] = *(const pl_lds_u2*)(uintptr_t)(((unsigned)xs[k] >> 16) << 3);
+    }
+    xs[NE] = 0;
+#pragma unroll
+    for (int m = 0; m < (NE + 1) / 2; ++m) wq[m] = pl_weights2(xs[2 * m], xs[2 * m + 1]);
+#pragma unroll
+    for (int q = 0; q < PlRefRegs<P>::NL; ++q) {
+      unsigned s[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = 4 * q + k;
+        if (j < NE) s[k] = (j & 1) ? pl_lerp<1>(tp[j], wq[j / 2]) : pl_lerp<0>(tp[j], wq[j / 2]);
+      }
+      unsigned pc, pgs;
+      pl_gather(s, NE - 4 * q, pc, pgs);
+      sc = __builtin_amdgcn_sad_u8(R.lc[q], pc, sc);
+      sg = __builtin_amdgcn_sad_u8(R.lg[q], pgs, sg);
+    }
+  }
+  const float mc = (float)(int)sc * pp.inv_n, mg = (float)(int)sg * pp.inv_n;
+  const float t0 = pp.alpha * fminf(mc, pp.tau_color);
+  const float t1 = pp.one_minus_alpha * fminf(mg, pp.tau_grad);
+  return t0 + t1;
+}
 template <int P, int WIN, int LWW>
 __device__ __forceinline__ float pl_cost_w(const PlTile& t, int lx, int ty, int xrel, float a, float b, float z,
                                            const PlanesParams& pp, float bound = __builtin_inff()) {
@@ -479,6 +612,25 @@ __device__ __forceinline__ void pl_offer(const PlTile& t, int lx, int ty, int xr
   // lanes without a candidate evaluate a harmless plane (their result is discarded)
   const float c = pl_quant<ST>(pl_cost_w<P, WIN, LWW>(t, lx, ty, xrel, need ? ca : 0.f, need ? cb : 0.f, need ? cz : 0.f, pp,
                                                  need ? px.c : -1.0f));
+  if (need && c < px.c) {
+    px.a = ca;
+    px.b = cb;
+    px.z = cz;
+    px.c = c;
+  }
+}
+
+// pl_offer with the reference window in registers (red-black stage, checkerboard windows whose row pairs share a group)
+template <int P, typename ST>
+__device__ __forceinline__ void pl_offer_regs(const PlTile& t, int ty, int xrel, int x, bool on, float ca, float cb, float cz,
+                                              PlPix& px, const PlanesParams& pp, const PlRefRegs<P>& R) {
+  ca = pl_quant<ST>(ca);
+  cb = pl_quant<ST>(cb);
+  cz = pl_quant<ST>(cz);
+  const float zmax = fminf((float)pp.max_disp, (float)x);
+  const bool need = on && cz >= 0.0f && cz <= zmax && !(ca == px.a && cb == px.b && cz == px.z);
+  if (!__any(need)) return;  // wave-uniform skip
+  const float c = pl_quant<ST>(pl_cost_checker_regs<P>(t, ty, xrel, need ? ca : 0.f, need ? cb : 0.f, need ? cz : 0.f, pp, R));
   if (need && c < px.c) {
     px.a = ca;
     px.b = cb;
@@ -516,7 +668,9 @@ __host__ __device__ constexpr int pl_ref_row_dwords(int LW, int win) {
   return win == 1 ? ((LW + 1) / 2 + 3) / 4 + 1 : (LW + 3) / 4 + 1;
 }
 template <int P, int STAGE, typename ST, int WIN>
-__global__ void __launch_bounds__(64 * pl_tile_h(STAGE)) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
+// (second launch bound = wavefronts per SIMD the register budget must allow: two of the red-black stage's 78 KB blocks fit
+// a CU's LDS -- four wavefronts per SIMD, 128 VGPRs -- and its register-resident reference window uses them)
+__global__ void __launch_bounds__(64 * pl_tile_h(STAGE), STAGE == PL_SPATIAL ? 4 : 1) k_planes(PlaneSet ps, PlaneState<ST> st, PlanesParams pp, PlArgs ar) {
   constexpr int h = P / 2;
   constexpr int kPlTileH = pl_tile_h(STAGE), kPlThreads = 64 * kPlTileH;
   constexpr int TW = pl_tile_w(STAGE);  // 64 lanes per tile row either way
@@ -756,6 +910,26 @@ __global__ void __launch_bounds__(64 * pl_tile_h(STAGE)) k_planes(PlaneSet ps, P
       // an even iteration, right + down in those of an odd one (uniform for the launch)
       const bool two = pp.neighbours == 1, odd_it = ((ar.arg >> 1) & 1) != 0;
       const bool lu = !two || !odd_it, rd = !two || odd_it;
+      if constexpr (WIN == 1 && PlPairOrder<P>::shared && PL_SPATIAL_REF_REGS) {
+        PlRefRegs<P> R;
+        pl_ref_load<P, LWW>(t, lx, ty, R);
+        if (lu) {
+          const float na = sa[c - 1], nb = sb[c - 1], nz = sz[c - 1];
+          pl_offer_regs<P, ST>(t, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp, R);
+        }
+        if (rd) {
+          const float na = sa[c + 1], nb = sb[c + 1], nz = sz[c + 1];
+          pl_offer_regs<P, ST>(t, ty, xrel, x, on && x < cols - 1, na, nb, nz - na, px, pp, R);
+        }
+        if (lu) {
+          const float na = sa[c - PW2], nb = sb[c - PW2], nz = sz[c - PW2];
+          pl_offer_regs<P, ST>(t, ty, xrel, x, on && y > 0, na, nb, nz + nb, px, pp, R);
+        }
+        if (rd) {
+          const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
+          pl_offer_regs<P, ST>(t, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp, R);
+        }
+      } else {
       if (lu) {
         const float na = sa[c - 1], nb = sb[c - 1], nz = sz[c - 1];
         pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && x > 0, na, nb, nz + na, px, pp);
@@ -771,6 +945,7 @@ __global__ void __launch_bounds__(64 * pl_tile_h(STAGE)) k_planes(PlaneSet ps, P
       if (rd) {
         const float na = sa[c + PW2], nb = sb[c + PW2], nz = sz[c + PW2];
         pl_offer<P, ST, WIN, LWW>(t, lx, ty, xrel, x, on && y < rows - 1, na, nb, nz - nb, px, pp);
+      }
       }
     }
     if constexpr (STAGE == PL_VIEW || STAGE == PL_VIEW_REFINE) {
