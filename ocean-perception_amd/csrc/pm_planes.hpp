@@ -44,9 +44,6 @@ enum { PL_RAND_INIT = 0, PL_RAND_REFINE = 1 };  // `stage` of the random key (or
 #ifndef PL_SPATIAL_REF_REGS
 #define PL_SPATIAL_REF_REGS 1
 #endif
-#ifndef PL_PAIR_BARRIER
-#define PL_PAIR_BARRIER  // (a scheduling barrier between the unrolled row pairs costs 12 spilled registers at the 128 allowed)
-#endif
 __host__ __device__ constexpr int pl_tile_h(int stage) { return stage == 1 /* PL_SPATIAL */ ? PL_TILE_H_SPATIAL : PL_TILE_H_OTHER; }
 
 struct PlanesParams {
@@ -556,7 +553,7 @@ __device__ __forceinline__ float pl_cost_checker_regs(const PlTile& t, int ty, i
       sg = __builtin_amdgcn_sad_u8(R.g[i][q], pgs, sg);
     }
     xrow = xrow_o + rowstep;
-    PL_PAIR_BARRIER
+    // (no scheduling barrier between the unrolled pairs: with one the kernel spills 12 registers at the 128 allowed)
   }
   {  // the last (even) row
     pl_u2 tp[NE];

@@ -19,13 +19,13 @@ fuzz)
   f=$out/fuzz.txt
   echo "Differential fuzzers on the tree of commit $head (tools/final.sh fuzz, one MI355X; every case bit-identical or the run stops)" > $f
   run() { name=$1; shift; echo "## $name $*" >> $f; timeout -k 10 900 python tools/$name "$@" > $out/fuzz_$name.log 2>&1; rc=$?; tail -1 $out/fuzz_$name.log >> $f; echo "exit $rc" >> $f; echo "$name done ($rc)"; [ $rc -eq 0 ]; }
-  run fuzz_api.py --cases 500 --seed 561 || { cat $f; exit 1; }
-  run fuzz_engines.py --cases 400 --seed 562 || { cat $f; exit 1; }
-  run fuzz_engines.py --cases 16 --seed 567 --big || { cat $f; exit 1; }
-  run fuzz_planes.py --cases 500 --seed 563 || { cat $f; exit 1; }
-  run fuzz_seed.py --cases 300 --seed 564 || { cat $f; exit 1; }
-  run fuzz_selfseed.py --cases 200 --seed 565 || { cat $f; exit 1; }
-  run fuzz_tiled.py --cases 250 --seed 566 || { cat $f; exit 1; }
+  run fuzz_api.py --cases 500 --seed 661 || { cat $f; exit 1; }
+  run fuzz_engines.py --cases 400 --seed 662 || { cat $f; exit 1; }
+  run fuzz_engines.py --cases 16 --seed 667 --big || { cat $f; exit 1; }
+  run fuzz_planes.py --cases 500 --seed 663 || { cat $f; exit 1; }
+  run fuzz_seed.py --cases 300 --seed 664 || { cat $f; exit 1; }
+  run fuzz_selfseed.py --cases 200 --seed 665 || { cat $f; exit 1; }
+  run fuzz_tiled.py --cases 250 --seed 666 || { cat $f; exit 1; }
   cat $f;;
 bench)
   python bench.py > $out/bench_default.json 2> $out/bench_default.err

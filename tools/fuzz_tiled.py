@@ -1,6 +1,9 @@
 """Differential fuzz of the row-tiled protocol (python/tiled.py + pm_tile_*; ranks as threads of one process on one
 GPU): random sizes, band counts, windows, iteration counts, exchange rounds (0 forces the repeat path), both
-semantics -- tiled == untiled bit for bit, or it prints the case and exits 1.
+semantics -- tiled == untiled bit for bit, or it prints the case and exits 1.  Every case also goes through the C-ABI
+driver (pm_tiled_*, csrc/pm_tiled.hip) with a random exchange mode and the bands accounted to random LOGICAL devices
+(include/pm/testing.h): the maps must be the same and the runtime log must not hold one call that would be an error --
+or a silent cross-device access -- with one band per GPU.
 
     python tools/fuzz_tiled.py [--cases 40] [--seed 1]
 """
@@ -41,8 +44,19 @@ for case in range(a.cases):
     with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
         ul, ur = e.match(p["left"], p["right"], sl, sr)
     ok = np.array_equal(dl, ul) and np.array_equal(dr, ur)
+    # the same pair through pm_tiled_*: bands on random logical devices, random exchange mode, random peer links
+    ndev = int(rng.integers(1, world + 1))
+    logical = sorted(int(v) for v in rng.integers(0, ndev, world))  # neighbours may share a device or not
+    if rng.random() < 0.3:
+        logical = logical[::-1]
+    mode, peer = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    with pm.TiledEngine(params, rows, cols, world, logical_devices=logical, simulate_peer_access=peer, exchange=mode) as t:
+        cl, cr, cinfo = t.match(p["left"], p["right"], sl, sr, rounds=rounds if rounds > 0 else 0)
+        _, bad = t.audit()
+    ok = ok and np.array_equal(cl, ul) and np.array_equal(cr, ur) and bad == 0
     print(f"case {case:3d}: sem {sem} {cols}x{rows} patch {patch} iters {iters} bands {world} rounds {rounds} "
-          f"repeated {int(bool(info['repeated']))} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
+          f"repeated {int(bool(info['repeated']))} | C driver: devices {logical} exchange {mode} peer {peer} "
+          f"marked calls {bad} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
     if not ok:
         sys.exit(1)
 print("all", a.cases, "cases bit-identical")
