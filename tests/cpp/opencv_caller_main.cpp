@@ -89,6 +89,34 @@ int main(int argc, char** argv) {
     if (seeds.rows != rows || seeds.cols != cols) return 6;
     write_rows(dir + "/sparse_init.f32", seeds);
     pm.SetSeeds(seeds, Image1f());
+    pm.SetSeeds(Image1f(), Image1f());  // cleared again: the sequence below seeds itself like Match()
+
+    // the frame-sequence and batch forms on the same image class: Submit / Collect (the Sequence caller's loop,
+    // patchmatch_gpu_test.cpp:118-128, with the copies off the critical path) and MatchBatch
+    {
+      PatchmatchGpu::Params p2 = params;
+      p2.max_batch = 2;
+      PatchmatchGpu seq(p2);
+      Image1f a, b, c, d;
+      if (!seq.Submit(il, ir, 1) || !seq.Submit(il, ir, 2)) return 7;
+      uint64_t tag = 0;
+      if (!seq.Collect(a, b, &tag) || tag != 1 || !seq.Collect(c, d, &tag) || tag != 2 || seq.Collect(c, d)) return 8;
+      write_rows(dir + "/seq_l.f32", c);
+      write_rows(dir + "/seq_r.f32", d);
+      std::vector<Image1b> ls{il, il}, rs{ir, ir};
+      std::vector<Image1f> dls, drs;
+      seq.MatchBatch(ls, rs, dls, drs);
+      if (dls.size() != 2 || dls[1].rows != rows || drs[1].cols != cols) return 9;
+      write_rows(dir + "/batch_l.f32", dls[1]);
+      write_rows(dir + "/batch_r.f32", drs[1]);
+      Image1f bound_l(rows, cols), bound_r(rows, cols);
+      seq.Register(bound_l);
+      seq.Register(bound_r);
+      if (!seq.Submit(il, ir, bound_l, bound_r, 3) || !seq.Collect(&tag) || tag != 3) return 11;
+      write_rows(dir + "/bound_l.f32", bound_l);
+      seq.Unregister(bound_l);
+      seq.Unregister(bound_r);
+    }
   } catch (const std::exception& e) {
     std::cout << "exception: " << e.what() << "\n";
     return 10;

@@ -135,3 +135,6 @@ def test_reference_call_sequence_on_cv_mat_hits_the_farmsim_fixture(opencv_calle
     assert_same(rd("strided_r.f32"), dr, "ROI input (step > cols), right")
     sp = oracle.seed_params(templ_cols=31, templ_rows=11, max_disp=128, max_matching_cost=0.15)
     assert_same(rd("sparse_init.f32"), oracle.sparse_init(l, r, 4, sp), "SparseInit into a cv::Mat1f")
+    # Submit / Collect, MatchBatch and bound page-locked maps on cv::Mat give Match()'s maps
+    for name, want in (("seq_l.f32", dl), ("seq_r.f32", dr), ("batch_l.f32", dl), ("batch_r.f32", dr), ("bound_l.f32", dl)):
+        assert_same(rd(name), want, name)
