@@ -153,7 +153,7 @@ def pmc_traffic(kernel_class):
     """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json,
     tools/make_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), CORRECTED as
     MI355X_MICROARCH.md's HBM section prescribes: on gfx950 FETCH_SIZE reports exactly half of the bytes read (confirmed on
-    this engine's access widths: profiles/r05_calib_fetch_write.txt), so bytes = 2 x fetch + write; WRITE_SIZE counts whole
+    this engine's access widths: profiles/r06_calib_fetch_write.txt), so bytes = 2 x fetch + write; WRITE_SIZE counts whole
     32-byte sectors of sparse stores (an upper bound for the sweeps' write-back).  The counters sit on the L2's memory
     side: Infinity-Cache hits are included.  None if the file is missing."""
     try:
@@ -529,9 +529,11 @@ def reference_test_shape_leg(pm, args, device):
                        "(patchmatch_gpu_test.cpp:68-88)",
            "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": med,
            "pairs_per_s_steady": 1e3 / med, "equals_the_golden_row_checksums": same,
-           "note": "bound by the chain of ~24 dependent launches of one view on the device (the views already overlap on "
-                   "two streams); a recorded HIP graph (0.71 ms) and both views per launch (0.69 ms) were built in round "
-                   "5, measured slower than this and removed: profiles/r05_reference_call_pattern.txt"}
+           "note": "bound by one view's chain of dependent launches on the device -- 12 sweeps of 25-60 us each on 240 / 376 "
+                   "short chains, back to back without gaps (kernel trace: profiles/r06_reference_call_timeline.txt), so "
+                   "a cooperative kernel with grid barriers has no launch latency to save; a recorded HIP graph (0.71 ms) "
+                   "and both views per launch (0.69 ms) were built in round 5, measured slower and removed: "
+                   "profiles/r05_reference_call_pattern.txt"}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -627,7 +629,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None, variant="
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom + variant) if (nb == 1 and state == "f32") else None,
-                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, profiles/r05_calib_fetch_write.txt)"
+                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, profiles/r06_calib_fetch_write.txt)"
                                   if (nb == 1 and state == "f32") else None,
                 "valu": pmc_valu(dom, prof, n_prof, variant) if (nb == 1 and state == "f32") else None,
                 "binding": binding_roof(dom, prof, n_prof, ms_per_step, variant) if (nb == 1 and state == "f32") else None,
@@ -652,7 +654,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None, variant="
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if nb == 1 else None,
             "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command, not measured in this run): 2 x FETCH_SIZE + WRITE_SIZE -- gfx950's FETCH_SIZE reports "
-                              "half of the bytes read (MI355X_MICROARCH.md; profiles/r05_calib_fetch_write.txt), WRITE_SIZE whole "
+                              "half of the bytes read (MI355X_MICROARCH.md; profiles/r06_calib_fetch_write.txt), WRITE_SIZE whole "
                               "32-byte sectors of the sparse write-back (an upper bound); the L2's memory side, Infinity-Cache "
                               "hits included" if nb == 1 else None,
             "valu": pmc_valu(dom, prof, n_prof) if nb == 1 else None,

@@ -4,7 +4,7 @@
 usage: tools/make_traffic.py <fetch.csv> <write.csv> <out.json> [<merge-into.json>] [--suffix @variant] [--head SHA]
 Per-launch averages in KiB for the dominant kernels (the counters report KiB; summed over XCD instances), and the
 CORRECTED byte counts: /opt/skills/guides/MI355X_MICROARCH.md (HBM section) -- on gfx950 FETCH_SIZE reports exactly 1/2 of
-the bytes read, confirmed on this engine's own access widths by tools/probe/fetch_calib.hip (profiles/r05_calib_fetch_write.txt:
+the bytes read, confirmed on this engine's own access widths by tools/probe/fetch_calib.hip (profiles/r06_calib_fetch_write.txt:
 4, 8 and 16 bytes per lane streaming and 16-byte records in 16-lane runs all read 0.500); WRITE_SIZE is exact for
 whole-line stores and counts whole 32-byte sectors for sparse ones (every fourth dword of a stretch: 4.0 x the bytes
 stored), so it is an upper bound of the bytes written where a kernel stores sparsely (the sweeps' write-back)."""
@@ -52,7 +52,7 @@ def main():
                      "planes [--plane-neighbours 1]]; per-launch averages",
            "correction": "bytes = fetch_kib * 1024 * 2 + write_kib * 1024: gfx950's FETCH_SIZE reports exactly half of the "
                          "bytes read (MI355X_MICROARCH.md, HBM section; confirmed for 4 / 8 / 16 B per lane and for 16-byte "
-                         "record gathers by tools/probe/fetch_calib.hip, profiles/r05_calib_fetch_write.txt); WRITE_SIZE is exact "
+                         "record gathers by tools/probe/fetch_calib.hip, profiles/r06_calib_fetch_write.txt); WRITE_SIZE is exact "
                          "for whole-line stores and counts whole 32-byte sectors for sparse ones (an upper bound there). "
                          "Both count the L2's memory-side requests: Infinity-Cache hits included.",
            "kernels": {}}
