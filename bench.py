@@ -629,7 +629,7 @@ def roofline_of(args, prof, n_prof, nb, mode, state, ms_per_step=None, variant="
         return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom + variant) if (nb == 1 and state == "f32") else None,
-                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, profiles/r06_calib_fetch_write.txt)"
+                "traffic_source": "profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, profiles/r06_calib_fetch_write.txt); a LOWER bound for these kernels: their reference fill loads 2 bytes per lane, which FETCH_SIZE does not count at all"
                                   if (nb == 1 and state == "f32") else None,
                 "valu": pmc_valu(dom, prof, n_prof, variant) if (nb == 1 and state == "f32") else None,
                 "binding": binding_roof(dom, prof, n_prof, ms_per_step, variant) if (nb == 1 and state == "f32") else None,
