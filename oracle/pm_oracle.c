@@ -364,6 +364,25 @@ void pmo_get_rect_subpix_f32(const float* src, int rows, int cols, int pw, int p
  * float (patchmatch_test.cpp:25). */
 static inline float mean_from_sum(double sum, int n) { return (float)(sum * (1. / (double)n)); }
 
+/* alpha * ec + (1 - alpha) * eg (patchmatch_test.cpp:44) as this build DEFINES it: two products and a sum, three roundings.
+ * The reference is compiled with g++'s default -ffp-contract=fast (CMakeLists.txt:17-25), so in its binary the expression
+ * may be ONE fused multiply-add on top of one product -- which of the two products is fused is the compiler's choice --
+ * and nothing in the reference pins it.  -DPMO_FUNCTOR_FMA=1 / =2 build those two contracted forms, for the sensitivity
+ * count of tools/fp_contract_sensitivity.py only (profiles/r06_fp_contract_sensitivity.txt); the shipped oracle and the
+ * engine use the uncontracted form. */
+static inline float functor_mix(float alpha, float error_color, float error_grad) {
+  const float one_minus = 1.f - alpha;
+#if defined(PMO_FUNCTOR_FMA) && PMO_FUNCTOR_FMA == 1
+  return fmaf(alpha, error_color, one_minus * error_grad);
+#elif defined(PMO_FUNCTOR_FMA) && PMO_FUNCTOR_FMA == 2
+  return fmaf(one_minus, error_grad, alpha * error_color);
+#else
+  const float t0 = alpha * error_color;
+  const float t1 = one_minus * error_grad;
+  return t0 + t1;
+#endif
+}
+
 /* L1GradientCostFunction (test/stereo_matching/patchmatch_test.cpp:30-45).  The functor is declared
  * with Image1b gradient parameters while Patchmatch passes Image1f patches (patchmatch.hpp:18), so
  * each gradient patch goes through Mat::convertTo(CV_8U) = saturate_cast<uchar>(cvRound(v)) before
@@ -377,10 +396,7 @@ float pmo_cpu_functor(const uint8_t* pl, const uint8_t* pr, const float* gl, con
   }
   const float error_color = fminf(mean_from_sum((double)sc, n), f->tau_color);
   const float error_grad = fminf(mean_from_sum((double)sg, n), f->tau_grad);
-  const float one_minus = 1.f - f->alpha;
-  const float t0 = f->alpha * error_color;
-  const float t1 = one_minus * error_grad;
-  return t0 + t1;
+  return functor_mix(f->alpha, error_color, error_grad);
 }
 
 #define PMO_MAX_PATCH (31 * 31)
@@ -433,10 +449,7 @@ float pmo_cpu_cost_direct(const pmo_images* im, int pw, int ph, int x, int y, fl
   const int n = pw * ph;
   const float error_color = fminf(mean_from_sum((double)sc, n), f->tau_color);
   const float error_grad = fminf(mean_from_sum((double)sg, n), f->tau_grad);
-  const float one_minus = 1.f - f->alpha;
-  const float t0 = f->alpha * error_color;
-  const float t1 = one_minus * error_grad;
-  return t0 + t1;
+  return functor_mix(f->alpha, error_color, error_grad);
 }
 
 static inline float cpu_cost(const pmo_images* im, int pw, int ph, int x, int y, float d,
