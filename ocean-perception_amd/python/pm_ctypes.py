@@ -463,7 +463,8 @@ class Engine:
     def submit_device(self, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l, d_disp_r, tag=0, ready_event=None):
         """Raw device addresses; nothing is copied.  collect_device() waits for the frame.  ready_event: a hipEvent_t
         (integer handle, e.g. torch.cuda.Event.cuda_event) recorded behind the producer of the inputs
-        (pm_submit_device_after); without it the inputs must be complete when this is called."""
+        (pm_submit_device_after); without it the inputs must be complete when this is called.  The event is consumed
+        inside the call (an internal stream waits for it): the caller may drop or re-record it as soon as this returns."""
         self._shape_q = getattr(self, "_shape_q", [])
         if ready_event:
             self._check(self.lib.pm_submit_device_after(self.h, d_left, d_right, rows, cols, d_seed_l, d_seed_r, d_disp_l,

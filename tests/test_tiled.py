@@ -166,3 +166,24 @@ def test_differential_fuzz_tiled_vs_untiled():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_tiled.py"), "--cases", "40", "--seed", "8"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", [0, 2])
+def test_single_process_bench_child_command_line(exchange):
+    """What bench.py's multi-rank configs[3] leg starts as a child (tiled_children): python/tiled.py --single-process N
+    [--exchange 2] prints one JSON object.  Here N = 1 with three bands on the one device and a small image."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "ocean-perception_amd", "python", "tiled.py"), "--rows", "300", "--cols",
+           "400", "--iters", "2", "--patch", "5", "--steps", "1", "--single-process", "1", "--bands", "3", "--exchange",
+           str(exchange)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["bands"] == 3 and out["n_gpus"] == 1 and out["ms_per_frame"] > 0
+    assert out["device_boundaries"] == 0 and out["peer_links"] == 0
+    assert ("direct" in out["exchange"]) == (exchange == 2)
