@@ -1,6 +1,8 @@
 """Row-tiled large-image mode (BASELINE configs[3]): the banded result must equal the untiled one bit for
 bit.  Runs the real protocol (boundary-row exchange, snapshot / re-sweep until no incoming row changes) with
 the ranks as threads of one process on one GPU; the band arithmetic is also checked on CPU."""
+import os
+
 import numpy as np
 import pytest
 
