@@ -59,6 +59,11 @@ int pm_tiled_create_logical(pm_handle* const* bands, int n_bands, int rows, int 
 /* copies the first `capacity` records (records may be NULL), *total = records logged, *violations = marked ones */
 int pm_tiled_audit(const pm_tiled_plan* plan, pm_tiled_audit_record* records, int capacity, int* total, int* violations);
 int pm_tiled_audit_reset(pm_tiled_plan* plan);
+/* Makes a logical-device plan BREAK the discipline on purpose at every boundary-row hand-over, so that a test can see the
+ * log catch it: bit 0 = the reader records an event of the PUBLISHER's device on its own stream (what the driver did until
+ * round 5); bit 1 = a stream is used while another band's device is current.  Harmless where all logical devices are one
+ * physical device (the events involved are waited for by nobody); 0 switches it off. */
+int pm_tiled_debug_inject(pm_tiled_plan* plan, int what);
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,7 @@ struct Band {
   // Created on THIS band's device and recorded on THIS band's stream; the predecessor waits for it.
   hipEvent_t ev_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   hipEvent_t unread[2] = {nullptr, nullptr};  // the reader's ev_done that guards sent[i], or null: nobody is reading it
+  hipEvent_t ev_probe = nullptr;  // logical-device plans only: an event nobody waits for (pm_tiled_debug_inject)
   int last = 0;  // the buffer of `sent` that holds the row this band published last
   // peer access is enabled in both directions between this band's device and its neighbour's (pm_tiled_create)
   bool peer_prev = false, peer_next = false;
@@ -68,6 +69,7 @@ struct Audit {
   std::unordered_map<const void*, int> obj;  // events and streams -> logical device
   int violations = 0;
   int simulate_peer = 0;
+  int inject = 0;  // pm_tiled_debug_inject: deliberate breaches of the discipline, to show that the log catches them
 };
 
 }  // namespace
@@ -348,6 +350,17 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
   };
   // band k, with its device current, marks its predecessor's sent[cur] as consumed: ITS event on ITS stream
   auto consumed = [&](Band& b, Band& s) -> int {
+    if (p->audit && p->audit->inject) {
+      // test hook (pm_tiled_debug_inject): what round 5's driver did -- an event of the PUBLISHER's device recorded on
+      // the reader's stream -- and a stream used while another band's device is current.  Both are harmless on the one
+      // physical device a logical plan runs on (nobody waits for ev_probe), and both must show up in the log.
+      if (p->audit->inject & 1) TL_HIP(p, rt_event_record(p, b, s.ev_probe));
+      if (p->audit->inject & 2) {
+        TL_HIP(p, rt_use(p, s));
+        TL_HIP(p, rt_wait_event(p, b, s.ev_probe));
+        TL_HIP(p, rt_use(p, b));
+      }
+    }
     TL_HIP(p, rt_event_record(p, b, b.ev_done[dir][cur]));
     s.unread[cur] = b.ev_done[dir][cur];
     ++*exchanges;
@@ -510,6 +523,11 @@ int create(pm_handle* const* bands, int n_bands, int rows, int cols, const int* 
     TL_HIP(p, rt_malloc(p, b, (void**)&b.incoming, row_bytes));
     TL_HIP(p, rt_malloc(p, b, (void**)&b.mask, sizeof(int) * (size_t)p->n_views * cols));
     TL_HIP(p, rt_malloc(p, b, (void**)&b.flag, sizeof(int)));
+    if (p->audit) {  // (not counted among a band's events by the tests: created outside the audited layer)
+      TL_HIP(p, hipEventCreateWithFlags(&b.ev_probe, hipEventDisableTiming));
+      p->audit->obj[(const void*)b.ev_probe] = b.ldev;
+      TL_HIP(p, hipEventRecord(b.ev_probe, b.stream));
+    }
   }
   // neighbouring bands on different devices: peer access over xGMI where the platform allows it (hipMemcpyPeerAsync is
   // then a direct copy; with PM_TILED_EXCHANGE_DIRECT the receiving band's kernel reads the row across the link)
@@ -589,6 +607,7 @@ void pm_tiled_destroy(pm_tiled_plan* plan) {
       for (int d = 0; d < 2; ++d)
         if (b.ev_done[d][i]) (void)hipEventDestroy(b.ev_done[d][i]);
     }
+    if (b.ev_probe) (void)hipEventDestroy(b.ev_probe);
   }
   delete plan->audit;
   delete plan;
@@ -612,6 +631,12 @@ int pm_tiled_audit(const pm_tiled_plan* plan, pm_tiled_audit_record* records, in
   if (violations) *violations = a.violations;
   if (records)
     for (int i = 0; i < capacity && i < (int)a.log.size(); ++i) records[i] = a.log[(size_t)i];
+  return PM_OK;
+}
+
+int pm_tiled_debug_inject(pm_tiled_plan* plan, int what) {
+  if (!plan || !plan->audit || what < 0 || what > 3) return PM_ERR_INVALID_ARG;
+  plan->audit->inject = what;
   return PM_OK;
 }
 

@@ -47,7 +47,7 @@ EXPORTS = [
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
     "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download", "pm_tiled_topology", "pm_tiled_set_exchange",
-    "pm_tiled_create_logical", "pm_tiled_audit", "pm_tiled_audit_reset",
+    "pm_tiled_create_logical", "pm_tiled_audit", "pm_tiled_audit_reset", "pm_tiled_debug_inject",
 ]
 
 
@@ -277,6 +277,8 @@ def load():
     lib.pm_tiled_audit.restype = C.c_int
     lib.pm_tiled_audit_reset.argtypes = [vp]
     lib.pm_tiled_audit_reset.restype = C.c_int
+    lib.pm_tiled_debug_inject.argtypes = [vp, C.c_int]
+    lib.pm_tiled_debug_inject.restype = C.c_int
     lib.pm_tile_restore_cols.argtypes = [vp, vp]
     lib.pm_tile_sweep_masked.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.pm_tile_exchange_round.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp]
@@ -841,6 +843,9 @@ class TiledEngine:
 
     def audit_reset(self):
         self._tcheck(self.lib.pm_tiled_audit_reset(self.plan), "pm_tiled_audit_reset")
+
+    def debug_inject(self, what):
+        self._tcheck(self.lib.pm_tiled_debug_inject(self.plan, int(what)), "pm_tiled_debug_inject")
 
     def topology(self):
         """(neighbouring bands on different devices, of which with direct peer access)"""

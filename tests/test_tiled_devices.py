@@ -83,6 +83,35 @@ def test_bands_on_logical_devices_keep_the_device_discipline(pm, synth, logical,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what,bit,name", [(1, 2, "event_record"), (2, 1, "stream_wait_event")])
+def test_the_log_catches_a_deliberate_breach(pm, synth, what, bit, name):
+    """The auditor is not vacuous: with the round-5 arrangement injected (an event of the publisher's device recorded on the
+    reader's stream) or a stream used under another band's current device, the log marks exactly those calls -- and only
+    at boundaries between DIFFERENT logical devices; the maps are unaffected (on one physical device the breach is harmless)."""
+    l, r, sl, sr, _ = _pair(synth, 94)
+    params = pm.default_params(0, patch=5, patchmatch_iters=2)
+    ul, ur = _untiled(pm, params, l, r, sl, sr)
+    logical = [0, 0, 1, 2]
+    with pm.TiledEngine(params, ROWS, COLS, 4, logical_devices=logical, simulate_peer_access=1) as t:
+        t.debug_inject(what)
+        dl, dr, _ = t.match(l, r, sl, sr)
+        recs, bad = t.audit()
+        assert_same(dl, ul, "left")
+        assert_same(dr, ur, "right")
+        marked = [x for x in recs if x["violation"]]
+        assert bad == len(marked) > 0
+        assert all(x["call_name"] == name and x["violation"] & bit for x in marked), marked[:3]
+        # bands 0 and 1 share logical device 0: the hand-overs between them breach nothing even with the injection on, so
+        # band 0 (whose only neighbour is band 1) is never the reader of a marked call; bands 2 and 3 always are
+        readers = {x["band"] for x in marked}
+        assert 0 not in readers and {2, 3} <= readers, readers
+        t.debug_inject(0)
+        t.audit_reset()
+        t.match(l, r, sl, sr)
+        assert t.audit()[1] == 0
+
+
+@pytest.mark.gpu
 def test_exchange_modes_agree_on_one_device(pm, synth):
     """PM_TILED_EXCHANGE_COPY forces the hipMemcpyPeerAsync path also between bands of one device (the path real devices
     take by default); all three modes give the untiled maps."""
