@@ -723,7 +723,7 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
     # (six warm-up steps: the engine's creation leaves the GPU idle for a few hundred ms and its clocks take ~20 ms of
     # work to come back; with two warm-up steps the leg read 3 % low.  Every 8th step carries per-kernel events, as in
     # the headline loop: a profiled step is ~3 % slower -- 33 launches bracketed by events -- and with every 4th of 12
-    # steps profiled the leg read 1 % below the same handle's unprofiled rate)
+    # steps profiled the same build read 460 pairs/s where it now reads 470)
     elapsed, prof, n_prof, step_stats = timed_loop(w, NoDist(), steps, 6, 8, False)
     w.step(0)
     w.eng.synchronize()
