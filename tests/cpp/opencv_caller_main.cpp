@@ -14,7 +14,16 @@
 
 #include <opencv2/core.hpp>
 
-#include "vision_core/cv_types.hpp"
+// What every translation unit of the vehicle tree has seen before it reaches the PatchMatch header: the image typedefs of
+// src/vehicle/vision_core/cv_types.hpp:8,12.  The header below declares them AGAIN (identically), which is legal C++ --
+// this block is here so that the compile test proves the two declarations coexist.
+namespace bm {
+namespace core {
+typedef cv::Mat1b Image1b;
+typedef cv::Mat1f Image1f;
+}  // namespace core
+}  // namespace bm
+
 #include "patchmatch_gpu/patchmatch_gpu.h"
 
 using namespace bm;
