@@ -805,6 +805,9 @@ def tiled_children(args):
         # peer access is enabled on every boundary and the default leg ran: the same frame with the receiving band's KERNEL reading the boundary row across the link (one copy less per
         # round; PM_TILED_EXCHANGE_DIRECT) -- in a child of its own: whatever it does stays beside the default leg's number
         res["direct_exchange"] = run_child(cmd + ["--exchange", "2"], args.tiled_timeout)
+    if single and rank == 0 and res is not None and "error" not in res:
+        # and with the bands sweeping IN ORDER instead of speculating (PM_TILED_SCHEDULE_PIPELINED; peer copies)
+        res["pipelined_schedule"] = run_child(cmd + ["--schedule", "1"], args.tiled_timeout)
     return res
 
 
@@ -1018,6 +1021,8 @@ def main():
                 # the C-ABI driver with 8 bands on THIS device: the protocol (boundary rows, masked re-sweeps, flag) at
                 # work, its cost beside the untiled frame; a real caller has one band per GPU
                 tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
+                tiled_result["eight_bands_on_this_device_pipelined"] = tiled.bench_single_process(
+                    args, [d.local_rank] * 8, steps=2, schedule=1)
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:

@@ -442,6 +442,17 @@ int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* pe
  * Results are identical in every mode. */
 typedef enum pm_tiled_exchange { PM_TILED_EXCHANGE_AUTO = 0, PM_TILED_EXCHANGE_COPY = 1, PM_TILED_EXCHANGE_DIRECT = 2 } pm_tiled_exchange;
 int pm_tiled_set_exchange(pm_tiled_plan* plan, int mode);
+/* How a vertical sweep crosses the band boundaries.
+ *   SPECULATIVE (default)  every band sweeps at once with its neighbour's OLD boundary row, the new rows travel one hop per
+ *                          round, a band re-sweeps the columns whose incoming value changed (snapshot, mask, `rounds`,
+ *                          the repeat rule: see above).  All bands work in every round.
+ *   PIPELINED              the bands sweep IN ORDER along the sweep direction: a band stores its predecessor's final row in
+ *                          front of its chains, sweeps once, publishes its own last row.  Nothing is guessed, so there is
+ *                          no snapshot, no mask, no re-sweep and no repeat (`rounds` is ignored; pm_tiled_info.rounds_used
+ *                          = 0); during a vertical sweep the bands take turns, everything else overlaps as before.
+ * Same maps either way (the sequential sweep). */
+typedef enum pm_tiled_schedule { PM_TILED_SCHEDULE_SPECULATIVE = 0, PM_TILED_SCHEDULE_PIPELINED = 1 } pm_tiled_schedule;
+int pm_tiled_set_schedule(pm_tiled_plan* plan, int schedule);
 
 /* ---- PM_MODE_PLANES stage by stage (device pointers; state stays resident in the handle) ------------------
  * pm_match_u8 / pm_match_batch_u8 / pm_submit_u8 / pm_match_device run the whole schedule

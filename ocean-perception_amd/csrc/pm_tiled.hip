@@ -81,6 +81,7 @@ struct pm_tiled_plan {
   int device_boundaries = 0;  // neighbouring bands that live on DIFFERENT devices (their rows cross by peer copy)
   int peer_links = 0;         // ... of which direct peer access could be enabled (the others are staged by the runtime)
   int exchange = PM_TILED_EXCHANGE_AUTO;
+  int schedule = PM_TILED_SCHEDULE_SPECULATIVE;
   Audit* audit = nullptr;  // only plans of pm_tiled_create_logical keep a log
   char err[512] = {0};
 };
@@ -249,7 +250,8 @@ enum {
   ST_EXCHANGE_ROUND,
   ST_ROW_MOVED,
   ST_BACKGROUND,
-  ST_FINISH
+  ST_FINISH,
+  ST_SET_ROW
 };
 
 int halo_rows(const pm_params& p) {
@@ -466,6 +468,79 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
   return PM_OK;
 }
 
+// PM_TILED_SCHEDULE_PIPELINED: a vertical sweep runs through the bands IN ORDER -- the first band of the sweep direction
+// sweeps its rows, publishes its boundary row, the next band stores that row in front of its chains and sweeps, and so
+// on.  Nothing is guessed, so nothing is snapshot, compared, restored or swept again: the result is the sequential sweep by
+// construction.  The bands' streams still overlap everything that does not cross a boundary (noise / cost, the horizontal
+// sweeps; band 0 is in its next horizontal sweep while band n - 1 still finishes the vertical one).  Same objects and rules
+// as the speculative schedule: the publisher records ev_sent on its stream, the reader waits for it, reads the row (peer
+// copy or in place) and records ITS ev_done, which the publisher waits for before it overwrites the buffer.
+int attempt_pipelined(pm_tiled_plan* p, int* exchanges) {
+  const int n = (int)p->bands.size(), cols = p->cols, nv = p->n_views;
+  const pm_params& prm = pm_internal::params(p->bands[0].h);
+  const size_t row_bytes = sizeof(float) * (size_t)nv * cols;
+  for (Band& b : p->bands) {
+    TL_STAGE(p, b, ST_BEGIN,
+             pm_tile_begin(b.h, &b.tile, b.d_left, b.d_right, b.band_rows, cols, p->have_seed_l ? b.d_seed_l : nullptr,
+                           p->have_seed_r ? b.d_seed_r : nullptr),
+             {b.d_left, false}, {b.d_right, false}, {p->have_seed_l ? b.d_seed_l : nullptr, false},
+             {p->have_seed_r ? b.d_seed_r : nullptr, false});
+  }
+  int cur = 0;
+  for (int it = 0; it < prm.patchmatch_iters; ++it) {
+    for (Band& b : p->bands) TL_STAGE(p, b, ST_NOISE, pm_tile_noise(b.h, it));
+    for (int k = 0; k < 4; ++k) {
+      if (k == 0 || k == 2) {
+        for (Band& b : p->bands) TL_STAGE(p, b, ST_SWEEP, pm_tile_sweep(b.h, it, k));
+        continue;
+      }
+      const bool down = k == 1;
+      const int dir = down ? 0 : 1;
+      cur ^= 1;  // one buffer per vertical sweep; its reader of two sweeps ago has long been waited for
+      for (int pos = 0; pos < n; ++pos) {
+        const int j = down ? pos : n - 1 - pos;
+        Band& b = p->bands[(size_t)j];
+        if (pos > 0) {  // the predecessor's final boundary row in front of this band's chains
+          Band& s = p->bands[(size_t)(down ? j - 1 : j + 1)];
+          const int pred_row = down ? b.tile.own_row0 - 1 : b.tile.own_row0 + b.tile.own_rows;
+          TL_HIP(p, rt_use(p, b));
+          TL_HIP(p, rt_wait_event(p, b, s.ev_sent[cur]));
+          if (direct(p, b, s)) {
+            TL_STAGE(p, b, ST_SET_ROW, pm_tile_set_row(b.h, pred_row, s.sent[cur]), {s.sent[cur], true});
+          } else {
+            TL_HIP(p, rt_copy_peer(p, b, b.incoming, s, s.sent[cur], row_bytes));
+            TL_STAGE(p, b, ST_SET_ROW, pm_tile_set_row(b.h, pred_row, b.incoming), {b.incoming, false});
+          }
+          TL_HIP(p, rt_event_record(p, b, b.ev_done[dir][cur]));
+          s.unread[cur] = b.ev_done[dir][cur];
+          ++*exchanges;
+        }
+        TL_STAGE(p, b, ST_SWEEP, pm_tile_sweep(b.h, it, k));
+        if (pos + 1 < n) {  // somebody continues from this band's last row
+          const int out_row = down ? b.tile.own_row0 + b.tile.own_rows - 1 : b.tile.own_row0;
+          if (b.unread[cur]) {
+            TL_HIP(p, rt_wait_event(p, b, b.unread[cur]));
+            b.unread[cur] = nullptr;
+          }
+          TL_STAGE(p, b, ST_GET_ROW, pm_tile_get_row(b.h, out_row, b.sent[cur]), {b.sent[cur], false});
+          TL_HIP(p, rt_event_record(p, b, b.ev_sent[cur]));
+        }
+      }
+    }
+  }
+  for (Band& b : p->bands) {
+    TL_STAGE(p, b, ST_BACKGROUND, pm_tile_background(b.h));
+    TL_STAGE(p, b, ST_FINISH, pm_tile_finish(b.h, b.d_out_l, nv > 1 ? b.d_out_r : nullptr), {b.d_out_l, false},
+             {nv > 1 ? b.d_out_r : nullptr, false});
+  }
+  for (Band& b : p->bands) {
+    TL_HIP(p, rt_use(p, b));
+    TL_HIP(p, rt_sync(p, b));
+  }
+  for (Band& b : p->bands) b.unread[0] = b.unread[1] = nullptr;
+  return PM_OK;
+}
+
 int create(pm_handle* const* bands, int n_bands, int rows, int cols, const int* logical, int simulate_peer,
            pm_tiled_plan** out) {
   if (!out) return PM_ERR_INVALID_ARG;
@@ -593,6 +668,14 @@ int pm_tiled_set_exchange(pm_tiled_plan* plan, int mode) {
   return PM_OK;
 }
 
+int pm_tiled_set_schedule(pm_tiled_plan* plan, int schedule) {
+  if (!plan) return PM_ERR_INVALID_ARG;
+  if (schedule != PM_TILED_SCHEDULE_SPECULATIVE && schedule != PM_TILED_SCHEDULE_PIPELINED)
+    return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_set_schedule: unknown schedule %d", schedule);
+  plan->schedule = schedule;
+  return PM_OK;
+}
+
 void pm_tiled_destroy(pm_tiled_plan* plan) {
   if (!plan) return;
   for (Band& b : plan->bands) {
@@ -662,6 +745,16 @@ int pm_tiled_run(pm_tiled_plan* plan, int rounds, pm_tiled_info* info) {
   if (!plan) return PM_ERR_INVALID_ARG;
   if (!plan->resident) return fail(plan, PM_ERR_INVALID_ARG, "pm_tiled_run: no pair uploaded (pm_tiled_upload_u8)");
   const int n = (int)plan->bands.size();
+  if (plan->schedule == PM_TILED_SCHEDULE_PIPELINED) {  // in order: exact without rounds
+    int ex = 0;
+    if (int rc = attempt_pipelined(plan, &ex)) return rc;
+    if (info) {
+      info->rounds_used = 0;
+      info->repeated = 0;
+      info->exchanges = ex;
+    }
+    return PM_OK;
+  }
   if (rounds < 0 || rounds > n - 1) rounds = n - 1;  // negative: the exact count, no repeat possible
   bool moved = false;
   int exchanges = 0;

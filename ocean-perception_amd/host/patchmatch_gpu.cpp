@@ -311,6 +311,12 @@ void TiledPatchmatchGpu::SetExchange(int mode) {
     throw std::runtime_error(std::string("pm_tiled_set_exchange: ") + pm_status_string(rc) + " -- " + pm_tiled_last_error(plan_));
 }
 
+void TiledPatchmatchGpu::SetSchedule(int schedule) {
+  const int rc = pm_tiled_set_schedule(plan_, schedule);
+  if (rc != PM_OK)
+    throw std::runtime_error(std::string("pm_tiled_set_schedule: ") + pm_status_string(rc) + " -- " + pm_tiled_last_error(plan_));
+}
+
 void TiledPatchmatchGpu::MatchViews(View1b iml, View1b imr, View1f disp, View1f dispr, int rounds) {
   if (iml.rows != rows_ || iml.cols != cols_ || imr.rows != rows_ || imr.cols != cols_ || iml.step != imr.step)
     throw std::runtime_error("TiledPatchmatchGpu::Match: image size differs from the plan");

@@ -364,6 +364,8 @@ class TiledPatchmatchGpu final {
   }
   // how a band reads its neighbour's boundary row (pm_tiled_exchange: AUTO, COPY, DIRECT); results do not depend on it
   void SetExchange(int mode);
+  // how a vertical sweep crosses the bands (pm_tiled_schedule: SPECULATIVE rounds or PIPELINED in order); same maps
+  void SetSchedule(int schedule);
 
   void SetSeedViews(ConstView1f seed_l, ConstView1f seed_r);
   void MatchViews(View1b iml, View1b imr, View1f disp, View1f dispr, int rounds);

@@ -47,6 +47,7 @@ EXPORTS = [
     "pm_planes_begin", "pm_planes_step", "pm_planes_read", "pm_planes_write", "pm_planes_finish",
     "pm_tiled_band_rows", "pm_tiled_create", "pm_tiled_destroy", "pm_tiled_match_u8", "pm_tiled_last_error",
     "pm_tiled_upload_u8", "pm_tiled_run", "pm_tiled_download", "pm_tiled_topology", "pm_tiled_set_exchange",
+    "pm_tiled_set_schedule",
     "pm_tiled_create_logical", "pm_tiled_audit", "pm_tiled_audit_reset", "pm_tiled_debug_inject",
 ]
 
@@ -270,6 +271,8 @@ def load():
     lib.pm_tiled_topology.restype = C.c_int
     lib.pm_tiled_set_exchange.argtypes = [vp, C.c_int]
     lib.pm_tiled_set_exchange.restype = C.c_int
+    lib.pm_tiled_set_schedule.argtypes = [vp, C.c_int]
+    lib.pm_tiled_set_schedule.restype = C.c_int
     lib.pm_tiled_create_logical.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                             C.POINTER(vp)]
     lib.pm_tiled_create_logical.restype = C.c_int
@@ -785,11 +788,12 @@ class Engine:
 
 
 PM_TILED_EXCHANGE_AUTO, PM_TILED_EXCHANGE_COPY, PM_TILED_EXCHANGE_DIRECT = 0, 1, 2
+PM_TILED_SCHEDULE_SPECULATIVE, PM_TILED_SCHEDULE_PIPELINED = 0, 1
 # include/pm/testing.h: pm_tiled_audit_call
 TILED_CALLS = {1: "set_device", 2: "malloc", 3: "event_create", 4: "event_record", 5: "stream_wait_event",
                6: "stream_sync", 7: "memset", 8: "copy_h2d", 9: "copy_d2h", 10: "copy_peer", 11: "stage", 12: "stage_arg"}
 TILED_STAGES = {1: "begin", 2: "noise", 3: "sweep", 4: "get_row", 5: "presweep", 6: "exchange_round", 7: "row_moved",
-                8: "background", 9: "finish"}
+                8: "background", 9: "finish", 10: "set_row"}
 
 
 class TiledEngine:
@@ -798,7 +802,7 @@ class TiledEngine:
     the plan logs every runtime call with the logical devices involved (audit())."""
 
     def __init__(self, params, rows, cols, n_bands, devices=None, logical_devices=None, simulate_peer_access=0,
-                 exchange=None):
+                 exchange=None, schedule=None):
         self.lib = load()
         self.rows, self.cols, self.n = rows, cols, n_bands
         self.params = params
@@ -821,9 +825,14 @@ class TiledEngine:
             raise PmError(rc, "pm_tiled_create", msg)
         if exchange is not None:
             self.set_exchange(exchange)
+        if schedule is not None:
+            self.set_schedule(schedule)
 
     def set_exchange(self, mode):
         self._tcheck(self.lib.pm_tiled_set_exchange(self.plan, int(mode)), "pm_tiled_set_exchange")
+
+    def set_schedule(self, schedule):
+        self._tcheck(self.lib.pm_tiled_set_schedule(self.plan, int(schedule)), "pm_tiled_set_schedule")
 
     def audit(self):
         """(records as dicts, number of violations) of a plan made with logical_devices"""

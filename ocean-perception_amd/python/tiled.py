@@ -342,7 +342,7 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
     return res
 
 
-def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1, exchange=0):
+def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1, exchange=0, schedule=0):
     """BASELINE configs[3] through the C-ABI driver (pm_tiled_* of include/pm/patchmatch.h): ONE process, band k on
     devices[k], boundary rows by hipMemcpyPeerAsync + events (no RCCL, no torch.distributed).  The pair is uploaded
     once and stays resident in the bands' HBM; a timed step is one pm_tiled_run (it returns after the one flag read
@@ -353,7 +353,7 @@ def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1
     params = pm.default_params(pm.PM_SEM_CPU, patch=args.patch, patchmatch_iters=args.iters)
     pair = synth.make_pair(0, rows, cols, n_points=200 * (rows * cols) // (720 * 1280))
     n = len(devices)
-    with pm.TiledEngine(params, rows, cols, n, devices, exchange=exchange) as te:
+    with pm.TiledEngine(params, rows, cols, n, devices, exchange=exchange, schedule=schedule) as te:
         topology = te.topology()
         te.upload(pair["left"], pair["right"], pair["seed_l"], pair["seed_r"])
         te.run(rounds)  # untimed: first-use allocations of the band handles
@@ -369,6 +369,8 @@ def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1
                         f"(BASELINE.json configs[3]), {args.iters} iterations, {args.patch}x{args.patch}, PM_SEM_CPU",
             "driver": "pm_tiled_* (C ABI, one process, hipMemcpyPeerAsync + events)", "n_gpus": len(set(devices)),
             "exchange": {0: "auto (in place on one device, peer copy across devices)", 1: "copy", 2: "direct (kernel reads across the link)"}[exchange],
+            "schedule": {0: "speculative (all bands sweep at once, boundary rows travel one hop per round, changed columns are re-swept)",
+                         1: "pipelined (the bands sweep in order along the sweep direction; nothing is re-swept)"}[schedule],
             "device_boundaries": topology[0], "peer_links": topology[1],
             "bands": n, "ms_per_frame": ms, "pairs_per_s": 1e3 / ms, "steps": steps,
             "exchange_rounds_per_vertical_sweep": 1 + infos[-1]["rounds"],
@@ -399,13 +401,14 @@ def main():
                     help="run the C-ABI driver (pm_tiled_*) in THIS process over devices 0..N-1 instead of one rank per GPU")
     ap.add_argument("--bands", type=int, default=0, help="--single-process: bands (default: one per device)")
     ap.add_argument("--exchange", type=int, default=0, help="--single-process: pm_tiled_exchange (0 auto, 1 copy, 2 direct)")
+    ap.add_argument("--schedule", type=int, default=0, help="--single-process: pm_tiled_schedule (0 speculative, 1 pipelined)")
     args = ap.parse_args()
     if args.single_process > 0:
         import json
         nb = args.bands if args.bands > 0 else args.single_process
         devices = [k * args.single_process // nb for k in range(nb)]
         print(json.dumps(bench_single_process(args, devices, steps=args.steps, rows=args.rows, cols=args.cols,
-                                              exchange=args.exchange)), flush=True)
+                                              exchange=args.exchange, schedule=args.schedule)), flush=True)
         return
     d = B.Dist(args)
     bench(args, d, rows=args.rows, cols=args.cols)

@@ -74,7 +74,8 @@ def test_bands_sharing_a_device_request_no_peer_access(tiled_exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sem,patch,bands,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 0), (0, 5, 2, 2)])
+@pytest.mark.parametrize("sem,patch,bands,rounds", [(0, 5, 4, 2), (0, 11, 3, 2), (1, 3, 4, 2), (0, 3, 7, 0), (0, 5, 2, 2),
+                                                    (0, 5, 4, -2), (1, 3, 6, -2)])  # -2: the pipelined schedule
 def test_cpp_tiled_equals_untiled_and_oracle(tiled_exe, tmp_path, oracle, synth, sem, patch, bands, rounds):
     rows, cols = 150, 200
     l, r, sl, sr, _ = small_pair(synth, 90 + bands, rows, cols, n_points=60, dilate_factor=3)
@@ -85,6 +86,8 @@ def test_cpp_tiled_equals_untiled_and_oracle(tiled_exe, tmp_path, oracle, synth,
     assert_same(tl, el, "tiled vs oracle (left)")
     assert_same(tr, er, "tiled vs oracle (right)")
     assert info["exchanges"] > 0
+    if rounds == -2:
+        assert info["repeated"] == 0 and info["rounds_used"] == 0 and info["exchanges"] == 2 * 3 * (bands - 1)
     if rounds == 0:
         assert info["repeated"] == 1 and info["rounds_used"] == bands - 1
     if bands == 2 and rounds >= 1:
@@ -101,6 +104,11 @@ def test_cpp_tiled_configs3_full_size(tiled_exe, tmp_path, synth):
     assert_same(tr, ur, "4096x2160, 8 bands vs untiled (right)")
     fg = tl > 0
     assert fg.mean() > 0.15 and (np.abs(tl - p["gt"])[fg] < 1.0).mean() > 0.95
+    # the same frame with the bands sweeping in order (PM_TILED_SCHEDULE_PIPELINED)
+    _, _, pl, pr, info = run(tiled_exe, tmp_path, p["left"], p["right"], p["seed_l"], p["seed_r"], 0, 11, 8, 8, -2)
+    assert_same(pl, ul, "4096x2160, 8 bands in order vs untiled (left)")
+    assert_same(pr, ur, "4096x2160, 8 bands in order vs untiled (right)")
+    assert info["exchanges"] == 2 * 8 * 7
 
 
 @pytest.mark.gpu

@@ -83,6 +83,37 @@ def test_bands_on_logical_devices_keep_the_device_discipline(pm, synth, logical,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("logical,peer,exchange", [([0, 1, 2, 3], 1, 0), ([0, 1, 2, 3], 1, 2), ([0, 0, 1, 1], 0, 0), ([2, 1, 0], 1, 1)])
+def test_pipelined_schedule_keeps_the_discipline_and_the_maps(pm, synth, logical, peer, exchange):
+    """PM_TILED_SCHEDULE_PIPELINED: the bands sweep in order along the sweep direction -- no snapshot, no rounds, no
+    re-sweep.  Same maps, same rules for events, streams and memory; kernels see foreign memory only as the source of
+    set_row in DIRECT mode."""
+    n = len(logical)
+    l, r, sl, sr, _ = _pair(synth, 95)
+    params = pm.default_params(0, patch=7, patchmatch_iters=3)
+    ul, ur = _untiled(pm, params, l, r, sl, sr)
+    with pm.TiledEngine(params, ROWS, COLS, n, logical_devices=logical, simulate_peer_access=peer, exchange=exchange,
+                        schedule=pm.PM_TILED_SCHEDULE_PIPELINED) as t:
+        for _ in range(2):  # the second Match reuses buffers and events
+            t.audit_reset() if _ else None
+            dl, dr, info = t.match(l, r, sl, sr)
+            recs, bad = t.audit()
+            assert_same(dl, ul, "pipelined schedule vs untiled (left)")
+            assert_same(dr, ur, "pipelined schedule vs untiled (right)")
+            assert bad == 0, [x for x in recs if x["violation"]][:5]
+            assert info["rounds"] == 0 and not info["repeated"] and info["exchanges"] == 2 * 3 * (n - 1)
+            stages = {x["stage"] for x in recs if x["call_name"] == "stage"}
+            assert "set_row" in stages and not stages & {"presweep", "exchange_round", "row_moved"}
+            for x in [x for x in recs if x["call_name"] == "event_record"]:
+                assert x["stream_device"] == x["object_device"] == x["current_device"] == logical[x["band"]], x
+            foreign = [x for x in recs if x["call_name"] == "stage_arg" and x["source_device"] != x["current_device"]]
+            if exchange == pm.PM_TILED_EXCHANGE_DIRECT and peer:
+                assert foreign and all(x["stage"] == "set_row" and x["foreign_allowed"] for x in foreign)
+            else:
+                assert not foreign
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("what,bit,name", [(1, 2, "event_record"), (2, 1, "stream_wait_event")])
 def test_the_log_catches_a_deliberate_breach(pm, synth, what, bit, name):
     """The auditor is not vacuous: with the round-5 arrangement injected (an event of the publisher's device recorded on the
@@ -119,13 +150,16 @@ def test_exchange_modes_agree_on_one_device(pm, synth):
     params = pm.default_params(0, patch=11, patchmatch_iters=3)
     ul, ur = _untiled(pm, params, l, r, sl, sr)
     for mode in (pm.PM_TILED_EXCHANGE_AUTO, pm.PM_TILED_EXCHANGE_COPY, pm.PM_TILED_EXCHANGE_DIRECT):
-        with pm.TiledEngine(params, ROWS, COLS, 5, exchange=mode) as t:
-            dl, dr, _ = t.match(l, r, sl, sr)
-        assert_same(dl, ul, f"exchange mode {mode} (left)")
-        assert_same(dr, ur, f"exchange mode {mode} (right)")
+        for schedule in (pm.PM_TILED_SCHEDULE_SPECULATIVE, pm.PM_TILED_SCHEDULE_PIPELINED):
+            with pm.TiledEngine(params, ROWS, COLS, 5, exchange=mode, schedule=schedule) as t:
+                dl, dr, _ = t.match(l, r, sl, sr)
+            assert_same(dl, ul, f"exchange mode {mode}, schedule {schedule} (left)")
+            assert_same(dr, ur, f"exchange mode {mode}, schedule {schedule} (right)")
     with pm.TiledEngine(params, ROWS, COLS, 2) as t:
         with pytest.raises(pm.PmError):
             t.set_exchange(7)
+        with pytest.raises(pm.PmError):
+            t.set_schedule(2)
         with pytest.raises(pm.PmError):
             t.audit()  # an ordinary plan keeps no log
 
@@ -136,15 +170,16 @@ def _gpus():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1])
 @pytest.mark.parametrize("exchange", [0, 1, 2])
-def test_two_bands_on_two_real_devices(pm, synth, exchange):
+def test_two_bands_on_two_real_devices(pm, synth, exchange, schedule):
     """The same on hardware, where a box has it: bands on devices 0 and 1, boundary rows over the link."""
     if _gpus() < 2:
         pytest.skip("needs two GPUs")
     l, r, sl, sr, _ = _pair(synth, 93)
     params = pm.default_params(0, patch=5, patchmatch_iters=3)
     ul, ur = _untiled(pm, params, l, r, sl, sr)
-    with pm.TiledEngine(params, ROWS, COLS, 2, devices=[0, 1], exchange=exchange) as t:
+    with pm.TiledEngine(params, ROWS, COLS, 2, devices=[0, 1], exchange=exchange, schedule=schedule) as t:
         assert t.topology()[0] == 1
         dl, dr, _ = t.match(l, r, sl, sr)
     assert_same(dl, ul, "two devices vs untiled (left)")

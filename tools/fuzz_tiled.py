@@ -49,13 +49,14 @@ for case in range(a.cases):
     logical = sorted(int(v) for v in rng.integers(0, ndev, world))  # neighbours may share a device or not
     if rng.random() < 0.3:
         logical = logical[::-1]
-    mode, peer = int(rng.integers(0, 3)), int(rng.integers(0, 2))
-    with pm.TiledEngine(params, rows, cols, world, logical_devices=logical, simulate_peer_access=peer, exchange=mode) as t:
+    mode, peer, sched = int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    with pm.TiledEngine(params, rows, cols, world, logical_devices=logical, simulate_peer_access=peer, exchange=mode,
+                        schedule=sched) as t:
         cl, cr, cinfo = t.match(p["left"], p["right"], sl, sr, rounds=rounds if rounds > 0 else 0)
         _, bad = t.audit()
     ok = ok and np.array_equal(cl, ul) and np.array_equal(cr, ur) and bad == 0
     print(f"case {case:3d}: sem {sem} {cols}x{rows} patch {patch} iters {iters} bands {world} rounds {rounds} "
-          f"repeated {int(bool(info['repeated']))} | C driver: devices {logical} exchange {mode} peer {peer} "
+          f"repeated {int(bool(info['repeated']))} | C driver: devices {logical} exchange {mode} peer {peer} schedule {sched} "
           f"marked calls {bad} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
     if not ok:
         sys.exit(1)
