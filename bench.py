@@ -806,8 +806,9 @@ def tiled_children(args):
         # round; PM_TILED_EXCHANGE_DIRECT) -- in a child of its own: whatever it does stays beside the default leg's number
         res["direct_exchange"] = run_child(cmd + ["--exchange", "2"], args.tiled_timeout)
     if single and rank == 0 and res is not None and "error" not in res:
-        # and with the bands sweeping IN ORDER instead of speculating (PM_TILED_SCHEDULE_PIPELINED; peer copies)
-        res["pipelined_schedule"] = run_child(cmd + ["--schedule", "1"], args.tiled_timeout)
+        # and with all bands sweeping at once and re-sweeping what changed (PM_TILED_SCHEDULE_SPECULATIVE; peer copies):
+        # the schedule that keeps every GPU busy in every round, at the price of the re-sweeps
+        res["speculative_schedule"] = run_child(cmd + ["--schedule", "0"], args.tiled_timeout)
     return res
 
 
@@ -1021,8 +1022,8 @@ def main():
                 # the C-ABI driver with 8 bands on THIS device: the protocol (boundary rows, masked re-sweeps, flag) at
                 # work, its cost beside the untiled frame; a real caller has one band per GPU
                 tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
-                tiled_result["eight_bands_on_this_device_pipelined"] = tiled.bench_single_process(
-                    args, [d.local_rank] * 8, steps=2, schedule=1)
+                tiled_result["eight_bands_on_this_device_speculative"] = tiled.bench_single_process(
+                    args, [d.local_rank] * 8, steps=2, schedule=0)
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:

@@ -390,18 +390,22 @@ int pm_tile_finish(pm_handle* h, float* d_disp_l_own, float* d_disp_r_own);
  * The C / C++ caller's form of BASELINE config 4 (the multi-process variant over torch.distributed / RCCL is
  * ocean-perception_amd/python/tiled.py; both run the same protocol).  Band k owns rows split as evenly as possible and
  * works on its rows plus patch_h/2 + 1 halo rows of image data.  Noise / cost, the horizontal sweeps, the background
- * mask and the cross-check are local to a band.  A vertical sweep carries one value per column across a band boundary:
- * every band sweeps with the neighbour's OLD boundary row, the new boundary rows travel one hop
- * (hipMemcpyPeerAsync on the receiving band's stream, ordered by events -- no host synchronisation, no RCCL inside one
- * process), and a band re-sweeps exactly the columns whose incoming value changed, `rounds` times per sweep (band k is
- * final after round k + 1).  Whether that sufficed is one device flag per band ("my boundary row still moved after
- * the last row I sent"), read once per Match; only if it is set is the Match repeated with n_bands - 1 rounds, which is
- * always enough.  The result equals the untiled Match() bit for bit (tests/test_cpp_tiled.py, 4096x2160).
+ * mask and the cross-check are local to a band.  A vertical sweep carries one value per column across a band boundary
+ * (one row of disparities, read by the receiving band behind an event of the sender's stream -- no host synchronisation,
+ * no RCCL inside one process).  Two schedules give the same maps (pm_tiled_set_schedule below):
+ *   PIPELINED (default)  the bands sweep in order along the sweep direction, each continuing from its predecessor's final
+ *                        row: exact by construction, `rounds` is ignored;
+ *   SPECULATIVE          every band sweeps with the neighbour's OLD boundary row, the new boundary rows travel one hop,
+ *                        and a band re-sweeps exactly the columns whose incoming value changed, `rounds` times per sweep
+ *                        (band k is final after round k + 1).  Whether that sufficed is one device flag per band ("my
+ *                        boundary row still moved after the last row I sent"), read once per Match; only if it is set is
+ *                        the Match repeated with n_bands - 1 rounds, which is always enough.
+ * The result equals the untiled Match() bit for bit (tests/test_cpp_tiled.py, 4096x2160).
  * Replaces, for one large image, PatchmatchGpu::Match(const Image1b&, const Image1b&, Image1f&, Image1f&)
  * (src/vehicle/patchmatch_gpu/patchmatch_gpu.h:99-102). */
 typedef struct pm_tiled_plan pm_tiled_plan;
 typedef struct pm_tiled_info {
-  int rounds_used;  /* exchange rounds per vertical sweep of the result that was returned            */
+  int rounds_used;  /* exchange rounds per vertical sweep of the result that was returned (0: pipelined) */
   int repeated;     /* 1: a boundary row still moved after `rounds` rounds and the Match was repeated  */
   int exchanges;    /* boundary rows that travelled between bands (all bands, both attempts)           */
 } pm_tiled_info;
@@ -412,7 +416,7 @@ int pm_tiled_band_rows(const pm_params* params, int global_rows, int n_bands);
 int pm_tiled_create(pm_handle* const* bands, int n_bands, int rows, int cols, pm_tiled_plan** out);
 void pm_tiled_destroy(pm_tiled_plan* plan);
 /* host buffers as in pm_match_u8 (seed maps may be NULL; the device seeder works on whole images and is not available
- * here); rounds = exchange rounds per vertical sweep: negative (recommended) or >= n_bands - 1 = n_bands - 1 rounds, which
+ * here); rounds (PM_TILED_SCHEDULE_SPECULATIVE only) = exchange rounds per vertical sweep: negative (recommended) or >= n_bands - 1 = n_bands - 1 rounds, which
  * are always enough (band k is final after round k + 1) -- a round in which nothing changed is three empty launches per
  * band, a repeated Match costs a whole Match (measured at 4096x2160 / 8 bands: 49 ms with 7 rounds, 88 ms with 2 rounds
  * and the repeat they always end in, tools/tiled_rounds.py); fewer rounds only pay when values rarely cross bands */
@@ -443,13 +447,16 @@ int pm_tiled_topology(const pm_tiled_plan* plan, int* device_boundaries, int* pe
 typedef enum pm_tiled_exchange { PM_TILED_EXCHANGE_AUTO = 0, PM_TILED_EXCHANGE_COPY = 1, PM_TILED_EXCHANGE_DIRECT = 2 } pm_tiled_exchange;
 int pm_tiled_set_exchange(pm_tiled_plan* plan, int mode);
 /* How a vertical sweep crosses the band boundaries.
- *   SPECULATIVE (default)  every band sweeps at once with its neighbour's OLD boundary row, the new rows travel one hop per
+ *   PIPELINED (default since round 6)  the bands sweep IN ORDER along the sweep direction: a band stores its predecessor's
+ *                          final row in front of its chains, sweeps once, publishes its own last row.  Nothing is guessed,
+ *                          so there is no snapshot, no mask, no re-sweep and no repeat (`rounds` is ignored;
+ *                          pm_tiled_info.rounds_used = 0); during a vertical sweep the bands take turns, everything that
+ *                          does not cross a boundary overlaps -- eight bands on ONE device: 28.5 ms per 4096x2160 frame,
+ *                          less than the untiled frame's 29.5 (neighbouring bands' phases fill each other's tails).
+ *   SPECULATIVE            every band sweeps at once with its neighbour's OLD boundary row, the new rows travel one hop per
  *                          round, a band re-sweeps the columns whose incoming value changed (snapshot, mask, `rounds`,
- *                          the repeat rule: see above).  All bands work in every round.
- *   PIPELINED              the bands sweep IN ORDER along the sweep direction: a band stores its predecessor's final row in
- *                          front of its chains, sweeps once, publishes its own last row.  Nothing is guessed, so there is
- *                          no snapshot, no mask, no re-sweep and no repeat (`rounds` is ignored; pm_tiled_info.rounds_used
- *                          = 0); during a vertical sweep the bands take turns, everything else overlaps as before.
+ *                          the repeat rule: see above).  All bands work in every round -- and re-sweep: 35.7 ms on one
+ *                          device.  Kept for boxes where several GPUs make the parallel rounds pay.
  * Same maps either way (the sequential sweep). */
 typedef enum pm_tiled_schedule { PM_TILED_SCHEDULE_SPECULATIVE = 0, PM_TILED_SCHEDULE_PIPELINED = 1 } pm_tiled_schedule;
 int pm_tiled_set_schedule(pm_tiled_plan* plan, int schedule);

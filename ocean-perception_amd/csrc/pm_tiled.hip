@@ -81,7 +81,7 @@ struct pm_tiled_plan {
   int device_boundaries = 0;  // neighbouring bands that live on DIFFERENT devices (their rows cross by peer copy)
   int peer_links = 0;         // ... of which direct peer access could be enabled (the others are staged by the runtime)
   int exchange = PM_TILED_EXCHANGE_AUTO;
-  int schedule = PM_TILED_SCHEDULE_SPECULATIVE;
+  int schedule = PM_TILED_SCHEDULE_PIPELINED;
   Audit* audit = nullptr;  // only plans of pm_tiled_create_logical keep a log
   char err[512] = {0};
 };

@@ -342,7 +342,7 @@ def bench(args, d, steps=None, rows=2160, cols=4096, quiet=False):
     return res
 
 
-def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1, exchange=0, schedule=0):
+def bench_single_process(args, devices, steps=2, rows=2160, cols=4096, rounds=-1, exchange=0, schedule=1):
     """BASELINE configs[3] through the C-ABI driver (pm_tiled_* of include/pm/patchmatch.h): ONE process, band k on
     devices[k], boundary rows by hipMemcpyPeerAsync + events (no RCCL, no torch.distributed).  The pair is uploaded
     once and stays resident in the bands' HBM; a timed step is one pm_tiled_run (it returns after the one flag read
@@ -401,7 +401,7 @@ def main():
                     help="run the C-ABI driver (pm_tiled_*) in THIS process over devices 0..N-1 instead of one rank per GPU")
     ap.add_argument("--bands", type=int, default=0, help="--single-process: bands (default: one per device)")
     ap.add_argument("--exchange", type=int, default=0, help="--single-process: pm_tiled_exchange (0 auto, 1 copy, 2 direct)")
-    ap.add_argument("--schedule", type=int, default=0, help="--single-process: pm_tiled_schedule (0 speculative, 1 pipelined)")
+    ap.add_argument("--schedule", type=int, default=1, help="--single-process: pm_tiled_schedule (1 pipelined: the default; 0 speculative)")
     args = ap.parse_args()
     if args.single_process > 0:
         import json

@@ -2,7 +2,7 @@
 // bm::pm::TiledPatchmatchGpu (pm_tiled_* of include/pm/patchmatch.h), and the same pair by the untiled
 // bm::pm::PatchmatchGpu::Match -- the construct-and-Match() calls of patchmatch_gpu.h:94-102.  Writes both results for
 // tests/test_cpp_tiled.py to compare bit for bit.
-// usage: tiled_main <dir> <rows> <cols> <semantics> <patch> <iters> <bands> <rounds>     (rounds = -2: PM_TILED_SCHEDULE_PIPELINED)
+// usage: tiled_main <dir> <rows> <cols> <semantics> <patch> <iters> <bands> <rounds>     (rounds = -2: the default schedule, PM_TILED_SCHEDULE_PIPELINED; else SPECULATIVE with that many rounds)
 //        tiled_main devices <d0,d1,...>   only construct the row-tiled matcher with band k on device dk (64x96 image)
 //                                          and print its topology, or the exception: the multi-device constructor path
 #include <cstdio>
@@ -76,7 +76,8 @@ int main(int argc, char** argv) {
     {
       TiledPatchmatchGpu tiled(params, rows, cols, std::vector<int>((size_t)bands, 0));  // every band on device 0
       tiled.SetSeeds(sl, sr);
-      if (rounds == -2) tiled.SetSchedule(PM_TILED_SCHEDULE_PIPELINED);  // the bands sweep in order: no rounds at all
+      // rounds = -2: the default schedule (the bands sweep in order: no rounds at all); else the speculative one
+      if (rounds != -2) tiled.SetSchedule(PM_TILED_SCHEDULE_SPECULATIVE);
       tiled.Match(il, ir, tdisp, tdispr, rounds);
       const pm_tiled_info& info = tiled.LastInfo();
       std::printf("rounds_used %d repeated %d exchanges %d\n", info.rounds_used, info.repeated, info.exchanges);

@@ -119,7 +119,7 @@ def test_python_tiled_engine_three_step_api(pm, oracle, synth):
     l, r, sl, sr, _ = small_pair(synth, 97, rows, cols, n_points=60, dilate_factor=3)
     prm = pm.default_params(0, patch=7, patchmatch_iters=3)
     el, er = oracle.match(oracle.default_params(0, patch=7, n_iters=3, nthreads=8), l, r, sl, sr)
-    with pm.TiledEngine(prm, rows, cols, bands) as te:
+    with pm.TiledEngine(prm, rows, cols, bands, schedule=pm.PM_TILED_SCHEDULE_SPECULATIVE) as te:
         te.upload(l, r, sl, sr)
         for rounds in (2, 0, 1):
             info = te.run(rounds)

@@ -49,12 +49,13 @@ def _check_log(recs, bad, n_bands, logical):
     ([0, 1, 2, 3], 0, 0), ([0, 1, 2, 3], 1, 0), ([0, 1, 2, 3], 1, 2), ([0, 1, 2, 3], 0, 2), ([0, 1, 2, 3], 1, 1),
     ([0, 0, 1, 1], 1, 0), ([0, 0, 1, 1], 1, 2), ([3, 1, 0], 1, 2)])
 def test_bands_on_logical_devices_keep_the_device_discipline(pm, synth, logical, peer, exchange):
+    """The speculative schedule (rounds, snapshots, masked re-sweeps): the richer protocol, every object of it audited."""
     n = len(logical)
     l, r, sl, sr, _ = _pair(synth)
     params = pm.default_params(0, patch=5, patchmatch_iters=3)
     ul, ur = _untiled(pm, params, l, r, sl, sr)
     with pm.TiledEngine(params, ROWS, COLS, n, logical_devices=logical, simulate_peer_access=peer,
-                        exchange=exchange) as t:
+                        exchange=exchange, schedule=pm.PM_TILED_SCHEDULE_SPECULATIVE) as t:
         boundaries = sum(1 for a, b in zip(logical, logical[1:]) if a != b)
         assert t.topology() == (boundaries, boundaries if peer else 0)
         dl, dr, info = t.match(l, r, sl, sr)
