@@ -319,6 +319,21 @@ int download(pm_tiled_plan* p, float* disp_l, float* disp_r, size_t disp_step) {
   return PM_OK;
 }
 
+// Test hook (pm_tiled_debug_inject), called where a reader marks a row as consumed: what round 5's driver did -- an event of
+// the PUBLISHER's device recorded on the reader's stream -- and a stream used while another band's device is current.
+// Both are harmless on the one physical device a logical plan runs on (nobody waits for ev_probe), and both must show up
+// in the log.
+int inject_breach(pm_tiled_plan* p, Band& b, Band& s) {
+  if (!p->audit || !p->audit->inject) return PM_OK;
+  if (p->audit->inject & 1) TL_HIP(p, rt_event_record(p, b, s.ev_probe));
+  if (p->audit->inject & 2) {
+    TL_HIP(p, rt_use(p, s));
+    TL_HIP(p, rt_wait_event(p, b, s.ev_probe));
+    TL_HIP(p, rt_use(p, b));
+  }
+  return PM_OK;
+}
+
 // one attempt on the resident pair with `rounds` exchange rounds per vertical sweep, results into the bands' output
 // buffers; *moved = some band's boundary row still changed.  Waits for the flags (the one host read per attempt).
 int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
@@ -352,17 +367,7 @@ int attempt(pm_tiled_plan* p, int rounds, bool* moved, int* exchanges) {
   };
   // band k, with its device current, marks its predecessor's sent[cur] as consumed: ITS event on ITS stream
   auto consumed = [&](Band& b, Band& s) -> int {
-    if (p->audit && p->audit->inject) {
-      // test hook (pm_tiled_debug_inject): what round 5's driver did -- an event of the PUBLISHER's device recorded on
-      // the reader's stream -- and a stream used while another band's device is current.  Both are harmless on the one
-      // physical device a logical plan runs on (nobody waits for ev_probe), and both must show up in the log.
-      if (p->audit->inject & 1) TL_HIP(p, rt_event_record(p, b, s.ev_probe));
-      if (p->audit->inject & 2) {
-        TL_HIP(p, rt_use(p, s));
-        TL_HIP(p, rt_wait_event(p, b, s.ev_probe));
-        TL_HIP(p, rt_use(p, b));
-      }
-    }
+    if (int rc = inject_breach(p, b, s)) return rc;
     TL_HIP(p, rt_event_record(p, b, b.ev_done[dir][cur]));
     s.unread[cur] = b.ev_done[dir][cur];
     ++*exchanges;
@@ -511,6 +516,7 @@ int attempt_pipelined(pm_tiled_plan* p, int* exchanges) {
             TL_HIP(p, rt_copy_peer(p, b, b.incoming, s, s.sent[cur], row_bytes));
             TL_STAGE(p, b, ST_SET_ROW, pm_tile_set_row(b.h, pred_row, b.incoming), {b.incoming, false});
           }
+          if (int rc = inject_breach(p, b, s)) return rc;
           TL_HIP(p, rt_event_record(p, b, b.ev_done[dir][cur]));
           s.unread[cur] = b.ev_done[dir][cur];
           ++*exchanges;

@@ -115,8 +115,9 @@ def test_pipelined_schedule_keeps_the_discipline_and_the_maps(pm, synth, logical
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1])
 @pytest.mark.parametrize("what,bit,name", [(1, 2, "event_record"), (2, 1, "stream_wait_event")])
-def test_the_log_catches_a_deliberate_breach(pm, synth, what, bit, name):
+def test_the_log_catches_a_deliberate_breach(pm, synth, what, bit, name, schedule):
     """The auditor is not vacuous: with the round-5 arrangement injected (an event of the publisher's device recorded on the
     reader's stream) or a stream used under another band's current device, the log marks exactly those calls -- and only
     at boundaries between DIFFERENT logical devices; the maps are unaffected (on one physical device the breach is harmless)."""
@@ -124,7 +125,7 @@ def test_the_log_catches_a_deliberate_breach(pm, synth, what, bit, name):
     params = pm.default_params(0, patch=5, patchmatch_iters=2)
     ul, ur = _untiled(pm, params, l, r, sl, sr)
     logical = [0, 0, 1, 2]
-    with pm.TiledEngine(params, ROWS, COLS, 4, logical_devices=logical, simulate_peer_access=1) as t:
+    with pm.TiledEngine(params, ROWS, COLS, 4, logical_devices=logical, simulate_peer_access=1, schedule=schedule) as t:
         t.debug_inject(what)
         dl, dr, _ = t.match(l, r, sl, sr)
         recs, bad = t.audit()
