@@ -69,7 +69,12 @@ def test_tiled_equals_untiled(pm, oracle, synth, sem, patch, world, rounds):
     rows, cols = 150, 200
     l, r, sl, sr, _ = small_pair(synth, 80 + world, rows, cols, n_points=60, dilate_factor=3)
     params = pm.default_params(sem, patch=patch, patchmatch_iters=3)
+    # the pipelined schedule (the ranks sweep in order: the default of match_band) first, then the speculative one
+    pl, pr, pinfo = tiled.match_tiled_local(params, l, r, sl, sr, world, pipelined=True)
+    assert pinfo["rounds"] == 0 and not pinfo["repeated"] and pinfo["exchanges_per_rank"] > 0
     dl, dr, info = tiled.match_tiled_local(params, l, r, sl, sr, world, rounds=rounds)
+    assert_same(pl, dl, "pipelined vs speculative schedule (left)")
+    assert_same(pr, dr, "pipelined vs speculative schedule (right)")
     if rounds == 0:
         assert info["repeated"] and info["rounds"] == world - 1
     if world == 2 and rounds >= 1:
@@ -101,6 +106,9 @@ def test_tiled_full_size_4096x2160_eight_bands(pm, oracle, synth):
         ul, ur = e.match(l, r, sl, sr)
     assert_same(dl, ul, "4096x2160, 8 bands vs untiled (left)")
     assert_same(dr, ur, "4096x2160, 8 bands vs untiled (right)")
+    pl, pr, _ = tiled.match_tiled_local(params, l, r, sl, sr, world, pipelined=True)
+    assert_same(pl, ul, "4096x2160, 8 bands in order vs untiled (left)")
+    assert_same(pr, ur, "4096x2160, 8 bands in order vs untiled (right)")
     fg = dl > 0
     assert fg.mean() > 0.15 and (np.abs(dl - p["gt"])[fg] < 1.0).mean() > 0.95
     band = np.s_[238:302, :]
@@ -128,9 +136,21 @@ def _comm_worker(rank, world, port, q):
     # is left, and both ends derive that from their positions (match_band)
     r, pos = 1, rank
     late = comm.shift(row + 10.0, True, send=pos + 1 > r and rank + 1 < world, recv=pos > r)
+    # the pipelined hand-over: a value travels down the ranks and back up, every rank adding its own
+    chain = torch.zeros((2, 5))
+    if rank > 0:
+        chain = comm.recv((2, 5), torch.device("cpu"), rank - 1, True)
+    chain = chain + 1.0
+    if rank + 1 < world:
+        comm.send(chain, rank + 1, True)
+        back = comm.recv((2, 5), torch.device("cpu"), rank + 1, False)
+    else:
+        back = chain
+    if rank > 0:
+        comm.send(back + 10.0, rank - 1, False)
     res = (None if down is None else float(down[0, 0]), None if up is None else float(up[0, 0]),
            comm.any(torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)), comm.any(torch.zeros(1, dtype=torch.int32)),
-           None if late is None else float(late[0, 0]))
+           None if late is None else float(late[0, 0]), float(chain[0, 0]), float(back[1, 4]))
     q.put((rank, res))
     dist.destroy_process_group()
 
@@ -154,9 +174,10 @@ def test_dist_comm_protocol_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out[0] == (None, 1.0, True, False, None)
-    assert out[1] == (0.0, 2.0, True, False, None)
-    assert out[2] == (1.0, None, True, False, 11.0)
+    # (the last two: the pipelined hand-over -- 1, 2, 3 on the way down, + 10 per hop on the way back up)
+    assert out[0] == (None, 1.0, True, False, None, 1.0, 23.0)
+    assert out[1] == (0.0, 2.0, True, False, None, 2.0, 13.0)
+    assert out[2] == (1.0, None, True, False, 11.0, 3.0, 3.0)
 
 
 @pytest.mark.gpu

@@ -40,7 +40,8 @@ for case in range(a.cases):
             x = int(rng.integers(patch, cols - patch))
             sl[:, x:x + 3] = np.float32(rng.uniform(2, 30))
     params = pm.default_params(sem, patch=patch, patchmatch_iters=iters)
-    dl, dr, info = tiled.match_tiled_local(params, p["left"], p["right"], sl, sr, world, rounds=rounds)
+    py_pipe = bool(rng.integers(0, 2))  # the Python driver's schedule: ranks in order, or speculative rounds
+    dl, dr, info = tiled.match_tiled_local(params, p["left"], p["right"], sl, sr, world, rounds=rounds, pipelined=py_pipe)
     with pm.Engine(params, max_rows=rows, max_cols=cols) as e:
         ul, ur = e.match(p["left"], p["right"], sl, sr)
     ok = np.array_equal(dl, ul) and np.array_equal(dr, ur)
@@ -56,7 +57,7 @@ for case in range(a.cases):
         _, bad = t.audit()
     ok = ok and np.array_equal(cl, ul) and np.array_equal(cr, ur) and bad == 0
     print(f"case {case:3d}: sem {sem} {cols}x{rows} patch {patch} iters {iters} bands {world} rounds {rounds} "
-          f"repeated {int(bool(info['repeated']))} | C driver: devices {logical} exchange {mode} peer {peer} schedule {sched} "
+          f"repeated {int(bool(info['repeated']))} pipelined {int(py_pipe)} | C driver: devices {logical} exchange {mode} peer {peer} schedule {sched} "
           f"marked calls {bad} {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
     if not ok:
         sys.exit(1)
