@@ -753,8 +753,9 @@ def tiled_children(args):
     """The configs[3] leg of a multi-rank run, crash-isolated: a CHILD process started before this process touches the
     GPU or joins its process group, waited for with a deadline; whatever it does -- exception, hang, abort -- ends in
     an {"error": ...} entry and never costs the headline.  Default: rank 0 alone starts ONE child that drives all
-    WORLD_SIZE GPUs through the C-ABI driver (pm_tiled_*: one process, one band per GPU, boundary rows by
-    hipMemcpyPeerAsync + events) while the other ranks wait at the rendezvous.  --tiled-rccl: every rank starts a
+    WORLD_SIZE GPUs through the C-ABI driver (pm_tiled_*: one process, one band per GPU; the default configuration --
+    pipelined schedule, boundary rows by hipMemcpyPeerAsync + events -- first, then the speculative schedule and the
+    direct exchange as variants of the same child, a JSON line each) while the other ranks wait at the rendezvous.  --tiled-rccl: every rank starts a
     `python/tiled.py` rank of its own (RCCL neighbour exchange on the engine's stream, own rendezvous port)."""
     import subprocess
     env = dict(os.environ)
@@ -778,37 +779,42 @@ def tiled_children(args):
                   "TORCHELASTIC_USE_AGENT_STORE"):
             env.pop(k, None)
         cmd = base + ["--single-process", str(world)]
-    def run_child(cmd, deadline):
-        try:
-            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        except OSError as e:
-            return {"error": "could not start the tiled leg: %r" % (e,)}
-        try:
-            out, err = p.communicate(timeout=deadline)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.communicate()
-            return {"error": "tiled leg did not finish within %d s (killed)" % deadline}
-        if rank != 0:
-            return None
-        for line in reversed(out.strip().splitlines()):
-            if line.startswith("{"):
-                try:
-                    return json.loads(line)
-                except ValueError:
-                    break
-        return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": err[-400:]}
-
-    res = run_child(cmd, args.tiled_timeout)
-    if (single and rank == 0 and res is not None and "error" not in res
-            and res.get("peer_links", 0) == res.get("device_boundaries", -1) > 0):
-        # peer access is enabled on every boundary and the default leg ran: the same frame with the receiving band's KERNEL reading the boundary row across the link (one copy less per
-        # round; PM_TILED_EXCHANGE_DIRECT) -- in a child of its own: whatever it does stays beside the default leg's number
-        res["direct_exchange"] = run_child(cmd + ["--exchange", "2"], args.tiled_timeout)
-    if single and rank == 0 and res is not None and "error" not in res:
-        # and with all bands sweeping at once and re-sweeping what changed (PM_TILED_SCHEDULE_SPECULATIVE; peer copies):
-        # the schedule that keeps every GPU busy in every round, at the price of the re-sweeps
-        res["speculative_schedule"] = run_child(cmd + ["--schedule", "0"], args.tiled_timeout)
+    try:
+        p = subprocess.Popen(cmd + (["--variants", "speculative,direct"] if single else []), env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return {"error": "could not start the tiled leg: %r" % (e,)}
+    timed_out = False
+    try:
+        out, err = p.communicate(timeout=args.tiled_timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, err = p.communicate()
+        timed_out = True
+    if rank != 0:
+        return None
+    # One JSON line per variant, each printed as soon as it was measured: the default configuration first (pipelined
+    # schedule, peer copies across devices), then -- single-process driver only -- `speculative` (all bands sweep at once and
+    # re-sweep what changed) and `direct` (the receiving band's kernel reads the boundary row across the link; only where
+    # peer access is enabled on every boundary; last, because it is the one thing that has never run on real devices).  A variant that hangs or kills the child costs itself, not the lines
+    # printed before it.
+    lines = []
+    for line in (out or "").strip().splitlines():
+        if line.startswith("{"):
+            try:
+                lines.append(json.loads(line))
+            except ValueError:
+                pass
+    if not lines:
+        if timed_out:
+            return {"error": "tiled leg did not finish within %d s (killed)" % args.tiled_timeout}
+        return {"error": "tiled leg exited with code %d" % p.returncode, "stderr_tail": (err or "")[-400:]}
+    res = lines[0]
+    for extra in lines[1:]:
+        res[{"direct": "direct_exchange", "speculative": "speculative_schedule"}.get(extra.get("variant"), str(extra.get("variant")))] = extra
+    if single and (timed_out or p.returncode != 0):
+        res["variants_note"] = ("the child %s after %d of its variants" %
+                                ("was killed at the deadline" if timed_out else "exited with code %d" % p.returncode, len(lines)))
     return res
 
 

@@ -477,13 +477,28 @@ def main():
     ap.add_argument("--bands", type=int, default=0, help="--single-process: bands (default: one per device)")
     ap.add_argument("--exchange", type=int, default=0, help="--single-process: pm_tiled_exchange (0 auto, 1 copy, 2 direct)")
     ap.add_argument("--schedule", type=int, default=1, help="--single-process: pm_tiled_schedule (1 pipelined: the default; 0 speculative)")
+    ap.add_argument("--variants", default="", help="--single-process: after the configured run, also (comma separated) "
+                    "`direct` = PM_TILED_EXCHANGE_DIRECT where every boundary has peer access, `speculative` = "
+                    "PM_TILED_SCHEDULE_SPECULATIVE; one JSON line each, printed as soon as it exists (a variant that "
+                    "kills the process cannot take the lines before it along)")
     args = ap.parse_args()
     if args.single_process > 0:
         import json
         nb = args.bands if args.bands > 0 else args.single_process
         devices = [k * args.single_process // nb for k in range(nb)]
-        print(json.dumps(bench_single_process(args, devices, steps=args.steps, rows=args.rows, cols=args.cols,
-                                              exchange=args.exchange, schedule=args.schedule)), flush=True)
+        first = bench_single_process(args, devices, steps=args.steps, rows=args.rows, cols=args.cols,
+                                     exchange=args.exchange, schedule=args.schedule)
+        first["variant"] = "default"
+        print(json.dumps(first), flush=True)
+        for v in [v for v in args.variants.split(",") if v]:
+            if v == "direct" and not (first["peer_links"] == first["device_boundaries"] > 0):
+                continue  # kernel reads of peer memory only where peer access is enabled on every boundary
+            kw = {"direct": dict(exchange=2, schedule=args.schedule), "speculative": dict(exchange=args.exchange, schedule=0)}.get(v)
+            if kw is None:
+                continue
+            res = bench_single_process(args, devices, steps=args.steps, rows=args.rows, cols=args.cols, **kw)
+            res["variant"] = v
+            print(json.dumps(res), flush=True)
         return
     d = B.Dist(args)
     bench(args, d, rows=args.rows, cols=args.cols)
