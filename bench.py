@@ -1030,6 +1030,9 @@ def main():
                 tiled_result["eight_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 8, steps=2)
                 tiled_result["eight_bands_on_this_device_speculative"] = tiled.bench_single_process(
                     args, [d.local_rank] * 8, steps=2, schedule=0)
+                # four bands: the fastest way through one device for an image of this size (bands in different phases
+                # fill each other's launch tails; more bands add hops: profiles/r06_tiled_bands_one_device.txt)
+                tiled_result["four_bands_on_this_device"] = tiled.bench_single_process(args, [d.local_rank] * 4, steps=2)
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline
                 tiled_result = {"error": repr(e)}
         if d.rank == 0 and tiled_result is not None:
