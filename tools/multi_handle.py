@@ -1,7 +1,7 @@
 """Aggregate Match() throughput of NH handles of one process, one host thread each, inputs resident (pm_match_device):
     python tools/multi_handle.py NH [start offset between the threads in ms]"""
 import os, sys, time, threading
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ocean-perception_amd", "python"))
 import numpy as np, torch
 import pm_ctypes as pm, synth
