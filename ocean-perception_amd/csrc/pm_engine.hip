@@ -298,7 +298,7 @@ int alloc_seed_scratch(pm_handle* h, SeedScratch& sc) {
 
 // SparseInit for view `view` of pair `b` straight into its disparity plane.  View 1 is seeded on the
 // mirrored pair (patchmatch_gpu.cu:362-365), whose map is already in the mirrored coordinates the plane uses.
-int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch) {
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch, unsigned stages) {
   SeedScratch& sc = h->seeds[scratch];
   if (!sc.eig) {
     if (h->capturing) {
@@ -312,10 +312,10 @@ int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scrat
   float* out = ps.disp + ((size_t)b * 2 + view) * ps.splane;  // a state plane: rows interleaved (out_pitch < 0 below)
   if (h->params.cpu_initialize_factor == 1)  // Patchmatch::Initialize(il, ir, 1) (patchmatch_test.cpp:149-150): 5x5, / 2
     PM_HIP(h, seed_initialize(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch, 1, out, -ps.pitch,
-                              h->stream));
+                              h->stream, stages));
   else
     PM_HIP(h, seed_sparse_init(sc, seed_params(h->params), ref, tgt, ps.rows, ps.cols, ps.pitch,
-                               h->params.init_dilate_factor, out, -ps.pitch, h->stream));
+                               h->params.init_dilate_factor, out, -ps.pitch, h->stream, stages));
   return PM_OK;
 }
 
@@ -534,22 +534,32 @@ int run_views_on(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* s
       mark_forked(h, vstream[v]);
       prof_break(h, vstream[v]);
     }
-    h->stream = vstream[v];
-    if (setup) {
-      {
-        Launch l(h, PM_K_PREP);
+  }
+  // The head of a view -- prep, transposed planes, the seeder's seven launches -- goes out like the sweeps behind it:
+  // launch k of BOTH views before launch k + 1 of either.  (One view's whole head first left the other view's stream
+  // empty for the ~55 us the host needs for nine launches, and the second view then ends that much later: a tenth of
+  // the reference's own 376x240 call, profiles/r06_reference_call_timeline.txt.)
+  for (int op = 0; op < 2 && setup && rc == PM_OK; ++op)
+    for (int v = 0; v < 2 && rc == PM_OK; ++v) {
+      h->stream = vstream[v];
+      Launch l(h, PM_K_PREP);
+      if (op == 0) {
         const PrepSeedMaps seeds{setup->d_seed_l, setup->d_seed_r};  // the seed copy rides along (one launch less)
         launch_prep(h, ps, setup->d_left, setup->d_right, setup->n, (size_t)ps.cols, v, &seeds);
         rc = launch_check(h, "prep");
-      }
-      if (rc == PM_OK) {
-        Launch l(h, PM_K_PREP);
+      } else {
         rc = run_transpose(h, ps, setup->n, v);
       }
     }
-    if (rc == PM_OK) rc = seed_views(h, ps, slots / 2, v, scratch + v);
-    h->stream = main_stream;
-  }
+  for (int b = 0; b < slots / 2 && rc == PM_OK; ++b)  // a view's pairs share its scratch: pair by pair
+    for (int st = 0; st < kSeedStages && rc == PM_OK; ++st)
+      for (int v = 0; v < 2 && rc == PM_OK; ++v) {
+        if (!h->need_seed[v]) continue;
+        h->stream = vstream[v];
+        Launch l(h, PM_K_SEED);
+        rc = run_sparse_init(h, ps, b, v, scratch + v, 1u << st);
+      }
+  h->stream = main_stream;
   if (rc == PM_OK) rc = run_view_sets(h, pv, vstream, 2, slots / 2);
   if (rc == PM_ERR_HIP && !h->err[0]) set_err(h, "per-view stream setup failed");
   return rc;

@@ -289,7 +289,7 @@ int seq_enqueue_chunk(pm_handle* h, int b, int c, const uint8_t* d_left, const u
 SeedParams seed_params(const pm_params& p);
 int alloc_seed_scratch(pm_handle* h, SeedScratch& sc);
 // SparseInit (or Patchmatch::Initialize(.., 1)) for view `view` of pair `b` straight into its disparity plane
-int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0);
+int run_sparse_init(pm_handle* h, const PlaneSet& ps, int b, int view, int scratch = 0, unsigned stages = kSeedAllStages);
 
 // ---- pm_launch.hip: one function per scalar-mode kernel, enqueued on h->stream -----------------------------------
 // k_prep, or k_prep_bgr when the call came in through pm_match_bgr_device (the gray images are then never stored)

@@ -74,6 +74,7 @@ struct RunStep2 {
   int mpos;
   bool adopt;
   float d0, c0, cost;
+  float val;  // what the position holds after the step (read where 0 <= mpos < advance)
 };
 
 // Ballot of this lane's group (GS = 32, 16 or 8 lanes), in the low GS bits.
@@ -89,7 +90,7 @@ __device__ __forceinline__ unsigned gballot(bool p, int gbase) {
 namespace pm {
 
 // One workgroup per chain; wavefront w carries segments (64 / GS) * w ...  Rounds and fix-up as described above, per
-// group.  grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 4 * (n + 1) floats + segments + 3 words.
+// group.  grid = (chains, 1, slots), block = 64 * nw, dynamic LDS = 5 * (n + 1) floats + segments + 3 words.
 template <int GS, int AXIS>
 __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, CostParams cp, SweepGeom g, int seg_len) {
   extern __shared__ float lds[];
@@ -99,11 +100,15 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   float* cin = lds + n1;
   float* dout = lds + 2 * n1;
   float* cout = lds + 3 * n1;
-  float* s_last = lds + 4 * n1;  // [nseg + 1] last values + [2] change flags
-  int* s_changed = (int*)(lds + 4 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1);
+  float* offer = lds + 4 * n1;   // what a position does with its predecessor's OLD value (pm_run_gpu.hpp::run2_gpu_offer)
+  float* s_last = lds + 5 * n1;  // [nseg + 1] last values + [2] change flags
+  int* s_changed = (int*)(lds + 5 * n1 + (kWave / GS) * (blockDim.x >> 6) + 1);
 
   const int chain = g.c_lo + xcd_band_index(blockIdx.x, gridDim.x);
   if (!chain_active(ps, blockIdx.z, chain)) return;  // uniform for the workgroup, before any barrier
+#ifdef PM_RUN2_PHASES  // analysis builds (tools/refshape_steps.py --phases): device wall clock (10 ns) per phase of the chain
+  const unsigned long long t_start = wall_clock64();
+#endif
   const View v = make_view(ps, blockIdx.z);
   const int lane = threadIdx.x & 63;
   constexpr int kPerWave = kWave / GS;
@@ -143,6 +148,11 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
     }
   }
   __syncthreads();
+  for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) offer[k] = run2_gpu_offer<AXIS>(v, ps, cp, g, chain, k, din, cin);
+  __syncthreads();
+#ifdef PM_RUN2_PHASES
+  const unsigned long long t_loaded = wall_clock64();
+#endif
 
   const int i0 = sidx * seg_len;
   const int i1 = min(n, i0 + seg_len);
@@ -156,16 +166,19 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
     int i = i0;
     while (__builtin_amdgcn_ballot_w64(active && i < i1) != 0ull) {
       const bool act = active && i < i1;
-      const RunStep2 st = run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, i1, cand, din, cin);
+      const RunStep2 st = run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, i1, cand, din, cin, offer);
       ++n_steps;
       if (st.mpos >= 0 && st.mpos < st.advance) {
-        dout[i + st.mpos + 1] = st.mpos == st.rej_pos ? st.rej_d0 : cand;
+        dout[i + st.mpos + 1] = st.val;
         cout[i + st.mpos + 1] = st.adopt ? st.cost : st.c0;
       }
       if (st.rej_pos >= 0) cand = st.rej_d0;
       i += st.advance;
     }
   }
+#ifdef PM_RUN2_PHASES
+  const unsigned long long t_round1 = wall_clock64();
+#endif
   float lastv = cand;
   if (active && gl == 0) s_last[sidx + 1] = lastv;
   if (threadIdx.x == 0) s_last[0] = in_used;
@@ -184,10 +197,10 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
       bool merged = false;
       while (__builtin_amdgcn_ballot_w64(redo && !merged && i < i1) != 0ull) {
         const bool act = redo && !merged && i < i1;
-        const RunStep2 st = run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, i1, c2, din, cin);
+        const RunStep2 st = run_step2_gpu<GS, AXIS>(v, ps, cp, g, chain, act, i, i1, c2, din, cin, offer);
         ++n_fix;
         const bool mine = st.mpos >= 0 && st.mpos < st.advance;
-        const float val = st.mpos == st.rej_pos ? st.rej_d0 : c2;
+        const float val = st.val;
         const float spec = mine ? dout[i + st.mpos + 1] : 0.f;
         const unsigned eq = gballot<GS>(mine && val == spec, gbase);
         int ms = -1;
@@ -221,12 +234,17 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
   __syncthreads();
   if (ps.counters && lane == 0) {
     const int base = AXIS * 4;
+#ifndef PM_RUN2_PHASES
     atomicAdd(&ps.counters[base + 0], (unsigned long long)n_steps);
     atomicAdd(&ps.counters[base + 1], (unsigned long long)n_fix);
     if (w == 0) atomicAdd(&ps.counters[base + 2], (unsigned long long)n_rounds);
     if (w == 0) atomicAdd(&ps.counters[base + 3], (unsigned long long)n);
+#endif
   }
 
+#ifdef PM_RUN2_PHASES
+  const unsigned long long t_fixed = wall_clock64();
+#endif
   for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) {
     const float d = dout[k];
     if (d != din[k]) {
@@ -235,6 +253,16 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
       v.cost[o] = cout[k];
     }
   }
+#ifdef PM_RUN2_PHASES
+  if (ps.counters && threadIdx.x == 0) {
+    const int base = AXIS * 4;
+    const unsigned long long ph[4] = {t_loaded - t_start, t_round1 - t_loaded, t_fixed - t_round1, wall_clock64() - t_fixed};
+    for (int e = 0; e < 4; ++e) {
+      if (PM_RUN2_PHASES == 2) atomicMax(&ps.counters[base + e], ph[e]);
+      else atomicAdd(&ps.counters[base + e], ph[e]);
+    }
+  }
+#endif
 }
 
 template <int GS, int AXIS>
@@ -247,7 +275,7 @@ inline void launch_run2_k(const PlaneSet& ps, const CostParams& cp, const SweepG
   int len = (n + per_block - 1) / per_block;
   if (len < 8) len = 8;
   const int n1 = (n + 1 + 3) & ~3;
-  const size_t lds_bytes = sizeof(float) * (4 * (size_t)n1 + per_block + 1 + 2);
+  const size_t lds_bytes = sizeof(float) * (5 * (size_t)n1 + per_block + 1 + 2);
   allow_big_lds(k_runblk2<GS, AXIS>, lds_bytes);
   hipLaunchKernelGGL((k_runblk2<GS, AXIS>), dim3((unsigned)chains, 1, (unsigned)slots), dim3(kWave * nwv), lds_bytes,
                      stream, ps, cp, g, len);

@@ -48,10 +48,43 @@ __device__ __forceinline__ float gpu_tap_at(const uint8_t* ref8, const float* re
   return gpu_tap(il, gl, r0, r1, g0, g1, tcol, cp);
 }
 
+// The five-tap cost of ONE position against sample column xr (>= 1), all taps by this lane -- what a thread of the
+// reference's kernels computes (L1GradientCost3x3, patchmatch_gpu.cu:72-114; pm_device.hpp::gpu_cost_lane is the same
+// sum with 64-bit addressing).  Row sweeps read the image planes, column sweeps the transposed ones, where the lanes'
+// consecutive rows are consecutive bytes.
+template <int AXIS>
+__device__ __forceinline__ float gpu_cost_own(const View& v, const PlaneSet& ps, int px, int py, float xr,
+                                              const CostParams& cp) {
+  const int dys[5] = {-1, -1, 0, 1, 1};
+  const int dxs[5] = {-1, 1, 0, -1, 1};
+  float cost = 0.f;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const float xs = xr + (float)dxs[t];
+    const float f0 = floorf(xs);
+    const unsigned col0 = (unsigned)(int)f0, col1 = (unsigned)(int)ceilf(xs);
+    const float tcol = xs - f0;
+    float s;
+    if (AXIS == 0) {
+      const unsigned row = __umul24((unsigned)(py + dys[t]), (unsigned)ps.pitch);
+      s = gpu_tap_at(v.ref8, v.refg, v.tgt8, v.tgtg, row + (unsigned)(px + dxs[t]), row + col0, row + col1, tcol, cp);
+    } else {
+      const unsigned Y = (unsigned)(py + dys[t]), pt = (unsigned)ps.pitch_t;
+      s = gpu_tap_at(v.tref8, v.trefg, v.ttgt8, v.ttgtg, __umul24((unsigned)(px + dxs[t]), pt) + Y,
+                     __umul24(col0, pt) + Y, __umul24(col1, pt) + Y, tcol, cp);
+    }
+    cost = cost + s;
+  }
+  return cost;
+}
+
+// One step of a group: the run of `cand` from position i on, then -- behind a stop that kept its own value -- the
+// positions that decline their predecessor's old value, up to and including the first one that adopts it.
 template <int GS, int AXIS>
 __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet& ps, const CostParams& cp,
                                                   const SweepGeom& g, int chain, bool act, int i, int n_end,
-                                                  float cand, const float* din, const float* cin) {
+                                                  float cand, const float* din, const float* cin,
+                                                  const float* offer) {
   const int lane = threadIdx.x & (kWave - 1);
   const int gl = lane & (GS - 1);
   const int gbase = lane & ~(GS - 1);
@@ -65,6 +98,8 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
   const bool inr = act && has_pos && (i + st.mpos < n_end);
   st.d0 = inr ? din[i + st.mpos + 1] : 0.f;
   st.c0 = inr ? cin[i + st.mpos + 1] : 0.f;
+  const float d_pred = inr ? din[i + st.mpos] : 0.f;     // the predecessor's old value and what this position does
+  const float cost_b = inr ? offer[i + st.mpos + 1] : -1.f;  // with it (k_runblk2: evaluated once per chain)
   auto first_pos = [&](unsigned m) -> int {  // m != 0, bits of lanes 1..GS-2
     return dir > 0 ? __ffs((int)m) - 2 : nd - (31 - __clz((int)m));
   };
@@ -82,13 +117,6 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
   const bool same_xr = inr && !neutral && (xr0 == xr1);
   const bool need_eval = inr && !neutral && !same_xr;
   const float newval = fminf(cand, fx - 1.f);
-
-  const unsigned nonneutral = gballot<GS>(inr && !neutral, gbase);
-  const bool has_need = nonneutral != 0u;
-  const int r = has_need ? first_pos(nonneutral) : 0;
-  const int r_gl = glane_of(r);
-  const unsigned need_m = gballot<GS>(need_eval, gbase);
-  const bool r_eval = has_need && ((need_m >> r_gl) & 1u);
 
   // ---- sample positions and the bitwise consistency of the neighbours ---------------------------
   // AXIS 0: lane column X samples S = X - v (kept inside the row for addressing; a position only uses a
@@ -109,13 +137,11 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
     sR = xu + 1.f;
     wide_ok = (xu >= 1.f) && (sR <= (float)(cols - 1));
   }
-  const unsigned wide_m = gballot<GS>(wide_ok, gbase);
-  const bool r_wide = r_eval && ((wide_m >> r_gl) & 1u);
-  const bool r_slow = r_eval && !r_wide;
+  const bool eval_wide = need_eval && wide_ok, eval_own = need_eval && !wide_ok;
 
   // ---- wide evaluation: tap values per lane, gathered by the positions ---------------------------
   float cost_w = 0.f;
-  if (__any(r_wide)) {
+  if (__any(eval_wide)) {
     if (AXIS == 0) {
       const unsigned X = (unsigned)min(max(pos, 0), cols - 1);
       const float f0 = floorf(S);
@@ -159,68 +185,75 @@ __device__ __forceinline__ RunStep2 run_step2_gpu(const View& v, const PlaneSet&
     }
   }
 
-  // ---- slow evaluation of position r alone: lanes 0..4 of the group take one tap each ------------
-  float cost_s = 0.f;
-  if (__any(r_slow)) {
-    const int src = gbase + r_gl;
-    const int x_r = __shfl(px, src, kWave), y_r = __shfl(py, src, kWave);
-    const float xr_r = __shfl(xr1, src, kWave);
-    const int tt = min(gl, 4);
-    const int dy = tt < 2 ? -1 : (tt == 2 ? 0 : 1);
-    const int dx = tt == 2 ? 0 : ((tt == 0 || tt == 3) ? -1 : 1);
-    float s = 0.f;
-    if (r_slow) {
-      const float xs = xr_r + (float)dx;
-      const float f0 = floorf(xs);
-      const int col0 = (int)f0, col1 = (int)ceilf(xs);
-      const float tcol = xs - f0;
-      const unsigned lrow = __umul24((unsigned)(y_r + dy), (unsigned)pitch);  // 32-bit offsets: no 64-bit multiply-adds
-      s = gpu_tap_at(v.ref8, v.refg, v.tgt8, v.tgtg, lrow + (unsigned)(x_r + dx), lrow + (unsigned)col0,
-                     lrow + (unsigned)col1, tcol, cp);
-    }
-    float c = 0.f + __shfl(s, gbase + 0, kWave);
-    c = c + __shfl(s, gbase + 1, kWave);
-    c = c + __shfl(s, gbase + 2, kWave);
-    c = c + __shfl(s, gbase + 3, kWave);
-    c = c + __shfl(s, gbase + 4, kWave);
-    cost_s = c;
+  // ---- positions whose samples cannot be shared (clamped candidate, binade crossing): all five taps by the lane ----
+  // (until round 6 such a position was evaluated ALONE, by five lanes, and ended the step: whole chains near the left
+  // image border, where every candidate is clamped, went one position per step)
+  float cost_o = 0.f;
+  if (__any(eval_own)) {
+    if (eval_own) cost_o = gpu_cost_own<AXIS>(v, ps, px, py, xr1, cp);
   }
 
   // ---- decide -----------------------------------------------------------------------------------
-  const bool is_r = has_pos && st.mpos == r;
-  const bool evald = need_eval && (r_wide ? wide_ok : (r_slow && is_r));
-  st.cost = r_wide ? cost_w : cost_s;
-  const bool adopt = evald && (st.cost < st.c0);
-  // the run of `cand` passes a position iff the position ends up holding `cand`
+  st.cost = wide_ok ? cost_w : cost_o;
+  const bool adopt = need_eval && (st.cost < st.c0);
+  // the run of `cand` passes a position iff the position ends up holding `cand`; lanes outside the segment stop it
   const bool pass = neutral || (adopt && newval == cand);
-  const bool before_r = inr && st.mpos < r;
-  // slow path: the step ends at r whatever the outcome (the next step continues from r + 1)
-  const bool cont = before_r || (pass && !(r_slow && is_r));
   const unsigned lanes_pos = ((1u << (GS - 1)) - 1u) & ~1u;  // lanes 1..GS-2
-  const unsigned stop = gballot<GS>(!cont, gbase) & lanes_pos;
+  const unsigned stop = gballot<GS>(!pass, gbase) & lanes_pos;
   const int q = stop ? first_pos(stop) : nd;
   const int q_gl = glane_of(min(q, nd - 1));
-  const unsigned inr_m = gballot<GS>(inr, gbase), evald_m = gballot<GS>(evald, gbase), same_m = gballot<GS>(same_xr, gbase);
-  // q is decided in this step if it was evaluated or needs no evaluation; otherwise the next step starts there
-  const bool q_in = (q < nd) && ((inr_m >> q_gl) & 1u);
-  const bool q_real = q_in && (((evald_m >> q_gl) & 1u) || ((same_m >> q_gl) & 1u));
+  const unsigned inr_m = gballot<GS>(inr, gbase), adopt_m = gballot<GS>(adopt, gbase);
+  const bool q_in = (q < nd) && ((inr_m >> q_gl) & 1u);  // the stop is a position of the segment: decided in this step
+  const int n_in = min(nd, n_end - i);                   // positions of this step inside the segment
+  // second phase: behind a stop that kept its own value (PropagateRow's rule leaves d0 in place on a reject), every
+  // position is offered its predecessor's old value until one adopts
+  const bool phase_b = q_in && !((adopt_m >> q_gl) & 1u) && (q + 1 < n_in);
+  const unsigned takes_m = gballot<GS>(cost_b >= 0.f && st.mpos > q, gbase) & lanes_pos;
 
   int advance, rej_pos;
-  if (!has_need) {
-    advance = min(nd, n_end - i);
+  bool ends_adopting = false;
+  if (!q_in) {
+    advance = q;  // = n_in unless the group is idle
     rej_pos = -1;
+  } else if (phase_b) {
+    ends_adopting = takes_m != 0u;
+    rej_pos = ends_adopting ? first_pos(takes_m) : n_in - 1;
+    advance = rej_pos + 1;
   } else {
-    advance = q_real ? q + 1 : q;
-    rej_pos = q_real ? q : -1;
+    advance = q + 1;
+    rej_pos = q;
   }
+  const bool in_b = phase_b && st.mpos > q;  // (only read where mpos < advance)
+  const bool takes = in_b && ends_adopting && st.mpos == rej_pos;
+  // what the position holds after the step
+  const float stop_val = takes ? fminf(d_pred, fx - 1.f) : ((!in_b && adopt) ? newval : st.d0);
   const int src_gl = glane_of(max(rej_pos, 0));
-  const float stop_val = adopt ? newval : st.d0;  // what the position holds afterwards
   st.rej_d0 = __shfl(stop_val, gbase + src_gl, kWave);
   st.rej_pos = act ? rej_pos : -1;
   st.advance = act ? advance : 0;
-  st.adopt = adopt && has_need && (st.mpos < q || (q_real && st.mpos == q));
+  st.adopt = (adopt && !in_b) || takes;
+  if (takes) st.cost = cost_b;
+  st.val = st.mpos >= q ? stop_val : cand;
   if (!has_pos) st.mpos = -1;
   return st;
+}
+
+// offer[k] for chain position k (1-based as din / cin; din[k - 1] = the OLD value of its predecessor): the cost at
+// which the position adopts that value, or -1 if it keeps its own (equal value, equal sample column, or no smaller
+// cost) -- PropagateRow / PropagateCol's rule for one position (patchmatch_gpu.cu:156-171), evaluated by the lane alone.
+template <int AXIS>
+__device__ __forceinline__ float run2_gpu_offer(const View& v, const PlaneSet& ps, const CostParams& cp,
+                                                const SweepGeom& g, int chain, int k, const float* din,
+                                                const float* cin) {
+  const int pos = g.s_first + (k - 1) * g.dir;
+  const int px = AXIS == 0 ? pos : chain;
+  const int py = AXIS == 0 ? chain : pos;
+  const float fx = (float)px;
+  const float d0 = din[k], bval = din[k - 1];
+  const float xr0 = fmaxf(fx - d0, 1.f), xr1 = fmaxf(fx - bval, 1.f);
+  if (d0 == bval || xr0 == xr1) return -1.f;
+  const float c = gpu_cost_own<AXIS>(v, ps, px, py, xr1, cp);
+  return c < cin[k] ? c : -1.f;
 }
 
 }  // namespace pm

@@ -893,13 +893,15 @@ inline bool seed_fused_enabled() {
 // half-width k, written as an out_rows x out_cols map (row pitch out_pitch elements) scaled by inv_scale.
 //   PatchmatchGpu::SparseInit(iml, imr, f)   k = 2^f + 1,     out = image size, inv_scale = 1   (patchmatch_gpu.cu:436)
 //   Patchmatch::Initialize(iml, imr, f)      k = 2^(f-1) + 1, out = size / f,   inv_scale = 2^-f (patchmatch.cpp:75-81)
-// Enqueue-only.
+// Enqueue-only.  `stages`: which of the kSeedStages parts of the sequence to enqueue (bit i = part i; the parts of one
+// map must be enqueued in order on one stream) -- a caller with two views on two streams enqueues part i of both before
+// part i + 1 of either, so neither stream waits for the host to get through the other's whole sequence.
 static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                            int rows, int cols, int pitch, int k, int out_rows, int out_cols, float inv_scale, float* out,
-                           int out_pitch, hipStream_t stream) {
+                           int out_pitch, hipStream_t stream, unsigned stages) {
   const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
   hipError_t e;
-  if ((e = hipMemsetAsync(sc.counters, 0, kSeedCounters * sizeof(unsigned), stream)) != hipSuccess) return e;
+  if ((stages & 1u) && (e = hipMemsetAsync(sc.counters, 0, kSeedCounters * sizeof(unsigned), stream)) != hipSuccess) return e;
   const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
   const int md = sp.min_distance;
   const int gx = md >= 1 ? (cols + md - 1) / md : 0, gy = md >= 1 ? (rows + md - 1) / md : 0;
@@ -907,8 +909,10 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   const bool packed_ok = md >= 1 && cols <= 32768 && rows <= 32768;
   const bool fused = packed_ok && seed_select_lds_bytes(gx, gy) <= 150 * 1024 && seed_fused_enabled();
   // the sort treats 0 as "unused slot"; the fused selection only reads the first counters[1] keys
-  if (!fused && (e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess) return e;
-  {
+  if ((stages & 1u) && !fused &&
+      (e = hipMemsetAsync(sc.keys, 0, sizeof(unsigned long long) * sc.cap, stream)) != hipSuccess)
+    return e;
+  if (stages & 1u) {
     const int hb = sp.block_size / 2;
     const size_t lds = sizeof(unsigned) * (size_t)(kEigTileW + 2 * hb) * (kEigTileH + 2 * hb);
     const dim3 tiles((unsigned)((cols + kEigTileW - 1) / kEigTileW), (unsigned)((rows + kEigTileH - 1) / kEigTileH));
@@ -919,15 +923,16 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
     hipLaunchKernelGGL(kern, tiles, block, lds, stream, left, rows, cols, pitch, sp.block_size, sp.use_harris,
                        sp.harris_k, sc.eig, sc.counters);
   }
-  hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
-                     rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);
-  if (fused) {
+  if (stages & 2u)
+    hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
+                       rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);
+  if ((stages & 4u) && fused) {
     const size_t lds = seed_select_lds_bytes(gx, gy);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_seed_select_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_seed_select_fused, dim3(1), dim3(1024), lds, stream, (const unsigned long long*)sc.keys,
                        sc.cap, md, maxf, sp.quality_level, gx, gy, sc.kp_xy, sc.counters);
-  } else {
+  } else if (stages & 4u) {
     size_t tmp_bytes = sc.sort_tmp_bytes;
     if ((e = hipcub::DeviceRadixSort::SortKeysDescending(sc.sort_tmp, tmp_bytes, sc.keys, sc.keys_sorted, sc.cap, 0, 64,
                                                          stream)) != hipSuccess)
@@ -944,7 +949,7 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                          maxf, sc.kp_xy, sc.counters);
     }
   }
-  {
+  if (stages & 8u) {
     const size_t px_bytes = 4 * ((size_t)sp.templ_rows * ((sp.templ_cols + 3) / 4) +
                                  (size_t)(sp.templ_rows + 2) * ((sp.max_disp + 3) / 4 + 1));
     if (sp.subpixel_corners)
@@ -955,6 +960,7 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                        rows, cols, pitch, sc.kp_xy, sp.subpixel_corners ? (const float*)sc.kp_f : (const float*)nullptr,
                        sc.counters, sp, sc.kp_d, (const float*)sc.sp_mask, sc.sp_buf);
   }
+  if (!(stages & 16u)) return hipGetLastError();
   const bool resized = out_rows != rows || out_cols != cols;
   // full-size splat target: the output itself, or the (idle by now) response plane when a resize follows
   float* full = resized ? sc.eig : out;
@@ -980,17 +986,17 @@ hipError_t seed_corner_subpix(const SeedScratch& sc, const SeedParams& sp, const
 }
 hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
                                    const uint8_t* right, int rows, int cols, int pitch, int dilate_factor, float* out,
-                                   int out_pitch, hipStream_t stream) {
+                                   int out_pitch, hipStream_t stream, unsigned stages) {
   return seed_map(sc, sp, left, right, rows, cols, pitch, (1 << dilate_factor) + 1, rows, cols, 1.0f, out, out_pitch,
-                  stream);
+                  stream, stages);
 }
 // downsample_factor >= 1
 hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left,
                                   const uint8_t* right, int rows, int cols, int pitch, int downsample_factor, float* out,
-                                  int out_pitch, hipStream_t stream) {
+                                  int out_pitch, hipStream_t stream, unsigned stages) {
   const float inv = 1.0f / (float)(1 << downsample_factor);
   return seed_map(sc, sp, left, right, rows, cols, pitch, (1 << (downsample_factor - 1)) + 1, rows / downsample_factor,
-                  cols / downsample_factor, inv, out, out_pitch, stream);
+                  cols / downsample_factor, inv, out, out_pitch, stream, stages);
 }
 
 }  // namespace pm

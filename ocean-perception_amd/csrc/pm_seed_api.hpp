@@ -57,16 +57,20 @@ hipError_t seed_subpix_prepare(SeedScratch& sc, const SeedParams& sp, hipStream_
 // cv::cornerSubPix with the detector's window parameters of `sp` on n device points (needs seed_subpix_prepare)
 hipError_t seed_corner_subpix(const SeedScratch& sc, const SeedParams& sp, const uint8_t* img, int rows, int cols, int pitch,
                               float* d_xs, float* d_ys, int n, hipStream_t stream);
+// The launch sequence of one map comes in kSeedStages parts (bit i of `stages` = part i; all by default).  Parts of one
+// map go onto one stream in order; a caller with several maps on several streams may interleave them part by part.
+constexpr int kSeedStages = 5;
+constexpr unsigned kSeedAllStages = (1u << kSeedStages) - 1u;
 // `out`: a row-major map with out_pitch elements per row, or -- out_pitch < 0 -- one of the engine's state planes (four
 // rows interleaved, pm_device.hpp::state_at, pitch -out_pitch).
 // PatchmatchGpu::SparseInit(iml, imr, f)  (patchmatch_gpu.cu:414-442): dilation half-width 2^f + 1, map at image size
 hipError_t seed_sparse_init(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                             int rows, int cols, int pitch, int dilate_factor, float* out, int out_pitch,
-                            hipStream_t stream);
+                            hipStream_t stream, unsigned stages = kSeedAllStages);
 // Patchmatch::Initialize(iml, imr, f)  (patchmatch.cpp:60-84): half-width 2^(f-1) + 1, map of size / f, scaled by 2^-f;
 // downsample_factor >= 1
 hipError_t seed_initialize(const SeedScratch& sc, const SeedParams& sp, const uint8_t* left, const uint8_t* right,
                            int rows, int cols, int pitch, int downsample_factor, float* out, int out_pitch,
-                           hipStream_t stream);
+                           hipStream_t stream, unsigned stages = kSeedAllStages);
 
 }  // namespace pm

@@ -11,9 +11,9 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 // by default; beyond that the kernel needs its limit raised (160 KB per CU on gfx950: chains of up to ~10 000
 // positions).  run_sweep falls back to the serial engine for longer chains.
 constexpr size_t kChainLdsMax = 160 * 1024 - 1024;
-inline size_t chain_lds_bytes(int n, int extra_words) {
+inline size_t chain_lds_bytes(int n, int extra_words, int planes = 4) {
   const int n1 = (n + 1 + 3) & ~3;
-  return sizeof(float) * (4 * (size_t)n1 + (size_t)extra_words);
+  return sizeof(float) * ((size_t)planes * (size_t)n1 + (size_t)extra_words);
 }
 template <typename K>
 inline void allow_big_lds(K kernel, size_t bytes) {

@@ -67,7 +67,11 @@ int runblk_group(int semantics, int axis, float amp, int win, int dir = 1) {
     return (g == 8 || g == 16 || g == 32) ? g : 0;
   }();
   if (v) return v;
-  if (semantics != PM_SEM_CPU) return 16;
+  if (semantics != PM_SEM_CPU) {
+    static const int gpu_g[2] = {[] { const char* e = pm::tune_env("PM_GPU_GROUP_FWD"); return e ? atoi(e) : 16; }(),
+                                 [] { const char* e = pm::tune_env("PM_GPU_GROUP_BWD"); return e ? atoi(e) : 16; }()};
+    return gpu_g[dir < 0 ? 1 : 0];
+  }
   if (win <= 5) return 16;  // small windows leave 11+ positions in a 16-lane strip: 16 wins at every amplitude
   struct Thr {
     float t[2], tn[2];  // forward sweeps, backward sweeps (PM_G16_*_AMP_NEG)
@@ -96,7 +100,7 @@ void launch_sweep(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, 
   if (engine == PM_ENGINE_AUTO) engine = PM_ENGINE_RUNBLK2;
   // the chain engines hold a chain in LDS: beyond the CU's capacity only the serial engine remains
   if (engine != PM_ENGINE_SERIAL && !(engine == PM_ENGINE_WAVE && cp.semantics == PM_SEM_CPU) &&
-      chain_lds_bytes(chain_len, 4 * kMaxSegWaves + 4) > kChainLdsMax)
+      chain_lds_bytes(chain_len, 4 * kMaxSegWaves + 4, cp.semantics == PM_SEM_CPU ? 4 : 5) > kChainLdsMax)
     engine = PM_ENGINE_SERIAL;
   // PM_SEM_GPU has two parallel engines: lane-per-segment (WAVE) and the shared-tap run step (RUNBLK2)
   if (engine == PM_ENGINE_SERIAL) {
@@ -108,8 +112,12 @@ void launch_sweep(const PlaneSet& ps, const CostParams& cp, const SweepGeom& g, 
     const int group = runblk_group(cp.semantics, g.axis, amp, g.axis == 0 ? cp.pw : cp.ph, g.dir);
     if (cp.semantics == PM_SEM_CPU)
       launch_sweep_run3(ps, cp, g, slots, runblk_waves(chain_len, chains * slots, g.axis, group), group, stream);
-    else
-      launch_sweep_run2(ps, cp, g, slots, runblk_waves(chain_len, chains * slots, g.axis, group), group, stream);
+    else {
+      static const int gpu_w[2] = {[] { const char* e = pm::tune_env("PM_GPU_WAVES_FWD"); return e ? atoi(e) : 0; }(),
+                                   [] { const char* e = pm::tune_env("PM_GPU_WAVES_BWD"); return e ? atoi(e) : 0; }()};
+      const int wv = gpu_w[g.dir < 0 ? 1 : 0];
+      launch_sweep_run2(ps, cp, g, slots, wv ? wv : runblk_waves(chain_len, chains * slots, g.axis, group), group, stream);
+    }
   }
 }
 
