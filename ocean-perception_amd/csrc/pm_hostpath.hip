@@ -483,10 +483,47 @@ int pm_match_batch_u8(pm_handle* h, int n, const uint8_t* const* left, const uin
   return rc_all;
 }
 
+#ifdef PM_HOST_PHASES  // analysis builds: where the HOST spends a pm_match_u8 call (stderr, every 25th call)
+#include <chrono>
+namespace {
+struct HostPhases {
+  static constexpr int kN = 8;
+  double sum[kN] = {};
+  std::chrono::steady_clock::time_point last, exit_of_last;
+  bool have_exit = false;
+  int calls = 0;
+  void begin() {
+    last = std::chrono::steady_clock::now();
+    if (have_exit) sum[0] += std::chrono::duration<double, std::micro>(last - exit_of_last).count();
+  }
+  void mark(int k) {
+    const auto t = std::chrono::steady_clock::now();
+    sum[k] += std::chrono::duration<double, std::micro>(t - last).count();
+    last = t;
+  }
+  void end() {
+    exit_of_last = std::chrono::steady_clock::now();
+    have_exit = true;
+    if (++calls % 25 == 0) {
+      const char* names[kN] = {"between calls", "checks + noise", "uploads", "enqueue", "downloads enqueued", "wait left", "unpack left", "wait + unpack right"};
+      fprintf(stderr, "pm_match_u8 host phases, us per call:");
+      for (int k = 0; k < kN; ++k) fprintf(stderr, " %s %.1f;", names[k], sum[k] / 25.0), sum[k] = 0.0;
+      fprintf(stderr, "\n");
+    }
+  }
+};
+HostPhases g_hp;
+}  // namespace
+#define HP(x) g_hp.x
+#else
+#define HP(x) (void)0
+#endif
+
 int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int rows, int cols, size_t image_step,
                 const float* seed_l, const float* seed_r, size_t seed_step, float* disp_l, float* disp_r,
                 size_t disp_step) {
   if (!h) return PM_ERR_INVALID_ARG;
+  HP(begin());
   if (int rc = refuse_while_capturing(h, "pm_match_u8")) return rc;
   if (!left || !right || !disp_l) {
     set_err(h, "pm_match_u8: null image or output pointer");
@@ -517,15 +554,18 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
   // every plane goes up as soon as it is ready -- by DMA from the caller's buffer if that is page-locked, else packed
   // into the pinned slab by a few host threads (pm_hostcopy.hpp): the DMA of one plane runs while the host packs the next
   if (!h->copy_pool) h->copy_pool = new pm::CopyPool();
+  HP(mark(1));
   if (int rc = upload_plane(h, h->st_left, left, image_step, (size_t)cols, rows, ps.l, h->stream)) return rc;
   if (int rc = upload_plane(h, h->st_right, right, image_step, (size_t)cols, rows, ps.r, h->stream)) return rc;
   if (seed_l)
     if (int rc = upload_plane(h, h->st_seed_l, seed_l, seed_step, frow, rows, ps.sl, h->stream)) return rc;
   if (seed_r)
     if (int rc = upload_plane(h, h->st_seed_r, seed_r, seed_step, frow, rows, ps.sr, h->stream)) return rc;
+  HP(mark(2));
   if (int rc = match_device_impl(h, 1, h->st_left, h->st_right, rows, cols, seed_l ? h->st_seed_l : nullptr,
                                seed_r ? h->st_seed_r : nullptr, h->st_disp_l, lr ? h->st_disp_r : nullptr))
     return rc;
+  HP(mark(3));
   // the left map is unpacked into the caller's buffer while the right one is still on the bus
   if (!h->left_out) {
     PM_HIP(h, hipEventCreateWithFlags(&h->left_out, hipEventDisableTiming));
@@ -538,12 +578,17 @@ int pm_match_u8(pm_handle* h, const uint8_t* left, const uint8_t* right, int row
     if (int rc = download_plane(h, disp_r, disp_step, h->st_disp_r, frow, rows, ps.dr, h->stream, &direct_r)) return rc;
     PM_HIP(h, hipEventRecord(h->right_out, h->stream));
   }
+  HP(mark(4));
   PM_HIP(h, hipEventSynchronize(h->left_out));
+  HP(mark(5));
   if (!direct_l) h->copy_pool->Copy2D(disp_l, disp_step, ps.dl, frow, frow, rows);
+  HP(mark(6));
   if (lr) {
     PM_HIP(h, hipEventSynchronize(h->right_out));
     if (!direct_r) h->copy_pool->Copy2D(disp_r, disp_step, ps.dr, frow, frow, rows);
   }
+  HP(mark(7));
+  HP(end());
   return PM_OK;
 }
 

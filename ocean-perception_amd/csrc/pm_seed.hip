@@ -21,6 +21,7 @@ hipError_t seed_scratch_alloc(SeedScratch& sc, size_t plane_elems, hipStream_t s
   sc.sp_mask_win = sc.sp_mask_zero = 0;
   sc.sort_tmp = nullptr;
   sc.sort_tmp_bytes = 0;
+  sc.counters_clean = false;
   if ((e = hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sc.sort_tmp_bytes, sc.keys, sc.keys_sorted, sc.cap, 0, 64,
                                                        stream)) != hipSuccess)
     return e;

@@ -177,11 +177,19 @@ __device__ inline int seed_first_shift(unsigned maxbits, unsigned thrbits) {
 // global atomic (same-address atomics cost ~11 ns each on this chip: per-candidate or even per-wavefront
 // appends made this kernel take 159 us at 720p).  The order of the keys is irrelevant: they are sorted next.
 constexpr int kNmsRows = 8;
+// `zero` (may be null): n4 float4 the launch clears on the side -- the plane the corners are splatted into later in the
+// sequence (one memset launch less per map).
 __global__ void __launch_bounds__(256) k_seed_nms(const float* __restrict__ eig, int rows, int cols, int pitch,
                                                   double quality, unsigned long long* __restrict__ keys,
-                                                  unsigned* __restrict__ counters, int cap) {
+                                                  unsigned* __restrict__ counters, int cap, float4* __restrict__ zero,
+                                                  unsigned n4) {
   __shared__ unsigned long long s_keys[256 * kNmsRows];
   __shared__ unsigned s_count, s_base;
+  if (zero) {
+    const unsigned nthreads = gridDim.x * gridDim.y * 256u;
+    for (unsigned e = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x; e < n4; e += nthreads)
+      zero[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,7 +257,10 @@ __global__ void __launch_bounds__(64) k_seed_select(const unsigned long long* __
       }
     }
   }
-  if (lane == 0) counters[2] = (unsigned)count;
+  if (lane == 0) {
+    counters[2] = (unsigned)count;
+    counters[0] = counters[1] = counters[3] = 0u;  // ready for the next map (SeedScratch::counters_clean)
+  }
 }
 
 // The same greedy selection with the accepted corners kept in a uniform GRID in LDS (cells of min_distance pixels,
@@ -268,6 +279,7 @@ __global__ void __launch_bounds__(64) k_seed_select_grid(const unsigned long lon
   for (int e = lane; e < gx * gy * 4; e += 64) s_cell[e] = -1;
   __builtin_amdgcn_s_waitcnt(0xc07f);
   const int ncand = min((int)counters[1], cap);
+  if (lane == 0) counters[3] = 0u;  // this map's overflow flag (set below, by this lane)
   const int md2 = min_distance * min_distance;
   // cell of a coordinate: floor(v / min_distance) up to float rounding -- any monotone map whose cells are at
   // least min_distance - 1 wide keeps two points closer than min_distance in adjacent cells, which is all the
@@ -317,7 +329,10 @@ __global__ void __launch_bounds__(64) k_seed_select_grid(const unsigned long lon
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the grid entries are visible to the next batch
   }
-  if (lane == 0) counters[2] = (unsigned)count;
+  if (lane == 0) {
+    counters[2] = (unsigned)count;
+    counters[0] = counters[1] = 0u;  // ready for the next map (SeedScratch::counters_clean)
+  }
 }
 
 // Sort + selection in ONE workgroup, without sorting what the greedy loop never looks at.  The loop stops after
@@ -395,13 +410,22 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
   const int md2 = min_distance * min_distance;
   const float inv_md = 1.0f / (float)min_distance;
   const unsigned maxbits = counters[0];
+  if (tid == 0) counters[3] = 0u;  // this map's overflow flag (set below by lanes of the same wavefront, later in program order)
   const unsigned thrbits = __builtin_bit_cast(unsigned, (float)((double)__builtin_bit_cast(float, maxbits) * quality));
   const int sh_top = seed_first_shift(maxbits, thrbits);
   const int want0 = min(kSelChunk, max(512, 4 * max_features));
   int count = 0, remaining = ncand;
   unsigned long long upper = ~0ull;  // keys >= upper are consumed
   __syncthreads();
+#ifdef PM_SEL_TRACE
+  unsigned long long tr_t[5] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0};
+  int tr_chunks = 0;
+#define TR(k) { const unsigned long long t_ = wall_clock64(); tr_t[k] += t_ - tr_t[0]; tr_t[0] = t_; }
+#else
+#define TR(k)
+#endif
   while (remaining > 0 && count < max_features) {
+    TR(4);
     // ---- 1. threshold
     unsigned long long tau = 0ull;
     if (remaining > want0) {
@@ -451,6 +475,7 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
         sh = nsh;
       }
     }
+    TR(1);
     // ---- 2. gather [tau, upper) ...
     if (tid == 0) s_misc[0] = 0u;
     for (int e = tid; e < kSelHist; e += 1024) s_hist[e] = 0u;
@@ -522,6 +547,7 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
     for (int u = 0; u < 2; ++u)
       if (tid + 1024 * u < n) s_tmp[mybin[u]] = mykey[u];
     __syncthreads();
+    TR(2);
     // ---- 3. greedy selection over the sorted chunk (wavefront 0; see k_seed_select_grid).  The grid carries a
     // border of cells that stay empty, so the 3x3 lookup needs no bounds tests: nine 16-byte reads, no branches.
     if (tid < 64) {
@@ -576,8 +602,19 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
     remaining -= n;
     upper = tau;
     __syncthreads();
+    TR(3);
+#ifdef PM_SEL_TRACE
+    ++tr_chunks;
+#endif
   }
-  if (tid == 0) counters[2] = (unsigned)count;
+#ifdef PM_SEL_TRACE
+  if (tid == 0) printf("select: ncand %d accepted %d chunks %d; ticks (10 ns) threshold %llu gather+sort %llu greedy %llu\n", ncand, count, tr_chunks, tr_t[1], tr_t[2], tr_t[3]);
+#endif
+  __syncthreads();  // every thread has read counters[0] and [1]
+  if (tid == 0) {
+    counters[2] = (unsigned)count;
+    counters[0] = counters[1] = 0u;  // ready for the next map (SeedScratch::counters_clean)
+  }
 }
 
 // ---- cv::cornerSubPix on the device (oracle: pm_seed_oracle.c::pmo_corner_subpix, which cites the OpenCV source it
@@ -901,7 +938,19 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                            int out_pitch, hipStream_t stream, unsigned stages) {
   const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
   hipError_t e;
-  if ((stages & 1u) && (e = hipMemsetAsync(sc.counters, 0, kSeedCounters * sizeof(unsigned), stream)) != hipSuccess) return e;
+  if (stages & 1u) {
+    if (!sc.counters_clean && (e = hipMemsetAsync(sc.counters, 0, kSeedCounters * sizeof(unsigned), stream)) != hipSuccess)
+      return e;
+    sc.counters_clean = false;  // until this map's selection kernel is behind them
+  }
+  // the plane the corners are splatted into: the output itself, or the (idle by then) response plane when a resize
+  // follows.  An engine state plane (16-byte multiples) is cleared by the suppression kernel on the side.
+  const bool resized = out_rows != rows || out_cols != cols;
+  float* full = resized ? sc.eig : out;
+  const int full_pitch = resized ? pitch : out_pitch;
+  const size_t full_elems = full_pitch < 0 ? (size_t)((rows + 3) & ~3) * (size_t)(-full_pitch) : (size_t)rows * full_pitch;
+  const bool zero_in_nms = !resized && full_pitch < 0 && (full_elems % 4) == 0 && ((uintptr_t)full % 16) == 0 &&
+                           full_elems / 4 < 0xffffffffull;
   const int maxf = sp.max_features < kSeedMaxFeatures ? sp.max_features : kSeedMaxFeatures;
   const int md = sp.min_distance;
   const int gx = md >= 1 ? (cols + md - 1) / md : 0, gy = md >= 1 ? (rows + md - 1) / md : 0;
@@ -925,7 +974,8 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
   }
   if (stages & 2u)
     hipLaunchKernelGGL(k_seed_nms, dim3(grid.x, (unsigned)((rows + kNmsRows - 1) / kNmsRows)), block, 0, stream, sc.eig,
-                       rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap);
+                       rows, cols, pitch, sp.quality_level, sc.keys, sc.counters, sc.cap,
+                       zero_in_nms ? (float4*)full : (float4*)nullptr, (unsigned)(full_elems / 4));
   if ((stages & 4u) && fused) {
     const size_t lds = seed_select_lds_bytes(gx, gy);
     if (lds > 64 * 1024)
@@ -949,6 +999,7 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                          maxf, sc.kp_xy, sc.counters);
     }
   }
+  if (stages & 4u) sc.counters_clean = hipPeekAtLastError() == hipSuccess;
   if (stages & 8u) {
     const size_t px_bytes = 4 * ((size_t)sp.templ_rows * ((sp.templ_cols + 3) / 4) +
                                  (size_t)(sp.templ_rows + 2) * ((sp.max_disp + 3) / 4 + 1));
@@ -961,12 +1012,7 @@ static hipError_t seed_map(const SeedScratch& sc, const SeedParams& sp, const ui
                        sc.counters, sp, sc.kp_d, (const float*)sc.sp_mask, sc.sp_buf);
   }
   if (!(stages & 16u)) return hipGetLastError();
-  const bool resized = out_rows != rows || out_cols != cols;
-  // full-size splat target: the output itself, or the (idle by now) response plane when a resize follows
-  float* full = resized ? sc.eig : out;
-  const int full_pitch = resized ? pitch : out_pitch;
-  const size_t full_elems = full_pitch < 0 ? (size_t)((rows + 3) & ~3) * (size_t)(-full_pitch) : (size_t)rows * full_pitch;
-  if ((e = hipMemsetAsync(full, 0, sizeof(float) * full_elems, stream)) != hipSuccess) return e;
+  if (!zero_in_nms && (e = hipMemsetAsync(full, 0, sizeof(float) * full_elems, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_seed_splat, dim3((unsigned)(maxf > 0 ? maxf : 1)), block, 0, stream, (const int*)sc.kp_xy,
                      (const float*)sc.kp_d, (const unsigned*)sc.counters, rows, cols, k, inv_scale, full, full_pitch,
                      sp.subpixel_corners);

@@ -43,6 +43,9 @@ struct SeedScratch {
   void* sort_tmp;
   size_t sort_tmp_bytes;
   int cap;
+  // the selection kernels leave counters[0], [1] and [3] at zero for the next map; false after an allocation or an
+  // enqueue that did not get as far as the selection: the next map then starts with a memset
+  mutable bool counters_clean;
 };
 
 // Allocates the scratch for planes of `plane_elems` pixels (rows x pitch of the plan).  Every pixel can be a candidate:
