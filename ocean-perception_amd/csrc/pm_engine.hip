@@ -488,7 +488,7 @@ int join_stream(pm_handle* h, hipStream_t from, hipEvent_t ev, hipStream_t onto)
 // a process of its own and at 400-435 beside other handles, depending on whether a view stream ended up behind the
 // download stream's waits: profiles/r04_stream_matrix.txt).  This creates the events the view streams fork and join on.
 int view_streams_create(pm_handle* h) {
-  if (h->view_fork && h->view1_join && h->out_join && h->in_join) return PM_OK;
+  if (h->view_fork && h->view1_join && h->out_join && h->in_join && h->view_end[0] && h->view_end[1]) return PM_OK;
   if (h->capturing) {
     set_err(h, "the view events do not exist yet: run this call once before capturing it");
     return PM_ERR_BUSY;
@@ -497,6 +497,8 @@ int view_streams_create(pm_handle* h) {
   if (!h->view1_join) PM_HIP(h, hipEventCreateWithFlags(&h->view1_join, hipEventDisableTiming));
   if (!h->out_join) PM_HIP(h, hipEventCreateWithFlags(&h->out_join, hipEventDisableTiming));
   if (!h->in_join) PM_HIP(h, hipEventCreateWithFlags(&h->in_join, hipEventDisableTiming));
+  for (int v = 0; v < 2; ++v)
+    if (!h->view_end[v]) PM_HIP(h, hipEventCreate(&h->view_end[v]));
   return PM_OK;
 }
 
@@ -571,11 +573,30 @@ int run_views(pm_handle* h, const PlaneSet& ps, int slots, const ViewSetup* setu
       if (int rc = seed_views(h, ps, slots / ps.n_views, v, 0)) return rc;
     return run_one_view_set(h, ps, slots);
   }
-  // the first view stays on the caller's stream, only the second forks off
+  // one view stays on the caller's stream, the other forks off
   if (int rc = view_streams_create(h)) return rc;
   PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
-  hipStream_t vs[2] = {h->stream, h->view1_stream};
+  // the view that ended last the time before stays on the handle's stream, the other one forks off (pm_handle::late_view)
+  if (!h->capturing && h->view_end_recorded) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->view_end[0], h->view_end[1]) == hipSuccess) {
+      h->late_view = ms >= 0.f ? 1 : 0;
+      h->view_end_recorded = false;
+    } else {
+      (void)hipGetLastError();  // that call is still running: ask again next time
+    }
+  }
+  static const int force_late = [] { const char* e = pm::tune_env("PM_LATE_VIEW"); return e ? atoi(e) : -1; }();  // tuning builds
+  if (force_late == 0 || force_late == 1) h->late_view = force_late;
+  hipStream_t vs[2];
+  vs[h->late_view] = h->stream;
+  vs[1 - h->late_view] = h->view1_stream;
   if (int rc = run_views_on(h, ps, slots, setup, vs, &h->view_fork, 1)) return rc;
+  // sampled: a timed event is a command of its own on the stream, in front of the join of every call it is recorded in
+  if (!h->capturing && !h->view_end_recorded && (h->view_calls++ % pm_handle::kViewEndEvery) == 0) {
+    for (int v = 0; v < 2; ++v) PM_HIP(h, hipEventRecord(h->view_end[v], vs[v]));
+    h->view_end_recorded = true;
+  }
   return join_stream(h, h->view1_stream, h->view1_join, h->stream);
 }
 
@@ -1030,7 +1051,8 @@ void pm_destroy(pm_handle* h) {
   for (hipStream_t st : streams)
     if (st) (void)hipStreamSynchronize(st);
   pm_internal::release_imaging(h);
-  hipEvent_t events[] = {h->ext_fork, h->ext_join, h->left_out, h->right_out, h->view1_join, h->out_join, h->in_join, h->view_fork};
+  hipEvent_t events[] = {h->ext_fork, h->ext_join, h->left_out, h->right_out, h->view1_join, h->out_join, h->in_join, h->view_fork,
+                         h->view_end[0], h->view_end[1]};
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);

@@ -137,6 +137,14 @@ struct pm_handle {
   hipEvent_t view_fork = nullptr;
   hipStream_t view1_stream = nullptr;
   hipEvent_t view1_join = nullptr;
+  // Which view of a single pair ended last the time before (view_end: timed events behind the views' last launches).
+  // That view goes onto the handle's stream: a join the waiting stream reaches AFTER its event has fired costs nothing,
+  // one it reaches before costs a cross-queue wake-up (~12 us of the reference's own 0.46 ms call).
+  hipEvent_t view_end[2] = {nullptr, nullptr};
+  bool view_end_recorded = false;
+  static constexpr unsigned kViewEndEvery = 16;  // the order is sampled in every 16th single-pair call
+  unsigned view_calls = 0;
+  int late_view = 1;
   hipEvent_t out_join = nullptr;  // s_out -> the handle's stream at the end of a batch
   hipEvent_t in_join = nullptr;   // s_in -> the handle's stream (only when a capture is ended with the head stream unjoined)
   void* imaging_state = nullptr;  // owned by pm_imaging.hip (pm_internal.hpp)
