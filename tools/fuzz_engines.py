@@ -17,12 +17,13 @@ ap.add_argument("--cases", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="sizes up to 2600 x 1800: chains beyond 1600 positions (8 wavefronts per chain),\n"
                 "column sweeps whose reference lines no longer fit the LDS budget")
+ap.add_argument("--gpu-share", type=float, default=0.2, help="share of PM_SEM_GPU cases")
 a = ap.parse_args()
 pm.load()
 rng = np.random.default_rng(a.seed)
 t0 = time.time()
 for case in range(a.cases):
-    sem = 0 if rng.random() < 0.8 else 1
+    sem = 1 if rng.random() < a.gpu_share else 0
     patch = int(rng.choice([3, 5, 7, 9, 11])) if sem == 0 else 3
     rows = int(rng.integers(2 * patch + 8, 260))
     cols = int(rng.integers(2 * patch + 40, 700))
