@@ -1067,7 +1067,7 @@ void pm_destroy(pm_handle* h) {
   }
   void* dev[] = {h->rpg,     h->rqk,      h->cpg,       h->img8,      h->g32,       h->g8,        h->timg8,
                  h->tg32,    h->tg8,      h->pk16,      h->tpk16,     h->disp,      h->cost,      h->noise,
-                 h->counters, h->st_left, h->st_right,  h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r,
+                 h->counters, h->st_left, h->st_seed_l, h->st_seed_r, h->st_disp_l, h->st_disp_r,
                  h->snap_disp, h->snap_cost, h->planes_state, h->texmask_scratch};
   for (auto& sc : h->seeds) seed_scratch_free(sc);
   for (void* p : dev)
@@ -1156,8 +1156,9 @@ int pm_create(const pm_params* params, int device, int max_rows, int max_cols, i
   if (params->mode == PM_MODE_PLANES)
     if (int rc = planes_alloc(h)) return rc;
   const size_t tight = (size_t)max_rows * max_cols;
-  PM_HIP(h, hipMalloc((void**)&h->st_left, B * tight));
-  PM_HIP(h, hipMalloc((void**)&h->st_right, B * tight));
+  // one block: a single small pair goes up as ONE copy, left and right back to back (pm_hostpath.hip::pm_match_u8)
+  PM_HIP(h, hipMalloc((void**)&h->st_left, 2 * B * tight + 64));
+  h->st_right = h->st_left + B * tight;
   PM_HIP(h, hipMalloc((void**)&h->st_seed_l, sizeof(float) * B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_seed_r, sizeof(float) * B * tight));
   PM_HIP(h, hipMalloc((void**)&h->st_disp_l, sizeof(float) * B * tight));

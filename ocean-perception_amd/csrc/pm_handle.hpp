@@ -335,6 +335,7 @@ void launch_tile_presweep(pm_handle* h, const PlaneSet& ps, float* snap_disp, fl
 // rows x cols floats from tight device memory into page-locked host memory (its DEVICE address), row stride in floats
 void launch_download(pm_handle* h, float* dst_dev, size_t dst_step_floats, const float* d_src, int rows, int cols,
                      hipStream_t stream);
+void launch_upload(pm_handle* h, float* d_dst, const float* src_dev, int words, hipStream_t stream);
 void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src);
 void launch_copy_out(pm_handle* h, const PlaneSet& ps, float* d_dst, int which);
 void launch_copy_disp_strided(pm_handle* h, const PlaneSet& ps, float* d_buf, size_t stride, int to_buf);

@@ -1,5 +1,7 @@
 // pm_launch.hip -- the translation unit of the scalar-mode kernels (pm_kernels.hpp): one launch function per kernel,
 // declared in pm_handle.hpp, each enqueuing on the handle's current stream.  No other unit includes pm_kernels.hpp.
+#include <algorithm>
+
 #include "pm_handle.hpp"
 #include "pm_kernels.hpp"
 #include "pm_sweeps.hpp"
@@ -185,6 +187,13 @@ void launch_restore_cols(pm_handle* h, const PlaneSet& ps, const float* snap_dis
 void launch_download(pm_handle* h, float* dst_dev, size_t dst_step_floats, const float* d_src, int rows, int cols,
                      hipStream_t stream) {
   hipLaunchKernelGGL(k_download, dim3(kDownloadBlocks), dim3(256), 0, stream, dst_dev, dst_step_floats, d_src, rows, cols);
+}
+
+// the same copy kernel the other way: `words` floats from page-locked host memory (device address) into device memory, one
+// 16-byte load per lane where the grid allows (every load is a round trip over the bus)
+void launch_upload(pm_handle* h, float* d_dst, const float* src_dev, int words, hipStream_t stream) {
+  const int blocks = std::min(64, std::max(1, (words / 4 + 255) / 256));
+  hipLaunchKernelGGL(k_download, dim3((unsigned)blocks), dim3(256), 0, stream, d_dst, (size_t)words, src_dev, 1, words);
 }
 
 void launch_copy_in(pm_handle* h, const PlaneSet& ps, const float* d_src) {

@@ -11,18 +11,28 @@
 // S[X] = fl(X - v).  They do unless x - v and x -+ 1 - v fall into different binades, which the step
 // checks per position (the samples are compared as floats, no tolerance).
 //
-// A step therefore works like pm_run2.hpp::run_step2: the 32 lanes of a group hold 32 consecutive
-// columns (row sweep) or rows (column sweep, on the transposed planes); every lane computes the three
-// tap values of its column/row the five-tap pattern can ask for; a position gathers its five taps from
-// its own lane and its two neighbours (DPP wave_shl / wave_shr) and adds them in the reference's order.
-// 30 positions per group and step.  Positions whose candidate is clamped (x - v < 1) or whose neighbour
-// samples disagree are evaluated alone, exactly like k_sweep_gpu_lanes does (slow path: lanes 0-4 of the
-// group take one tap each).
+// A step therefore works like pm_run2.hpp::run_step2: the lanes of a group hold consecutive columns (row sweep) or rows
+// (column sweep, on the transposed planes); every lane computes the three tap values of its column/row the five-tap
+// pattern can ask for; a position gathers its five taps from its own lane and its two neighbours (DPP wave_shl /
+// wave_shr) and adds them in the reference's order: GS - 2 positions per group and step.  Positions whose candidate is
+// clamped (x - v < 1) or whose neighbour samples disagree compute all five taps themselves (gpu_cost_own), in the same
+// step.
 //
 // Rule per position holding (d0, c0), predecessor value v (pm_device.hpp::sweep_step, semantics 1):
 //   xr0 = max(x - d0, 1), xr1 = max(x - v, 1);  xr0 == xr1 -> unchanged;
 //   else c1 = cost(xr1); c1 < c0 -> (min(v, x - 1), c1); else unchanged.
 // The run of v continues through a position iff the position ends up holding v.
+//
+// Two candidates per step (round 6).  With a 3 x 3 window most positions of a converged map REJECT what their
+// predecessor offers: the run of v stops after one or two positions and a step was spent per stop -- 13 steps for a
+// segment of 23 positions on the reference's own 376 x 240 call.  But behind a stop that kept its own value the next
+// candidate is that position's OLD value, and so on for every further position that keeps its value: what position p
+// does when offered d0[p - 1] depends on the state before the sweep only.  k_runblk2 evaluates that for every position
+// of the chain in one parallel pass before the first step (`offer`: the cost if p adopts, -1 if it declines -- one
+// five-tap evaluation per position, all lanes busy), and a step then runs through the stop AND through all following
+// positions that decline, up to and including the first one that adopts its predecessor's old value (whose new value is
+// the next step's candidate).  Steps per segment on that call: 12.9 -> 4.9 (rows), 8.7 -> 3.0 (columns); results
+// identical by construction -- every decision is the rule above with the value the predecessor really ends up holding.
 #pragma once
 
 namespace pm {
