@@ -529,11 +529,14 @@ def reference_test_shape_leg(pm, args, device):
                        "(patchmatch_gpu_test.cpp:68-88)",
            "ms_per_call_first_five": [round(c, 3) for c in calls], "ms_per_call_steady_median": med,
            "pairs_per_s_steady": 1e3 / med, "equals_the_golden_row_checksums": same,
-           "note": "bound by one view's chain of dependent launches on the device -- 12 sweeps of 25-60 us each on 240 / 376 "
-                   "short chains, back to back without gaps (kernel trace: profiles/r06_reference_call_timeline.txt), so "
-                   "a cooperative kernel with grid barriers has no launch latency to save; a recorded HIP graph (0.71 ms) "
-                   "and both views per launch (0.69 ms) were built in round 5, measured slower and removed: "
-                   "profiles/r05_reference_call_pattern.txt"}
+           "note": "round 6: 0.64 -> 0.45 ms.  The sweeps of this 3x3-window semantics were bound by run steps that ended at "
+                   "every position rejecting its predecessor's value (13 steps per 23-position segment); the step now "
+                   "also follows the predecessor's OLD value through the positions that decline it, from a per-chain "
+                   "pre-pass (4.9 steps), clamped positions no longer take a step each, the seeder lost two memset "
+                   "launches per view, the view that ends last stays on the handle's stream (no cross-queue wake-up in "
+                   "front of the cross-check) and the pair goes up as one kernel copy.  What is left: 12 sweeps of "
+                   "13-27 us per view back to back, a 107 us seeder head (its selection kernel 46 us), ~70 us on the host "
+                   "between two calls: profiles/r06_reference_call_timeline.txt"}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O

@@ -13,9 +13,12 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pm::", "")[:60], r["Queue_Id"]) for r in rows)
 fin = [i for i, e in enumerate(ev) if "k_finalize" in e[2]]
-a, b = fin[-3] + 1, fin[-2] + 1   # the launches of the second to last call
+# the call of median length among the steady-state ones (launches from behind one k_finalize up to the next)
+calls = sorted(((ev[fin[j + 1]][1] - ev[fin[j] + 1][0]), j) for j in range(5, len(fin) - 1))
+j = calls[len(calls) // 2][1]
+a, b = fin[j] + 1, fin[j + 1] + 1
 t0 = ev[a][0]
-print("launches of one call: %d; first start -> last end %.1f us; previous call's finalize end -> first start %.1f us" % (b - a, (ev[b - 1][1] - t0) / 1e3, (t0 - ev[a - 1][1]) / 1e3))
+print("launches of the median call of %d: %d; first start -> last end %.1f us; previous call's finalize end -> first start %.1f us" % (len(calls), b - a, (ev[b - 1][1] - t0) / 1e3, (t0 - ev[a - 1][1]) / 1e3))
 qs = sorted(set(e[3] for e in ev[a:b]))
 for e in ev[a:b]:
     print("%8.1f %8.1f  %6.1f us  q%-2d %s" % ((e[0] - t0) / 1e3, (e[1] - t0) / 1e3, (e[1] - e[0]) / 1e3, qs.index(e[3]), e[2]))
