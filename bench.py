@@ -712,9 +712,13 @@ def timed_loop(w, d, steps, warmup, every, no_profile):
     return elapsed, prof, n_prof, stats
 
 
-def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbours=0):
+def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbours=0, nb=1):
     """One plane-mode measurement for the default run's JSON line (rank 0, N=1).  plane_neighbours = 1: the spatial stage's
-    two-neighbour option (pm_params.plane_neighbours = PM_PL_NEIGH_TWO), an option, not the default."""
+    two-neighbour option (pm_params.plane_neighbours = PM_PL_NEIGH_TWO), an option, not the default.  nb > 1: batches of nb
+    pairs per call (BASELINE configs[2] / [4] are batches: the engine advances the two halves of a batch on two streams)."""
+    import argparse
+    args = argparse.Namespace(**vars(args))
+    args.pairs_per_gpu = nb
     class NoDist:
         def barrier(self):
             pass
@@ -722,7 +726,7 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
         def max_over_ranks(self, v):
             return v
     w = Workload(args, pm, torch, np, synth, dev, d.local_rank, d.rank, "planes", state, enhance, plane_neighbours)
-    steps = 16
+    steps = 16 if nb == 1 else max(4, 32 // nb)
     # (six warm-up steps: the engine's creation leaves the GPU idle for a few hundred ms and its clocks take ~20 ms of
     # work to come back; with two warm-up steps the leg read 3 % low.  Every 8th step carries per-kernel events, as in
     # the headline loop: a profiled step is ~3 % slower -- 33 launches bracketed by events -- and with every 4th of 12
@@ -735,7 +739,8 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
                        f"{state} plane/cost state" + (", stereo-ready enhancement of both BGR images fused into the "
                                                       "Match's load path (pm_match_bgr_device; BASELINE configs[4] per-GPU shape)" if enhance
                                                       else " (BASELINE configs[1] shape)") +
-                       ("; spatial stage with TWO neighbours per pass (PM_PL_NEIGH_TWO: an option, not the default)" if plane_neighbours else ""),
+                       ("; spatial stage with TWO neighbours per pass (PM_PL_NEIGH_TWO: an option, not the default)" if plane_neighbours else "") +
+                       (f"; batches of {nb} pairs per call, the halves of a batch on two streams" if nb > 1 else ""),
            "value": w.nb * steps / elapsed, "unit": "pairs/s", "ms_per_frame": 1e3 * elapsed / steps / w.nb, "steps": steps,
            "step_ms": step_stats,
            "dtype": "u8 window cost, " + state + " state",
@@ -1044,7 +1049,14 @@ def main():
         if d.world == 1 and not planes and not args.no_side_legs and nb == 1:
             result["planes"] = {"f32": side_leg(args, pm, torch, np, synth, dev, d, "f32", False),
                                 "f16_enhanced": side_leg(args, pm, torch, np, synth, dev, d, "f16", True),
-                                "f32_two_neighbours": side_leg(args, pm, torch, np, synth, dev, d, "f32", False, 1)}
+                                "f32_two_neighbours": side_leg(args, pm, torch, np, synth, dev, d, "f32", False, 1),
+                                "f32_batch4": side_leg(args, pm, torch, np, synth, dev, d, "f32", False, nb=4),
+                                "f16_enhanced_batch4": side_leg(args, pm, torch, np, synth, dev, d, "f16", True, nb=4)}
+            pl = result["planes"]
+            if pl["f32"].get("_maps") is not None and pl["f32_batch4"].get("_maps") is not None:
+                pl["f32_batch4"]["check"]["slot_0_equals_the_single_pair_leg"] = bool(
+                    np.array_equal(pl["f32"]["_maps"][0], pl["f32_batch4"]["_maps"][0]) and
+                    np.array_equal(pl["f32"]["_maps"][1], pl["f32_batch4"]["_maps"][1]))
         plane_maps = {k: v.pop("_maps", None) for k, v in result.get("planes", {}).items()}
         if d.world == 1 and not args.no_cpu_baseline:
             # the CPU baselines run the oracle on the WHOLE frame of pair 0 anyway: their maps are the checker of the

@@ -636,6 +636,20 @@ int pair_chunk() {
 
 int seq_chunk_pairs() { return pair_chunk(); }
 
+PlaneSet pair_plane_set(const PlaneSet& ps, int b) { return plane_set_of_pair(ps, b); }
+
+// A second lane for half of a batch (plane mode, pm_planes_host.hip): view1_stream runs behind everything the handle's
+// stream holds now; lane_join makes the handle's stream wait for the lane again.
+int lane_fork(pm_handle* h) {
+  if (int rc = view_streams_create(h)) return rc;
+  PM_HIP(h, hipEventRecord(h->view_fork, h->stream));
+  PM_HIP(h, hipStreamWaitEvent(h->view1_stream, h->view_fork, 0));
+  mark_forked(h, h->view1_stream);
+  prof_break(h, h->view1_stream);
+  return PM_OK;
+}
+int lane_join(pm_handle* h) { return join_stream(h, h->view1_stream, h->view1_join, h->stream); }
+
 bool seq_pipelined(const pm_handle* h) {
   return h->params.mode == PM_MODE_SCALAR && h->params.left_right_check != 0 && view_streams_enabled() && !h->bgr;
 }

@@ -288,6 +288,9 @@ int match_device_impl(pm_handle* h, int n, const uint8_t* d_left, const uint8_t*
                       const float* d_seed_l, const float* d_seed_r, float* d_disp_l, float* d_disp_r);
 // view streams, chunk events, and one chunk of a batch / frame sequence (pm_engine.hip)
 int view_streams_create(pm_handle* h);
+PlaneSet pair_plane_set(const PlaneSet& ps, int b);  // the plane set of the pairs from b on
+int lane_fork(pm_handle* h);
+int lane_join(pm_handle* h);
 int seq_events_create(pm_handle* h);
 int seq_chunk_pairs();
 bool seq_pipelined(const pm_handle* h);

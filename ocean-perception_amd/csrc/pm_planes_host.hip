@@ -76,11 +76,24 @@ int planes_alloc(pm_handle* h) {
 
 namespace {
 
+// PM_PLANES_LANES=1 (tuning builds): the whole batch through every launch on one stream, as until round 6
+bool planes_two_lanes() {
+  static const bool on = [] {
+    const char* e = pm::tune_env("PM_PLANES_LANES");
+    return !(e && atoi(e) == 1);
+  }();
+  return on;
+}
+
+// pair0: the launch covers the pairs from pair0 on (`ps` is the plan's plane set; slots counts from that pair)
 template <int STAGE>
-int planes_stage(pm_handle* h, const PlaneSet& ps, const PlArgs& ar, int slots, int klass, const char* what) {
+int planes_stage(pm_handle* h, const PlaneSet& ps0, const PlArgs& ar, int slots, int klass, const char* what, int pair0 = 0) {
   Launch l(h, klass);
-  const hipError_t e = pl_launch<STAGE>(ps, h->planes_state, h->params.state_dtype == PM_STATE_F16,
-                                        planes_params(h->params), ar, slots, h->stream);
+  const bool f16 = h->params.state_dtype == PM_STATE_F16;
+  const PlaneSet ps = pair0 ? pair_plane_set(ps0, pair0) : ps0;
+  // PlaneState::arr: a pair holds 2 views x 4 arrays of `plane` elements
+  char* state = (char*)h->planes_state + (size_t)pair0 * 8 * ps0.plane * (f16 ? sizeof(_Float16) : sizeof(float));
+  const hipError_t e = pl_launch<STAGE>(ps, state, f16, planes_params(h->params), ar, slots, h->stream);
   if (e != hipSuccess) {
     set_err(h, "launch of planes %s failed: %s", what, hipGetErrorString(e));
     return PM_ERR_HIP;
@@ -88,7 +101,7 @@ int planes_stage(pm_handle* h, const PlaneSet& ps, const PlArgs& ar, int slots, 
   return PM_OK;
 }
 
-int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
+int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg, int pair0 = 0) {
   const int nv = ps.n_views;
   PlArgs ar{};
   ar.dbg = planes_dbg();
@@ -97,22 +110,22 @@ int planes_step(pm_handle* h, const PlaneSet& ps, int n, int stage, int arg) {
   ar.view_fixed = -1;
   switch (stage) {
     case PM_PL_SPATIAL:
-      return planes_stage<PL_SPATIAL>(h, ps, ar, n * nv, PM_K_PL_SPATIAL, "spatial propagation");
+      return planes_stage<PL_SPATIAL>(h, ps, ar, n * nv, PM_K_PL_SPATIAL, "spatial propagation", pair0);
     case PM_PL_VIEW:
       if (nv < 2) return PM_OK;
       ar.view_fixed = arg;
-      return planes_stage<PL_VIEW>(h, ps, ar, n, PM_K_PL_VIEW, "view propagation");
+      return planes_stage<PL_VIEW>(h, ps, ar, n, PM_K_PL_VIEW, "view propagation", pair0);
     case PM_PL_REFINE:
       ar.refine_amp = h->params.noise_amp[arg];
-      return planes_stage<PL_REFINE>(h, ps, ar, n * nv, PM_K_PL_REFINE, "refinement");
+      return planes_stage<PL_REFINE>(h, ps, ar, n * nv, PM_K_PL_REFINE, "refinement", pair0);
     case PM_PL_VIEW_REFINE: {  // arg = iteration * 2 + view: view propagation into `view`, then its refinement
       const int view = arg & 1, it = arg >> 1;
       if (view >= nv) return PM_OK;
       ar.arg = it;
       ar.view_fixed = view;
       ar.refine_amp = h->params.noise_amp[it];
-      if (nv < 2) return planes_stage<PL_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "refinement");
-      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_VIEW_REFINE, "view propagation + refinement");
+      if (nv < 2) return planes_stage<PL_REFINE>(h, ps, ar, n, PM_K_PL_REFINE, "refinement", pair0);
+      return planes_stage<PL_VIEW_REFINE>(h, ps, ar, n, PM_K_PL_VIEW_REFINE, "view propagation + refinement", pair0);
     }
     default:
       set_err(h, "unknown planes stage %d", stage);
@@ -201,13 +214,40 @@ int planes_match(pm_handle* h, int n, const uint8_t* d_left, const uint8_t* d_ri
   if (int rc = planes_begin(h, n, d_left, d_right, rows, cols, d_seed_l, d_seed_r)) return rc;
   const int nv = h->params.left_right_check ? 2 : 1;
   const PlaneSet ps = plane_set(h, rows, cols, nv);
+  // A batch runs as TWO LANES: the first half of its pairs through the iterations on the handle's stream, the second
+  // half on view1_stream, launch k of both before launch k + 1 of either.  The 33 launches of a pair's iterations each end
+  // with a tail in which a few tiles hold the chip; the other lane's launch fills it (two handles side by side matched
+  // 560 pairs/s where one matched 469 / 521 / 552 with 1 / 2 / 4 pairs per launch: tools/multi_handle.py, round 6).
+  const int n_lane[2] = {planes_two_lanes() && n >= 2 ? (n + 1) / 2 : n, planes_two_lanes() && n >= 2 ? n / 2 : 0};
+  hipStream_t lane_stream[2] = {h->stream, h->stream};
+  if (n_lane[1]) {
+    if (int rc = lane_fork(h)) return rc;
+    lane_stream[1] = h->view1_stream;
+  }
+  struct Restore {
+    pm_handle* h;
+    hipStream_t s;
+    ~Restore() { h->stream = s; }
+  } restore{h, h->stream};
+  auto both = [&](int stage, int arg) -> int {
+    for (int lane = 0; lane < 2; ++lane) {
+      if (!n_lane[lane]) continue;
+      h->stream = lane_stream[lane];  // every launch helper enqueues on h->stream
+      if (int rc = planes_step(h, ps, n_lane[lane], stage, arg, lane ? n_lane[0] : 0)) return rc;
+    }
+    h->stream = restore.s;
+    return PM_OK;
+  };
   for (int it = 0; it < h->params.patchmatch_iters; ++it) {
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 2 * it)) return rc;
-    if (int rc = planes_step(h, ps, n, PM_PL_SPATIAL, 2 * it + 1)) return rc;
+    if (int rc = both(PM_PL_SPATIAL, 2 * it)) return rc;
+    if (int rc = both(PM_PL_SPATIAL, 2 * it + 1)) return rc;
     // per view: view propagation then refinement, fused in one launch (one tile fill for 1 + R candidates)
     for (int v = 0; v < nv; ++v)
-      if (int rc = planes_step(h, ps, n, PM_PL_VIEW_REFINE, it * 2 + v)) return rc;
+      if (int rc = both(PM_PL_VIEW_REFINE, it * 2 + v)) return rc;
   }
+  h->stream = restore.s;
+  if (n_lane[1])
+    if (int rc = lane_join(h)) return rc;
   return planes_finish(h, d_disp_l, d_disp_r);
 }
 

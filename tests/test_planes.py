@@ -506,3 +506,40 @@ def test_configs4_workload_bgr_enhanced_f16_planes_full_size(pm, oracle, synth):
     e_l, e_r = oracle.planes_match(oracle.planes_params(**okw(prm)), ol[band], orr[band])
     assert_same(b_l, e_l, "configs[4] band, left")
     assert_same(b_r, e_r, "configs[4] band, right")
+
+
+@gpu
+def test_batches_run_as_two_lanes_and_equal_their_singles(pm, synth):
+    """A plane-mode batch advances its first half on the handle's stream and its second half on a side stream
+    (pm_planes_host.hip::planes_match): five different pairs (3 + 2), with and without the device seeder, f32 and f16
+    state -- every slot must equal that pair matched alone; and pm_match_bgr_device on a batch of three."""
+    import torch
+    rows, cols = 96, 256
+    pairs = [synth.make_pair(60 + i, rows, cols, n_points=30, dilate_factor=2) for i in range(5)]
+    for kw in (dict(iters=3, max_disp=48), dict(iters=2, max_disp=64, sparse_init=1, init_dilate_factor=2), dict(iters=2, max_disp=48, f16=1)):
+        prm = pparams(pm, **kw)
+        seeded = not kw.get("sparse_init")
+        with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=5) as e:
+            sl = [q["seed_l"] for q in pairs] if seeded else None
+            sr = [q["seed_r"] for q in pairs] if seeded else None
+            dls, drs = e.match_batch([q["left"] for q in pairs], [q["right"] for q in pairs], sl, sr)
+            for i, q in enumerate(pairs):
+                one = e.match(q["left"], q["right"], q["seed_l"] if seeded else None, q["seed_r"] if seeded else None)
+                assert_same(dls[i], one[0], f"{kw}: slot {i} left")
+                assert_same(drs[i], one[1], f"{kw}: slot {i} right")
+    # BGR inputs, enhancement in the load path
+    dev = torch.device("cuda")
+    prm = pparams(pm, iters=2, f16=1)
+    BL = torch.from_numpy(np.stack([synth.to_bgr(q["left"], 1) for q in pairs[:3]])).to(dev).contiguous()
+    BR = torch.from_numpy(np.stack([synth.to_bgr(q["right"], 2) for q in pairs[:3]])).to(dev).contiguous()
+    DL = torch.empty((3, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    OL = torch.empty((1, rows, cols), dtype=torch.float32, device=dev)
+    OR = torch.empty_like(OL)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=3) as e:
+        e.match_bgr_device(3, BL.data_ptr(), BR.data_ptr(), rows, cols, None, None, DL.data_ptr(), DR.data_ptr())
+        e.synchronize()
+        for i in range(3):
+            e.match_bgr_device(1, BL[i].data_ptr(), BR[i].data_ptr(), rows, cols, None, None, OL.data_ptr(), OR.data_ptr())
+            e.synchronize()
+            assert torch.equal(DL[i], OL[0]) and torch.equal(DR[i], OR[0]), f"BGR batch slot {i}"

@@ -8,14 +8,23 @@ import numpy as np
 import pm_ctypes as pm
 
 pm.load()
-g = np.load(os.path.join(ROOT, "tests", "golden", "farmsim_fs1_376x240.npz"))
-l, r = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
-rows, cols = l.shape
 iters = 3
-prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=iters, sparse_init=1)
+if os.environ.get("SHAPE") == "720p":  # PM_SEM_GPU on the headline's synthetic pair, given seeds
+    import synth
+    p = synth.make_pair(0, 720, 1280)
+    l, r = p["left"], p["right"]
+    rows, cols = l.shape
+    prm = pm.default_params(pm.PM_SEM_GPU, patchmatch_iters=iters)
+    args = (l, r, p["seed_l"], p["seed_r"])
+else:
+    g = np.load(os.path.join(ROOT, "tests", "golden", "farmsim_fs1_376x240.npz"))
+    l, r = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+    rows, cols = l.shape
+    prm = pm.default_params(pm.PM_SEM_GPU, cost_alpha=0.9, patchmatch_iters=iters, sparse_init=1)
+    args = (l, r)
 with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
     e.debug_counters_enable(True)
-    e.match(l, r)
+    e.match(*args)
     d = e.debug_counters()
 waves = int(os.environ.get("PM_RUNBLK_WAVES", "4"))
 if os.environ.get("PHASES"):  # a -DPM_RUN2_PHASES=1 (sums) / =2 (maxima over all launches) build: device wall clock per phase, 10 ns ticks
