@@ -43,10 +43,21 @@ for case in range(a.cases):
     seeded = rng.random() < 0.4
     sl, sr = (p["seed_l"], p["seed_r"]) if seeded else (None, None)
     want = oracle.planes_match(oracle.planes_params(**okw(prm)), p["left"], p["right"], sl, sr)
-    with pm.Engine(prm, max_rows=rows, max_cols=cols) as e:
-        got = e.match(p["left"], p["right"], sl, sr)
+    # a third of the cases: the pair sits in a random slot of a batch of 2-5 pairs (the batch runs as two lanes on two
+    # streams: pm_planes_host.hip::planes_match); its maps must be the same
+    nb = int(rng.integers(2, 6)) if rng.random() < 0.34 else 1
+    slot = int(rng.integers(0, nb))
+    with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=nb) as e:
+        if nb == 1:
+            got = e.match(p["left"], p["right"], sl, sr)
+        else:
+            others = [synth.make_pair(int(rng.integers(0, 1000)), rows=rows, cols=cols, n_points=10, dilate_factor=2) for _ in range(nb)]
+            others[slot] = p
+            dls, drs = e.match_batch([q["left"] for q in others], [q["right"] for q in others],
+                                     [q["seed_l"] for q in others] if seeded else None, [q["seed_r"] for q in others] if seeded else None)
+            got = (dls[slot], drs[slot] if lr else None)
     ok = np.array_equal(got[0], want[0]) and (not lr or np.array_equal(got[1], want[1]))
-    print(f"case {case:3d}: {cols}x{rows} patch {patch} window {kw['plane_window']} neigh {kw['plane_neighbours']} iters {iters} max_disp {max_disp} f16 {f16} lr {lr} seeded {int(seeded)} "
+    print(f"case {case:3d}: {cols}x{rows} patch {patch} window {kw['plane_window']} neigh {kw['plane_neighbours']} iters {iters} max_disp {max_disp} f16 {f16} lr {lr} seeded {int(seeded)} batch {nb}/{slot} "
           f"{'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
     if not ok:
         print("params:", kw)
