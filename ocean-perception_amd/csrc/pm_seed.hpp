@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(1024) k_seed_select_fused(const unsigned long 
     counters[2] = (unsigned)count;
     counters[0] = counters[1] = 0u;  // ready for the next map (SeedScratch::counters_clean)
   }
+#undef TR
 }
 
 // ---- cv::cornerSubPix on the device (oracle: pm_seed_oracle.c::pmo_corner_subpix, which cites the OpenCV source it
