@@ -438,7 +438,7 @@ def sequence_device_leg(pm, torch, w, args, device, depth=4, frames=96):
     with pm.Engine(w.params, device=device, max_rows=a.rows, max_cols=a.cols, max_batch=depth) as e:
         DL = torch.empty((depth, a.rows, a.cols), dtype=torch.float32, device=w.DL.device)
         DR = torch.empty_like(DL)
-        seeded = not a.self_seed
+        seeded = w.mode == "scalar" and not a.self_seed  # as Workload.step passes them
         L = torch.cat([w.L[g][:1] for g in range(N_ROTATE)]).contiguous()
         R = torch.cat([w.R[g][:1] for g in range(N_ROTATE)]).contiguous()
         SL = torch.cat([w.SL[g][:1] for g in range(N_ROTATE)]).contiguous()
@@ -465,9 +465,11 @@ def sequence_device_leg(pm, torch, w, args, device, depth=4, frames=96):
         same = bool(torch.equal(DL[last0 % depth], w.DL[0]))
     return {"value": frames / dt, "unit": "pairs/s", "ms_per_frame": 1e3 * dt / frames, "frames": frames, "depth": depth,
             "equals_the_headline_maps": same,
-            "note": "one device-resident pair per pm_submit_device call, up to `depth` in flight: frames run back to "
-                    "back on the handle's two view streams (no fork / join per frame), two of them through every "
-                    "launch together while the device is busy"}
+            "note": ("one device-resident pair per pm_submit_device call, up to `depth` in flight: frames run back to "
+                     "back on the handle's two view streams (no fork / join per frame), two of them through every "
+                     "launch together while the device is busy") if w.mode == "scalar" else
+                    ("one device-resident pair per pm_submit_device call, up to `depth` in flight: while the device is busy "
+                     "a frame waits for the next one and the two run as a batch of two lanes on two streams")}
 
 
 def batch_leg(pm, torch, np, synth, args, dev, device, nb, steps):
@@ -747,6 +749,12 @@ def side_leg(args, pm, torch, np, synth, dev, d, state, enhance, plane_neighbour
            "roofline": roofline_of(args, prof, n_prof, w.nb, "planes", state, 1e3 * elapsed / steps, variant),
            "kernels_ms_per_step": {k: v[1] / max(n_prof, 1) for k, v in prof.items() if v[0]},
            "check": w.quality()}
+    if nb == 1 and not enhance and not plane_neighbours:
+        # the frame sequence in plane mode (pm_submit_device / pm_collect, the reference's Sequence caller): one pair per
+        # call like the leg above, but consecutive frames may share the chip
+        seq = sequence_device_leg(pm, torch, w, args, d.local_rank, depth=4, frames=64)
+        seq["equals_this_leg's_maps"] = seq.pop("equals_the_headline_maps")
+        out["sequence_device"] = seq
     w.eng.close()
     return out
 

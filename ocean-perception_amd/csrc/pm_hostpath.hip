@@ -111,11 +111,19 @@ int enqueue_frames(pm_handle* h, int b, int c) {
   } else {
     if (ready) PM_HIP(h, hipStreamWaitEvent(h->stream, ready, 0));
     if (ready2) PM_HIP(h, hipStreamWaitEvent(h->stream, ready2, 0));
-    for (int i = 0; i < c; ++i) {
-      pm_handle::PipeSlot& f = h->pipe[(size_t)(b + i)];
-      if (int rc = match_device_impl(h, 1, f.d_left, f.d_right, rows, cols, f.d_seed_l, f.d_seed_r, f.d_out_l,
-                                     lr ? f.d_out_r : nullptr))
+    if (c > 1 && h->params.mode == PM_MODE_PLANES) {
+      // plane mode: the frames of a chunk are neighbours in memory (can_gang) and run as ONE batch -- two lanes on two
+      // streams, each filling the other's launch tails (pm_planes_host.hip::planes_match)
+      if (int rc = match_device_impl(h, c, f0.d_left, f0.d_right, rows, cols, f0.d_seed_l, f0.d_seed_r, f0.d_out_l,
+                                     lr ? f0.d_out_r : nullptr))
         return rc;
+    } else {
+      for (int i = 0; i < c; ++i) {
+        pm_handle::PipeSlot& f = h->pipe[(size_t)(b + i)];
+        if (int rc = match_device_impl(h, 1, f.d_left, f.d_right, rows, cols, f.d_seed_l, f.d_seed_r, f.d_out_l,
+                                       lr ? f.d_out_r : nullptr))
+          return rc;
+      }
     }
     PM_HIP(h, hipEventRecord(f0.v_done[0], h->stream));
     PM_HIP(h, hipStreamWaitEvent(h->s_out, f0.v_done[0], 0));
@@ -167,7 +175,9 @@ bool can_gang(const pm_handle* h, const pm_handle::PipeSlot& a, const pm_handle:
 // a new frame starts at once on an idle device and is held for a partner while the device is busy with earlier chunks
 // anyway and a neighbour slot exists
 int enqueue_or_hold(pm_handle* h, int slot) {
-  const bool hold = seq_pipelined(h) && seq_chunk_pairs() >= 2 && slot + 1 < h->max_batch && device_busy(h);
+  // (plane mode is not pipelined over the view streams, but two of its frames make a batch of two lanes)
+  const bool gangs = seq_pipelined(h) || (h->params.mode == PM_MODE_PLANES && !h->bgr);
+  const bool hold = gangs && seq_chunk_pairs() >= 2 && slot + 1 < h->max_batch && device_busy(h);
   return hold ? PM_OK : enqueue_frames(h, slot, 1);
 }
 

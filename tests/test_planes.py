@@ -543,3 +543,37 @@ def test_batches_run_as_two_lanes_and_equal_their_singles(pm, synth):
             e.match_bgr_device(1, BL[i].data_ptr(), BR[i].data_ptr(), rows, cols, None, None, OL.data_ptr(), OR.data_ptr())
             e.synchronize()
             assert torch.equal(DL[i], OL[0]) and torch.equal(DR[i], OR[0]), f"BGR batch slot {i}"
+
+
+@gpu
+def test_plane_mode_frames_of_a_sequence_run_in_pairs_and_equal_their_singles(pm, synth):
+    """pm_submit_device in plane mode: while the device is busy a frame waits for its successor and the two run as one
+    batch of two lanes (pm_hostpath.hip::enqueue_frames); whatever the grouping, every frame's maps are those of the
+    pair matched alone.  Device-resident frames in neighbouring buffers (they can gang) and in scattered ones (they cannot)."""
+    import torch
+    rows, cols, depth = 96, 256, 4
+    dev = torch.device("cuda")
+    pairs = [synth.make_pair(70 + i, rows, cols, n_points=30, dilate_factor=2) for i in range(4)]
+    prm = pparams(pm, iters=3, max_disp=48)
+    L = torch.from_numpy(np.stack([q["left"] for q in pairs])).to(dev).contiguous()
+    R = torch.from_numpy(np.stack([q["right"] for q in pairs])).to(dev).contiguous()
+    DL = torch.empty((depth, rows, cols), dtype=torch.float32, device=dev)
+    DR = torch.empty_like(DL)
+    with pm.Engine(prm, max_rows=rows, max_cols=cols, max_batch=depth) as e:
+        singles = [e.match(q["left"], q["right"]) for q in pairs]
+        def check(tag, pair_of, what):
+            q = pair_of[tag]
+            assert_same(DL[tag % depth].cpu().numpy(), singles[q][0], f"{what}: frame {tag} (pair {q}) left")
+            assert_same(DR[tag % depth].cpu().numpy(), singles[q][1], f"{what}: frame {tag} (pair {q}) right")
+
+        for order in ([0, 1, 2, 3], [2, 0, 3, 1]):  # inputs that are neighbours in memory / that are not
+            pair_of = {}
+            for i in range(12):
+                if e.in_flight() == depth:  # the oldest frame's output slot is the one frame i writes
+                    check(e.collect_device(), pair_of, f"order {order}")
+                q = order[i % 4]
+                pair_of[i] = q
+                e.submit_device(L[q].data_ptr(), R[q].data_ptr(), rows, cols, None, None, DL[i % depth].data_ptr(),
+                                DR[i % depth].data_ptr(), tag=i)
+            while e.in_flight():
+                check(e.collect_device(), pair_of, f"order {order}")
