@@ -261,6 +261,9 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk2(PlaneSet ps, Cost
       if (PM_RUN2_PHASES == 2) atomicMax(&ps.counters[base + e], ph[e]);
       else atomicAdd(&ps.counters[base + e], ph[e]);
     }
+    if (PM_RUN2_PHASES == 3 && ph[0] + ph[1] + ph[2] + ph[3] > 1800)  // chains slower than 18 us, one line each
+      printf("slow chain: axis %d dir %d chain %d view %d: load %llu round1 %llu fixup %llu wb %llu ticks; wave 0: %u + %u steps, %u rounds\n",
+             AXIS, g.dir, chain, (int)blockIdx.z, ph[0], ph[1], ph[2], ph[3], n_steps, n_fix, n_rounds);
   }
 #endif
 }
