@@ -728,12 +728,18 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
     }
   }
   if (chain_log && blockIdx.z == 0) {  // per chain: what its slowest wavefront did, and when (tools/chain_tail.py)
-    __shared__ unsigned s_ms, s_mf;
-    if (threadIdx.x == 0) s_ms = s_mf = 0;
+    __shared__ unsigned s_ms, s_mf, s_ss, s_sf, s_ws, s_wf;
+    if (threadIdx.x == 0) s_ms = s_mf = s_ss = s_sf = s_ws = s_wf = 0;
     __syncthreads();
     if (lane == 0) {
       atomicMax(&s_ms, n_steps);
       atomicMax(&s_mf, n_fix);
+      atomicAdd(&s_ss, n_steps);  // all wavefronts' steps: balance inside the chain (tools/chain_tail.py)
+      atomicAdd(&s_sf, n_fix);
+      if (w < 4) {  // per wavefront, 8 bits each (saturating): WHICH part of the chain is the slow one
+        atomicOr(&s_ws, (n_steps > 255u ? 255u : n_steps) << (8 * w));
+        atomicOr(&s_wf, (n_fix > 255u ? 255u : n_fix) << (8 * w));
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -741,11 +747,12 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
       r[0] = (unsigned)chain;
       r[1] = s_ms;
       r[2] = s_mf;
-      r[3] = n_rounds;
       r[4] = t_wall0;
       r[5] = (unsigned)wall_clock64();
-      r[6] = (unsigned)(t_r1 - t_start);
-      r[7] = (unsigned)(clock64() - t_r1);
+      r[3] = n_rounds | (s_ss << 8);  // rounds (8 bits) | steps of all wavefronts, round 1
+      r[6] = s_ws;
+      r[7] = s_wf;
+      (void)s_sf;
     }
   }
 #endif

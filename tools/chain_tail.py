@@ -108,7 +108,7 @@ def main():
             cdur.append(cd)
             steps.append(w[:, 1] + w[:, 2])
             fix.append(w[:, 2])
-            rounds.append(w[:, 3].max())
+            rounds.append((w[:, 3] & 0xff).max())
             tail.append(int((d1 / 100.0 > 0.8 * lt).sum()))
             idle.append(1.0 - cd.sum() / (len(cd) * lt))
         cd, st, fx = np.concatenate(cdur), np.concatenate(steps), np.concatenate(fix)
@@ -118,6 +118,32 @@ def main():
                      f"{st.min():3d} / {q(st, 50):5.1f} / {q(st, 99):5.1f} / {st.max():3d} | {q(fx, 50):4.1f} / {fx.max():3d} | "
                      f"{max(rounds)} | {np.mean(tail):6.1f} of {rs[0]['chains']} | {np.mean(idle):.2f}")
     lines.append(f"# sum of the mean launch times over one view's 32 sweeps: {tot_launch / 1e3:.3f} ms")
+    # ---- balance INSIDE the chains: steps per wavefront (words 6 / 7 of the log: 8 bits per wavefront, chains of <= 4) ---------
+    def per_wave(w, word, nwv):
+        return np.stack([(w[:, word] >> (8 * i)) & 255 for i in range(nwv)], 1).astype(np.float64)
+    lines.append("# inside the chains (wavefront i holds the i-th quarter of the chain in SWEEP order; steps = round 1 + fix-up rounds):")
+    lines.append("it sweep | the 8 chains that end a launch: slowest wavefront, round-1 / fix-up steps | mean over their wavefronts | "
+                 "steps by wavefront 0..3, these chains | steps by wavefront 0..3, all chains")
+    crit_now = crit_bal = 0.0
+    for (it, k), rs in sorted(cells.items()):
+        acc, by_top, by_all = [], [], []
+        for r in rs:
+            w = r["w"].astype(np.int64)
+            nwv = min(4, int(r["waves"]))
+            s1, sf = per_wave(w, 6, nwv), per_wave(w, 7, nwv)
+            tot = (w[:, 1] + w[:, 2]).astype(np.float64)
+            top = np.argsort(tot)[-8:]
+            acc.append([w[top, 1].mean(), w[top, 2].mean(), s1[top].mean(), sf[top].mean()])
+            by_top.append((s1 + sf)[top].mean(0))
+            by_all.append((s1 + sf).mean(0))
+            crit_now += tot.max() / len(rs)
+            crit_bal += (s1 + sf).mean(1).max() / len(rs)
+        a = np.mean(acc, 0)
+        fmt = lambda v: " ".join("%5.1f" % x for x in np.mean(v, 0))
+        lines.append(f"{it} {['row+', 'col+', 'row-', 'col-'][k]} | {a[0]:5.1f} / {a[1]:5.1f} | {a[2]:5.1f} / {a[3]:5.1f} | "
+                     f"{fmt(by_top)} | {fmt(by_all)}")
+    lines.append(f"# sum over one view's 32 sweeps of the slowest chain's steps: {crit_now:.0f}; if every chain took the MEAN of its "
+                 f"wavefronts (perfect balance inside a chain, nothing else changed): {crit_bal:.0f}")
     # ---- is a chain's step count predictable from the SAME sweep of the iteration before? ------------------------------
     lines.append("# prediction: chains whose steps in sweep (it - 1, k) exceeded F x that launch's mean are 'predicted slow' for (it, k)")
     lines.append("it sweep | corr(steps it-1, steps it) | F=1.25: predicted / chains, actual max steps, max steps of the NOT predicted chains | F=1.5: the same")
