@@ -201,7 +201,10 @@ __device__ __forceinline__ Run3Bases run3_bases(const View& v, const PlaneSet& p
 
 // TP = square window 3 .. 11, or 0: any window from cp (GS = 32).  One step of every group of the wavefront.
 // inr_m: lanes whose position exists (inside their segment, group still running).
-template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX>
+// WIDE (fix-up rounds only): ALL groups of the wavefront work on ONE run -- group j tests the candidate at the positions
+// behind group j - 1's (the caller set ipm that way and hands every lane the same candidate slot); what a group found
+// counts only if every group before it passed all of its positions without merging (see the decisions below).
+template <int GS, int AXIS, int TP, int DIR, bool LREF, bool FIX, bool WIDE = false>
 __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, const CostParams& cp, const SweepGeom& g,
                                           int chain, const Run3Lane& k, const Run3Bases& bases,
                                           unsigned long long inr_m, int& ipm, float4* st4, LdsSlot cand_slot,
@@ -470,28 +473,52 @@ __device__ __forceinline__ void run3_step(const View& v, const PlaneSet& ps, con
   const unsigned long long stop_m = (POSM & ~(neutral_m | adopt_m)) | S;
   const unsigned long long q_m = stop_m & ~(stop_m - F);   // one bit per group: its first stop (or the sentinel)
   const unsigned long long passed_m = q_m - F0;            // positions before it
-  const unsigned long long real_m = q_m & inr_m & (~valid_m | same_m);  // the stop is a decided position
-  const unsigned long long done_m = passed_m | real_m;     // positions resolved by this step
+  unsigned long long real_m = q_m & inr_m & (~valid_m | same_m);  // the stop is a decided position
+  unsigned long long done_m = passed_m | real_m;           // positions resolved by this step
   const float dval = in_mask(real_m) ? d0 : cand;
   const float cval = in_mask(adopt_m & passed_m) ? cost : c0;
   unsigned long long write_m = done_m;
+  unsigned long long m_m = S;  // first position of every field where a re-run meets its stored trajectory (S: none)
   if constexpr (FIX) {
     // a re-run merges with the stored trajectory at the first position where both hold the same value
     const float spec = my->z;
     const unsigned long long eq_m = (mask_of(dval == spec) & done_m) | S;
-    const unsigned long long m_m = eq_m & ~(eq_m - F);
+    m_m = eq_m & ~(eq_m - F);
     write_m = done_m & (m_m - F0);
+  }
+  const unsigned long long merged1 = m_m & ~S;  // at most one bit per field, below the field's top bit
+  if constexpr (WIDE) {
+    // The fields are consecutive stretches of ONE run: field j + 1 was offered the candidate on the assumption that
+    // field j hands it on, i.e. that all of field j's positions passed (first stop = sentinel) and none merged (first
+    // merge = sentinel).  Fields behind the first one that did not are void: nothing written, nothing counted.
+    const unsigned long long clean = q_m & m_m & S;
+    constexpr unsigned long long fld = GS == 32 ? 0xffffffffull : 0xffffull;
+    unsigned long long vfill = fld;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j + 1 < kWave / GS; ++j) {
+      ok = ok && ((clean >> (j * GS + POS0 + nd)) & 1ull) != 0ull;
+      if (ok) vfill |= fld << ((j + 1) * GS);
+    }
+    real_m &= vfill;
+    done_m &= vfill;
+    write_m &= vfill;
+    if (FIX && (merged1 & vfill) != 0ull) merged_fill = ~0ull;  // the run has met its stored trajectory: the re-run is over
+  } else if constexpr (FIX) {
     // groups that merged stop: fill their fields
     constexpr unsigned long long H = F << (GS - 1);
-    const unsigned long long merged1 = m_m & ~S;  // at most one bit per field, below the field's top bit
     const unsigned long long nz = F & ~((H - merged1) >> (GS - 1));
     merged_fill |= (nz << GS) - nz;
   }
   if (in_mask(write_m)) *(float2*)&my->z = make_float2(dval, cval);
   if (in_mask(real_m)) *cand_slot = d0;
-  const unsigned field = GS == 16 ? ((unsigned)(done_m >> k.gbase) & 0xffffu)
-                                  : (k.gbase ? (unsigned)(done_m >> 32) : (unsigned)done_m);
-  ipm += __builtin_popcount(field);
+  if constexpr (WIDE) {
+    ipm += __builtin_popcountll(done_m);  // the resolved positions are one stretch from the run's first position on
+  } else {
+    const unsigned field = GS == 16 ? ((unsigned)(done_m >> k.gbase) & 0xffffu)
+                                    : (k.gbase ? (unsigned)(done_m >> 32) : (unsigned)done_m);
+    ipm += __builtin_popcount(field);
+  }
 }
 
 // One workgroup per chain; a wavefront carries 64 / GS segments.  grid = (chains, 1, slots), block = 64 * nw,
@@ -653,6 +680,9 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const long long t_start = clock64();
   unsigned n_gsteps = 0;
 #endif
+  // (Round 1 does not go wide when a wavefront's last group is alone: built and measured, 450 -> 445 pairs/s.  The chip is
+  // full of round-1 steps then, the helpers' loads compete with them for the memory pipeline, and short runs void most of
+  // what the helpers evaluate.  In the fix-up rounds below few groups are at work and the same step is free.)
   for (;;) {
     const unsigned long long inr_m = mask_of(ipm < k.lim);
     if (inr_m == 0ull) break;
@@ -684,12 +714,52 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
         if (k.gl == 0) *cand_slot = in;
       }
       unsigned long long merged_fill = 0ull;
+      // A re-run that is ALONE in its wavefront -- the other groups have merged, or had nothing to re-run -- goes WIDE:
+      // the wavefront's groups line up behind each other on its segment and test its candidate at kPerWave x the positions
+      // per step (run3_step<WIDE>).  Long re-runs are what the fix-up rounds of the forward sweeps consist of: a value
+      // that runs through whole segments, one round per segment, nd positions per step (profiles/r06_chain_balance.txt).
+      const int lim_own = k.lim;
+      bool wide = false;       // uniform in the wavefront
+      LdsSlot wide_slot = cand_slot;
+      unsigned long long merged_before = 0ull, own_fill = 0ull;  // who had merged when the last group went wide; its field
       for (;;) {
-        const unsigned long long inr_m = mask_of(ipm < k.lim) & redo_m & ~merged_fill;
-        if (inr_m == 0ull) break;
-        run3_step<GS, AXIS, TP, DIR, LREF, true>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, cand_slot, merged_fill);
+        unsigned long long inr_m = mask_of(ipm < k.lim) & ~merged_fill;
+        if (!wide) {
+          inr_m &= redo_m;
+          if (inr_m == 0ull) break;
+#ifndef PM_RUN3_NO_WIDE  // (A/B switch of tools/build_variant.sh)
+          if constexpr (kPerWave > 1) {
+            unsigned act = 0u;  // groups of the wavefront with a position left
+#pragma unroll
+            for (int j = 0; j < kPerWave; ++j)
+              act |= ((inr_m >> (j * GS)) & (GS == 32 ? 0xffffffffull : 0xffffull)) != 0ull ? 1u << j : 0u;
+            if (__builtin_popcount(act) == 1) {
+              const int a = __builtin_ctz(act);
+              const int src = a * GS + POS0;  // the lane of the running group that holds its first unresolved position
+              const int wp = __builtin_amdgcn_readlane(ipm, src);
+              const int wlim = __builtin_amdgcn_readlane(k.lim, src);
+              wide_slot = (LdsSlot)(s_cand + kPerWave * w + a);
+              wide = true;
+              merged_before = merged_fill;  // (their fields take part in the wide steps: the mask starts afresh)
+              merged_fill = 0ull;
+              own_fill = (GS == 32 ? 0xffffffffull : 0xffffull) << (a * GS);
+              ipm = wp + (lane / GS) * nd + k.mpos;
+              k.lim = (k.mpos >= 0 && k.mpos < nd) ? wlim : (int)0x80000000;
+              inr_m = mask_of(ipm < k.lim);
+            }
+          }
+#endif
+        } else if (inr_m == 0ull) {
+          break;
+        }
+        if (wide)
+          run3_step<GS, AXIS, TP, DIR, LREF, true, true>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, wide_slot, merged_fill);
+        else
+          run3_step<GS, AXIS, TP, DIR, LREF, true>(v, ps, cp, g, chain, k, bases, inr_m, ipm, st4, cand_slot, merged_fill);
         ++n_fix;
       }
+      k.lim = lim_own;
+      if (wide) merged_fill = merged_before | (merged_fill != 0ull ? own_fill : 0ull);
       const float c2 = *cand_slot;
       if (redo && !in_mask(merged_fill) && c2 != lastv) {
         lastv = c2;
