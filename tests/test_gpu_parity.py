@@ -135,6 +135,47 @@ def test_cpu_propagate_lerp_weight_extremes(pm, oracle, synth, engine, pw):
                         f"weight extremes, pass mask {mask}")
 
 
+@pytest.mark.parametrize("engine", [1, 5])
+@pytest.mark.parametrize("pw", [5, 11])
+@pytest.mark.parametrize("layout", ["rows", "cols"])
+def test_cpu_propagate_runs_through_every_segment(pm, oracle, engine, pw, layout):
+    """PM_SEM_CPU sweeps in which ONE value runs along whole chains: the right image is the left one shifted by 6 pixels, the
+    map is wrong everywhere except for one pixel per chain that holds 6.0 -- at the chain's first position, somewhere in
+    the middle, or not at all -- and stretches without texture stop the run (every candidate costs the same there, and
+    the rule is a strict <).  The run engine hands such a run from segment to segment in its fix-up rounds, one round per
+    segment, and since round 6 a re-run that is alone in its wavefront goes wide (run3_step<WIDE>: two or four groups on one
+    run; windows of 5 take 16-lane groups, 11 takes 32 here); chains of 890 positions are 8 / 16 segments."""
+    rng = np.random.default_rng(23)
+    long_, short = 900, 22
+    rows, cols = (short, long_) if layout == "rows" else (long_, short + 30)
+    l = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    if layout == "rows":
+        l[14:, 300:330] = 77          # no texture: the run stops here in the lower rows
+    else:
+        l[400:430, 30:] = 77
+    r = np.roll(l, -6, axis=1)        # left (x) = right (x - 6)
+    d = rng.uniform(8.0, 40.0, (rows, cols)).astype(np.float32)
+    h = pw // 2
+    if layout == "rows":
+        d[:8, h] = 6.0                # from the first position of the forward sweep
+        d[4:12, cols - 1 - h] = 6.0   # ... and of the backward sweep
+        for y in range(12, rows):
+            d[y, rng.integers(h, cols - h)] = 6.0
+    else:
+        d[h, 7:25] = 6.0
+        d[rows - 1 - h, 20:40] = 6.0
+        for x in range(40, cols):
+            d[rng.integers(h, rows - h), x] = 6.0
+    ims = oracle.ImageSet(l, r)
+    with mk(pm, 0, engine, rows=rows, cols=cols) as e:
+        for mask in (1, 2, 4, 8, 15):
+            want = oracle.cpu_propagate(ims, d, pw, pw, pass_mask=mask, nthreads=8)
+            assert_same(e.propagate(l, r, d, pw, pw, mask), want, f"{layout} pass mask {mask}")
+            if mask in (1, 2) and layout == ("rows" if mask == 1 else "cols"):
+                # the test is what it claims to be: the value did run far
+                assert (want == 6.0).mean() > 0.2
+
+
 def test_remove_background_and_mask_occlusions(pm, oracle, synth):
     rows, cols = 50, 90
     l, r, sl, sr, _ = small_pair(synth, 13, rows, cols, n_points=30, dilate_factor=2)
