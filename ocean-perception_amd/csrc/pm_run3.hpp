@@ -680,9 +680,11 @@ __global__ void __launch_bounds__(64 * kMaxSegWaves) k_runblk3(PlaneSet ps, Cost
   const long long t_start = clock64();
   unsigned n_gsteps = 0;
 #endif
-  // (Round 1 does not go wide when a wavefront's last group is alone: built and measured, 450 -> 445 pairs/s.  The chip is
-  // full of round-1 steps then, the helpers' loads compete with them for the memory pipeline, and short runs void most of
-  // what the helpers evaluate.  In the fix-up rounds below few groups are at work and the same step is free.)
+  // (Round 1 does not go wide when a wavefront's last group is alone: built and measured, 450 -> 445 pairs/s, and 438 when
+  // the helpers join only behind a step that passed all of a group's positions.  The chip is full of round-1 steps then:
+  // the helpers' loads compete with them for the memory pipeline, short runs void most of what the helpers evaluate, and
+  // a second copy of the step in this loop is 2000 more instructions in every wavefront's path.  In the fix-up rounds
+  // below few groups are at work and the same step is free.)
   for (;;) {
     const unsigned long long inr_m = mask_of(ipm < k.lim);
     if (inr_m == 0ull) break;
